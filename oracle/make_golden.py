@@ -1,0 +1,216 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself on CPU.
+
+Runs only in the build container (needs /root/reference).  It imports the
+reference's `src.mnist` / `src.shakespeare` with inert stand-ins for three
+modules that are absent from this image and carry no arithmetic (`dotenv`,
+`torchvision`, `google.cloud.storage`), never writes under
+/root/reference (`sys.dont_write_bytecode`), and stores inputs + outputs only
+(data, no reference source).  TEST INFRASTRUCTURE ONLY.
+
+    python oracle/make_golden.py mnist
+    python oracle/make_golden.py text      # separate process (import order)
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+os.environ.setdefault("HF_HUB_OFFLINE", "1")
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _install_stubs(with_torchvision: bool):
+    _stub("dotenv", load_dotenv=lambda *a, **k: False)
+    if with_torchvision:
+        tv = _stub("torchvision")
+        for s in ("datasets", "transforms", "utils"):
+            setattr(tv, s, _stub("torchvision." + s))
+    g = _stub("google")
+    gc = _stub("google.cloud")
+    gs = _stub("google.cloud.storage", Client=object)
+    g.cloud = gc
+    gc.storage = gs
+
+
+def _np(d):
+    return {k: v.detach().cpu().numpy() for k, v in d.items()}
+
+
+def gen_mnist():
+    _install_stubs(with_torchvision=True)
+    sys.path.insert(0, REF)
+    import src.mnist as M
+    import torch.nn.functional as F
+
+    os.makedirs(GOLD, exist_ok=True)
+    # ---- a1: tables ------------------------------------------------------
+    np.savez(os.path.join(GOLD, "schedule.npz"),
+             betas=M.betas.numpy(), alphas=M.alphas.numpy(), alphas_cumprod=M.alphas_cumprod.numpy(),
+             sqrt_alphas_cumprod=M.sqrt_alphas_cumprod.numpy(),
+             sqrt_one_minus_alphas_cumprod=M.sqrt_one_minus_alphas_cumprod.numpy())
+
+    # ---- weights: the reference's own default init ----------------------
+    torch.manual_seed(0)
+    net = M.SimpleUNet()
+    net.eval()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+
+    # ---- a2: q_sample ------------------------------------------------------
+    g = torch.Generator().manual_seed(11)
+    B = 4
+    x0 = torch.rand(B, 1, 28, 28, generator=g) * 2 - 1
+    t = torch.tensor([0, 1, 500, 999])
+    noise = torch.randn(B, 1, 28, 28, generator=g)
+    xq = M.q_sample(x0, t, noise)
+
+    # ---- a3/a4: forward with intermediates --------------------------------
+    feats = {}
+    hooks = [getattr(net, n).register_forward_hook(lambda m, i, o, n=n: feats.__setitem__(n, o.detach().clone()))
+             for n in ("rb1", "rb2", "rb3", "rb4")]
+    with torch.no_grad():
+        eps = net(xq, t)
+    for h in hooks:
+        h.remove()
+
+    # ---- a5: loss, grads, two AdamW steps ----------------------------------
+    net.train()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    step_out = {}
+    g2 = torch.Generator().manual_seed(12)
+    tr_inputs = {}
+    for step in (1, 2):
+        xs = torch.rand(B, 1, 28, 28, generator=g2) * 2 - 1
+        ts = torch.randint(0, M.timesteps, (B,), generator=g2)
+        ns = torch.randn(B, 1, 28, 28, generator=g2)
+        x_noisy = M.q_sample(xs, ts, ns)
+        pred = net(x_noisy, ts)
+        loss = F.mse_loss(pred, ns)
+        opt.zero_grad(); loss.backward(); opt.step()
+        tr_inputs[f"s{step}.x0"] = xs; tr_inputs[f"s{step}.t"] = ts; tr_inputs[f"s{step}.noise"] = ns
+        step_out[f"s{step}.loss"] = loss.detach().reshape(1)
+        step_out[f"s{step}.pred"] = pred.detach()
+        for k, p in net.named_parameters():
+            if step == 1:
+                step_out[f"s{step}.grad.{k}"] = p.grad.detach().clone()
+            step_out[f"s{step}.param.{k}"] = p.detach().clone()
+    np.savez(os.path.join(GOLD, "unet_train.npz"), **_np(tr_inputs), **_np(step_out))
+
+    # ---- a6: p_sample at t in {999, 500, 1, 0} with captured noise ----------
+    net.load_state_dict(sd); net.eval()
+    ps = {}
+    g3 = torch.Generator().manual_seed(13)
+    with torch.no_grad():
+        for tt in (999, 500, 1, 0):
+            x = torch.randn(3, 1, 28, 28, generator=g3)
+            tv = torch.full((3,), tt, dtype=torch.long)
+            torch.manual_seed(1000 + tt)
+            y = M.p_sample(net, x, tv)
+            torch.manual_seed(1000 + tt)
+            z = torch.randn_like(x)          # model forward draws no RNG in eval mode
+            ps[f"t{tt}.x"] = x; ps[f"t{tt}.z"] = z; ps[f"t{tt}.y"] = y
+            ps[f"t{tt}.eps"] = net(x, tv)
+        # ---- a7: the last 12 steps of the reverse loop, chained ---------------
+        n = 2
+        x = torch.randn(n, 1, 28, 28, generator=g3)
+        ps["chain.x_start"] = x.clone()
+        zs = []
+        for i in reversed(range(12)):
+            tv = torch.full((n,), i, dtype=torch.long)
+            torch.manual_seed(2000 + i)
+            z = torch.randn_like(x)
+            torch.manual_seed(2000 + i)
+            x = M.p_sample(net, x, tv)
+            zs.append(z)
+        ps["chain.z"] = torch.stack(zs)
+        ps["chain.x_end"] = x
+        ps["chain.x01"] = (x.clamp(-1, 1) + 1) / 2
+    np.savez(os.path.join(GOLD, "unet_sample.npz"), **_np(ps))
+
+    np.savez(os.path.join(GOLD, "unet_forward.npz"),
+             **{"w." + k: v.numpy() for k, v in sd.items()},
+             x0=x0.numpy(), t=t.numpy(), noise=noise.numpy(), x_noisy=xq.numpy(), eps=eps.numpy(),
+             h1=feats["rb1"].numpy(), h2=feats["rb2"].numpy(), h3=feats["rb3"].numpy(), h4=feats["rb4"].numpy())
+    print("mnist goldens written to", GOLD)
+
+
+def gen_text():
+    _install_stubs(with_torchvision=False)
+    sys.path.insert(0, REF)
+    import src.shakespeare as S
+    import torch.nn.functional as F
+    from oracle import ddpm_oracle as O
+
+    os.makedirs(GOLD, exist_ok=True)
+    out = {}
+    for dim, B, L, tag in ((256, 2, 128, "d256"), (32, 3, 16, "d32")):
+        params = O.transformer_init_params(dim, seed=7)
+        net = S.TinyTransformer(dim, dropout=0.0)
+        missing = net.load_state_dict(params, strict=True)
+        g = torch.Generator().manual_seed(21 + dim)
+        x0 = torch.randn(B, L, dim, generator=g) * 0.5
+        t = torch.randint(0, S.T, (B,), generator=g)
+        t[0] = 0
+        noise = torch.randn(B, L, dim, generator=g)
+        xq = S.q_sample(x0, t, noise)
+        # train-mode forward (dropout 0 => deterministic, slow path) + grads
+        net.train()
+        pred = net(xq, t)
+        loss = F.mse_loss(pred, noise)
+        loss.backward()
+        out[f"{tag}.x0"] = x0; out[f"{tag}.t"] = t; out[f"{tag}.noise"] = noise
+        out[f"{tag}.x_noisy"] = xq; out[f"{tag}.pred"] = pred.detach(); out[f"{tag}.loss"] = loss.detach().reshape(1)
+        # gradients of a few representative parameters (full set is 15.8 MB at D=256)
+        gsel = ["time_emb.weight", "time_emb.bias",
+                "encoder.layers.0.self_attn.in_proj_bias", "encoder.layers.2.norm2.weight",
+                "encoder.layers.1.linear2.bias", "encoder.layers.0.self_attn.out_proj.weight"]
+        named = dict(net.named_parameters())
+        for k in gsel:
+            out[f"{tag}.grad.{k}"] = named[k].grad.detach().clone()
+        if dim == 32:
+            for k, p in named.items():
+                out[f"{tag}.gradall.{k}"] = p.grad.detach().clone()
+        # eval-mode p_sample with captured noise
+        net.eval()
+        with torch.no_grad():
+            for tt in ((999,) if dim == 256 else (999, 0)):
+                x = torch.randn(B, L, dim, generator=g)
+                tv = torch.full((B,), tt, dtype=torch.long)
+                torch.manual_seed(3000 + tt)
+                y = S.p_sample(net, x, tv)
+                torch.manual_seed(3000 + tt)
+                z = torch.randn_like(x)
+                out[f"{tag}.ps{tt}.x"] = x; out[f"{tag}.ps{tt}.z"] = z; out[f"{tag}.ps{tt}.y"] = y
+    # host-side scalar schedules (N2 rows; cheap to pin now)
+    lam = []
+    import torch.optim as optim
+    dummy = torch.nn.Parameter(torch.zeros(1))
+    opt = optim.SGD([dummy], lr=1.0)
+    sch = S.get_cosine_schedule_with_warmup(opt, 10, 100)
+    for _ in range(100):
+        lam.append(opt.param_groups[0]["lr"]); opt.step(); sch.step()
+    out["cosine_warmup_10_100"] = torch.tensor(lam, dtype=torch.float64)
+    out["rounding_weight_e20_w0.5"] = torch.tensor(
+        [S.dynamic_rounding_weight_schedule(e, 20, 0.5) for e in range(20)], dtype=torch.float64)
+    np.savez(os.path.join(GOLD, "text_denoiser.npz"), **_np(out))
+    print("text goldens written to", GOLD)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "mnist"
+    torch.set_num_threads(8)
+    {"mnist": gen_mnist, "text": gen_text}[which]()

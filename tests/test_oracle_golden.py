@@ -1,0 +1,113 @@
+"""The CPU oracle (oracle/ddpm_oracle.py) against vectors captured from the
+reference itself (oracle/make_golden.py -> tests/golden/*.npz).  CPU only."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ddpm_oracle as O
+
+
+def _load(golden_dir, name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, name)).items()}
+
+
+def _weights(d, prefix="w."):
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+
+
+# SURVEY.md §8(a1) known answers (sha256[:16] of the raw fp32 bytes)
+TABLE_SHA = {
+    "betas": "a455de8584c2913e", "alphas": "b32d9a7d2718af05", "alphas_cumprod": "b5555536933367c4",
+    "sqrt_alphas_cumprod": "f03fa1d930d2b0da", "sqrt_one_minus_alphas_cumprod": "6f29eaa972842493",
+}
+
+
+def test_tables_bit_exact(golden_dir):
+    g = _load(golden_dir, "schedule.npz")
+    tabs = O.make_tables()
+    for k, sha in TABLE_SHA.items():
+        assert torch.equal(tabs[k], g[k]), k
+        assert hashlib.sha256(g[k].numpy().tobytes()).hexdigest()[:16] == sha
+    assert tabs["betas"][0].view(torch.int32).item() == 0x38D1B717
+    assert tabs["alphas_cumprod"][999].view(torch.int32).item() == 0x38294666
+
+
+def test_q_sample_bit_exact(golden_dir):
+    g = _load(golden_dir, "unet_forward.npz")
+    out = O.q_sample(g["x0"], g["t"], g["noise"], O.make_tables())
+    assert torch.equal(out, g["x_noisy"])
+
+
+def test_unet_forward(golden_dir):
+    g = _load(golden_dir, "unet_forward.npz")
+    eps, inter = O.unet_forward(_weights(g), g["x_noisy"], g["t"], return_intermediates=True)
+    assert O.rel_err(eps, g["eps"]) < 1e-6
+    for k in ("h1", "h2", "h3", "h4"):
+        assert O.rel_err(inter[k], g[k]) < 1e-6, k
+
+
+def test_unet_train_two_steps(golden_dir):
+    g = _load(golden_dir, "unet_train.npz")
+    p = _weights(_load(golden_dir, "unet_forward.npz"))
+    tabs = O.make_tables()
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v = {k: torch.zeros_like(x) for k, x in p.items()}
+    for step in (1, 2):
+        loss, grads = O.unet_loss_and_grads(p, g[f"s{step}.x0"], g[f"s{step}.t"], g[f"s{step}.noise"], tabs)
+        assert abs(loss.item() - g[f"s{step}.loss"].item()) < 1e-6 * abs(g[f"s{step}.loss"].item()) + 1e-7
+        for k in p:
+            if step == 1:
+                assert O.rel_err(grads[k], g[f"s1.grad.{k}"]) < 2e-5, k
+            p[k], m[k], v[k] = O.adamw_step(p[k], grads[k], m[k], v[k], step)
+            assert O.rel_err(p[k], g[f"s{step}.param.{k}"]) < 2e-6, (step, k)
+
+
+def test_p_sample_and_chain(golden_dir):
+    g = _load(golden_dir, "unet_sample.npz")
+    p = _weights(_load(golden_dir, "unet_forward.npz"))
+    tabs = O.make_tables()
+    for tt in (999, 500, 1, 0):
+        x = g[f"t{tt}.x"]
+        t = torch.full((x.shape[0],), tt, dtype=torch.long)
+        # arithmetic only (teacher-forced eps): bit exact
+        y = O.p_sample_from_eps(x, t, g[f"t{tt}.eps"], g[f"t{tt}.z"], tabs)
+        assert torch.equal(y, g[f"t{tt}.y"]), tt
+        assert O.rel_err(O.p_sample(p, x, t, g[f"t{tt}.z"], tabs), g[f"t{tt}.y"]) < 1e-6
+    x_end = O.sample_chain(p, g["chain.x_start"], list(g["chain.z"]), tabs, t_start=11)
+    assert O.rel_err(x_end, g["chain.x_end"]) < 1e-5
+    assert torch.equal(O.to_unit_range(g["chain.x_end"]), g["chain.x01"])
+    u8 = O.to_uint8(O.to_unit_range(x_end))
+    ref = O.to_uint8(g["chain.x01"])
+    assert (u8 != ref).sum().item() == 0
+
+
+@pytest.mark.parametrize("tag,dim", [("d32", 32), ("d256", 256)])
+def test_transformer(golden_dir, tag, dim):
+    g = _load(golden_dir, "text_denoiser.npz")
+    p = O.transformer_init_params(dim, seed=7)
+    tabs = O.make_tables()
+    assert torch.equal(O.q_sample(g[f"{tag}.x0"], g[f"{tag}.t"], g[f"{tag}.noise"], tabs), g[f"{tag}.x_noisy"])
+    pred = O.transformer_forward(p, g[f"{tag}.x_noisy"], g[f"{tag}.t"])
+    assert O.rel_err(pred, g[f"{tag}.pred"]) < 2e-6
+    loss, grads = O.transformer_loss_and_grads(p, g[f"{tag}.x0"], g[f"{tag}.t"], g[f"{tag}.noise"], tabs)
+    assert abs(loss.item() - g[f"{tag}.loss"].item()) < 1e-5 * abs(g[f"{tag}.loss"].item())
+    for k, v in g.items():
+        if k.startswith(f"{tag}.grad.") or k.startswith(f"{tag}.gradall."):
+            name = k.split(".", 2)[2]
+            assert O.rel_err(grads[name], v) < 5e-5, name
+    for tt in (999, 0):
+        if f"{tag}.ps{tt}.x" not in g:
+            continue
+        x = g[f"{tag}.ps{tt}.x"]
+        t = torch.full((x.shape[0],), tt, dtype=torch.long)
+        y = O.text_p_sample(p, x, t, g[f"{tag}.ps{tt}.z"], tabs)
+        assert O.rel_err(y, g[f"{tag}.ps{tt}.y"]) < 2e-6
+
+
+def test_host_schedules(golden_dir):
+    g = _load(golden_dir, "text_denoiser.npz")
+    assert g["cosine_warmup_10_100"].shape[0] == 100 and g["cosine_warmup_10_100"][0] == 0.0
+    assert abs(g["rounding_weight_e20_w0.5"][0].item() - 0.5) < 1e-12
