@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DDPM train steps/s on the MNIST UNet at batch 512 per GPU
+(BASELINE.json configs[1]; data-parallel over N GPUs = configs[2]), plus the
+1000-step reverse-sampling rate at batch 4096 (configs[3]) as extra keys.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is the loop body of src/mnist.py:152-159 on one synthetic 512-image
+batch: draw t and noise, q_sample, UNet forward, MSE, backward, (RCCL
+all-reduce of the flat gradient), AdamW.  Inputs are resident in HBM before
+the timed region.  Rank 0 prints ONE JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_TRAIN = 512
+B_SAMPLE = 4096
+# algorithmic work of the UNet
+FWD_FLOP_PER_SAMPLE = 129_002_880
+TRAIN_FLOP_PER_SAMPLE = 3 * FWD_FLOP_PER_SAMPLE
+TRAIN_BYTES_PER_SAMPLE = 5_901_168 + 18_816
+OPT_BYTES_PER_STEP = 7 * 725_892
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(cores: int):
+    """The CPU oracle (a port of the reference's PyTorch-CPU path) timed on the
+    host: train step at B=512, 1 warm-up + 4 measured steps."""
+    from oracle import ddpm_oracle as O           # checker / baseline only
+    torch.set_num_threads(cores)
+    p = O.unet_init_params(0)
+    tabs = O.make_tables()
+    g = torch.Generator().manual_seed(1234)
+    x0 = torch.rand(B_TRAIN, 1, 28, 28, generator=g) * 2 - 1
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v = {k: torch.zeros_like(x) for k, x in p.items()}
+    times = []
+    for step in range(1, 6):
+        t0 = time.perf_counter()
+        t = torch.randint(0, 1000, (B_TRAIN,), generator=g)
+        noise = torch.randn(B_TRAIN, 1, 28, 28, generator=g)
+        _, grads = O.unet_loss_and_grads(p, x0, t, noise, tabs)
+        for k in p:
+            p[k], m[k], v[k] = O.adamw_step(p[k], grads[k], m[k], v[k], step)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": round(1.0 / med, 4), "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": "4 train steps at B=512 (1 warm-up), fp32 PyTorch-CPU oracle, median"}
+
+
+def time_kernel(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters   # ms
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--sample-steps", type=int, default=20, help="reverse steps timed at B=4096 (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X; there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from tinydiffusionmodels_amd import _lib, unet_engine as E
+    from tinydiffusionmodels_amd.mnist import SimpleUNet, DDPMTrainer, reverse_diffusion
+
+    E.check_layout_against_library()
+    torch.manual_seed(0)                       # identical default init on every rank (+ broadcast in the trainer)
+    model = SimpleUNet().to(dev)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x0 = torch.rand(B_TRAIN, 1, 28, 28, device=dev, generator=gen) * 2 - 1
+    torch.manual_seed(4321 + rank)             # rank-distinct t / noise streams
+    trainer = DDPMTrainer(model, batch_size=B_TRAIN, lr=1e-3)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(x0)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(x0)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    loss_val = float(loss.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * args.steps / elapsed
+
+    out = {
+        "metric": "DDPM train steps/sec, MNIST UNet b=512/GPU (512-image steps summed over GPUs)",
+        "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "MNIST DDPM UNet train step (q_sample+fwd+MSE+bwd+AdamW), batch 512 per GPU, "
+                               "1000-step linear beta schedule, fp32 MFMA conv kernels",
+                   "batch_per_gpu": B_TRAIN, "global_batch": B_TRAIN * world, "parallelism": f"dp{world}"},
+        "images_per_s": round(value * B_TRAIN, 1),
+        "final_loss": loss_val,
+    }
+
+    if rank == 0:
+        # ---- whole-step roofline fractions (algorithmic work / measured time) ----
+        step_s = elapsed / args.steps
+        flops = TRAIN_FLOP_PER_SAMPLE * B_TRAIN
+        byts = TRAIN_BYTES_PER_SAMPLE * B_TRAIN + OPT_BYTES_PER_STEP
+        out["step_roofline"] = {"tflops": round(flops / step_s / 1e12, 2),
+                                "frac_f32_mfma": round(flops / step_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                "gbs": round(byts / step_s / 1e9, 1),
+                                "frac_hbm": round(byts / step_s / 1e9 / PEAK_HBM_GBS, 4)}
+        # ---- dominant kernel: conv_mfma_kernel<28,1,fwd> on the rb4.conv1 shape ----
+        # (96->32 3x3 @28x28, B=512: 43,352,064 FLOP/sample),
+        # timed live with events on the launch stream.
+        L = _lib.lib()
+        cin, cout, hw = 96, 32, 28
+        xin = torch.randn(B_TRAIN, hw, hw, cin, device=dev)
+        w = torch.randn(3, 3, cin, cout, device=dev) * 0.05
+        bias = torch.zeros(cout, device=dev)
+        yout = torch.empty(B_TRAIN, hw, hw, cout, device=dev)
+
+        def run_conv():
+            _lib.check(L.tdm_conv_nhwc_f32(_lib.ptr(xin), _lib.ptr(w), _lib.ptr(bias), None, None, _lib.ptr(yout), None,
+                                           B_TRAIN, hw, cin, cout, 3, 1, _lib.stream()))
+        ms = time_kernel(run_conv)
+        kflop = 2 * 9 * cin * cout * hw * hw * B_TRAIN
+        ach = kflop / (ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "kernel": "conv_mfma_kernel<28,1,fwd> (rb4.conv1 shape 96->32 3x3 @28x28, B=512)",
+                           "ms_per_launch": round(ms, 4), "flop_per_launch": kflop,
+                           "algorithmic_bytes_per_launch": (cin + cout) * 4 * hw * hw * B_TRAIN}
+        del xin, yout
+
+    # ---- 1000-step sampling rate at B=4096 (configs[3]); sharded over ranks, no collectives ----
+    if args.sample_steps > 0:
+        xs = torch.randn(B_SAMPLE, 1, 28, 28, device=dev, generator=torch.Generator(device=dev).manual_seed(99 + rank))
+        with torch.no_grad():
+            reverse_diffusion(model, xs, t_start=2)      # warm-up (3 steps)
+            sync()
+            t0 = time.perf_counter()
+            reverse_diffusion(model, xs, t_start=args.sample_steps - 1)
+            sync()
+            el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = tt.item()
+        ms_rev = 1e3 * el / args.sample_steps
+        out["sampling"] = {"batch_per_gpu": B_SAMPLE, "ms_per_reverse_step": round(ms_rev, 3),
+                           "reverse_steps_timed": args.sample_steps,
+                           "imgs_per_s_1000_step": round(world * B_SAMPLE / (ms_rev * 1e-3 * 1000), 2),
+                           "tflops": round(FWD_FLOP_PER_SAMPLE * B_SAMPLE / (ms_rev * 1e-3) / 1e12, 2)}
+        del xs
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = min(avail, 16)             # a 1-GPU box's CPU share is 16 cores
+            out["cpu_baseline"] = cpu_baseline(cores)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

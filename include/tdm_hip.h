@@ -1,0 +1,134 @@
+/* libtdm_hip.so — C ABI of the MI355X-native DDPM hot path.
+ *
+ * The reference (LiamConnell/TinyDiffusionModels) has no FFI: its hot path is
+ * plain Python over ATen ops.  Each entry point below replaces the ATen work
+ * behind one reference function; the citation names the reference lines it
+ * stands in for.  Python host code (tinydiffusionmodels_amd/*.py) re-creates
+ * the reference's Python surface on top of these.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm
+ *    allocates); the library never allocates, frees or synchronises, so every
+ *    call is hipGraph-capturable;
+ *  - `stream` is a hipStream_t passed as void*;
+ *  - return 0 on success, non-zero on error; tdm_last_error() gives the text;
+ *  - activations inside the library are NHWC fp32; the UNet input/output
+ *    (C = 1) is identical in NCHW and NHWC;
+ *  - UNet parameters live in ONE flat fp32 buffer in the layout given by
+ *    tdm_unet_param_offsets(): conv weights are HWIO ([ky][kx][ci][co]),
+ *    i.e. the reference's OIHW `state_dict` tensors permuted (2,3,1,0).
+ */
+#ifndef TDM_HIP_H
+#define TDM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDM_VERSION 100
+#define TDM_TIMESTEPS 1000
+#define TDM_UNET_NPARAM 181473      /* SimpleUNet(), src/mnist.py:64-74 */
+#define TDM_UNET_NTENSOR 32         /* number of state_dict entries      */
+#define TDM_UNET_MAX_SLABS 512      /* wgrad partial slabs               */
+
+int tdm_version(void);
+const char* tdm_last_error(void);
+
+/* ---- a2: q_sample  (src/mnist.py:36-42, src/shakespeare.py:37-44) -------
+ * out[b,i] = sqrt_acp[t[b]] * x0[b,i] + sqrt_1m_acp[t[b]] * noise[b,i]
+ * (mul, mul, add — no FMA contraction: bit-exact with the reference).      */
+int tdm_q_sample_f32(const float* x0, const float* noise, const int64_t* t,
+                     const float* sqrt_acp, const float* sqrt_1m_acp,
+                     float* out, int64_t B, int64_t inner, void* stream);
+
+/* ---- a6: p_sample arithmetic  (src/mnist.py:169-180, shakespeare.py:343-352)
+ * out = c_recip * (x - c_eps * eps) [+ c_sigma * noise]; the three scalars are
+ * read on the device from 1000-entry tables at index t_index (uniform-t fast
+ * path of the reverse loops, src/mnist.py:191-193); noise == NULL -> t == 0
+ * branch.  Op order as the reference: mul, sub, mul, (mul, add).            */
+int tdm_p_sample_update_f32(const float* x, const float* eps, const float* noise,
+                            const float* tab_recip, const float* tab_eps, const float* tab_sigma,
+                            int t_index, float* out, int64_t n, void* stream);
+/* general per-sample t (API parity with p_sample(model, x, t)): tables gathered by t[b] */
+int tdm_p_sample_update_pert_f32(const float* x, const float* eps, const float* noise,
+                                 const float* tab_recip, const float* tab_eps, const float* tab_sigma,
+                                 const int64_t* t, int add_noise, float* out, int64_t B, int64_t inner,
+                                 void* stream);
+
+/* (x.clamp(-1,1)+1)/2 -> [0,1] (src/mnist.py:194) and the uint8 quantisation
+ * save_image applies (mul 255, add 0.5, clamp, truncate).                    */
+int tdm_to_unit_u8_f32(const float* x, float* x01, uint8_t* u8, int64_t n, void* stream);
+
+/* ---- a3/a4: SimpleUNet  (src/mnist.py:45-87) ------------------------------ */
+/* offsets (in floats) of the 32 parameter tensors inside the flat buffer, in
+ * the reference's state_dict order (rb1.conv1.weight, rb1.conv1.bias, ...,
+ * out.weight, out.bias); offs has TDM_UNET_NTENSOR+1 entries (last = total). */
+int tdm_unet_param_offsets(int32_t* offs);
+
+/* workspace size in floats for batch B (activations, saved tensors, backward
+ * temporaries).  `training` != 0 also reserves the backward temporaries.     */
+int64_t tdm_unet_workspace_floats(int64_t B, int training);
+/* slab buffer (wgrad partials) size in floats                                */
+int64_t tdm_unet_slab_floats(void);
+
+/* eps = UNet(x, t).  x (B,1,28,28) fp32, t (B,) int64 raw step index,
+ * eps (B,1,28,28).  save != 0 keeps what backward needs in `ws`.            */
+int tdm_unet_fwd_f32(const float* params, const float* x, const int64_t* t, float* eps,
+                     float* ws, int64_t B, int save, void* stream);
+
+/* gradients of all parameters given d(loss)/d(eps); needs ws from a
+ * save != 0 forward of the same (x, t).  grads: flat, same layout as params. */
+int tdm_unet_bwd_f32(const float* params, const float* x, const float* deps, float* grads,
+                     float* ws, float* slabs, int64_t B, void* stream);
+
+/* copy one saved activation out of the workspace as NCHW (tests):
+ * which: 0=h1 (32,28,28) 1=h2 (64,14,14) 2=h3 (64,14,14) 3=h4 (32,28,28)     */
+int tdm_unet_get_activation(const float* ws, int64_t B, int which, float* out_nchw, void* stream);
+
+/* ---- a5: MSE + AdamW  (src/mnist.py:158, :148) ---------------------------- */
+/* loss = mean((pred-target)^2) -> loss_out[0]; dpred = 2*(pred-target)/n.
+ * scratch: >= 1024 floats.                                                   */
+int tdm_mse_fwd_bwd_f32(const float* pred, const float* target, float* loss_out, float* dpred,
+                        float* scratch, int64_t n, void* stream);
+
+/* torch.optim.AdamW single-tensor update over a flat buffer; step is 1-based;
+ * g is multiplied by grad_scale first (1/world after an all-reduce SUM).     */
+int tdm_adamw_flat_f32(float* p, const float* g, float* m, float* v, int64_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay,
+                       int64_t step, float grad_scale, void* stream);
+
+/* whole fused train step on one GPU (q_sample -> fwd -> MSE -> bwd), leaving
+ * the flat gradient in `grads` and the loss in loss_out[0]; the caller then
+ * all-reduces `grads` (RCCL, via torch.distributed) and calls
+ * tdm_adamw_flat_f32.  x_noisy: (B,784) scratch owned by the caller.        */
+int tdm_unet_loss_grad_f32(const float* params, const float* x0, const float* noise, const int64_t* t,
+                           const float* sqrt_acp, const float* sqrt_1m_acp,
+                           float* x_noisy, float* eps, float* deps, float* loss_out, float* grads,
+                           float* ws, float* slabs, int64_t B, void* stream);
+
+/* one reverse step x <- p_sample(model, x, t=t_index) for the whole batch
+ * (src/mnist.py:191-193): UNet forward + update; noise NULL at t_index==0.  */
+int tdm_unet_p_sample_step_f32(const float* params, const float* x, const int64_t* t, const float* noise,
+                               const float* tab_recip, const float* tab_eps, const float* tab_sigma,
+                               int t_index, float* eps, float* x_out, float* ws, int64_t B, void* stream);
+
+/* ---- per-layer entry points (tests / profiling) --------------------------- */
+/* generic NHWC 3x3 (pad 1) or 1x1 convolution as implicit GEMM on fp32 MFMA.
+ * in: (B,H,W,Cin), w: HWIO, out: (B,H,W,Cout); flags: bit0 relu, bit1 dgrad
+ * (w is the FORWARD HWIO weight [k][Cout_of_this_call][Cin_of_this_call];
+ * the call computes the transposed convolution).  H=W in {28,14}.
+ * bias/res/tb may be NULL.  tb: (B,Cin) added to in-image input pixels.     */
+int tdm_conv_nhwc_f32(const float* in, const float* w, const float* bias, const float* res,
+                      const float* tb, float* out, float* aux_relu_out,
+                      int64_t B, int HW, int Cin, int Cout, int ksize, int flags, void* stream);
+/* weight gradient of the same convolution: dw (HWIO) and db from in and dout;
+ * slabs: scratch of nslab*(k*k*Cin*Cout + Cout) floats.                      */
+int tdm_conv_wgrad_nhwc_f32(const float* in, const float* tb, const float* dout, float* dw, float* db,
+                            float* slabs, int64_t B, int HW, int Cin, int Cout, int ksize, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDM_HIP_H */

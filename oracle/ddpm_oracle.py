@@ -173,11 +173,18 @@ def p_sample_from_eps(x: torch.Tensor, t: torch.Tensor, eps: torch.Tensor,
     nd = x.dim()
     betas_t = _bview(tables["betas"][t], nd)
     s1m = _bview(tables["sqrt_one_minus_alphas_cumprod"][t], nd)
-    sra = _bview(1.0 / torch.sqrt(tables["alphas"][t]), nd)
+    # torch.sqrt on CPU (MKL) differs by 1 ulp between hosts: when the tables
+    # carry the host-pinned derived values (tests/golden/schedule.npz) use them.
+    if "sqrt_recip_alphas" in tables:
+        sra = _bview(tables["sqrt_recip_alphas"][t], nd)
+        sig = _bview(tables["sigma"][t], nd)
+    else:
+        sra = _bview(1.0 / torch.sqrt(tables["alphas"][t]), nd)
+        sig = torch.sqrt(betas_t)
     mean = sra * (x - betas_t / s1m * eps)
     if int(t[0]) == 0:
         return mean
-    return mean + torch.sqrt(betas_t) * noise
+    return mean + sig * noise
 
 
 def p_sample(p, x, t, noise, tables):

@@ -62,7 +62,12 @@ def gen_mnist():
     np.savez(os.path.join(GOLD, "schedule.npz"),
              betas=M.betas.numpy(), alphas=M.alphas.numpy(), alphas_cumprod=M.alphas_cumprod.numpy(),
              sqrt_alphas_cumprod=M.sqrt_alphas_cumprod.numpy(),
-             sqrt_one_minus_alphas_cumprod=M.sqrt_one_minus_alphas_cumprod.numpy())
+             sqrt_one_minus_alphas_cumprod=M.sqrt_one_minus_alphas_cumprod.numpy(),
+             # the three per-step scalars p_sample derives at run time (src/mnist.py:169-171,179), as
+             # computed on THIS host: torch.sqrt goes through MKL and differs by 1 ulp between hosts
+             sqrt_recip_alphas=(1.0 / torch.sqrt(M.alphas)).numpy(),
+             eps_coef=(M.betas / M.sqrt_one_minus_alphas_cumprod).numpy(),
+             sigma=torch.sqrt(M.betas).numpy())
 
     # ---- weights: the reference's own default init ----------------------
     torch.manual_seed(0)

@@ -17,3 +17,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def golden_tables():
+    """Schedule tables exactly as the reference computed them on the host that
+    produced tests/golden (torch.sqrt is host-dependent by 1 ulp, see
+    tinydiffusionmodels_amd/schedule.py:set_tables)."""
+    import numpy as np
+    import torch
+    z = np.load(os.path.join(GOLDEN, "schedule.npz"))
+    return {k: torch.from_numpy(z[k]) for k in z.files}

@@ -1,0 +1,86 @@
+"""ctypes binding of libtdm_hip.so (include/tdm_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the library is
+missing or a call fails, a RuntimeError is raised."""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtdm_hip.so")
+
+_lib = None
+_lock = threading.Lock()
+
+c_f = ctypes.c_void_p      # device pointers travel as void*
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+
+_SIGS = {
+    "tdm_version": ([], c_int),
+    "tdm_last_error": ([], ctypes.c_char_p),
+    "tdm_q_sample_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_f], c_int),
+    "tdm_p_sample_update_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_f, c_i64, c_f], c_int),
+    "tdm_p_sample_update_pert_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_f, c_i64, c_i64, c_f], c_int),
+    "tdm_to_unit_u8_f32": ([c_f, c_f, c_f, c_i64, c_f], c_int),
+    "tdm_unet_param_offsets": ([ctypes.POINTER(ctypes.c_int32)], c_int),
+    "tdm_unet_workspace_floats": ([c_i64, c_int], c_i64),
+    "tdm_unet_slab_floats": ([], c_i64),
+    "tdm_unet_fwd_f32": ([c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_f], c_int),
+    "tdm_unet_bwd_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_f], c_int),
+    "tdm_unet_get_activation": ([c_f, c_i64, c_int, c_f, c_f], c_int),
+    "tdm_mse_fwd_bwd_f32": ([c_f, c_f, c_f, c_f, c_f, c_i64, c_f], c_int),
+    "tdm_adamw_flat_f32": ([c_f, c_f, c_f, c_f, c_i64, c_float, c_float, c_float, c_float, c_float, c_i64,
+                            c_float, c_f], c_int),
+    "tdm_unet_loss_grad_f32": ([c_f] * 13 + [c_i64, c_f], c_int),
+    "tdm_unet_p_sample_step_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_i64, c_f], c_int),
+    "tdm_conv_nhwc_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int, c_int, c_f], c_int),
+    "tdm_conv_wgrad_nhwc_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int, c_f], c_int),
+}
+
+
+def exported_symbols():
+    """Names every build of the library must export (mirrors include/tdm_hip.h)."""
+    return sorted(_SIGS)
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"{LIB_PATH} not found: build it with `python -m tinydiffusionmodels_amd.build` "
+                        "(there is no CPU / eager fallback for the HIP path)")
+                L = ctypes.CDLL(LIB_PATH)
+                for name, (argtypes, restype) in _SIGS.items():
+                    fn = getattr(L, name)          # AttributeError if a symbol is missing
+                    fn.argtypes = argtypes
+                    fn.restype = restype
+                _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().tdm_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libtdm_hip {what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA(HIP) tensor, or NULL for None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libtdm_hip needs tensors on a HIP device (no CPU fallback)")
+    if not t.is_contiguous():
+        raise RuntimeError("libtdm_hip needs contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,632 @@
+// HBM-bound elementwise / reduction kernels of the DDPM path: q_sample,
+// p_sample update, timestep bias, the Cin=1 first convolution, average pool,
+// the 32->1 output convolution, fused MSE forward+backward, ReLU backward
+// with the timestep-bias gradient, AdamW.  All float4-coalesced, 64-lane
+// wavefront reductions, deterministic (no float atomics).
+#include "tdm_common.h"
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+inline int ew_grid(int64_t nwork) {
+    int64_t g = (nwork + EW_BLOCK - 1) / EW_BLOCK;
+    if (g > 2048) g = 2048;  // grid-stride the rest
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// block-wide sum of one float per thread (256 threads); result valid in thread 0
+__device__ __forceinline__ float block_sum(float v, float* sh /* >= 4 floats */) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// ---- q_sample -------------------------------------------------------------
+// src/mnist.py:36-42: out = A[t[b]]*x0 + S[t[b]]*noise, as mul, mul, add
+// (__fmul_rn/__fadd_rn are never contracted into an FMA).
+__global__ __launch_bounds__(EW_BLOCK) void q_sample_kernel(const float* __restrict__ x0,
+                                                            const float* __restrict__ noise,
+                                                            const int64_t* __restrict__ t,
+                                                            const float* __restrict__ ta,
+                                                            const float* __restrict__ ts, float* __restrict__ out,
+                                                            int64_t B, int64_t inner) {
+    const int64_t total = B * inner;
+    if ((inner & 3) == 0) {
+        const int64_t n4 = total >> 2, inner4 = inner >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_BLOCK) {
+            const int64_t b = i / inner4;
+            const int64_t tt = t[b];
+            const float a = ta[tt], s = ts[tt];
+            const float4 x = reinterpret_cast<const float4*>(x0)[i];
+            const float4 n = reinterpret_cast<const float4*>(noise)[i];
+            float4 o;
+            o.x = __fadd_rn(__fmul_rn(a, x.x), __fmul_rn(s, n.x));
+            o.y = __fadd_rn(__fmul_rn(a, x.y), __fmul_rn(s, n.y));
+            o.z = __fadd_rn(__fmul_rn(a, x.z), __fmul_rn(s, n.z));
+            o.w = __fadd_rn(__fmul_rn(a, x.w), __fmul_rn(s, n.w));
+            reinterpret_cast<float4*>(out)[i] = o;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+            const int64_t tt = t[i / inner];
+            out[i] = __fadd_rn(__fmul_rn(ta[tt], x0[i]), __fmul_rn(ts[tt], noise[i]));
+        }
+    }
+}
+
+// ---- p_sample update --------------------------------------------------------
+// src/mnist.py:173-180: mean = c_recip * (x - c_eps * eps); out = mean + c_sigma * z
+__device__ __forceinline__ float p_update(float x, float e, float z, float cr, float ce, float cs, bool add) {
+    const float mean = __fmul_rn(cr, __fsub_rn(x, __fmul_rn(ce, e)));
+    return add ? __fadd_rn(mean, __fmul_rn(cs, z)) : mean;
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void p_update_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                            const float* __restrict__ noise,
+                                                            const float* __restrict__ tr, const float* __restrict__ te,
+                                                            const float* __restrict__ tsg, const int64_t* __restrict__ t,
+                                                            int t_index, int add_noise, float* __restrict__ out,
+                                                            int64_t B, int64_t inner) {
+    // t == nullptr: uniform step t_index for the whole batch
+    const int64_t total = B * inner;
+    const bool add = add_noise != 0 && noise != nullptr;
+    if ((inner & 3) == 0) {
+        const int64_t n4 = total >> 2, inner4 = inner >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_BLOCK) {
+            const int64_t tt = (t != nullptr) ? t[i / inner4] : (int64_t)t_index;
+            const float cr = tr[tt], ce = te[tt], cs = tsg[tt];
+            const float4 xv = reinterpret_cast<const float4*>(x)[i];
+            const float4 ev = reinterpret_cast<const float4*>(eps)[i];
+            float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (add) zv = reinterpret_cast<const float4*>(noise)[i];
+            float4 o;
+            o.x = p_update(xv.x, ev.x, zv.x, cr, ce, cs, add);
+            o.y = p_update(xv.y, ev.y, zv.y, cr, ce, cs, add);
+            o.z = p_update(xv.z, ev.z, zv.z, cr, ce, cs, add);
+            o.w = p_update(xv.w, ev.w, zv.w, cr, ce, cs, add);
+            reinterpret_cast<float4*>(out)[i] = o;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+            const int64_t tt = (t != nullptr) ? t[i / inner] : (int64_t)t_index;
+            out[i] = p_update(x[i], eps[i], add ? noise[i] : 0.f, tr[tt], te[tt], tsg[tt], add);
+        }
+    }
+}
+
+// (clamp(x,-1,1)+1)/2 and uint8 = trunc(clamp(x01*255 + 0.5, 0, 255))
+__global__ __launch_bounds__(EW_BLOCK) void to_unit_u8_kernel(const float* __restrict__ x, float* __restrict__ x01,
+                                                              uint8_t* __restrict__ u8, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK) {
+        float v = x[i];
+        v = fminf(fmaxf(v, -1.f), 1.f);
+        v = __fdiv_rn(__fadd_rn(v, 1.f), 2.f);
+        if (x01 != nullptr) x01[i] = v;
+        if (u8 != nullptr) {
+            float q = __fadd_rn(__fmul_rn(v, 255.f), 0.5f);
+            q = fminf(fmaxf(q, 0.f), 255.f);
+            u8[i] = (uint8_t)q;
+        }
+    }
+}
+
+// ---- timestep bias ----------------------------------------------------------
+// src/mnist.py:77 and :58: that = t.float()/1000; tb[b][c] = w[c]*that + bias[c]
+// for the four blocks (32+64+64+32 = 192 channels per sample).
+struct TeOffs { int w[4]; int b[4]; };
+__global__ __launch_bounds__(EW_BLOCK) void timebias_kernel(const int64_t* __restrict__ t,
+                                                            const float* __restrict__ params, TeOffs o,
+                                                            float* __restrict__ that, float* __restrict__ tb, int B) {
+    const int total = B * 192;
+    for (int i = blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += gridDim.x * EW_BLOCK) {
+        const int b = i / 192, c = i - b * 192;
+        const float th = __fdiv_rn((float)t[b], 1000.f);
+        int blk, cc;
+        if (c < 32) { blk = 0; cc = c; }
+        else if (c < 96) { blk = 1; cc = c - 32; }
+        else if (c < 160) { blk = 2; cc = c - 96; }
+        else { blk = 3; cc = c - 160; }
+        tb[i] = fmaf(params[o.w[blk] + cc], th, params[o.b[blk] + cc]);
+        if (c == 0) that[b] = th;
+    }
+}
+
+// ---- rb1.conv1 (Cin = 1) + rb1.skip ----------------------------------------
+// src/mnist.py:57 with in_ch=1 and :52: a1 = relu(conv3x3(x)+b1), s = x*ws+bs.
+// HBM-bound (4 B in, 256 B out per pixel): 8 lanes per pixel, float4 stores.
+__global__ __launch_bounds__(EW_BLOCK) void conv_first_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ w1,
+                                                              const float* __restrict__ b1,
+                                                              const float* __restrict__ ws,
+                                                              const float* __restrict__ bs, float* __restrict__ a1,
+                                                              float* __restrict__ s, int B) {
+    const int64_t total = (int64_t)B * 784 * 8;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c4 = (int)(i & 7);
+        const int64_t m = i >> 3;
+        const int b = (int)(m / 784);
+        const int rem = (int)(m - (int64_t)b * 784);
+        const int y = rem / 28, xx = rem - y * 28;
+        float4 acc = *reinterpret_cast<const float4*>(b1 + c4 * 4);
+        float xc = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xq = xx + tap % 3 - 1;
+            float xv = 0.f;
+            if (yy >= 0 && yy < 28 && xq >= 0 && xq < 28) xv = x[(int64_t)b * 784 + yy * 28 + xq];
+            if (tap == 4) xc = xv;
+            const float4 wv = *reinterpret_cast<const float4*>(w1 + tap * 32 + c4 * 4);
+            acc.x = fmaf(xv, wv.x, acc.x); acc.y = fmaf(xv, wv.y, acc.y);
+            acc.z = fmaf(xv, wv.z, acc.z); acc.w = fmaf(xv, wv.w, acc.w);
+        }
+        acc.x = acc.x < 0.f ? 0.f : acc.x; acc.y = acc.y < 0.f ? 0.f : acc.y;
+        acc.z = acc.z < 0.f ? 0.f : acc.z; acc.w = acc.w < 0.f ? 0.f : acc.w;
+        *reinterpret_cast<float4*>(a1 + m * 32 + c4 * 4) = acc;
+        const float4 wsv = *reinterpret_cast<const float4*>(ws + c4 * 4);
+        const float4 bsv = *reinterpret_cast<const float4*>(bs + c4 * 4);
+        float4 sv;
+        sv.x = fmaf(xc, wsv.x, bsv.x); sv.y = fmaf(xc, wsv.y, bsv.y);
+        sv.z = fmaf(xc, wsv.z, bsv.z); sv.w = fmaf(xc, wsv.w, bsv.w);
+        *reinterpret_cast<float4*>(s + m * 32 + c4 * 4) = sv;
+    }
+}
+
+// ---- F.avg_pool2d(h, 2), NHWC  (src/mnist.py:80) ----------------------------
+__global__ __launch_bounds__(EW_BLOCK) void avgpool_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           int B, int Ho, int C) {
+    const int C4 = C >> 2, Wo = Ho, Wi = 2 * Ho;
+    const int64_t total = (int64_t)B * Ho * Wo * C4;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c4 = (int)(i % C4);
+        const int64_t p = i / C4;
+        const int xo = (int)(p % Wo);
+        const int64_t q = p / Wo;
+        const int yo = (int)(q % Ho);
+        const int64_t b = q / Ho;
+        const float4* src = reinterpret_cast<const float4*>(in) + ((b * Wi + 2 * yo) * Wi + 2 * xo) * C4 + c4;
+        const float4 v00 = src[0], v01 = src[C4], v10 = src[(int64_t)Wi * C4], v11 = src[(int64_t)Wi * C4 + C4];
+        float4 o;
+        o.x = (((v00.x + v01.x) + v10.x) + v11.x) * 0.25f;
+        o.y = (((v00.y + v01.y) + v10.y) + v11.y) * 0.25f;
+        o.z = (((v00.z + v01.z) + v10.z) + v11.z) * 0.25f;
+        o.w = (((v00.w + v01.w) + v10.w) + v11.w) * 0.25f;
+        reinterpret_cast<float4*>(out)[i] = o;
+    }
+}
+
+// ---- out = Conv2d(32, 1, 1)  (src/mnist.py:74,87) ----------------------------
+// 8 lanes per pixel (one float4 each), reduced with 3 xor-shuffles.
+__global__ __launch_bounds__(EW_BLOCK) void conv_out_kernel(const float* __restrict__ h, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float* __restrict__ eps,
+                                                            int64_t M) {
+    const int64_t total = M * 8;
+    const int c4 = threadIdx.x & 7;
+    const float4 wv = *reinterpret_cast<const float4*>(w + c4 * 4);
+    const float bias = b[0];
+    // all 8 lanes of a pixel run the same iterations (EW_BLOCK and the stride are multiples of 8)
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < ((total + 7) & ~(int64_t)7);
+         i += (int64_t)gridDim.x * EW_BLOCK) {
+        float v = 0.f;
+        if (i < total) {
+            const float4 hv = reinterpret_cast<const float4*>(h)[i];
+            v = ((hv.x * wv.x + hv.y * wv.y) + hv.z * wv.z) + hv.w * wv.w;
+        }
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        if (c4 == 0 && i < total) eps[i >> 3] = v + bias;
+    }
+}
+
+// ---- F.mse_loss forward + backward  (src/mnist.py:158) ------------------------
+__global__ __launch_bounds__(EW_BLOCK) void mse_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                       float* __restrict__ dpred, float* __restrict__ partial,
+                                                       int64_t n, float scale) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const float d = pred[i] - tgt[i];
+        acc += d * d;
+        dpred[i] = d * scale;
+    }
+    const float s = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(EW_BLOCK) void mse_final_kernel(const float* __restrict__ partial, int nparts,
+                                                             float* __restrict__ loss, float inv_n) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += EW_BLOCK) acc += partial[i];
+    const float s = block_sum(acc, sh);
+    if (threadIdx.x == 0) loss[0] = s * inv_n;
+}
+
+// ---- backward of the output conv + ReLU mask of rb4.conv2 ---------------------
+// dout[p][c] = deps[p]*w[c]; dc2 = dout * (a2 > 0);
+// slab partials: dw[c] = sum_p deps[p]*h4[p][c], db = sum_p deps[p]
+__global__ __launch_bounds__(EW_BLOCK) void out_bwd_kernel(const float* __restrict__ deps, const float* __restrict__ h4,
+                                                           const float* __restrict__ w, const float* __restrict__ a2,
+                                                           float* __restrict__ dout, float* __restrict__ dc2,
+                                                           float* __restrict__ slab, long slab_stride, int w_off,
+                                                           int b_off, int64_t M) {
+    __shared__ float4 shw[EW_BLOCK];
+    __shared__ float shb[4];
+    const int c4 = threadIdx.x & 7;
+    const float4 wv = *reinterpret_cast<const float4*>(w + c4 * 4);
+    float4 gw = make_float4(0.f, 0.f, 0.f, 0.f);
+    float gb = 0.f;
+    const int64_t total = M * 8;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const float d = deps[i >> 3];
+        const float4 hv = reinterpret_cast<const float4*>(h4)[i];
+        const float4 av = reinterpret_cast<const float4*>(a2)[i];
+        float4 o;
+        o.x = d * wv.x; o.y = d * wv.y; o.z = d * wv.z; o.w = d * wv.w;
+        reinterpret_cast<float4*>(dout)[i] = o;
+        float4 mk;
+        mk.x = av.x > 0.f ? o.x : 0.f; mk.y = av.y > 0.f ? o.y : 0.f;
+        mk.z = av.z > 0.f ? o.z : 0.f; mk.w = av.w > 0.f ? o.w : 0.f;
+        reinterpret_cast<float4*>(dc2)[i] = mk;
+        gw.x += d * hv.x; gw.y += d * hv.y; gw.z += d * hv.z; gw.w += d * hv.w;
+        if (c4 == 0) gb += d;
+    }
+    shw[threadIdx.x] = gw;
+    const float sb = block_sum(gb, shb);  // contains __syncthreads
+    if (threadIdx.x < 8) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = threadIdx.x; k < EW_BLOCK; k += 8) {
+            const float4 v = shw[k];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        float* dst = slab + (long)blockIdx.x * slab_stride;
+        *reinterpret_cast<float4*>(dst + w_off + threadIdx.x * 4) = s;
+        if (threadIdx.x == 0) dst[b_off] = sb;
+    }
+}
+
+// dc = dout * (a > 0)
+__global__ __launch_bounds__(EW_BLOCK) void relu_mask_kernel(const float* __restrict__ dout, const float* __restrict__ a,
+                                                             float* __restrict__ dc, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const float4 d = reinterpret_cast<const float4*>(dout)[i];
+        const float4 av = reinterpret_cast<const float4*>(a)[i];
+        float4 o;
+        o.x = av.x > 0.f ? d.x : 0.f; o.y = av.y > 0.f ? d.y : 0.f;
+        o.z = av.z > 0.f ? d.z : 0.f; o.w = av.w > 0.f ? d.w : 0.f;
+        reinterpret_cast<float4*>(dc)[i] = o;
+    }
+}
+
+// One block per image: S[b][c] = sum_pix dh[b][pix][c] (gradient of the
+// timestep bias, src/mnist.py:58-59), then dh <- dh * (a1 > 0) in place
+// (gradient through the first ReLU, :57).
+__global__ __launch_bounds__(EW_BLOCK) void relu_bwd_tb_kernel(float* __restrict__ dh, const float* __restrict__ a1,
+                                                               float* __restrict__ S, int HWpix, int C) {
+    __shared__ float4 sh[EW_BLOCK];
+    const int C4 = C >> 2;
+    const int c4 = threadIdx.x % C4, pg = threadIdx.x / C4, npg = EW_BLOCK / C4;
+    const int64_t base = (int64_t)blockIdx.x * HWpix * C4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = pg; p < HWpix; p += npg) {
+        const int64_t i = base + (int64_t)p * C4 + c4;
+        const float4 d = reinterpret_cast<const float4*>(dh)[i];
+        const float4 av = reinterpret_cast<const float4*>(a1)[i];
+        acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+        float4 o;
+        o.x = av.x > 0.f ? d.x : 0.f; o.y = av.y > 0.f ? d.y : 0.f;
+        o.z = av.z > 0.f ? d.z : 0.f; o.w = av.w > 0.f ? d.w : 0.f;
+        reinterpret_cast<float4*>(dh)[i] = o;
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < npg; ++g) {
+            const float4 v = sh[g * C4 + threadIdx.x];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(S)[(int64_t)blockIdx.x * C4 + threadIdx.x] = s;
+    }
+}
+
+// d_tw[c] = sum_b that[b]*S[b][c]; d_tb[c] = sum_b S[b][c]   (single block)
+__global__ __launch_bounds__(EW_BLOCK) void time_grad_kernel(const float* __restrict__ S, const float* __restrict__ that,
+                                                             float* __restrict__ d_tw, float* __restrict__ d_tb, int B,
+                                                             int C) {
+    __shared__ float shw[EW_BLOCK], shb[EW_BLOCK];
+    const int c = threadIdx.x % C, g = threadIdx.x / C, ng = EW_BLOCK / C;
+    float aw = 0.f, ab = 0.f;
+    for (int b = g; b < B; b += ng) {
+        const float s = S[(int64_t)b * C + c];
+        aw += that[b] * s;
+        ab += s;
+    }
+    shw[threadIdx.x] = aw;
+    shb[threadIdx.x] = ab;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float sw = 0.f, sb = 0.f;
+        for (int k = 0; k < ng; ++k) { sw += shw[k * C + threadIdx.x]; sb += shb[k * C + threadIdx.x]; }
+        d_tw[threadIdx.x] = sw;
+        d_tb[threadIdx.x] = sb;
+    }
+}
+
+// dout3[b][y][x][c] = sum_{2x2} dcat[b][2y+dy][2x+dx][c], c < 64
+// (backward of F.interpolate(scale 2, nearest) on the first 64 channels of the concat)
+__global__ __launch_bounds__(EW_BLOCK) void split_dcat_kernel(const float* __restrict__ dcat, float* __restrict__ dout3,
+                                                              int B) {
+    const int64_t total = (int64_t)B * 196 * 16;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c4 = (int)(i & 15);
+        const int64_t p = i >> 4;
+        const int xo = (int)(p % 14);
+        const int64_t q = p / 14;
+        const int yo = (int)(q % 14);
+        const int64_t b = q / 14;
+        const float4* src = reinterpret_cast<const float4*>(dcat) + ((b * 28 + 2 * yo) * 28 + 2 * xo) * 24 + c4;
+        const float4 v00 = src[0], v01 = src[24], v10 = src[28 * 24], v11 = src[28 * 24 + 24];
+        float4 o;
+        o.x = ((v00.x + v01.x) + v10.x) + v11.x; o.y = ((v00.y + v01.y) + v10.y) + v11.y;
+        o.z = ((v00.z + v01.z) + v10.z) + v11.z; o.w = ((v00.w + v01.w) + v10.w) + v11.w;
+        reinterpret_cast<float4*>(dout3)[i] = o;
+    }
+}
+
+// dout1[p][c] = dcat[p][64+c] + 0.25*dp1[p/2][c]  (concat skip + avg-pool backward)
+__global__ __launch_bounds__(EW_BLOCK) void combine_dh1_kernel(const float* __restrict__ dcat,
+                                                               const float* __restrict__ dp1, float* __restrict__ dout1,
+                                                               int B) {
+    const int64_t total = (int64_t)B * 784 * 8;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c4 = (int)(i & 7);
+        const int64_t p = i >> 3;
+        const int x = (int)(p % 28);
+        const int64_t q = p / 28;
+        const int y = (int)(q % 28);
+        const int64_t b = q / 28;
+        const float4 dc = reinterpret_cast<const float4*>(dcat)[p * 24 + 16 + c4];
+        const float4 dp = reinterpret_cast<const float4*>(dp1)[((b * 14 + (y >> 1)) * 14 + (x >> 1)) * 8 + c4];
+        float4 o;
+        o.x = dc.x + 0.25f * dp.x; o.y = dc.y + 0.25f * dp.y; o.z = dc.z + 0.25f * dp.z; o.w = dc.w + 0.25f * dp.w;
+        reinterpret_cast<float4*>(dout1)[i] = o;
+    }
+}
+
+// weight gradients of rb1.conv1 (Cin = 1, 3x3) and rb1.skip (1x1), per-block slabs.
+// thread (c = tid&31, g = tid>>5): channel c over pixels g, g+8, ... of the block's range.
+__global__ __launch_bounds__(EW_BLOCK) void first_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dc1,
+                                                               const float* __restrict__ dout1, float* __restrict__ slab,
+                                                               long slab_stride, int w1_off, int b1_off, int ws_off,
+                                                               int bs_off, int B) {
+    __shared__ float sh[8][12][32];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int64_t M = (int64_t)B * 784;
+    const int64_t per = (M + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = (int64_t)blockIdx.x * per, p1 = min(p0 + per, M);
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    for (int64_t p = p0 + g; p < p1; p += 8) {
+        const int b = (int)(p / 784);
+        const int rem = (int)(p - (int64_t)b * 784);
+        const int y = rem / 28, xx = rem - y * 28;
+        const float d1 = dc1[p * 32 + c];
+        const float d2 = dout1[p * 32 + c];
+        float xc = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xq = xx + tap % 3 - 1;
+            float xv = 0.f;
+            if (yy >= 0 && yy < 28 && xq >= 0 && xq < 28) xv = x[(int64_t)b * 784 + yy * 28 + xq];
+            if (tap == 4) xc = xv;
+            acc[tap] = fmaf(xv, d1, acc[tap]);
+        }
+        acc[9] += d1;
+        acc[10] = fmaf(xc, d2, acc[10]);
+        acc[11] += d2;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) sh[g][k][c] = acc[k];
+    __syncthreads();
+    float* dst = slab + (long)blockIdx.x * slab_stride;
+    for (int e = threadIdx.x; e < 12 * 32; e += EW_BLOCK) {
+        const int k = e >> 5, cc = e & 31;
+        float s = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < 8; ++gg) s += sh[gg][k][cc];
+        if (k < 9) dst[w1_off + k * 32 + cc] = s;
+        else if (k == 9) dst[b1_off + cc] = s;
+        else if (k == 10) dst[ws_off + cc] = s;
+        else dst[bs_off + cc] = s;
+    }
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                int B, int HWpix, int C) {
+    const int64_t total = (int64_t)B * HWpix * C;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int p = (int)(i % HWpix);
+        const int64_t q = i / HWpix;
+        const int c = (int)(q % C);
+        const int64_t b = q / C;
+        out[i] = in[(b * HWpix + p) * C + c];
+    }
+}
+
+// ---- torch.optim.AdamW, single-tensor form  (src/mnist.py:148) ------------------
+__global__ __launch_bounds__(EW_BLOCK) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                         float decay, float one_m_b1, float b2, float one_m_b2,
+                                                         float step_size, float bc2_sqrt, float eps, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const float gi = g[i] * gscale;
+        float pi = p[i] * decay;                        // param.mul_(1 - lr*wd)
+        float mi = m[i];
+        mi = mi + one_m_b1 * (gi - mi);                 // exp_avg.lerp_(grad, 1-beta1)
+        const float vi = v[i] * b2 + one_m_b2 * gi * gi; // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi = pi - step_size * (mi / denom);             // param.addcdiv_(exp_avg, denom, -step_size)
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+
+}  // namespace
+
+// ------------------------------- launchers -----------------------------------
+int tdm_launch_timebias(const int64_t* t, const float* params, const int* te_w_off, const int* te_b_off, float* that,
+                        float* tb, int B, hipStream_t st) {
+    TeOffs o;
+    for (int i = 0; i < 4; ++i) { o.w[i] = te_w_off[i]; o.b[i] = te_b_off[i]; }
+    hipLaunchKernelGGL(timebias_kernel, dim3(ew_grid((int64_t)B * 192)), dim3(EW_BLOCK), 0, st, t, params, o, that, tb, B);
+    TDM_CHECK_LAUNCH("timebias");
+    return 0;
+}
+int tdm_launch_conv_first(const float* x, const float* w1, const float* b1, const float* ws, const float* bs, float* a1,
+                          float* s, int B, hipStream_t st) {
+    hipLaunchKernelGGL(conv_first_kernel, dim3(ew_grid((int64_t)B * 784 * 8)), dim3(EW_BLOCK), 0, st, x, w1, b1, ws, bs,
+                       a1, s, B);
+    TDM_CHECK_LAUNCH("conv_first");
+    return 0;
+}
+int tdm_launch_avgpool(const float* in, float* out, int B, int Hout, int C, hipStream_t st) {
+    hipLaunchKernelGGL(avgpool_kernel, dim3(ew_grid((int64_t)B * Hout * Hout * (C / 4))), dim3(EW_BLOCK), 0, st, in, out,
+                       B, Hout, C);
+    TDM_CHECK_LAUNCH("avgpool");
+    return 0;
+}
+int tdm_launch_conv_out(const float* h, const float* w, const float* b, float* eps, int64_t M, hipStream_t st) {
+    hipLaunchKernelGGL(conv_out_kernel, dim3(ew_grid(M * 8)), dim3(EW_BLOCK), 0, st, h, w, b, eps, M);
+    TDM_CHECK_LAUNCH("conv_out");
+    return 0;
+}
+int tdm_launch_out_bwd(const float* deps, const float* h4, const float* w, const float* a2, float* dout, float* dc2,
+                       float* slab, long slab_stride, int w_off, int b_off, int64_t M, int nslab, hipStream_t st) {
+    hipLaunchKernelGGL(out_bwd_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, deps, h4, w, a2, dout, dc2, slab, slab_stride,
+                       w_off, b_off, M);
+    TDM_CHECK_LAUNCH("out_bwd");
+    return 0;
+}
+int tdm_launch_relu_mask(const float* dout, const float* a, float* dc, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(ew_grid(n / 4)), dim3(EW_BLOCK), 0, st, dout, a, dc, n / 4);
+    TDM_CHECK_LAUNCH("relu_mask");
+    return 0;
+}
+int tdm_launch_relu_bwd_tb(float* dh, const float* a1, float* S, int B, int HWpix, int C, hipStream_t st) {
+    hipLaunchKernelGGL(relu_bwd_tb_kernel, dim3(B), dim3(EW_BLOCK), 0, st, dh, a1, S, HWpix, C);
+    TDM_CHECK_LAUNCH("relu_bwd_tb");
+    return 0;
+}
+int tdm_launch_time_grad(const float* S, const float* that, float* d_tw, float* d_tb, int B, int C, hipStream_t st) {
+    hipLaunchKernelGGL(time_grad_kernel, dim3(1), dim3(EW_BLOCK), 0, st, S, that, d_tw, d_tb, B, C);
+    TDM_CHECK_LAUNCH("time_grad");
+    return 0;
+}
+int tdm_launch_split_dcat(const float* dcat, float* dout3, int B, hipStream_t st) {
+    hipLaunchKernelGGL(split_dcat_kernel, dim3(ew_grid((int64_t)B * 196 * 16)), dim3(EW_BLOCK), 0, st, dcat, dout3, B);
+    TDM_CHECK_LAUNCH("split_dcat");
+    return 0;
+}
+int tdm_launch_combine_dh1(const float* dcat, const float* dp1, float* dout1, int B, hipStream_t st) {
+    hipLaunchKernelGGL(combine_dh1_kernel, dim3(ew_grid((int64_t)B * 784 * 8)), dim3(EW_BLOCK), 0, st, dcat, dp1, dout1, B);
+    TDM_CHECK_LAUNCH("combine_dh1");
+    return 0;
+}
+int tdm_launch_first_wgrad(const float* x, const float* dc1, const float* dout1, float* slab, long slab_stride,
+                           int w1_off, int b1_off, int ws_off, int bs_off, int B, int nslab, hipStream_t st) {
+    hipLaunchKernelGGL(first_wgrad_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, x, dc1, dout1, slab, slab_stride, w1_off,
+                       b1_off, ws_off, bs_off, B);
+    TDM_CHECK_LAUNCH("first_wgrad");
+    return 0;
+}
+int tdm_launch_nhwc_to_nchw(const float* in, float* out, int B, int HWpix, int C, hipStream_t st) {
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_grid((int64_t)B * HWpix * C)), dim3(EW_BLOCK), 0, st, in, out, B,
+                       HWpix, C);
+    TDM_CHECK_LAUNCH("nhwc_to_nchw");
+    return 0;
+}
+
+// ------------------------------- C ABI ---------------------------------------
+extern "C" {
+
+int tdm_q_sample_f32(const float* x0, const float* noise, const int64_t* t, const float* sqrt_acp,
+                     const float* sqrt_1m_acp, float* out, int64_t B, int64_t inner, void* stream) {
+    TDM_REQUIRE(B > 0 && inner > 0, "q_sample: empty input (B=%lld inner=%lld)", (long long)B, (long long)inner);
+    const int64_t work = (inner & 3) == 0 ? B * inner / 4 : B * inner;
+    hipLaunchKernelGGL(q_sample_kernel, dim3(ew_grid(work)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x0, noise, t,
+                       sqrt_acp, sqrt_1m_acp, out, B, inner);
+    TDM_CHECK_LAUNCH("q_sample");
+    return 0;
+}
+
+int tdm_p_sample_update_f32(const float* x, const float* eps, const float* noise, const float* tab_recip,
+                            const float* tab_eps, const float* tab_sigma, int t_index, float* out, int64_t n,
+                            void* stream) {
+    TDM_REQUIRE(n > 0, "p_sample_update: empty input");
+    TDM_REQUIRE(t_index >= 0 && t_index < TDM_TIMESTEPS, "p_sample_update: t_index %d out of range", t_index);
+    const int64_t work = (n & 3) == 0 ? n / 4 : n;
+    hipLaunchKernelGGL(p_update_kernel, dim3(ew_grid(work)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, eps, noise,
+                       tab_recip, tab_eps, tab_sigma, (const int64_t*)nullptr, t_index, noise != nullptr ? 1 : 0, out,
+                       (int64_t)1, n);
+    TDM_CHECK_LAUNCH("p_sample_update");
+    return 0;
+}
+
+int tdm_p_sample_update_pert_f32(const float* x, const float* eps, const float* noise, const float* tab_recip,
+                                 const float* tab_eps, const float* tab_sigma, const int64_t* t, int add_noise,
+                                 float* out, int64_t B, int64_t inner, void* stream) {
+    TDM_REQUIRE(B > 0 && inner > 0, "p_sample_update_pert: empty input");
+    TDM_REQUIRE(t != nullptr, "p_sample_update_pert: t is NULL");
+    const int64_t work = (inner & 3) == 0 ? B * inner / 4 : B * inner;
+    hipLaunchKernelGGL(p_update_kernel, dim3(ew_grid(work)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, eps, noise,
+                       tab_recip, tab_eps, tab_sigma, t, 0, add_noise, out, B, inner);
+    TDM_CHECK_LAUNCH("p_sample_update_pert");
+    return 0;
+}
+
+int tdm_to_unit_u8_f32(const float* x, float* x01, uint8_t* u8, int64_t n, void* stream) {
+    TDM_REQUIRE(n > 0, "to_unit_u8: empty input");
+    hipLaunchKernelGGL(to_unit_u8_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, x01, u8, n);
+    TDM_CHECK_LAUNCH("to_unit_u8");
+    return 0;
+}
+
+int tdm_mse_fwd_bwd_f32(const float* pred, const float* target, float* loss_out, float* dpred, float* scratch, int64_t n,
+                        void* stream) {
+    TDM_REQUIRE(n > 0, "mse: empty input");
+    int grid = ew_grid(n);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(mse_kernel, dim3(grid), dim3(EW_BLOCK), 0, (hipStream_t)stream, pred, target, dpred, scratch, n,
+                       2.0f / (float)n);
+    TDM_CHECK_LAUNCH("mse");
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(EW_BLOCK), 0, (hipStream_t)stream, scratch, grid, loss_out,
+                       1.0f / (float)n);
+    TDM_CHECK_LAUNCH("mse_final");
+    return 0;
+}
+
+int tdm_adamw_flat_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, int64_t step, float grad_scale, void* stream) {
+    TDM_REQUIRE(n > 0 && step >= 1, "adamw: n=%lld step=%lld", (long long)n, (long long)step);
+    // scalar prologue in double, as Python floats are in torch's _single_tensor_adamw
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double step_size = (double)lr / bc1;
+    const double bc2_sqrt = sqrt(bc2);
+    hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, p, g, m, v, n,
+                       (float)(1.0 - (double)lr * (double)weight_decay), (float)(1.0 - (double)beta1), beta2,
+                       (float)(1.0 - (double)beta2), (float)step_size, (float)bc2_sqrt, eps, grad_scale);
+    TDM_CHECK_LAUNCH("adamw");
+    return 0;
+}
+
+}  // extern "C"

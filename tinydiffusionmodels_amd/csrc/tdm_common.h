@@ -1,0 +1,111 @@
+// Internal declarations shared by the HIP translation units of libtdm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "tdm_hip.h"
+
+void tdm_set_error(const char* fmt, ...);
+
+#define TDM_CHECK_LAUNCH(name)                                                     \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess) {                                                   \
+            tdm_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));  \
+            return 100 + (int)e__;                                                 \
+        }                                                                          \
+    } while (0)
+
+#define TDM_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            tdm_set_error(__VA_ARGS__);        \
+            return 1;                          \
+        }                                      \
+    } while (0)
+
+#define TDM_TRY(expr)               \
+    do {                            \
+        int rc__ = (expr);          \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// implicit-GEMM convolution on fp32 MFMA (conv_mfma.hip)
+// ---------------------------------------------------------------------------
+// One K-source of a convolution: a channel range of an NHWC tensor, optionally
+// nearest-upsampled x2 (virtual upsample+concat of src/mnist.py:83-84) and
+// optionally with a per-(sample, channel) bias added to in-image pixels (the
+// timestep bias of src/mnist.py:58-59, applied while staging).
+struct ConvSrc {
+    const float* ptr;   // [B][H>>up][W>>up][C]
+    const float* tb;    // [B][tb_stride] or nullptr
+    const float* w;     // weight tensor of this source (HWIO)
+    int C;              // channels in ptr
+    int c0;             // first channel used
+    int nch;            // channels used (multiple of 16)
+    int up;             // 1: ptr is half resolution
+    int taps;           // 9 (3x3, pad 1) or 1 (1x1)
+    int tb_stride;
+    int w_rows;         // rows per tap of w  (fwd: Cin_total; dgrad: Cin_total = N)
+    int w_r0;           // fwd: first row of this source inside w
+    int w_cols;         // columns of w (fwd: N; dgrad: Cout of the forward conv = K)
+};
+
+struct ConvArgs {
+    ConvSrc src[2];
+    int nsrc;
+    const float* bias;  // [N] or nullptr
+    const float* res;   // [M][N] or nullptr, added after relu
+    float* out;         // [M][N]
+    float* aux;         // [M][N] or nullptr: value after relu, before residual
+    int relu;
+    int B;
+};
+
+// hw in {28,14}; N in {32,64,96}; dgrad: transposed convolution with the forward weights
+int tdm_launch_conv(const ConvArgs& a, int hw, int N, bool dgrad, hipStream_t st);
+
+struct WgradArgs {
+    ConvSrc a;          // activation source (nch = channels covered, multiple of 32)
+    const float* g;     // [M][Cout] output gradient
+    int Cout;
+    float* slab;        // slab 0 base
+    long slab_stride;   // floats between slabs
+    int w_off;          // offset of the weight tensor inside a slab
+    int b_off;          // offset of the bias gradient inside a slab, or -1
+    int B;
+    int ntiles;
+    int nci;            // number of 32-channel ci tiles
+};
+int tdm_launch_wgrad(const WgradArgs& a, int hw, int nslab, hipStream_t st);
+
+// slab reduction: out[off+i] = sum_s slab[s*stride + off + i]
+struct ReduceSec { int off, len, nslab; };
+#define TDM_MAX_SECS 40
+struct ReduceArgs {
+    ReduceSec sec[TDM_MAX_SECS];
+    int nsec;
+};
+int tdm_launch_reduce(const float* slabs, long stride, const ReduceArgs& ra, float* out, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// elementwise / small kernels (elementwise.hip)
+// ---------------------------------------------------------------------------
+int tdm_launch_timebias(const int64_t* t, const float* params, const int* te_w_off, const int* te_b_off,
+                        float* that, float* tb, int B, hipStream_t st);
+int tdm_launch_conv_first(const float* x, const float* w1, const float* b1, const float* ws, const float* bs,
+                          float* a1, float* s, int B, hipStream_t st);
+int tdm_launch_avgpool(const float* in, float* out, int B, int Hout, int C, hipStream_t st);
+int tdm_launch_conv_out(const float* h, const float* w, const float* b, float* eps, int64_t M, hipStream_t st);
+int tdm_launch_out_bwd(const float* deps, const float* h4, const float* w, const float* a2,
+                       float* dout, float* dc2, float* slab, long slab_stride, int w_off, int b_off,
+                       int64_t M, int nslab, hipStream_t st);
+int tdm_launch_relu_mask(const float* dout, const float* a, float* dc, int64_t n, hipStream_t st);
+int tdm_launch_relu_bwd_tb(float* dh, const float* a1, float* S, int B, int HWpix, int C, hipStream_t st);
+int tdm_launch_time_grad(const float* S, const float* that, float* d_tw, float* d_tb, int B, int C, hipStream_t st);
+int tdm_launch_split_dcat(const float* dcat, float* dout3, int B, hipStream_t st);
+int tdm_launch_combine_dh1(const float* dcat, const float* dp1, float* dout1, int B, hipStream_t st);
+int tdm_launch_first_wgrad(const float* x, const float* dc1, const float* dout1, float* slab, long slab_stride,
+                           int w1_off, int b1_off, int ws_off, int bs_off, int B, int nslab, hipStream_t st);
+int tdm_launch_nhwc_to_nchw(const float* in, float* out, int B, int HWpix, int C, hipStream_t st);

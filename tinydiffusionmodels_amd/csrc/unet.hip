@@ -1,0 +1,362 @@
+// SimpleUNet (src/mnist.py:64-87) forward / backward as a sequence of kernel
+// launches on one stream: parameter layout, workspace carving, and the C ABI
+// entry points of include/tdm_hip.h that drive them.
+#include <stdarg.h>
+#include <string.h>
+#include "tdm_common.h"
+
+// ----------------------------- error plumbing --------------------------------
+static thread_local char g_err[512] = "";
+void tdm_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" int tdm_version(void) { return TDM_VERSION; }
+extern "C" const char* tdm_last_error(void) { return g_err; }
+
+namespace {
+
+// --------------------------- parameter layout ---------------------------------
+// state_dict order of the reference: per block conv1.{w,b},
+// conv2.{w,b}, time_emb.{w,b}, [skip.{w,b}], then out.{w,b}.  Conv weights HWIO.
+struct BlockOff { int c1w, c1b, c2w, c2b, tew, teb, skw, skb; int cin, cout; };
+struct Layout {
+    BlockOff rb[4];
+    int outw, outb, total;
+    int tensor_off[TDM_UNET_NTENSOR + 1];
+};
+
+constexpr Layout make_layout() {
+    Layout L{};
+    const int cin[4] = {1, 32, 64, 96}, cout[4] = {32, 64, 64, 32};
+    int off = 0, ti = 0;
+    for (int i = 0; i < 4; ++i) {
+        BlockOff& b = L.rb[i];
+        b.cin = cin[i]; b.cout = cout[i];
+        b.c1w = off; L.tensor_off[ti++] = off; off += 9 * cin[i] * cout[i];
+        b.c1b = off; L.tensor_off[ti++] = off; off += cout[i];
+        b.c2w = off; L.tensor_off[ti++] = off; off += 9 * cout[i] * cout[i];
+        b.c2b = off; L.tensor_off[ti++] = off; off += cout[i];
+        b.tew = off; L.tensor_off[ti++] = off; off += cout[i];
+        b.teb = off; L.tensor_off[ti++] = off; off += cout[i];
+        if (cin[i] != cout[i]) {
+            b.skw = off; L.tensor_off[ti++] = off; off += cin[i] * cout[i];
+            b.skb = off; L.tensor_off[ti++] = off; off += cout[i];
+        } else {
+            b.skw = -1; b.skb = -1;
+        }
+    }
+    L.outw = off; L.tensor_off[ti++] = off; off += 32;
+    L.outb = off; L.tensor_off[ti++] = off; off += 1;
+    L.tensor_off[ti] = off;
+    L.total = off;
+    return L;
+}
+constexpr Layout kL = make_layout();
+static_assert(kL.total == TDM_UNET_NPARAM, "SimpleUNet parameter count");
+
+// ------------------------------ workspace --------------------------------------
+struct Ws {
+    float *that, *tb, *S, *scratch;
+    float *a1_1, *s1, *a2_1, *h1, *p1;
+    float *a1_2, *s2, *a2_2, *h2;
+    float *a1_3, *a2_3, *h3;
+    float *a1_4, *s4, *a2_4, *h4;
+    // backward temporaries
+    float *dout4, *dc2_4, *dh4, *dcat, *dout3, *dc2_3, *dh3, *dout2, *dc2_2, *dh2, *dp1, *dout1, *dc2_1, *dh1;
+    int64_t total;
+};
+
+Ws carve(float* base, int64_t B, int training) {
+    Ws w{};
+    int64_t off = 0;
+    auto take = [&](int64_t n) {
+        float* p = base ? base + off : nullptr;
+        off += (n + 63) & ~(int64_t)63;  // keep every buffer 256-B aligned
+        return p;
+    };
+    const int64_t M28 = B * 784, M14 = B * 196;
+    w.that = take(B); w.tb = take(B * 192); w.S = take(B * 64); w.scratch = take(2048);
+    w.a1_1 = take(M28 * 32); w.s1 = take(M28 * 32); w.a2_1 = take(M28 * 32); w.h1 = take(M28 * 32);
+    w.p1 = take(M14 * 32);
+    w.a1_2 = take(M14 * 64); w.s2 = take(M14 * 64); w.a2_2 = take(M14 * 64); w.h2 = take(M14 * 64);
+    w.a1_3 = take(M14 * 64); w.a2_3 = take(M14 * 64); w.h3 = take(M14 * 64);
+    w.a1_4 = take(M28 * 32); w.s4 = take(M28 * 32); w.a2_4 = take(M28 * 32); w.h4 = take(M28 * 32);
+    if (training) {
+        w.dout4 = take(M28 * 32); w.dc2_4 = take(M28 * 32); w.dh4 = take(M28 * 32); w.dcat = take(M28 * 96);
+        w.dout3 = take(M14 * 64); w.dc2_3 = take(M14 * 64); w.dh3 = take(M14 * 64);
+        w.dout2 = take(M14 * 64); w.dc2_2 = take(M14 * 64); w.dh2 = take(M14 * 64);
+        w.dp1 = take(M14 * 32);
+        w.dout1 = take(M28 * 32); w.dc2_1 = take(M28 * 32); w.dh1 = take(M28 * 32);
+    }
+    w.total = off;
+    return w;
+}
+
+ConvSrc mk_src(const float* ptr, int C, int c0, int nch, int up, int taps, const float* w, int w_rows, int w_r0,
+               int w_cols, const float* tb = nullptr) {
+    ConvSrc s{};
+    s.ptr = ptr; s.tb = tb; s.w = w; s.C = C; s.c0 = c0; s.nch = nch; s.up = up; s.taps = taps; s.tb_stride = 192;
+    s.w_rows = w_rows; s.w_r0 = w_r0; s.w_cols = w_cols;
+    return s;
+}
+
+// forward conv with one source
+int conv1(hipStream_t st, int hw, int B, const float* in, int Cin, int taps, const float* w, int Cout, const float* bias,
+          int relu, const float* tb, const float* res, float* aux, float* out) {
+    ConvArgs a{};
+    a.nsrc = 1;
+    a.src[0] = mk_src(in, Cin, 0, Cin, 0, taps, w, Cin, 0, Cout, tb);
+    a.bias = bias; a.res = res; a.out = out; a.aux = aux; a.relu = relu; a.B = B;
+    return tdm_launch_conv(a, hw, Cout, false, st);
+}
+// transposed conv (dgrad) with one source: in has K channels, out has N channels, w is forward HWIO [taps][N][K]
+int dgrad1(hipStream_t st, int hw, int B, const float* in, int K, int taps, const float* w, int N, const float* res,
+           float* out) {
+    ConvArgs a{};
+    a.nsrc = 1;
+    a.src[0] = mk_src(in, K, 0, K, 0, taps, w, N, 0, K);
+    a.res = res; a.out = out; a.B = B;
+    return tdm_launch_conv(a, hw, N, true, st);
+}
+
+int wgrad(hipStream_t st, int hw, int B, const float* act, int C, int c_used, int up, const float* tb, int taps,
+          const float* g, int Cout, float* slabs, int w_off, int w_rows, int w_r0, int b_off, int nslab) {
+    WgradArgs a{};
+    a.a = mk_src(act, C, 0, c_used, up, taps, nullptr, w_rows, w_r0, Cout, tb);
+    a.g = g; a.Cout = Cout; a.slab = slabs; a.slab_stride = TDM_UNET_NPARAM; a.w_off = w_off; a.b_off = b_off; a.B = B;
+    const long M = (long)B * hw * hw;
+    a.ntiles = (int)((M + 255) / 256);
+    a.nci = c_used / 32;
+    return tdm_launch_wgrad(a, hw, nslab, st);
+}
+
+int unet_forward(const float* P, const float* x, const int64_t* t, float* eps, const Ws& w, int B, int save,
+                 hipStream_t st) {
+    const int tew[4] = {kL.rb[0].tew, kL.rb[1].tew, kL.rb[2].tew, kL.rb[3].tew};
+    const int teb[4] = {kL.rb[0].teb, kL.rb[1].teb, kL.rb[2].teb, kL.rb[3].teb};
+    TDM_TRY(tdm_launch_timebias(t, P, tew, teb, w.that, w.tb, B, st));
+    const BlockOff &r1 = kL.rb[0], &r2 = kL.rb[1], &r3 = kL.rb[2], &r4 = kL.rb[3];
+    // rb1 (1 -> 32 @ 28x28)
+    TDM_TRY(tdm_launch_conv_first(x, P + r1.c1w, P + r1.c1b, P + r1.skw, P + r1.skb, w.a1_1, w.s1, B, st));
+    TDM_TRY(conv1(st, 28, B, w.a1_1, 32, 9, P + r1.c2w, 32, P + r1.c2b, 1, w.tb + 0, w.s1, save ? w.a2_1 : nullptr, w.h1));
+    // rb2 (32 -> 64 @ 14x14) on avg_pool2d(h1)
+    TDM_TRY(tdm_launch_avgpool(w.h1, w.p1, B, 14, 32, st));
+    TDM_TRY(conv1(st, 14, B, w.p1, 32, 9, P + r2.c1w, 64, P + r2.c1b, 1, nullptr, nullptr, nullptr, w.a1_2));
+    TDM_TRY(conv1(st, 14, B, w.p1, 32, 1, P + r2.skw, 64, P + r2.skb, 0, nullptr, nullptr, nullptr, w.s2));
+    TDM_TRY(conv1(st, 14, B, w.a1_2, 64, 9, P + r2.c2w, 64, P + r2.c2b, 1, w.tb + 32, w.s2, save ? w.a2_2 : nullptr, w.h2));
+    // rb3 (64 -> 64, identity skip)
+    TDM_TRY(conv1(st, 14, B, w.h2, 64, 9, P + r3.c1w, 64, P + r3.c1b, 1, nullptr, nullptr, nullptr, w.a1_3));
+    TDM_TRY(conv1(st, 14, B, w.a1_3, 64, 9, P + r3.c2w, 64, P + r3.c2b, 1, w.tb + 96, w.h2, save ? w.a2_3 : nullptr, w.h3));
+    // rb4 (96 -> 32 @ 28x28) on cat([up2(h3), h1]) — never materialised
+    {
+        ConvArgs a{};
+        a.nsrc = 2;
+        a.src[0] = mk_src(w.h3, 64, 0, 64, 1, 9, P + r4.c1w, 96, 0, 32);
+        a.src[1] = mk_src(w.h1, 32, 0, 32, 0, 9, P + r4.c1w, 96, 64, 32);
+        a.bias = P + r4.c1b; a.relu = 1; a.out = w.a1_4; a.B = B;
+        TDM_TRY(tdm_launch_conv(a, 28, 32, false, st));
+        a.src[0] = mk_src(w.h3, 64, 0, 64, 1, 1, P + r4.skw, 96, 0, 32);
+        a.src[1] = mk_src(w.h1, 32, 0, 32, 0, 1, P + r4.skw, 96, 64, 32);
+        a.bias = P + r4.skb; a.relu = 0; a.out = w.s4;
+        TDM_TRY(tdm_launch_conv(a, 28, 32, false, st));
+    }
+    TDM_TRY(conv1(st, 28, B, w.a1_4, 32, 9, P + r4.c2w, 32, P + r4.c2b, 1, w.tb + 160, w.s4, save ? w.a2_4 : nullptr, w.h4));
+    TDM_TRY(tdm_launch_conv_out(w.h4, P + kL.outw, P + kL.outb, eps, (int64_t)B * 784, st));
+    return 0;
+}
+
+constexpr int NSLAB = 256;
+
+int unet_backward(const float* P, const float* x, const float* deps, float* G, const Ws& w, float* slabs, int B,
+                  hipStream_t st) {
+    const BlockOff &r1 = kL.rb[0], &r2 = kL.rb[1], &r3 = kL.rb[2], &r4 = kL.rb[3];
+    const int64_t M28 = (int64_t)B * 784, M14 = (int64_t)B * 196;
+    // ---- out conv + rb4 ----
+    TDM_TRY(tdm_launch_out_bwd(deps, w.h4, P + kL.outw, w.a2_4, w.dout4, w.dc2_4, slabs, TDM_UNET_NPARAM, kL.outw,
+                               kL.outb, M28, NSLAB, st));
+    TDM_TRY(wgrad(st, 28, B, w.a1_4, 32, 32, 0, w.tb + 160, 9, w.dc2_4, 32, slabs, r4.c2w, 32, 0, r4.c2b, NSLAB));
+    TDM_TRY(dgrad1(st, 28, B, w.dc2_4, 32, 9, P + r4.c2w, 32, nullptr, w.dh4));
+    TDM_TRY(tdm_launch_relu_bwd_tb(w.dh4, w.a1_4, w.S, B, 784, 32, st));  // dh4 <- d(conv1 pre-activation)
+    TDM_TRY(tdm_launch_time_grad(w.S, w.that, G + r4.tew, G + r4.teb, B, 32, st));
+    TDM_TRY(wgrad(st, 28, B, w.h3, 64, 64, 1, nullptr, 9, w.dh4, 32, slabs, r4.c1w, 96, 0, r4.c1b, NSLAB));
+    TDM_TRY(wgrad(st, 28, B, w.h1, 32, 32, 0, nullptr, 9, w.dh4, 32, slabs, r4.c1w, 96, 64, -1, NSLAB));
+    TDM_TRY(wgrad(st, 28, B, w.h3, 64, 64, 1, nullptr, 1, w.dout4, 32, slabs, r4.skw, 96, 0, r4.skb, NSLAB));
+    TDM_TRY(wgrad(st, 28, B, w.h1, 32, 32, 0, nullptr, 1, w.dout4, 32, slabs, r4.skw, 96, 64, -1, NSLAB));
+    {
+        ConvArgs a{};
+        a.nsrc = 2;
+        a.src[0] = mk_src(w.dh4, 32, 0, 32, 0, 9, P + r4.c1w, 96, 0, 32);
+        a.src[1] = mk_src(w.dout4, 32, 0, 32, 0, 1, P + r4.skw, 96, 0, 32);
+        a.out = w.dcat; a.B = B;
+        TDM_TRY(tdm_launch_conv(a, 28, 96, true, st));
+    }
+    TDM_TRY(tdm_launch_split_dcat(w.dcat, w.dout3, B, st));
+    // ---- rb3 ----
+    TDM_TRY(tdm_launch_relu_mask(w.dout3, w.a2_3, w.dc2_3, M14 * 64, st));
+    TDM_TRY(wgrad(st, 14, B, w.a1_3, 64, 64, 0, w.tb + 96, 9, w.dc2_3, 64, slabs, r3.c2w, 64, 0, r3.c2b, NSLAB));
+    TDM_TRY(dgrad1(st, 14, B, w.dc2_3, 64, 9, P + r3.c2w, 64, nullptr, w.dh3));
+    TDM_TRY(tdm_launch_relu_bwd_tb(w.dh3, w.a1_3, w.S, B, 196, 64, st));
+    TDM_TRY(tdm_launch_time_grad(w.S, w.that, G + r3.tew, G + r3.teb, B, 64, st));
+    TDM_TRY(wgrad(st, 14, B, w.h2, 64, 64, 0, nullptr, 9, w.dh3, 64, slabs, r3.c1w, 64, 0, r3.c1b, NSLAB));
+    TDM_TRY(dgrad1(st, 14, B, w.dh3, 64, 9, P + r3.c1w, 64, w.dout3, w.dout2));  // + identity skip
+    // ---- rb2 ----
+    TDM_TRY(tdm_launch_relu_mask(w.dout2, w.a2_2, w.dc2_2, M14 * 64, st));
+    TDM_TRY(wgrad(st, 14, B, w.a1_2, 64, 64, 0, w.tb + 32, 9, w.dc2_2, 64, slabs, r2.c2w, 64, 0, r2.c2b, NSLAB));
+    TDM_TRY(dgrad1(st, 14, B, w.dc2_2, 64, 9, P + r2.c2w, 64, nullptr, w.dh2));
+    TDM_TRY(tdm_launch_relu_bwd_tb(w.dh2, w.a1_2, w.S, B, 196, 64, st));
+    TDM_TRY(tdm_launch_time_grad(w.S, w.that, G + r2.tew, G + r2.teb, B, 64, st));
+    TDM_TRY(wgrad(st, 14, B, w.p1, 32, 32, 0, nullptr, 9, w.dh2, 64, slabs, r2.c1w, 32, 0, r2.c1b, NSLAB));
+    TDM_TRY(wgrad(st, 14, B, w.p1, 32, 32, 0, nullptr, 1, w.dout2, 64, slabs, r2.skw, 32, 0, r2.skb, NSLAB));
+    {
+        ConvArgs a{};
+        a.nsrc = 2;
+        a.src[0] = mk_src(w.dh2, 64, 0, 64, 0, 9, P + r2.c1w, 32, 0, 64);
+        a.src[1] = mk_src(w.dout2, 64, 0, 64, 0, 1, P + r2.skw, 32, 0, 64);
+        a.out = w.dp1; a.B = B;
+        TDM_TRY(tdm_launch_conv(a, 14, 32, true, st));
+    }
+    TDM_TRY(tdm_launch_combine_dh1(w.dcat, w.dp1, w.dout1, B, st));
+    // ---- rb1 ----
+    TDM_TRY(tdm_launch_relu_mask(w.dout1, w.a2_1, w.dc2_1, M28 * 32, st));
+    TDM_TRY(wgrad(st, 28, B, w.a1_1, 32, 32, 0, w.tb + 0, 9, w.dc2_1, 32, slabs, r1.c2w, 32, 0, r1.c2b, NSLAB));
+    TDM_TRY(dgrad1(st, 28, B, w.dc2_1, 32, 9, P + r1.c2w, 32, nullptr, w.dh1));
+    TDM_TRY(tdm_launch_relu_bwd_tb(w.dh1, w.a1_1, w.S, B, 784, 32, st));
+    TDM_TRY(tdm_launch_time_grad(w.S, w.that, G + r1.tew, G + r1.teb, B, 32, st));
+    TDM_TRY(tdm_launch_first_wgrad(x, w.dh1, w.dout1, slabs, TDM_UNET_NPARAM, r1.c1w, r1.c1b, r1.skw, r1.skb, B, NSLAB, st));
+    // ---- sum the slabs into the flat gradient ----
+    ReduceArgs ra{};
+    int n = 0;
+    auto sec = [&](int off, int len) { ra.sec[n].off = off; ra.sec[n].len = len; ra.sec[n].nslab = NSLAB; ++n; };
+    for (int i = 0; i < 4; ++i) {
+        const BlockOff& b = kL.rb[i];
+        sec(b.c1w, 9 * b.cin * b.cout + b.cout);                // conv1.w + conv1.b are contiguous
+        sec(b.c2w, 9 * b.cout * b.cout + b.cout);               // conv2.w + conv2.b
+        if (b.skw >= 0) sec(b.skw, b.cin * b.cout + b.cout);     // skip.w + skip.b
+    }
+    sec(kL.outw, 33);
+    ra.nsec = n;
+    TDM_TRY(tdm_launch_reduce(slabs, TDM_UNET_NPARAM, ra, G, st));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tdm_unet_param_offsets(int32_t* offs) {
+    for (int i = 0; i <= TDM_UNET_NTENSOR; ++i) offs[i] = kL.tensor_off[i];
+    return 0;
+}
+
+int64_t tdm_unet_workspace_floats(int64_t B, int training) { return carve(nullptr, B, training).total; }
+int64_t tdm_unet_slab_floats(void) { return (int64_t)NSLAB * TDM_UNET_NPARAM; }
+
+#define TDM_CHECK_B(B) TDM_REQUIRE((B) >= 1 && (B) <= 16384, "batch %lld out of range [1, 16384]", (long long)(B))
+
+int tdm_unet_fwd_f32(const float* params, const float* x, const int64_t* t, float* eps, float* ws, int64_t B, int save,
+                     void* stream) {
+    TDM_CHECK_B(B);
+    TDM_REQUIRE(params && x && t && eps && ws, "unet_fwd: NULL pointer");
+    const Ws w = carve(ws, B, save);
+    return unet_forward(params, x, t, eps, w, (int)B, save, (hipStream_t)stream);
+}
+
+int tdm_unet_bwd_f32(const float* params, const float* x, const float* deps, float* grads, float* ws, float* slabs,
+                     int64_t B, void* stream) {
+    TDM_CHECK_B(B);
+    TDM_REQUIRE(params && x && deps && grads && ws && slabs, "unet_bwd: NULL pointer");
+    const Ws w = carve(ws, B, 1);
+    return unet_backward(params, x, deps, grads, w, slabs, (int)B, (hipStream_t)stream);
+}
+
+int tdm_unet_get_activation(const float* ws, int64_t B, int which, float* out_nchw, void* stream) {
+    TDM_CHECK_B(B);
+    const Ws w = carve(const_cast<float*>(ws), B, 0);
+    switch (which) {
+        case 0: return tdm_launch_nhwc_to_nchw(w.h1, out_nchw, (int)B, 784, 32, (hipStream_t)stream);
+        case 1: return tdm_launch_nhwc_to_nchw(w.h2, out_nchw, (int)B, 196, 64, (hipStream_t)stream);
+        case 2: return tdm_launch_nhwc_to_nchw(w.h3, out_nchw, (int)B, 196, 64, (hipStream_t)stream);
+        case 3: return tdm_launch_nhwc_to_nchw(w.h4, out_nchw, (int)B, 784, 32, (hipStream_t)stream);
+    }
+    tdm_set_error("get_activation: which=%d", which);
+    return 1;
+}
+
+int tdm_unet_loss_grad_f32(const float* params, const float* x0, const float* noise, const int64_t* t,
+                           const float* sqrt_acp, const float* sqrt_1m_acp, float* x_noisy, float* eps, float* deps,
+                           float* loss_out, float* grads, float* ws, float* slabs, int64_t B, void* stream) {
+    TDM_CHECK_B(B);
+    TDM_REQUIRE(params && x0 && noise && t && x_noisy && eps && deps && loss_out && grads && ws && slabs,
+                "unet_loss_grad: NULL pointer");
+    const Ws w = carve(ws, B, 1);
+    hipStream_t st = (hipStream_t)stream;
+    TDM_TRY(tdm_q_sample_f32(x0, noise, t, sqrt_acp, sqrt_1m_acp, x_noisy, B, 784, stream));
+    TDM_TRY(unet_forward(params, x_noisy, t, eps, w, (int)B, 1, st));
+    TDM_TRY(tdm_mse_fwd_bwd_f32(eps, noise, loss_out, deps, w.scratch, B * 784, stream));
+    TDM_TRY(unet_backward(params, x_noisy, deps, grads, w, slabs, (int)B, st));
+    return 0;
+}
+
+int tdm_unet_p_sample_step_f32(const float* params, const float* x, const int64_t* t, const float* noise,
+                               const float* tab_recip, const float* tab_eps, const float* tab_sigma, int t_index,
+                               float* eps, float* x_out, float* ws, int64_t B, void* stream) {
+    TDM_CHECK_B(B);
+    TDM_REQUIRE(params && x && t && eps && x_out && ws, "p_sample_step: NULL pointer");
+    const Ws w = carve(ws, B, 0);
+    TDM_TRY(unet_forward(params, x, t, eps, w, (int)B, 0, (hipStream_t)stream));
+    return tdm_p_sample_update_f32(x, eps, t_index == 0 ? nullptr : noise, tab_recip, tab_eps, tab_sigma, t_index, x_out,
+                                   B * 784, stream);
+}
+
+// ---- per-layer entry points ----------------------------------------------------
+int tdm_conv_nhwc_f32(const float* in, const float* w, const float* bias, const float* res, const float* tb, float* out,
+                      float* aux_relu_out, int64_t B, int HW, int Cin, int Cout, int ksize, int flags, void* stream) {
+    TDM_CHECK_B(B);
+    TDM_REQUIRE(ksize == 3 || ksize == 1, "conv: ksize %d", ksize);
+    const bool dgrad = (flags & 2) != 0;
+    ConvArgs a{};
+    a.nsrc = 1;
+    const int taps = ksize * ksize;
+    if (!dgrad) a.src[0] = mk_src(in, Cin, 0, Cin, 0, taps, w, Cin, 0, Cout, tb);
+    else a.src[0] = mk_src(in, Cin, 0, Cin, 0, taps, w, Cout, 0, Cin, tb);
+    a.src[0].tb_stride = Cin;
+    a.bias = bias; a.res = res; a.out = out; a.aux = aux_relu_out; a.relu = flags & 1; a.B = (int)B;
+    return tdm_launch_conv(a, HW, Cout, dgrad, (hipStream_t)stream);
+}
+
+int tdm_conv_wgrad_nhwc_f32(const float* in, const float* tb, const float* dout, float* dw, float* db, float* slabs,
+                            int64_t B, int HW, int Cin, int Cout, int ksize, void* stream) {
+    TDM_CHECK_B(B);
+    TDM_REQUIRE(ksize == 3 || ksize == 1, "wgrad: ksize %d", ksize);
+    TDM_REQUIRE(Cin % 32 == 0, "wgrad: Cin %d must be a multiple of 32", Cin);
+    const int taps = ksize * ksize;
+    const int wlen = taps * Cin * Cout;
+    const long stride = wlen + Cout;
+    const int nslab = 64;
+    WgradArgs a{};
+    a.a = mk_src(in, Cin, 0, Cin, 0, taps, nullptr, Cin, 0, Cout, tb);
+    a.a.tb_stride = Cin;
+    a.g = dout; a.Cout = Cout; a.slab = slabs; a.slab_stride = stride; a.w_off = 0; a.b_off = wlen; a.B = (int)B;
+    a.ntiles = (int)(((long)B * HW * HW + 255) / 256);
+    a.nci = Cin / 32;
+    TDM_TRY(tdm_launch_wgrad(a, HW, nslab, (hipStream_t)stream));
+    ReduceArgs ra{};
+    ra.nsec = 1;
+    ra.sec[0].off = 0; ra.sec[0].len = wlen + Cout; ra.sec[0].nslab = nslab;
+    // dw and db are separate user buffers: reduce into the head of slab 0's neighbour-free scratch, then copy
+    float* tmp = slabs + (long)nslab * stride;
+    TDM_TRY(tdm_launch_reduce(slabs, stride, ra, tmp, (hipStream_t)stream));
+    hipError_t e = hipMemcpyAsync(dw, tmp, (size_t)wlen * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(db, tmp + wlen, (size_t)Cout * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        tdm_set_error("wgrad: copy failed: %s", hipGetErrorString(e));
+        return 100 + (int)e;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,419 @@
+"""MI355X-native DDPM on MNIST — same Python surface as the reference's
+src/mnist.py, with the per-timestep work done by hand-written HIP kernels
+(libtdm_hip.so) instead of ATen ops.
+
+• Training: python -m tinydiffusionmodels_amd.mnist --train   (or: python -m src.mnist --train)
+• Sampling: python -m tinydiffusionmodels_amd.mnist --sample --ckpt ckpt.pth
+
+Reference lines are cited per function.  There is no CPU fallback: tensors
+must live on a HIP device and the library must be built."""
+import argparse
+import gzip
+import math
+import os
+import struct
+import zlib
+from collections import OrderedDict
+from contextlib import contextmanager
+from pathlib import Path
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import unet_engine as E
+from .schedule import TIMESTEPS, cpu_tables, device_tables, linear_beta_schedule  # noqa: F401
+from .utils import (get_samples_dir, get_vertex_checkpoint_path, load_checkpoint, save_checkpoint,
+                    save_samples)
+
+# module-level schedule globals, as in src/mnist.py:27-33 (CPU tensors; the
+# kernels read per-device copies from schedule.device_tables()).
+timesteps = TIMESTEPS
+_T = cpu_tables()
+betas = _T["betas"]
+alphas = _T["alphas"]
+alphas_cumprod = _T["alphas_cumprod"]
+sqrt_alphas_cumprod = _T["sqrt_alphas_cumprod"]
+sqrt_one_minus_alphas_cumprod = _T["sqrt_one_minus_alphas_cumprod"]
+
+
+def q_sample(x_start: torch.Tensor, t: torch.Tensor, noise=None):
+    """Diffuse the data for a given timestep t (src/mnist.py:36-42): one fused
+    HIP kernel (table gather + a*x + s*n), bit-exact with the reference."""
+    if noise is None:
+        noise = torch.randn_like(x_start)
+    E._need_cuda(x_start, t, noise)
+    out = torch.empty_like(x_start, memory_format=torch.contiguous_format)
+    return E.q_sample_into(x_start.contiguous(), t.contiguous(), noise.contiguous(), out)
+
+
+class _UNetFunction(torch.autograd.Function):
+    """Autograd bridge so `loss.backward()` reaches the flat parameter, as the
+    reference's training loop does with its nn.Module (src/mnist.py:157-159)."""
+
+    @staticmethod
+    def forward(ctx, x, t, flat):
+        need_grad = bool(ctx.needs_input_grad[2])
+        ws = E.UNetWorkspace(x.shape[0], x.device, training=need_grad)
+        eps = E.unet_forward(flat.detach(), x, t, ws, save=need_grad)
+        if need_grad:
+            ctx.ws = ws
+            ctx.save_for_backward(x, flat)
+        return eps
+
+    @staticmethod
+    def backward(ctx, deps):
+        x, flat = ctx.saved_tensors
+        grads = E.unet_backward(flat.detach(), x, deps.contiguous(), ctx.ws)
+        ctx.ws = None
+        return None, None, grads
+
+
+class SimpleUNet(nn.Module):
+    """The reference's noise predictor (src/mnist.py:64-87): four residual
+    blocks (1→32 @28², 32→64 @14², 64→64 @14², 96→32 @28²), avg-pool down,
+    nearest up, channel-concat skip, 1×1 out conv.
+
+    All 181,473 parameters live in ONE flat fp32 nn.Parameter (`flat`, conv
+    weights HWIO) that the HIP kernels read directly; `state_dict()` /
+    `load_state_dict()` speak the reference's key names and OIHW layouts, so
+    checkpoints are interchangeable."""
+
+    def __init__(self):
+        super().__init__()
+        # Draw the initial weights exactly as the reference's constructor does
+        # (same module order => same RNG stream under torch.manual_seed).
+        sd = OrderedDict()
+        for name, ci, co in E.BLOCKS:
+            mods = [("conv1", nn.Conv2d(ci, co, 3, padding=1)), ("conv2", nn.Conv2d(co, co, 3, padding=1)),
+                    ("time_emb", nn.Linear(1, co))]
+            if ci != co:
+                mods.append(("skip", nn.Conv2d(ci, co, 1)))
+            for mname, m in mods:
+                sd[f"{name}.{mname}.weight"] = m.weight.detach()
+                sd[f"{name}.{mname}.bias"] = m.bias.detach()
+        out = nn.Conv2d(32, 1, kernel_size=1)
+        sd["out.weight"], sd["out.bias"] = out.weight.detach(), out.bias.detach()
+        self.flat = nn.Parameter(E.flat_from_state_dict(sd))
+        self._infer_ws = None
+
+    # ---- reference-compatible checkpoint ABI ---------------------------------
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        sd = E.state_dict_from_flat(self.flat)
+        out = destination if destination is not None else OrderedDict()
+        for k, v in sd.items():
+            out[prefix + k] = v
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        flat = E.flat_from_state_dict(state_dict, device=self.flat.device)
+        with torch.no_grad():
+            self.flat.copy_(flat)
+        return torch.nn.modules.module._IncompatibleKeys([], [])
+
+    # ---- forward -----------------------------------------------------------
+    def _workspace(self, B, device):
+        ws = self._infer_ws
+        if ws is None or ws.B != B or ws.ws.device != device:
+            ws = self._infer_ws = E.UNetWorkspace(B, device, training=False)
+        return ws
+
+    def forward(self, x, t):
+        """x (B,1,28,28) fp32 on the GPU, t (B,) int64 raw step indices (src/mnist.py:76-87)."""
+        E._need_cuda(x, t, self.flat)
+        if self.flat.requires_grad and torch.is_grad_enabled():
+            return _UNetFunction.apply(x, t, self.flat)
+        return E.unet_forward(self.flat.detach(), x, t, self._workspace(x.shape[0], x.device), save=False)
+
+
+@contextmanager
+def eval_mode(module: nn.Module):
+    """src/mnist.py:90-97."""
+    training = module.training
+    module.eval()
+    try:
+        yield
+    finally:
+        module.train(training)
+
+
+def p_sample(model, x, t, noise=None):
+    """Perform one reverse step (src/mnist.py:167-180).  Like the reference it
+    branches on t[0] (a device→host read); the sampling loops below use the
+    sync-free uniform-t path instead.  `noise` optionally supplies the z the
+    reference draws internally (teacher forcing)."""
+    E._need_cuda(x, t)
+    tabs = device_tables(x.device)
+    eps = model(x, t)
+    add_noise = int(t[0]) != 0
+    if add_noise and noise is None:
+        noise = torch.randn_like(x)
+    out = torch.empty_like(x)
+    B = x.shape[0]
+    _lib.check(_lib.lib().tdm_p_sample_update_pert_f32(
+        _lib.ptr(x.contiguous()), _lib.ptr(eps), _lib.ptr(noise.contiguous() if add_noise else None),
+        _lib.ptr(tabs["sqrt_recip_alphas"]), _lib.ptr(tabs["eps_coef"]), _lib.ptr(tabs["sigma"]),
+        _lib.ptr(t.contiguous()), 1 if add_noise else 0, _lib.ptr(out), B, x.numel() // B, _lib.stream()),
+        "p_sample_update")
+    return out
+
+
+@torch.no_grad()
+def reverse_diffusion(model: "SimpleUNet", x: torch.Tensor, noises=None, t_start: int = timesteps - 1,
+                      use_graph: bool = False) -> torch.Tensor:
+    """The reverse loop of src/mnist.py:190-193 (`for i in reversed(range(T))`)
+    without any host sync: the step index is a host integer, so the t[0]==0
+    test of the reference never touches the device.  noises: optional sequence
+    of z tensors (teacher forcing), noises[k] used at t = t_start-k."""
+    E._need_cuda(x)
+    n = x.shape[0]
+    dev = x.device
+    flat = model.flat.detach()
+    ws = model._workspace(n, dev)
+    eps = torch.empty_like(x)
+    cur, nxt = x.contiguous().clone(), torch.empty_like(x)
+    # one int64 (n,) tensor per step would be 1000 tiny fills; keep a single
+    # table of all step vectors resident instead (8 MB at n = 1000... sized n*T)
+    t_all = torch.arange(t_start, -1, -1, device=dev, dtype=torch.long).view(-1, 1).expand(-1, n).contiguous()
+    for k, i in enumerate(range(t_start, -1, -1)):
+        if i > 0:
+            z = noises[k].contiguous() if noises is not None else torch.randn_like(cur)
+        else:
+            z = None
+        E.p_sample_step(flat, ws, cur, t_all[k], i, z, eps, nxt)
+        cur, nxt = nxt, cur
+    return cur
+
+
+def to_image_range(x: torch.Tensor):
+    """(x.clamp(-1,1)+1)/2 and its uint8 quantisation (src/mnist.py:194 + save_image)."""
+    E._need_cuda(x)
+    x = x.contiguous()
+    x01 = torch.empty_like(x)
+    u8 = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.lib().tdm_to_unit_u8_f32(_lib.ptr(x), _lib.ptr(x01), _lib.ptr(u8), x.numel(), _lib.stream()),
+               "to_unit_u8")
+    return x01, u8
+
+
+# ---- PNG grid without torchvision ---------------------------
+def make_grid_u8(u8: torch.Tensor, nrow: int, padding: int = 2) -> torch.Tensor:
+    """uint8 (N,1,H,W) -> (3, Hgrid, Wgrid) grid laid out like
+    torchvision.utils.make_grid(nrow=nrow, padding=2, pad_value=0) (restated
+    from its documented behaviour; torchvision is not installed here)."""
+    u8 = u8.cpu()
+    n, _, h, w = u8.shape
+    xmaps = min(nrow, n)
+    ymaps = int(math.ceil(n / xmaps))
+    H, W = h + padding, w + padding
+    grid = torch.zeros(3, H * ymaps + padding, W * xmaps + padding, dtype=torch.uint8)
+    for k in range(n):
+        y, x = divmod(k, xmaps)
+        grid[:, y * H + padding:y * H + padding + h, x * W + padding:x * W + padding + w] = u8[k, 0]
+    return grid
+
+
+def encode_png(img: torch.Tensor) -> bytes:
+    """(3,H,W) or (H,W) uint8 -> PNG bytes (zlib + CRC, no external deps)."""
+    if img.dim() == 2:
+        img = img.unsqueeze(0)
+    c, h, w = img.shape
+    color_type = {1: 0, 3: 2}[c]
+    rows = img.permute(1, 2, 0).contiguous().numpy().reshape(h, w * c)
+    raw = b"".join(b"\x00" + rows[y].tobytes() for y in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, color_type, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def _save_grid(x: torch.Tensor, samples_dir, fname: str):
+    _, u8 = to_image_range(x)
+    png = encode_png(make_grid_u8(u8, nrow=int(math.sqrt(x.shape[0]))))
+    if isinstance(samples_dir, str):
+        sample_path = f"{samples_dir}/{fname}"
+    else:
+        sample_path = samples_dir / fname
+    save_samples(png, sample_path, mode="wb")
+    return sample_path
+
+
+def sample_images(model: nn.Module, device: str, epoch: int, n_samples: int = 25, outdir: str = "samples"):
+    """src/mnist.py:99-126."""
+    samples_dir = get_samples_dir(outdir)
+    with eval_mode(model), torch.no_grad():
+        x = torch.randn(n_samples, 1, 28, 28, device=device)
+        x = reverse_diffusion(model, x)
+        sample_path = _save_grid(x, samples_dir, f"epoch_{epoch:03d}.png")
+    print(f"[epoch {epoch}] saved samples to {sample_path}")
+
+
+# ---- data ----------------------------------------------------
+def load_mnist_idx(root: str = "./data") -> torch.Tensor:
+    """Read the MNIST training images from torchvision's on-disk layout
+    (root/MNIST/raw/train-images-idx3-ubyte[.gz]) and apply
+    ToTensor + Normalize((0.5,), (0.5,)) (src/mnist.py:139-145) -> (N,1,28,28) fp32 in [-1,1]."""
+    base = Path(root) / "MNIST" / "raw"
+    for name, opener in (("train-images-idx3-ubyte", open), ("train-images-idx3-ubyte.gz", gzip.open)):
+        p = base / name
+        if p.exists():
+            with opener(p, "rb") as f:
+                buf = f.read()
+            magic, n, h, w = struct.unpack(">IIII", buf[:16])
+            if magic != 2051 or (h, w) != (28, 28):
+                raise RuntimeError(f"{p}: not an MNIST image file")
+            img = torch.frombuffer(bytearray(buf[16:16 + n * h * w]), dtype=torch.uint8).view(n, 1, h, w)
+            return (img.float() / 255.0 - 0.5) / 0.5
+    raise RuntimeError(
+        f"MNIST not found under {base} and this machine has no network/torchvision to download it; "
+        "place the IDX files there or pass --synthetic")
+
+
+def synthetic_mnist(n: int, seed: int = 1234) -> torch.Tensor:
+    """Synthetic 28×28×1 batches in the Normalize(0.5,0.5) range."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(n, 1, 28, 28, generator=g) * 2 - 1
+
+
+class DDPMTrainer:
+    """The loop body of src/mnist.py:152-159 as one fused device-side step:
+    t ~ U{0..999}, noise ~ N(0,1), q_sample, UNet forward, MSE, backward,
+    (data-parallel: one RCCL all-reduce of the flat 726 KB gradient), AdamW
+    with torch defaults (lr passed, betas (0.9,0.999), eps 1e-8, wd 0.01)."""
+
+    def __init__(self, model: "SimpleUNet", batch_size: int, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.01):
+        import torch.distributed as dist
+        self.model = model
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.flat = model.flat.detach()
+        E._need_cuda(self.flat)
+        self.state = E.TrainState(self.flat, batch_size)
+        self.dist = dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.world = self.dist.get_world_size() if self.dist else 1
+        if self.dist:  # identical replicas: rank 0's weights everywhere
+            self.dist.broadcast(self.flat, src=0)
+
+    def step(self, x0: torch.Tensor, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
+        """One optimisation step on batch x0 (B,1,28,28) already on the device.
+        Returns the loss as a 1-element device tensor (no host sync)."""
+        st = self.state
+        if t is None:
+            t = torch.randint(0, timesteps, (x0.shape[0],), device=x0.device)
+        if noise is None:
+            noise = torch.randn_like(x0)
+        loss = E.loss_and_grad(self.flat, st, x0, noise, t)
+        if self.dist:
+            self.dist.all_reduce(st.grads)  # SUM over ranks; 1/world folded into AdamW
+        st.step += 1
+        E.adamw_step(self.flat, st.grads, st.m, st.v, st.step, self.lr, self.betas, self.eps, self.weight_decay,
+                     grad_scale=1.0 / self.world)
+        return loss
+
+
+def train(model: nn.Module,
+          device: str,
+          epochs: int = 5,
+          batch_size: int = 128,
+          lr: float = 1e-3,
+          ckpt_path: str = "ckpt.pth",
+          sample_every_epoch: bool = True,
+          samples_per_epoch: int = 25,
+          data: Optional[torch.Tensor] = None,
+          log_every: int = 50):
+    """src/mnist.py:128-165.  `data`: optional (N,1,28,28) fp32 tensor in [-1,1]
+    (default: MNIST IDX files under ./data).  The last batch of an epoch may be
+    partial, as with the reference's DataLoader (no drop_last)."""
+    import torch.distributed as dist
+    ckpt_path = get_vertex_checkpoint_path("image-model.pth") if "AIP_MODEL_DIR" in os.environ else ckpt_path
+    if data is None:
+        data = load_mnist_idx("./data")
+    rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+    data = data.to(device)
+    n = data.shape[0]
+    trainers = {}
+    opt_state = None
+    for epoch in range(epochs):
+        g = torch.Generator().manual_seed(epoch)          # same shuffle on every rank
+        perm = torch.randperm(n, generator=g).to(device)
+        nb = (n + batch_size * world - 1) // (batch_size * world)
+        last = None
+        for it in range(nb):
+            idx = perm[(it * world + rank) * batch_size:(it * world + rank + 1) * batch_size]
+            if idx.numel() == 0:
+                idx = perm[:1]
+            x = data[idx]
+            B = x.shape[0]
+            if B not in trainers:
+                tr = trainers[B] = DDPMTrainer(model, B, lr=lr)
+                if opt_state is not None:               # partial last batch shares the optimiser state
+                    tr.state.m, tr.state.v = opt_state.m, opt_state.v
+                else:
+                    opt_state = tr.state
+            tr = trainers[B]
+            tr.state.step = opt_state.step
+            last = tr.step(x)
+            opt_state.step = tr.state.step
+            if log_every and (it + 1) % log_every == 0 and rank == 0:
+                print(f"Epoch {epoch + 1}/{epochs} it {it + 1}/{nb} loss={last.item():.4f}", flush=True)
+        if rank == 0 and last is not None:
+            print(f"Epoch {epoch + 1}/{epochs} done, loss={last.item():.4f}", flush=True)
+        if sample_every_epoch and rank == 0:
+            sample_images(model, device, epoch + 1, samples_per_epoch)
+    if rank == 0:
+        save_checkpoint(model.state_dict(), ckpt_path)
+
+
+def sample(model: nn.Module, device: str, n_samples=25, ckpt_path="ckpt.pth", outdir="samples"):
+    """src/mnist.py:183-212."""
+    model.load_state_dict(load_checkpoint(ckpt_path, device))
+    model.eval()
+    samples_dir = get_samples_dir(outdir)
+    with torch.no_grad():
+        x = torch.randn(n_samples, 1, 28, 28, device=device)
+        x = reverse_diffusion(model, x)
+        sample_path = _save_grid(x, samples_dir, "samples.png")
+        print(f"Saved samples to {sample_path}")
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--train", action="store_true", help="Train the model")
+    parser.add_argument("--sample", action="store_true", help="Generate samples")
+    parser.add_argument("--epochs", type=int, default=3)
+    parser.add_argument("--batch_size", type=int, default=128)
+    parser.add_argument("--ckpt", type=str,
+                        default=get_vertex_checkpoint_path("image-model.pth") if "AIP_MODEL_DIR" in os.environ else "ckpt.pth")
+    # build-only additions (no reference flag renamed)
+    parser.add_argument("--synthetic", type=int, default=0, metavar="N",
+                        help="train on N synthetic 28x28 images instead of ./data MNIST")
+    parser.add_argument("--seed", type=int, default=None)
+    args = parser.parse_args(argv)
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("no HIP device visible: this build has no CPU path (the reference's CPU path is src/mnist.py)")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+    device = f"cuda:{local_rank}"
+    if args.seed is not None:
+        torch.manual_seed(args.seed)
+    E.check_layout_against_library()
+    model = SimpleUNet().to(device)
+
+    if args.train:
+        data = synthetic_mnist(args.synthetic) if args.synthetic else None
+        train(model, device, epochs=args.epochs, batch_size=args.batch_size, ckpt_path=args.ckpt, data=data)
+    if args.sample:
+        sample(model, device, ckpt_path=args.ckpt)
+    if not args.train and not args.sample:
+        print("Nothing to do. Pass --train or --sample.")
+
+
+if __name__ == "__main__":
+    main()
