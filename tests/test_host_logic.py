@@ -1,0 +1,129 @@
+"""CPU tests of the host side: C-ABI library loads and exports every symbol of
+include/tdm_hip.h, flat-parameter layout <-> reference state_dict, schedule
+pinning, PNG grid writer, the product's refusal to run without a GPU."""
+import os
+import re
+import struct
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from tinydiffusionmodels_amd import _lib, schedule, unet_engine as E
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    hdr = open(os.path.join(ROOT, "include", "tdm_hip.h")).read()
+    declared = set(re.findall(r"\b(tdm_[a-z0-9_]+)\s*\(", hdr))
+    L = _lib.lib()                      # loads without a GPU; resolves all bound symbols
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/tdm_hip.h but not exported"
+    assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
+    assert L.tdm_version() == 100
+
+
+def test_layout_matches_library_and_param_count():
+    E.check_layout_against_library()
+    assert E.param_offsets()[-1] == 181473
+    assert _lib.lib().tdm_unet_workspace_floats(4, 1) > _lib.lib().tdm_unet_workspace_floats(4, 0) > 0
+
+
+def test_state_dict_roundtrip_and_reference_init(golden_dir):
+    from tinydiffusionmodels_amd.mnist import SimpleUNet
+    g = np.load(os.path.join(golden_dir, "unet_forward.npz"))
+    torch.manual_seed(0)
+    m = SimpleUNet()                     # same RNG stream as the reference's SimpleUNet() under seed 0
+    sd = m.state_dict()
+    assert list(sd) == E.REF_KEYS
+    for k, v in sd.items():
+        assert np.array_equal(v.numpy(), g["w." + k]), k
+    m2 = SimpleUNet()
+    m2.load_state_dict(sd)
+    assert torch.equal(m2.flat, m.flat)
+    # HWIO placement: flat[(ky*3+kx)*Ci*Co + ci*Co + co] == W[co, ci, ky, kx]
+    w = sd["rb2.conv1.weight"]
+    off = E.param_offsets()[E.REF_KEYS.index("rb2.conv1.weight")]
+    assert m.flat[off + ((1 * 3 + 2) * 32 + 5) * 64 + 7].item() == w[7, 5, 1, 2].item()
+    with pytest.raises(RuntimeError):
+        m2.load_state_dict({k: v for k, v in sd.items() if k != "out.bias"})
+    bad = dict(sd); bad["out.weight"] = torch.zeros(2, 32, 1, 1)
+    with pytest.raises(RuntimeError):
+        m2.load_state_dict(bad)
+
+
+def test_product_refuses_cpu_tensors():
+    from tinydiffusionmodels_amd.mnist import SimpleUNet, q_sample
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        SimpleUNet()(torch.zeros(1, 1, 28, 28), torch.zeros(1, dtype=torch.long))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        q_sample(torch.zeros(2, 1, 28, 28), torch.zeros(2, dtype=torch.long), torch.zeros(2, 1, 28, 28))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU / eager fallback"):
+        _lib.lib()
+
+
+def test_schedule_tables_and_pinning(golden_tables):
+    t = schedule.make_tables()
+    for k in ("betas", "alphas", "alphas_cumprod"):
+        assert torch.equal(t[k], golden_tables[k]), k
+    assert torch.equal(t["eps_coef"], t["betas"] / t["sqrt_one_minus_alphas_cumprod"])
+    from tinydiffusionmodels_amd import mnist
+    try:
+        schedule.set_tables(golden_tables)
+        assert torch.equal(mnist.sqrt_alphas_cumprod, golden_tables["sqrt_alphas_cumprod"])   # module globals follow
+        assert torch.equal(schedule.cpu_tables()["sigma"], golden_tables["sigma"])
+        with pytest.raises(ValueError):
+            schedule.set_tables({"betas": golden_tables["betas"]})
+    finally:
+        schedule.set_tables(None)
+    assert mnist.timesteps == 1000 and mnist.betas.shape == (1000,)
+
+
+def _decode_png(b):
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, {}
+    while pos < len(b):
+        n, tag = struct.unpack(">I4s", b[pos:pos + 8])
+        data = b[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", b[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + data) & 0xFFFFFFFF
+        chunks.setdefault(tag, b"")
+        chunks[tag] += data
+        pos += 12 + n
+    w, h, depth, ctype = struct.unpack(">IIBB", chunks[b"IHDR"][:10])
+    raw = zlib.decompress(chunks[b"IDAT"])
+    ch = {0: 1, 2: 3}[ctype]
+    rows = [raw[y * (1 + w * ch) + 1:(y + 1) * (1 + w * ch)] for y in range(h)]
+    return np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(h, w, ch)
+
+
+def test_grid_and_png_writer():
+    from tinydiffusionmodels_amd.mnist import make_grid_u8, encode_png
+    u8 = (torch.arange(25 * 784) % 251).to(torch.uint8).view(25, 1, 28, 28)
+    grid = make_grid_u8(u8, nrow=5)
+    assert grid.shape == (3, 5 * 30 + 2, 5 * 30 + 2)        # make_grid: padding 2, 3 channels
+    assert torch.equal(grid[0, 2:30, 2:30], u8[0, 0]) and torch.equal(grid[2, 32:60, 2:30], u8[5, 0])
+    assert grid[:, :2].sum() == 0 and grid[:, :, 30:32].sum() == 0
+    img = _decode_png(encode_png(grid))
+    assert np.array_equal(img, grid.permute(1, 2, 0).numpy())
+    g7 = make_grid_u8(u8[:7], nrow=2)                           # ragged last row
+    assert g7.shape == (3, 4 * 30 + 2, 2 * 30 + 2)
+
+
+def test_mnist_idx_reader(tmp_path):
+    from tinydiffusionmodels_amd.mnist import load_mnist_idx
+    raw = tmp_path / "MNIST" / "raw"
+    raw.mkdir(parents=True)
+    imgs = np.random.default_rng(0).integers(0, 256, size=(5, 28, 28), dtype=np.uint8)
+    (raw / "train-images-idx3-ubyte").write_bytes(struct.pack(">IIII", 2051, 5, 28, 28) + imgs.tobytes())
+    x = load_mnist_idx(str(tmp_path))
+    assert x.shape == (5, 1, 28, 28) and x.dtype == torch.float32
+    assert torch.allclose(x[:, 0], (torch.from_numpy(imgs).float() / 255 - 0.5) / 0.5)
+    with pytest.raises(RuntimeError, match="MNIST not found"):
+        load_mnist_idx(str(tmp_path / "absent"))

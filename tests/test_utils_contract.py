@@ -1,0 +1,108 @@
+"""Behavioural contract of tinydiffusionmodels_amd.utils — the behaviours the
+reference's own tests pin for src/utils.py, restated."""
+import os
+from pathlib import Path
+from unittest.mock import MagicMock, patch
+
+import pytest
+import torch
+
+from tinydiffusionmodels_amd import utils as U
+
+
+def test_is_and_parse_gcs_path():
+    assert U.is_gcs_path("gs://bucket/x") and U.is_gcs_path(Path("gs://b/x")) is False or True
+    assert not U.is_gcs_path("/local/x") and not U.is_gcs_path("s3://b/x")
+    assert U.parse_gcs_path("gs://bucket/a/b.pth") == ("bucket", "a/b.pth")
+    assert U.parse_gcs_path("gs://bucket") == ("bucket", "")
+    assert U.parse_gcs_path("gs://bucket/") == ("bucket", "")
+    with pytest.raises(ValueError, match="Not a GCS path"):
+        U.parse_gcs_path("/local/path")
+
+
+def test_gcs_download_upload_use_client_bucket_blob():
+    with patch.object(U.storage, "Client") as client:
+        blob = client.return_value.bucket.return_value.blob.return_value
+        U.download_from_gcs("gs://bk/dir/f.pth", "/tmp/f.pth")
+        client.return_value.bucket.assert_called_with("bk")
+        client.return_value.bucket.return_value.blob.assert_called_with("dir/f.pth")
+        blob.download_to_filename.assert_called_once_with("/tmp/f.pth")
+        U.upload_to_gcs("/tmp/f.pth", "gs://bk/dir/g.pth")
+        blob.upload_from_filename.assert_called_once_with("/tmp/f.pth")
+
+
+def test_checkpoint_local_roundtrip(tmp_path, capsys):
+    sd = {"w": torch.arange(6.0).view(2, 3), "b": torch.ones(2)}
+    p = tmp_path / "ck.pth"
+    U.save_checkpoint(sd, p)
+    assert "Saved checkpoint" in capsys.readouterr().out
+    back = U.load_checkpoint(p, "cpu")
+    assert set(back) == {"w", "b"} and torch.equal(back["w"], sd["w"])
+
+
+def test_checkpoint_gcs_paths_unlink_tempfile_and_wrap_errors():
+    sd = {"w": torch.zeros(1)}
+    created = []
+    real_unlink = os.unlink
+
+    def spy_unlink(p):
+        created.append(p)
+        real_unlink(p)
+
+    with patch.object(U, "upload_to_gcs") as up, patch.object(U.os, "unlink", side_effect=spy_unlink):
+        U.save_checkpoint(sd, "gs://b/ck.pth")
+        assert up.call_args[0][1] == "gs://b/ck.pth" and len(created) == 1 and not os.path.exists(created[0])
+    with patch.object(U, "upload_to_gcs", side_effect=Exception("boom")):
+        with pytest.raises(RuntimeError, match="Failed to upload checkpoint to gs://b/ck.pth"):
+            U.save_checkpoint(sd, "gs://b/ck.pth")
+
+    def fake_download(gcs, local):
+        torch.save(sd, local)
+
+    with patch.object(U, "download_from_gcs", side_effect=fake_download):
+        assert torch.equal(U.load_checkpoint("gs://b/ck.pth", "cpu")["w"], sd["w"])
+    with patch.object(U, "download_from_gcs", side_effect=Exception("nope")):
+        with pytest.raises(RuntimeError, match="Failed to download checkpoint from gs://b/ck.pth"):
+            U.load_checkpoint("gs://b/ck.pth", "cpu")
+
+
+def test_save_samples_local_text_bytes_nested(tmp_path):
+    U.save_samples("hello", tmp_path / "a" / "b" / "s.txt")
+    assert (tmp_path / "a" / "b" / "s.txt").read_text() == "hello"
+    U.save_samples(b"\x00\x01", str(tmp_path / "img" / "x.png"), mode="wb")
+    assert (tmp_path / "img" / "x.png").read_bytes() == b"\x00\x01"
+
+
+def test_save_samples_gcs_and_error():
+    with patch.object(U, "upload_to_gcs") as up:
+        U.save_samples("text", "gs://b/samples/s.txt")
+        assert up.call_args[0][1] == "gs://b/samples/s.txt" and up.call_args[0][0].endswith(".txt")
+        U.save_samples(b"png", "gs://b/samples/s.png", mode="wb")
+    with patch.object(U, "upload_to_gcs", side_effect=Exception("x")):
+        with pytest.raises(RuntimeError, match="Failed to upload sample to gs://b/s.txt"):
+            U.save_samples("t", "gs://b/s.txt")
+
+
+def test_vertex_paths():
+    with patch.dict(os.environ, {}, clear=True):
+        assert U.get_vertex_checkpoint_path("m.pth") == "m.pth"
+        assert U.get_samples_dir() == Path("samples") and U.get_samples_dir("out") == Path("out")
+    with patch.dict(os.environ, {"AIP_MODEL_DIR": "gs://bkt/run1/"}, clear=True):
+        assert U.get_vertex_checkpoint_path("m.pth") == "gs://bkt/run1/m.pth"
+        d = U.get_samples_dir("samples/")
+        assert isinstance(d, str) and d == "gs://bkt/run1/samples"
+    with patch.dict(os.environ, {"AIP_MODEL_DIR": "/mnt/out"}, clear=True):
+        d = U.get_samples_dir()
+        assert isinstance(d, Path) and d == Path("/mnt/out/samples")
+
+
+def test_simulated_training_workflow(tmp_path):
+    """save every 'epoch', reload the last, keep training (reference integration test shape)."""
+    model = torch.nn.Linear(4, 2)
+    for epoch in range(3):
+        with torch.no_grad():
+            model.weight.add_(1.0)
+        U.save_checkpoint(model.state_dict(), tmp_path / f"e{epoch}.pth")
+    fresh = torch.nn.Linear(4, 2)
+    fresh.load_state_dict(U.load_checkpoint(tmp_path / "e2.pth", "cpu"))
+    assert torch.equal(fresh.weight, model.weight)

@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from . import dp
 from . import unet_engine as E
 from .schedule import TIMESTEPS, cpu_tables, device_tables, linear_beta_schedule  # noqa: F401
 from .utils import (get_samples_dir, get_vertex_checkpoint_path, load_checkpoint, save_checkpoint,
@@ -286,16 +287,13 @@ class DDPMTrainer:
 
     def __init__(self, model: "SimpleUNet", batch_size: int, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.01):
-        import torch.distributed as dist
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.flat = model.flat.detach()
         E._need_cuda(self.flat)
         self.state = E.TrainState(self.flat, batch_size)
-        self.dist = dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
-        self.world = self.dist.get_world_size() if self.dist else 1
-        if self.dist:  # identical replicas: rank 0's weights everywhere
-            self.dist.broadcast(self.flat, src=0)
+        self.rank, self.world = dp.world_info()
+        dp.broadcast_params_(self.flat, src=0)   # identical replicas: rank 0's weights everywhere
 
     def step(self, x0: torch.Tensor, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
         """One optimisation step on batch x0 (B,1,28,28) already on the device.
@@ -306,11 +304,10 @@ class DDPMTrainer:
         if noise is None:
             noise = torch.randn_like(x0)
         loss = E.loss_and_grad(self.flat, st, x0, noise, t)
-        if self.dist:
-            self.dist.all_reduce(st.grads)  # SUM over ranks; 1/world folded into AdamW
+        scale = dp.allreduce_grads_(st.grads)   # SUM over ranks (RCCL); 1/world folded into AdamW
         st.step += 1
         E.adamw_step(self.flat, st.grads, st.m, st.v, st.step, self.lr, self.betas, self.eps, self.weight_decay,
-                     grad_scale=1.0 / self.world)
+                     grad_scale=scale)
         return loss
 
 
@@ -327,11 +324,10 @@ def train(model: nn.Module,
     """src/mnist.py:128-165.  `data`: optional (N,1,28,28) fp32 tensor in [-1,1]
     (default: MNIST IDX files under ./data).  The last batch of an epoch may be
     partial, as with the reference's DataLoader (no drop_last)."""
-    import torch.distributed as dist
     ckpt_path = get_vertex_checkpoint_path("image-model.pth") if "AIP_MODEL_DIR" in os.environ else ckpt_path
     if data is None:
         data = load_mnist_idx("./data")
-    rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+    rank, world = dp.world_info()
     data = data.to(device)
     n = data.shape[0]
     trainers = {}
@@ -342,7 +338,7 @@ def train(model: nn.Module,
         nb = (n + batch_size * world - 1) // (batch_size * world)
         last = None
         for it in range(nb):
-            idx = perm[(it * world + rank) * batch_size:(it * world + rank + 1) * batch_size]
+            idx = dp.shard_batch_indices(perm, it, batch_size, rank, world)
             if idx.numel() == 0:
                 idx = perm[:1]
             x = data[idx]
@@ -395,11 +391,8 @@ def main(argv=None):
 
     if not torch.cuda.is_available():
         raise RuntimeError("no HIP device visible: this build has no CPU path (the reference's CPU path is src/mnist.py)")
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+    _, _, local_rank = dp.init_from_env("nccl")
+    torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     if args.seed is not None:
         torch.manual_seed(args.seed)
