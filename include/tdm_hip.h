@@ -128,6 +128,41 @@ int tdm_conv_nhwc_f32(const float* in, const float* w, const float* bias, const 
 int tdm_conv_wgrad_nhwc_f32(const float* in, const float* tb, const float* dout, float* dw, float* db,
                             float* slabs, int64_t B, int HW, int Cin, int Cout, int ksize, void* stream);
 
+/* ---- a8-a10: TinyTransformer embedding-space denoiser (src/shakespeare.py:105-120) ----
+ * x (B,L,D) fp32, t (B,) int64; post-LN encoder layers (packed in_proj, H heads,
+ * ReLU FFN of width ffn, LayerNorm eps 1e-5), no mask, no positional encoding,
+ * eval / dropout 0.  Parameters: ONE flat fp32 buffer in the reference's
+ * state_dict order and native layouts (tdm_tt_param_offsets: 12 tensors per
+ * layer, then time_emb.weight, time_emb.bias; last entry = total).          */
+int64_t tdm_tt_param_count(int D, int depth, int ffn);
+int tdm_tt_param_offsets(int D, int depth, int ffn, int64_t* offs);
+int64_t tdm_tt_workspace_floats(int64_t B, int L, int D, int H, int depth, int ffn, int training);
+int64_t tdm_tt_slab_floats(int D, int depth, int ffn);
+/* out = TinyTransformer(x, t)  (src/shakespeare.py:115-120) */
+int tdm_tt_fwd_f32(const float* params, const float* x, const int64_t* t, float* out, float* ws,
+                   int64_t B, int L, int D, int H, int depth, int ffn, int save, void* stream);
+/* parameter gradients given d(loss)/d(out); needs ws of a save != 0 forward;
+ * dx (B,L,D), may be NULL: d(loss)/d(x) (needed by learned embeddings,
+ * src/shakespeare.py:225-226)                                                 */
+int tdm_tt_bwd_f32(const float* params, const float* dout, float* grads, float* dx, float* ws, float* slabs,
+                   int64_t B, int L, int D, int H, int depth, int ffn, void* stream);
+/* denoiser part of the text train step (src/shakespeare.py:230-236): q_sample ->
+ * forward -> MSE -> backward; flat gradient in grads, loss in loss_out[0]     */
+int tdm_tt_loss_grad_f32(const float* params, const float* x0, const float* noise, const int64_t* t,
+                         const float* sqrt_acp, const float* sqrt_1m_acp, float* x_noisy, float* pred,
+                         float* dpred, float* loss_out, float* grads, float* ws, float* slabs,
+                         int64_t B, int L, int D, int H, int depth, int ffn, void* stream);
+/* one reverse step of src/shakespeare.py:382-385 / :343-352 for a uniform t_index */
+int tdm_tt_p_sample_step_f32(const float* params, const float* x, const int64_t* t, const float* noise,
+                             const float* tab_recip, const float* tab_eps, const float* tab_sigma,
+                             int t_index, float* eps, float* x_out, float* ws,
+                             int64_t B, int L, int D, int H, int depth, int ffn, void* stream);
+/* general strided fp32-MFMA GEMM (tests / profiling):
+ * C[i][j] = sum_k A[i*a_rs + k*a_cs] * B[k*b_rs + j*b_cs] (+bias[j]) (+res[i][j]) (relu)      */
+int tdm_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs,
+                 float* C, int64_t c_rs, const float* bias, const float* res, int M, int N, int K,
+                 int relu, int splitk, int64_t c_split_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

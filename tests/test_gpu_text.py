@@ -1,0 +1,194 @@
+"""GPU parity tests of the HIP text-diffusion denoiser path (TinyTransformer,
+src/shakespeare.py:105-120, :230-236, :343-352) through the C ABI, against the
+golden vectors captured from the reference and the CPU oracle.
+Tolerance: north-star 1e-3 rel; the fp32-MFMA path is asserted at 3e-5."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ddpm_oracle as O
+
+TOL = 3e-5
+
+
+def _load(golden_dir, name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, name)).items()}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def pinned_tables(golden_tables):
+    from tinydiffusionmodels_amd import schedule
+    schedule.set_tables(golden_tables)
+    yield golden_tables
+    schedule.set_tables(None)
+
+
+def _model(dim, dev):
+    from tinydiffusionmodels_amd.shakespeare import TinyTransformer
+    from tinydiffusionmodels_amd import transformer_engine as TE
+    TE.check_layout_against_library(dim)
+    m = TinyTransformer(dim, dropout=0.0)
+    m.load_state_dict(O.transformer_init_params(dim, seed=7))
+    return m.to(dev)
+
+
+GEMM_CASES = [  # (M, N, K, mode)
+    (256, 768, 256, "nt"), (48, 96, 32, "nt"), (300, 130, 64, "nt"), (256, 256, 2048, "nt"),
+    (256, 2048, 256, "nn"), (77, 40, 100, "nn"),
+    (768, 256, 1000, "tn"), (96, 32, 48, "tn"), (2048, 256, 4096, "tn"),
+]
+
+
+@pytest.mark.parametrize("M,N,K,mode", GEMM_CASES)
+def test_gemm(dev, M, N, K, mode):
+    from tinydiffusionmodels_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    if mode == "nt":      # C = A[M][K] @ B[N][K]^T + bias, relu, + res
+        A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+        bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+        ref = F.relu(A.double() @ B.double().T + bias.double() + res.double()).float()
+        C = torch.empty(M, N, device=dev)
+        Ad, Bd, bd, rd = A.to(dev), B.to(dev), bias.to(dev), res.to(dev)   # keep alive until the kernel ran
+        _lib.check(L.tdm_gemm_f32(_lib.ptr(Ad), K, 1, _lib.ptr(Bd), 1, K, _lib.ptr(C), N, _lib.ptr(bd),
+                                  _lib.ptr(rd), M, N, K, 1, 1, 0, _lib.stream()))
+        out = C.cpu()
+    elif mode == "nn":    # C = A[M][K] @ B[K][N]
+        A, B = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
+        ref = (A.double() @ B.double()).float()
+        C = torch.empty(M, N, device=dev)
+        Ad, Bd = A.to(dev), B.to(dev)
+        _lib.check(L.tdm_gemm_f32(_lib.ptr(Ad), K, 1, _lib.ptr(Bd), N, 1, _lib.ptr(C), N, None, None, M, N, K, 0, 1, 0,
+                                  _lib.stream()))
+        out = C.cpu()
+    else:                 # tn, split-K: C[M][N] = A[K][M]^T @ B[K][N] summed over 8 slabs
+        A, B = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+        ref = (A.double().T @ B.double()).float()
+        C = torch.empty(8, M, N, device=dev)
+        Ad, Bd = A.to(dev), B.to(dev)
+        _lib.check(L.tdm_gemm_f32(_lib.ptr(Ad), 1, M, _lib.ptr(Bd), N, 1, _lib.ptr(C), N, None, None, M, N, K, 0, 8,
+                                  M * N, _lib.stream()))
+        out = C.sum(0).cpu()
+    torch.cuda.synchronize()
+    assert O.rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("tag,dim", [("d32", 32), ("d256", 256)])
+def test_transformer_forward_and_grads_golden(dev, golden_dir, golden_tables, tag, dim):
+    from tinydiffusionmodels_amd import transformer_engine as TE
+    from tinydiffusionmodels_amd.shakespeare import q_sample
+    g = _load(golden_dir, "text_denoiser.npz")
+    m = _model(dim, dev)
+    x0, t, noise = g[f"{tag}.x0"].to(dev), g[f"{tag}.t"].to(dev), g[f"{tag}.noise"].to(dev)
+    xq = q_sample(x0, t, noise)
+    assert torch.equal(xq.cpu(), g[f"{tag}.x_noisy"])                      # bit-exact, (B,1,1) broadcast
+    m.eval()
+    with torch.no_grad():
+        pred = m(xq, t)
+    assert O.rel_err(pred.cpu(), g[f"{tag}.pred"]) < TOL
+    # fused loss + gradients
+    st = TE.TTTrainState(m.cfg, m.flat.detach(), x0.shape[0], x0.shape[1])
+    loss = TE.tt_loss_and_grad(m.flat.detach(), st, x0, noise, t)
+    assert abs(loss.item() - g[f"{tag}.loss"].item()) < 1e-5 * abs(g[f"{tag}.loss"].item())
+    got = TE.state_dict_from_flat(st.grads, dim)
+    n_checked = 0
+    for k, v in g.items():
+        if k.startswith(f"{tag}.grad.") or k.startswith(f"{tag}.gradall."):
+            name = k.split(".", 2)[2]
+            assert O.rel_err(got[name].cpu(), v) < 1e-4, name
+            n_checked += 1
+    assert n_checked >= 6
+
+
+@pytest.mark.parametrize("B,L,dim", [(2, 37, 64), (1, 130, 128), (3, 128, 256)])
+def test_transformer_oracle_shapes_and_autograd_bridge(dev, golden_tables, B, L, dim):
+    """Ragged sequence lengths (not multiples of 128), other widths, and the
+    nn.Module surface: loss.backward() fills model.flat.grad AND x.grad."""
+    from tinydiffusionmodels_amd import transformer_engine as TE
+    m = _model(dim, dev)
+    p = O.transformer_init_params(dim, seed=7)
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    x = torch.randn(B, L, dim, generator=g) * 0.7
+    t = torch.randint(0, 1000, (B,), generator=g)
+    target = torch.randn(B, L, dim, generator=g)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xr = x.clone().requires_grad_(True)
+    F.mse_loss(O.transformer_forward(leaf, xr, t), target).backward()
+    m.train()
+    m.zero_grad()
+    xd = x.to(dev).requires_grad_(True)
+    loss = F.mse_loss(m(xd, t.to(dev)), target.to(dev))
+    loss.backward()
+    got = TE.state_dict_from_flat(m.flat.grad, dim)
+    for k, v in leaf.items():
+        assert O.rel_err(got[k].cpu(), v.grad) < 3e-4, k      # fp32 vs fp32 (oracle); north-star bound 1e-3
+    assert O.rel_err(xd.grad.cpu(), xr.grad) < 3e-4
+
+
+def test_text_p_sample_and_chain(dev, golden_dir, golden_tables):
+    from tinydiffusionmodels_amd.shakespeare import p_sample, reverse_diffusion
+    g = _load(golden_dir, "text_denoiser.npz")
+    for tag, dim, tts in (("d256", 256, (999,)), ("d32", 32, (999, 0))):
+        m = _model(dim, dev).eval()
+        with torch.no_grad():
+            for tt in tts:
+                x = g[f"{tag}.ps{tt}.x"].to(dev)
+                t = torch.full((x.shape[0],), tt, dtype=torch.long, device=dev)
+                y = p_sample(m, x, t, noise=g[f"{tag}.ps{tt}.z"].to(dev))
+                assert O.rel_err(y.cpu(), g[f"{tag}.ps{tt}.y"]) < TOL, (tag, tt)
+    # short chain vs oracle with shared noise
+    dim, B, L = 32, 2, 16
+    m = _model(dim, dev).eval()
+    p = O.transformer_init_params(dim, seed=7)
+    gg = torch.Generator().manual_seed(9)
+    x = torch.randn(B, L, dim, generator=gg)
+    zs = [torch.randn(B, L, dim, generator=gg) for _ in range(6)]
+    ref = x
+    for k, i in enumerate(range(5, -1, -1)):
+        ref = O.text_p_sample(p, ref, torch.full((B,), i, dtype=torch.long), zs[k], golden_tables)
+    out = reverse_diffusion(m, x.to(dev), noises=[z.to(dev) for z in zs], t_start=5)
+    assert O.rel_err(out.cpu(), ref) < 1e-4
+
+
+def test_denoiser_trainer_step_matches_oracle_adamw(dev, golden_tables):
+    from tinydiffusionmodels_amd import transformer_engine as TE
+    from tinydiffusionmodels_amd.shakespeare import DenoiserTrainer
+    dim, B, L = 64, 4, 24
+    m = _model(dim, dev)
+    m.train()
+    p = O.transformer_init_params(dim, seed=7)
+    g = torch.Generator().manual_seed(4)
+    x0 = torch.randn(B, L, dim, generator=g) * 0.02
+    t = torch.randint(0, 1000, (B,), generator=g)
+    noise = torch.randn(B, L, dim, generator=g)
+    _, grads = O.transformer_loss_and_grads(p, x0, t, noise, golden_tables)
+    tr = DenoiserTrainer(m, B, L, lr=1e-4, weight_decay=1e-4)
+    tr.step(x0.to(dev), t=t.to(dev), noise=noise.to(dev))
+    sd = m.state_dict()
+    lr = 1e-4
+    for k in p:
+        ref, _, _ = O.adamw_step(p[k], grads[k], torch.zeros_like(p[k]), torch.zeros_like(p[k]), 1, lr=lr,
+                                 weight_decay=1e-4)
+        assert (sd[k].cpu() - ref).abs().max().item() < 0.05 * lr, k
+
+
+def test_train_mode_dropout_refused(dev):
+    from tinydiffusionmodels_amd.shakespeare import TinyTransformer
+    m = TinyTransformer(32).to(dev)          # default dropout 0.1
+    m.train()
+    with pytest.raises(RuntimeError, match="dropout"):
+        m(torch.zeros(1, 4, 32, device=dev), torch.zeros(1, dtype=torch.long, device=dev))
+    m.eval()
+    with torch.no_grad():
+        assert m(torch.zeros(1, 4, 32, device=dev), torch.zeros(1, dtype=torch.long, device=dev)).shape == (1, 4, 32)

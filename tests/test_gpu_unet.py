@@ -280,8 +280,9 @@ def test_p_sample_golden(dev, model, golden_dir):
             # update arithmetic alone, teacher-forced with the reference's eps: bit exact
             out = torch.empty_like(x)
             z = g[f"t{tt}.z"].to(dev) if tt > 0 else None
+            eps_ref = g[f"t{tt}.eps"].to(dev)
             _lib.check(_lib.lib().tdm_p_sample_update_f32(
-                _lib.ptr(x), _lib.ptr(g[f"t{tt}.eps"].to(dev)), _lib.ptr(z), _lib.ptr(tabs["sqrt_recip_alphas"]),
+                _lib.ptr(x), _lib.ptr(eps_ref), _lib.ptr(z), _lib.ptr(tabs["sqrt_recip_alphas"]),
                 _lib.ptr(tabs["eps_coef"]), _lib.ptr(tabs["sigma"]), tt, _lib.ptr(out), x.numel(), _lib.stream()))
             assert torch.equal(out.cpu(), g[f"t{tt}.y"]), tt
 

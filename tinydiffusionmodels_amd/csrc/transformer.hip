@@ -1,0 +1,733 @@
+// TinyTransformer embedding-space denoiser (src/shakespeare.py:105-120):
+//   x + Linear(1,D)(t/1000)  ->  depth x post-LN nn.TransformerEncoderLayer
+//   (packed in_proj, n_heads-way softmax attention without mask, out_proj,
+//    residual + LayerNorm, ReLU FFN, residual + LayerNorm), eval / dropout 0.
+// Forward, backward and the text reverse step, as launches on one stream.
+// Linear layers and their gradients run on the fp32 MFMA GEMM (gemm_mfma.hip);
+// attention (5 % of the FLOPs at L=128) is an fp32 kernel with K/V (or Q/dO)
+// tiles broadcast from LDS; LayerNorm is one wavefront per token row.
+#include <math.h>
+#include "tdm_common.h"
+#include "tdm_transformer.h"
+
+namespace {
+
+constexpr int SPLITK = 8;      // weight-gradient GEMMs: split of the token (contraction) dimension
+constexpr int LN_SLABS = 256;  // per-wave partials of the LayerNorm affine gradients
+constexpr int CS_SLABS = 128;  // row-block partials of the bias gradients
+
+// ----------------------------- parameter layout ---------------------------------
+struct LayerOff { long in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b; };
+struct TTLayout {
+    LayerOff L[8];
+    long te_w, te_b, total;
+    int ntensor;
+    long tensor_off[8 * 12 + 3];
+};
+TTLayout tt_layout(int D, int depth, int F) {
+    TTLayout t{};
+    long off = 0;
+    int ti = 0;
+    auto take = [&](long n) { long o = off; t.tensor_off[ti++] = off; off += n; return o; };
+    for (int l = 0; l < depth; ++l) {
+        LayerOff& o = t.L[l];
+        o.in_w = take(3L * D * D); o.in_b = take(3L * D);
+        o.out_w = take((long)D * D); o.out_b = take(D);
+        o.l1_w = take((long)F * D); o.l1_b = take(F);
+        o.l2_w = take((long)D * F); o.l2_b = take(D);
+        o.n1_w = take(D); o.n1_b = take(D); o.n2_w = take(D); o.n2_b = take(D);
+    }
+    t.te_w = take(D); t.te_b = take(D);
+    t.tensor_off[ti] = off;
+    t.ntensor = ti;
+    t.total = off;
+    return t;
+}
+
+// --------------------------------- workspace -------------------------------------
+struct LayerWs { float *hin, *qkv, *o, *lse, *s1, *mean1, *rstd1, *h1, *f1, *s2, *mean2, *rstd2; };
+struct TTWs {
+    float *that, *tb, *abuf;
+    LayerWs L[8];
+    // backward temporaries
+    float *g_h, *g_s, *g_s1, *g_f, *g_h1, *g_o, *g_qkv, *Dvec, *Sb, *part;
+    long total;
+};
+TTWs tt_carve(float* base, long B, int Lq, int D, int H, int depth, int F, int training) {
+    TTWs w{};
+    long off = 0;
+    auto take = [&](long n) {
+        float* p = base ? base + off : nullptr;
+        off += (n + 63) & ~63L;
+        return p;
+    };
+    const long M = B * Lq;
+    w.that = take(B); w.tb = take(B * D); w.abuf = take(M * D);
+    for (int l = 0; l < depth; ++l) {
+        LayerWs& x = w.L[l];
+        x.hin = take(M * D); x.qkv = take(M * 3 * D); x.o = take(M * D); x.lse = take(B * H * Lq);
+        x.s1 = take(M * D); x.mean1 = take(M); x.rstd1 = take(M); x.h1 = take(M * D); x.f1 = take(M * F);
+        x.s2 = take(M * D); x.mean2 = take(M); x.rstd2 = take(M);
+    }
+    if (training) {
+        w.g_h = take(M * D); w.g_s = take(M * D); w.g_s1 = take(M * D); w.g_f = take(M * F); w.g_h1 = take(M * D);
+        w.g_o = take(M * D); w.g_qkv = take(M * 3 * D); w.Dvec = take(B * H * Lq); w.Sb = take(B * D);
+        long pmax = (long)LN_SLABS * 2 * D;
+        const long c1 = (long)CS_SLABS * (F > 3 * D ? F : 3 * D);
+        if (c1 > pmax) pmax = c1;
+        w.part = take(pmax + (F > 3 * D ? F : 3 * D));
+    }
+    w.total = off;
+    return w;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// h0[m][d] = x[m][d] + (w[d]*t[b]/1000 + bias[d])      (src/shakespeare.py:116-118)
+__global__ __launch_bounds__(256) void add_timebias_kernel(const float* __restrict__ x, const int64_t* __restrict__ t,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ that, float* __restrict__ tb,
+                                                           float* __restrict__ h0, long B, int L, int D) {
+    const long total = B * L * D;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int d = (int)(i % D);
+        const long m = i / D;
+        const long b = m / L;
+        const float th = __fdiv_rn((float)t[b], 1000.f);
+        const float tv = fmaf(w[d], th, bias[d]);
+        h0[i] = x[i] + tv;
+        if (m - b * L == 0) {
+            tb[b * D + d] = tv;
+            if (d == 0) that[b] = th;
+        }
+    }
+}
+
+// ------------------------------- attention ---------------------------------------
+// one thread per query row, 128 rows per block, keys/values streamed through LDS
+// in chunks of 128 (all lanes read the same K/V row: LDS broadcast).
+template <int HD>
+__global__ __launch_bounds__(128) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                       float* __restrict__ lse, int L, int D, int H, float scale) {
+    extern __shared__ float4 sm4[];
+    float* Ks = reinterpret_cast<float*>(sm4);
+    float* Vs = Ks + 128 * HD;
+    const int tid = threadIdx.x;
+    const int bh = blockIdx.x, b = bh / H, hh = bh - b * H;
+    const int i = blockIdx.y * 128 + tid;
+    const bool valid = i < L;
+    float q[HD], acc[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { q[d] = 0.f; acc[d] = 0.f; }
+    if (valid) {
+        const float* src = qkv + ((long)(b * L + i)) * 3 * D + hh * HD;
+#pragma unroll
+        for (int d4 = 0; d4 < HD / 4; ++d4) {
+            const float4 v = *reinterpret_cast<const float4*>(src + d4 * 4);
+            q[d4 * 4 + 0] = v.x; q[d4 * 4 + 1] = v.y; q[d4 * 4 + 2] = v.z; q[d4 * 4 + 3] = v.w;
+        }
+    }
+    float m = -INFINITY, l = 0.f;
+    for (int j0 = 0; j0 < L; j0 += 128) {
+        __syncthreads();
+        for (int e = tid; e < 128 * (HD / 4); e += 128) {
+            const int jj = e / (HD / 4), d4 = e - jj * (HD / 4);
+            const int jg = j0 + jj;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (jg < L) {
+                const float* base = qkv + ((long)(b * L + jg)) * 3 * D + hh * HD + d4 * 4;
+                kv = *reinterpret_cast<const float4*>(base + D);
+                vv = *reinterpret_cast<const float4*>(base + 2 * D);
+            }
+            *reinterpret_cast<float4*>(Ks + jj * HD + d4 * 4) = kv;
+            *reinterpret_cast<float4*>(Vs + jj * HD + d4 * 4) = vv;
+        }
+        __syncthreads();
+        const int jmax = min(128, L - j0);
+        for (int jj = 0; jj < jmax; ++jj) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) s = fmaf(q[d], Ks[jj * HD + d], s);
+            s *= scale;
+            if (s > m) {
+                const float corr = expf(m - s);
+                l *= corr;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) acc[d] *= corr;
+                m = s;
+            }
+            const float p = expf(s - m);
+            l += p;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] = fmaf(p, Vs[jj * HD + d], acc[d]);
+        }
+    }
+    if (valid) {
+        const float inv = 1.f / l;
+        float* dst = o + ((long)(b * L + i)) * D + hh * HD;
+#pragma unroll
+        for (int d4 = 0; d4 < HD / 4; ++d4)
+            *reinterpret_cast<float4*>(dst + d4 * 4) =
+                make_float4(acc[d4 * 4] * inv, acc[d4 * 4 + 1] * inv, acc[d4 * 4 + 2] * inv, acc[d4 * 4 + 3] * inv);
+        lse[(long)bh * L + i] = m + logf(l);
+    }
+}
+
+// backward pass 1: dQ and D_i = dO_i . O_i   (thread per query row)
+template <int HD>
+__global__ __launch_bounds__(128) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                          const float* __restrict__ lse, const float* __restrict__ dO,
+                                                          float* __restrict__ dqkv, float* __restrict__ Dvec, int L,
+                                                          int D, int H, float scale) {
+    extern __shared__ float4 sm4[];
+    float* Ks = reinterpret_cast<float*>(sm4);
+    float* Vs = Ks + 128 * HD;
+    const int tid = threadIdx.x;
+    const int bh = blockIdx.x, b = bh / H, hh = bh - b * H;
+    const int i = blockIdx.y * 128 + tid;
+    const bool valid = i < L;
+    float q[HD], dov[HD], dq[HD];
+    float Di = 0.f, lse_i = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { q[d] = 0.f; dov[d] = 0.f; dq[d] = 0.f; }
+    if (valid) {
+        const float* qs = qkv + ((long)(b * L + i)) * 3 * D + hh * HD;
+        const float* ds = dO + ((long)(b * L + i)) * D + hh * HD;
+        const float* os = o + ((long)(b * L + i)) * D + hh * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            q[d] = qs[d];
+            dov[d] = ds[d];
+            Di = fmaf(dov[d], os[d], Di);
+        }
+        lse_i = lse[(long)bh * L + i];
+    }
+    for (int j0 = 0; j0 < L; j0 += 128) {
+        __syncthreads();
+        for (int e = tid; e < 128 * (HD / 4); e += 128) {
+            const int jj = e / (HD / 4), d4 = e - jj * (HD / 4);
+            const int jg = j0 + jj;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (jg < L) {
+                const float* base = qkv + ((long)(b * L + jg)) * 3 * D + hh * HD + d4 * 4;
+                kv = *reinterpret_cast<const float4*>(base + D);
+                vv = *reinterpret_cast<const float4*>(base + 2 * D);
+            }
+            *reinterpret_cast<float4*>(Ks + jj * HD + d4 * 4) = kv;
+            *reinterpret_cast<float4*>(Vs + jj * HD + d4 * 4) = vv;
+        }
+        __syncthreads();
+        const int jmax = min(128, L - j0);
+        for (int jj = 0; jj < jmax; ++jj) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                s = fmaf(q[d], Ks[jj * HD + d], s);
+                dp = fmaf(dov[d], Vs[jj * HD + d], dp);
+            }
+            const float p = expf(s * scale - lse_i);
+            const float dsv = p * (dp - Di);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) dq[d] = fmaf(dsv, Ks[jj * HD + d], dq[d]);
+        }
+    }
+    if (valid) {
+        float* dst = dqkv + ((long)(b * L + i)) * 3 * D + hh * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) dst[d] = dq[d] * scale;
+        Dvec[(long)bh * L + i] = Di;
+    }
+}
+
+// backward pass 2: dK and dV   (thread per key row; Q, dO, lse, D streamed through LDS)
+template <int HD>
+__global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ lse,
+                                                           const float* __restrict__ dO, const float* __restrict__ Dvec,
+                                                           float* __restrict__ dqkv, int L, int D, int H, float scale) {
+    extern __shared__ float4 sm4[];
+    float* Qs = reinterpret_cast<float*>(sm4);
+    float* Os = Qs + 128 * HD;
+    float* Ls = Os + 128 * HD;   // 128 lse
+    float* Ds = Ls + 128;        // 128 D
+    const int tid = threadIdx.x;
+    const int bh = blockIdx.x, b = bh / H, hh = bh - b * H;
+    const int jg = blockIdx.y * 128 + tid;
+    const bool valid = jg < L;
+    float k[HD], v[HD], dk[HD], dv[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { k[d] = 0.f; v[d] = 0.f; dk[d] = 0.f; dv[d] = 0.f; }
+    if (valid) {
+        const float* base = qkv + ((long)(b * L + jg)) * 3 * D + hh * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { k[d] = base[D + d]; v[d] = base[2 * D + d]; }
+    }
+    for (int i0 = 0; i0 < L; i0 += 128) {
+        __syncthreads();
+        for (int e = tid; e < 128 * (HD / 4); e += 128) {
+            const int ii = e / (HD / 4), d4 = e - ii * (HD / 4);
+            const int ig = i0 + ii;
+            float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), ov = qv;
+            if (ig < L) {
+                qv = *reinterpret_cast<const float4*>(qkv + ((long)(b * L + ig)) * 3 * D + hh * HD + d4 * 4);
+                ov = *reinterpret_cast<const float4*>(dO + ((long)(b * L + ig)) * D + hh * HD + d4 * 4);
+            }
+            *reinterpret_cast<float4*>(Qs + ii * HD + d4 * 4) = qv;
+            *reinterpret_cast<float4*>(Os + ii * HD + d4 * 4) = ov;
+        }
+        {
+            const int ig = i0 + tid;
+            Ls[tid] = (ig < L) ? lse[(long)bh * L + ig] : INFINITY;   // exp(s - inf) = 0 for padded rows
+            Ds[tid] = (ig < L) ? Dvec[(long)bh * L + ig] : 0.f;
+        }
+        __syncthreads();
+        const int imax = min(128, L - i0);
+        for (int ii = 0; ii < imax; ++ii) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                s = fmaf(Qs[ii * HD + d], k[d], s);
+                dp = fmaf(Os[ii * HD + d], v[d], dp);
+            }
+            const float p = expf(s * scale - Ls[ii]);
+            const float dsv = p * (dp - Ds[ii]);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                dv[d] = fmaf(p, Os[ii * HD + d], dv[d]);
+                dk[d] = fmaf(dsv, Qs[ii * HD + d], dk[d]);
+            }
+        }
+    }
+    if (valid) {
+        float* dst = dqkv + ((long)(b * L + jg)) * 3 * D + hh * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { dst[D + d] = dk[d] * scale; dst[2 * D + d] = dv[d]; }
+    }
+}
+
+// ------------------------------- LayerNorm ---------------------------------------
+// y = LN(x + r) * gamma + beta, one wavefront per row, row cached in registers (D <= 1024)
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ y, float* __restrict__ s_out,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out, long M,
+                                                     int D, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= M) return;
+    const int D4 = D >> 2;
+    float4 buf[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c4 = lane + 64 * q;
+        buf[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c4 < D4) {
+            const float4 a = reinterpret_cast<const float4*>(x + row * D)[c4];
+            const float4 b = reinterpret_cast<const float4*>(r + row * D)[c4];
+            buf[q] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+            sum += (buf[q].x + buf[q].y) + (buf[q].z + buf[q].w);
+        }
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c4 = lane + 64 * q;
+        if (c4 < D4) {
+            const float dx = buf[q].x - mean, dy = buf[q].y - mean, dz = buf[q].z - mean, dw = buf[q].w - mean;
+            var += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)D + eps);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c4 = lane + 64 * q;
+        if (c4 < D4) {
+            const float4 g = reinterpret_cast<const float4*>(gamma)[c4];
+            const float4 be = reinterpret_cast<const float4*>(beta)[c4];
+            float4 o;
+            o.x = (buf[q].x - mean) * rstd * g.x + be.x;
+            o.y = (buf[q].y - mean) * rstd * g.y + be.y;
+            o.z = (buf[q].z - mean) * rstd * g.z + be.z;
+            o.w = (buf[q].w - mean) * rstd * g.w + be.w;
+            reinterpret_cast<float4*>(y + row * D)[c4] = o;
+            if (s_out != nullptr) reinterpret_cast<float4*>(s_out + row * D)[c4] = buf[q];
+        }
+    }
+    if (lane == 0 && mean_out != nullptr) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// ds = rstd * (g - mean(g) - xhat*mean(g*xhat)), g = (dy + dy2) * gamma;
+// per-wave partials of dgamma = sum dy*xhat and dbeta = sum dy -> part[(block*4+wave)][2][D]
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dy2,
+                                                     const float* __restrict__ s, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                     float* __restrict__ ds, float* __restrict__ part, long M, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D4 = D >> 2;
+    float4 gacc[4], bacc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { gacc[q] = make_float4(0.f, 0.f, 0.f, 0.f); bacc[q] = gacc[q]; }
+    for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float4 g[4], xh[4];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c4 = lane + 64 * q;
+            g[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            xh[q] = g[q];
+            if (c4 < D4) {
+                float4 d = reinterpret_cast<const float4*>(dy + row * D)[c4];
+                if (dy2 != nullptr) {
+                    const float4 d2 = reinterpret_cast<const float4*>(dy2 + row * D)[c4];
+                    d.x += d2.x; d.y += d2.y; d.z += d2.z; d.w += d2.w;
+                }
+                const float4 sv = reinterpret_cast<const float4*>(s + row * D)[c4];
+                const float4 gm = reinterpret_cast<const float4*>(gamma)[c4];
+                xh[q] = make_float4((sv.x - mu) * rs, (sv.y - mu) * rs, (sv.z - mu) * rs, (sv.w - mu) * rs);
+                g[q] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+                c1 += (g[q].x + g[q].y) + (g[q].z + g[q].w);
+                c2 += (g[q].x * xh[q].x + g[q].y * xh[q].y) + (g[q].z * xh[q].z + g[q].w * xh[q].w);
+                gacc[q].x += d.x * xh[q].x; gacc[q].y += d.y * xh[q].y; gacc[q].z += d.z * xh[q].z; gacc[q].w += d.w * xh[q].w;
+                bacc[q].x += d.x; bacc[q].y += d.y; bacc[q].z += d.z; bacc[q].w += d.w;
+            }
+        }
+        c1 = wave_sum(c1) / (float)D;
+        c2 = wave_sum(c2) / (float)D;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c4 = lane + 64 * q;
+            if (c4 < D4) {
+                float4 o;
+                o.x = rs * (g[q].x - c1 - xh[q].x * c2);
+                o.y = rs * (g[q].y - c1 - xh[q].y * c2);
+                o.z = rs * (g[q].z - c1 - xh[q].z * c2);
+                o.w = rs * (g[q].w - c1 - xh[q].w * c2);
+                reinterpret_cast<float4*>(ds + row * D)[c4] = o;
+            }
+        }
+    }
+    float* dst = part + ((long)blockIdx.x * 4 + wave) * 2 * D;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c4 = lane + 64 * q;
+        if (c4 < D4) {
+            reinterpret_cast<float4*>(dst)[c4] = gacc[q];
+            reinterpret_cast<float4*>(dst + D)[c4] = bacc[q];
+        }
+    }
+}
+
+// column sums over row blocks: part[blockIdx.x][n] = sum_{rows of block} a[row][n]   (N <= 2048)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, float* __restrict__ part, long M, int N) {
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    for (long row = blockIdx.x; row < M; row += gridDim.x) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c = threadIdx.x + 256 * q;
+            if (c < N) acc[q] += a[row * N + c];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = threadIdx.x + 256 * q;
+        if (c < N) part[(long)blockIdx.x * N + c] = acc[q];
+    }
+}
+
+// Sb[b][d] = sum_l g[b][l][d]
+__global__ __launch_bounds__(256) void seqsum_kernel(const float* __restrict__ g, float* __restrict__ Sb, int L, int D) {
+    const long b = blockIdx.x;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) acc += g[(b * L + l) * D + d];
+        Sb[b * D + d] = acc;
+    }
+}
+
+// ----------------------------------- launchers -----------------------------------
+template <int HD>
+int attn_launch(int which, const float* qkv, const float* o, const float* lse, const float* dO, float* out, float* aux,
+                long B, int L, int D, int H, hipStream_t st) {
+    const float scale = 1.0f / sqrtf((float)HD);
+    dim3 grid((unsigned)(B * H), (L + 127) / 128);
+    const size_t lds2 = (size_t)2 * 128 * HD * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {   // HD = 64 needs 64-65 KB of dynamic LDS
+        const int want = (int)(lds2 + 256 * sizeof(float));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<HD>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, want);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<HD>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, want);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<HD>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, want);
+        if (e != hipSuccess) {
+            tdm_set_error("attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return 100 + (int)e;
+        }
+        attr_set = true;
+    }
+    if (which == 0) {
+        hipLaunchKernelGGL((attn_fwd_kernel<HD>), grid, dim3(128), lds2, st, qkv, out, aux, L, D, H, scale);
+        TDM_CHECK_LAUNCH("attn_fwd");
+    } else if (which == 1) {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), grid, dim3(128), lds2, st, qkv, o, lse, dO, out, aux, L, D, H, scale);
+        TDM_CHECK_LAUNCH("attn_bwd_dq");
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD>), grid, dim3(128), lds2 + 256 * sizeof(float), st, qkv, lse, dO, aux,
+                           out, L, D, H, scale);
+        TDM_CHECK_LAUNCH("attn_bwd_dkv");
+    }
+    return 0;
+}
+int attn_dispatch(int which, int hd, const float* qkv, const float* o, const float* lse, const float* dO, float* out,
+                  float* aux, long B, int L, int D, int H, hipStream_t st) {
+    switch (hd) {
+        case 8: return attn_launch<8>(which, qkv, o, lse, dO, out, aux, B, L, D, H, st);
+        case 16: return attn_launch<16>(which, qkv, o, lse, dO, out, aux, B, L, D, H, st);
+        case 32: return attn_launch<32>(which, qkv, o, lse, dO, out, aux, B, L, D, H, st);
+        case 64: return attn_launch<64>(which, qkv, o, lse, dO, out, aux, B, L, D, H, st);
+    }
+    tdm_set_error("attention: head_dim %d not supported (8, 16, 32, 64)", hd);
+    return 1;
+}
+
+// Y[M][N] = X[M][K] W[N][K]^T + bias (+res) (relu)
+int linear_fwd(const float* X, const float* W, const float* bias, const float* res, float* Y, long M, int N, int K,
+               int relu, hipStream_t st) {
+    GemmArgs g{};
+    g.A = X; g.a_rs = K; g.a_cs = 1;
+    g.B = W; g.b_rs = 1; g.b_cs = K;
+    g.C = Y; g.c_rs = N; g.bias = bias; g.res = res; g.relu = relu; g.M = (int)M; g.N = N; g.K = K; g.splitk = 1;
+    return tdm_launch_gemm(g, st);
+}
+// dX[M][K] = dY[M][N] W[N][K] (+res)
+int linear_dgrad(const float* dY, const float* W, const float* res, float* dX, long M, int N, int K, hipStream_t st) {
+    GemmArgs g{};
+    g.A = dY; g.a_rs = N; g.a_cs = 1;
+    g.B = W; g.b_rs = K; g.b_cs = 1;
+    g.C = dX; g.c_rs = K; g.res = res; g.M = (int)M; g.N = K; g.K = N; g.splitk = 1;
+    return tdm_launch_gemm(g, st);
+}
+// dW[N][K] partials = dY[M][N]^T X[M][K], split over M into SPLITK slabs at slabs + w_off
+int linear_wgrad(const float* dY, const float* X, float* slabs, long slab_stride, long w_off, long M, int N, int K,
+                 hipStream_t st) {
+    GemmArgs g{};
+    g.A = dY; g.a_rs = 1; g.a_cs = N;
+    g.B = X; g.b_rs = K; g.b_cs = 1;
+    g.C = slabs + w_off; g.c_rs = K; g.M = N; g.N = K; g.K = (int)M; g.splitk = SPLITK; g.c_split_stride = slab_stride;
+    return tdm_launch_gemm(g, st);
+}
+// bias gradient: db[N] = colsum(dY) via partials + reduce
+int bias_grad(const float* dY, float* part, float* db, long M, int N, hipStream_t st) {
+    const int nb = (int)(M < CS_SLABS ? M : CS_SLABS);
+    hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, dY, part, M, N);
+    TDM_CHECK_LAUNCH("colsum");
+    ReduceArgs ra{};
+    ra.nsec = 1; ra.sec[0].off = 0; ra.sec[0].len = N; ra.sec[0].nslab = nb;
+    return tdm_launch_reduce(part, N, ra, db, st);
+}
+int ln_bwd(const float* dy, const float* dy2, const float* s, const float* mean, const float* rstd, const float* gamma,
+           float* ds, float* part, float* dgamma_dbeta /* [2D] contiguous */, long M, int D, hipStream_t st) {
+    long nb = (M + 3) / 4;
+    if (nb > LN_SLABS / 4) nb = LN_SLABS / 4;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, dy2, s, mean, rstd, gamma, ds, part, M, D);
+    TDM_CHECK_LAUNCH("ln_bwd");
+    ReduceArgs ra{};
+    ra.nsec = 1; ra.sec[0].off = 0; ra.sec[0].len = 2 * D; ra.sec[0].nslab = (int)nb * 4;
+    return tdm_launch_reduce(part, 2L * D, ra, dgamma_dbeta, st);
+}
+int ln_fwd(const float* x, const float* r, const float* gamma, const float* beta, float* y, float* s, float* mean,
+           float* rstd, long M, int D, hipStream_t st) {
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, r, gamma, beta, y, s, mean, rstd,
+                       M, D, 1e-5f);
+    TDM_CHECK_LAUNCH("ln_fwd");
+    return 0;
+}
+
+int tt_check(long B, int L, int D, int H, int depth, int F) {
+    TDM_REQUIRE(B >= 1 && B <= 65536 && L >= 1 && L <= 4096, "transformer: B=%ld L=%d out of range", B, L);
+    TDM_REQUIRE(depth >= 1 && depth <= 8, "transformer: depth %d (1..8)", depth);
+    TDM_REQUIRE(D % 4 == 0 && D <= 1024 && D % H == 0, "transformer: D=%d H=%d", D, H);
+    TDM_REQUIRE(F % 4 == 0 && F <= 2048, "transformer: ffn %d (<= 2048, multiple of 4)", F);
+    TDM_REQUIRE(B * L * (long)(F > 3 * D ? F : 3 * D) < 2147483647L, "transformer: B*L*max(F,3D) must fit int32");
+    const int hd = D / H;
+    TDM_REQUIRE(hd == 8 || hd == 16 || hd == 32 || hd == 64, "transformer: head_dim %d not in {8,16,32,64}", hd);
+    return 0;
+}
+
+int tt_forward(const float* P, const TTLayout& lay, const float* x, const int64_t* t, float* out, const TTWs& w, long B,
+               int L, int D, int H, int depth, int F, hipStream_t st) {
+    const long M = B * L;
+    {
+        long n = M * D;
+        int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+        hipLaunchKernelGGL(add_timebias_kernel, dim3(grid), dim3(256), 0, st, x, t, P + lay.te_w, P + lay.te_b, w.that,
+                           w.tb, w.L[0].hin, B, L, D);
+        TDM_CHECK_LAUNCH("add_timebias");
+    }
+    for (int l = 0; l < depth; ++l) {
+        const LayerOff& o = lay.L[l];
+        const LayerWs& a = w.L[l];
+        float* hout = (l + 1 < depth) ? w.L[l + 1].hin : out;
+        TDM_TRY(linear_fwd(a.hin, P + o.in_w, P + o.in_b, nullptr, a.qkv, M, 3 * D, D, 0, st));
+        TDM_TRY(attn_dispatch(0, D / H, a.qkv, nullptr, nullptr, nullptr, a.o, a.lse, B, L, D, H, st));
+        TDM_TRY(linear_fwd(a.o, P + o.out_w, P + o.out_b, nullptr, w.abuf, M, D, D, 0, st));
+        TDM_TRY(ln_fwd(a.hin, w.abuf, P + o.n1_w, P + o.n1_b, a.h1, a.s1, a.mean1, a.rstd1, M, D, st));
+        TDM_TRY(linear_fwd(a.h1, P + o.l1_w, P + o.l1_b, nullptr, a.f1, M, F, D, 1, st));
+        TDM_TRY(linear_fwd(a.f1, P + o.l2_w, P + o.l2_b, nullptr, w.abuf, M, D, F, 0, st));
+        TDM_TRY(ln_fwd(a.h1, w.abuf, P + o.n2_w, P + o.n2_b, hout, a.s2, a.mean2, a.rstd2, M, D, st));
+    }
+    return 0;
+}
+
+int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G, float* dx, const TTWs& w, float* slabs,
+                long B, int L, int D, int H, int depth, int F, hipStream_t st) {
+    const long M = B * L;
+    const long NP = lay.total;
+    const float* gh = dout;  // gradient w.r.t. the current layer's output
+    for (int l = depth - 1; l >= 0; --l) {
+        const LayerOff& o = lay.L[l];
+        const LayerWs& a = w.L[l];
+        // LayerNorm 2: hout = LN(h1 + f2)
+        TDM_TRY(ln_bwd(gh, nullptr, a.s2, a.mean2, a.rstd2, P + o.n2_w, w.g_s, w.part, G + o.n2_w, M, D, st));
+        // f2 = f1 W2^T + b2
+        TDM_TRY(bias_grad(w.g_s, w.part, G + o.l2_b, M, D, st));
+        TDM_TRY(linear_wgrad(w.g_s, a.f1, slabs, NP, o.l2_w, M, D, F, st));
+        TDM_TRY(linear_dgrad(w.g_s, P + o.l2_w, nullptr, w.g_f, M, D, F, st));
+        // relu
+        TDM_TRY(tdm_launch_relu_mask(w.g_f, a.f1, w.g_f, M * F, st));
+        // z1 = h1 W1^T + b1
+        TDM_TRY(bias_grad(w.g_f, w.part, G + o.l1_b, M, F, st));
+        TDM_TRY(linear_wgrad(w.g_f, a.h1, slabs, NP, o.l1_w, M, F, D, st));
+        TDM_TRY(linear_dgrad(w.g_f, P + o.l1_w, nullptr, w.g_h1, M, F, D, st));
+        // LayerNorm 1: h1 = LN(hin + a); d(h1) = g_h1 (FFN path) + g_s (residual)
+        TDM_TRY(ln_bwd(w.g_h1, w.g_s, a.s1, a.mean1, a.rstd1, P + o.n1_w, w.g_s1, w.part, G + o.n1_w, M, D, st));
+        // a = o Wout^T + bout
+        TDM_TRY(bias_grad(w.g_s1, w.part, G + o.out_b, M, D, st));
+        TDM_TRY(linear_wgrad(w.g_s1, a.o, slabs, NP, o.out_w, M, D, D, st));
+        TDM_TRY(linear_dgrad(w.g_s1, P + o.out_w, nullptr, w.g_o, M, D, D, st));
+        // attention
+        TDM_TRY(attn_dispatch(1, D / H, a.qkv, a.o, a.lse, w.g_o, w.g_qkv, w.Dvec, B, L, D, H, st));
+        TDM_TRY(attn_dispatch(2, D / H, a.qkv, nullptr, a.lse, w.g_o, w.g_qkv, w.Dvec, B, L, D, H, st));
+        // qkv = hin Win^T + bin ; d(hin) = g_qkv Win + g_s1 (residual)
+        TDM_TRY(bias_grad(w.g_qkv, w.part, G + o.in_b, M, 3 * D, st));
+        TDM_TRY(linear_wgrad(w.g_qkv, a.hin, slabs, NP, o.in_w, M, 3 * D, D, st));
+        float* gout = (l == 0 && dx != nullptr) ? dx : w.g_h;   // layer 0: this is d(loss)/d(x)
+        TDM_TRY(linear_dgrad(w.g_qkv, P + o.in_w, w.g_s1, gout, M, 3 * D, D, st));
+        gh = gout;
+    }
+    // time embedding: hin0 = x + (w*that + b)
+    hipLaunchKernelGGL(seqsum_kernel, dim3((unsigned)B), dim3(256), 0, st, gh, w.Sb, L, D);
+    TDM_CHECK_LAUNCH("seqsum");
+    if (256 % D == 0) {
+        TDM_TRY(tdm_launch_time_grad(w.Sb, w.that, G + lay.te_w, G + lay.te_b, (int)B, D, st));
+    } else {
+        tdm_set_error("transformer backward: D=%d must divide 256 for the time-embedding gradient kernel", D);
+        return 1;
+    }
+    // sum the split-K weight-gradient slabs
+    ReduceArgs ra{};
+    int n = 0;
+    for (int l = 0; l < depth; ++l) {
+        const LayerOff& o = lay.L[l];
+        const long offs[4] = {o.in_w, o.out_w, o.l1_w, o.l2_w};
+        const long lens[4] = {3L * D * D, (long)D * D, (long)F * D, (long)D * F};
+        for (int k = 0; k < 4; ++k) {
+            ra.sec[n].off = (int)offs[k]; ra.sec[n].len = (int)lens[k]; ra.sec[n].nslab = SPLITK; ++n;
+        }
+    }
+    ra.nsec = n;
+    return tdm_launch_reduce(slabs, NP, ra, G, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t tdm_tt_param_count(int D, int depth, int ffn) { return tt_layout(D, depth, ffn).total; }
+
+int tdm_tt_param_offsets(int D, int depth, int ffn, int64_t* offs) {
+    TDM_REQUIRE(depth >= 1 && depth <= 8, "tt_param_offsets: depth %d", depth);
+    const TTLayout t = tt_layout(D, depth, ffn);
+    for (int i = 0; i <= t.ntensor; ++i) offs[i] = t.tensor_off[i];
+    return 0;
+}
+
+int64_t tdm_tt_workspace_floats(int64_t B, int L, int D, int H, int depth, int ffn, int training) {
+    if (depth < 1 || depth > 8) return -1;
+    return tt_carve(nullptr, B, L, D, H, depth, ffn, training).total;
+}
+
+int64_t tdm_tt_slab_floats(int D, int depth, int ffn) {
+    if (depth < 1 || depth > 8) return -1;
+    return (int64_t)SPLITK * tt_layout(D, depth, ffn).total;
+}
+
+int tdm_tt_fwd_f32(const float* params, const float* x, const int64_t* t, float* out, float* ws, int64_t B, int L, int D,
+                   int H, int depth, int ffn, int save, void* stream) {
+    TDM_TRY(tt_check(B, L, D, H, depth, ffn));
+    TDM_REQUIRE(params && x && t && out && ws, "tt_fwd: NULL pointer");
+    const TTLayout lay = tt_layout(D, depth, ffn);
+    const TTWs w = tt_carve(ws, B, L, D, H, depth, ffn, save);
+    return tt_forward(params, lay, x, t, out, w, B, L, D, H, depth, ffn, (hipStream_t)stream);
+}
+
+int tdm_tt_bwd_f32(const float* params, const float* dout, float* grads, float* dx, float* ws, float* slabs, int64_t B,
+                   int L, int D, int H, int depth, int ffn, void* stream) {
+    TDM_TRY(tt_check(B, L, D, H, depth, ffn));
+    TDM_REQUIRE(params && dout && grads && ws && slabs, "tt_bwd: NULL pointer");
+    const TTLayout lay = tt_layout(D, depth, ffn);
+    const TTWs w = tt_carve(ws, B, L, D, H, depth, ffn, 1);
+    return tt_backward(params, lay, dout, grads, dx, w, slabs, B, L, D, H, depth, ffn, (hipStream_t)stream);
+}
+
+int tdm_tt_loss_grad_f32(const float* params, const float* x0, const float* noise, const int64_t* t,
+                         const float* sqrt_acp, const float* sqrt_1m_acp, float* x_noisy, float* pred, float* dpred,
+                         float* loss_out, float* grads, float* ws, float* slabs, int64_t B, int L, int D, int H,
+                         int depth, int ffn, void* stream) {
+    TDM_TRY(tt_check(B, L, D, H, depth, ffn));
+    TDM_REQUIRE(params && x0 && noise && t && x_noisy && pred && dpred && loss_out && grads && ws && slabs,
+                "tt_loss_grad: NULL pointer");
+    const TTLayout lay = tt_layout(D, depth, ffn);
+    const TTWs w = tt_carve(ws, B, L, D, H, depth, ffn, 1);
+    hipStream_t st = (hipStream_t)stream;
+    TDM_TRY(tdm_q_sample_f32(x0, noise, t, sqrt_acp, sqrt_1m_acp, x_noisy, B, (int64_t)L * D, stream));
+    TDM_TRY(tt_forward(params, lay, x_noisy, t, pred, w, B, L, D, H, depth, ffn, st));
+    TDM_TRY(tdm_mse_fwd_bwd_f32(pred, noise, loss_out, dpred, w.part, B * L * D, stream));
+    return tt_backward(params, lay, dpred, grads, nullptr, w, slabs, B, L, D, H, depth, ffn, st);
+}
+
+int tdm_tt_p_sample_step_f32(const float* params, const float* x, const int64_t* t, const float* noise,
+                             const float* tab_recip, const float* tab_eps, const float* tab_sigma, int t_index,
+                             float* eps, float* x_out, float* ws, int64_t B, int L, int D, int H, int depth, int ffn,
+                             void* stream) {
+    TDM_TRY(tt_check(B, L, D, H, depth, ffn));
+    TDM_REQUIRE(params && x && t && eps && x_out && ws, "tt_p_sample_step: NULL pointer");
+    const TTLayout lay = tt_layout(D, depth, ffn);
+    const TTWs w = tt_carve(ws, B, L, D, H, depth, ffn, 0);
+    TDM_TRY(tt_forward(params, lay, x, t, eps, w, B, L, D, H, depth, ffn, (hipStream_t)stream));
+    return tdm_p_sample_update_f32(x, eps, t_index == 0 ? nullptr : noise, tab_recip, tab_eps, tab_sigma, t_index, x_out,
+                                   B * L * D, stream);
+}
+
+int tdm_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float* C,
+                 int64_t c_rs, const float* bias, const float* res, int M, int N, int K, int relu, int splitk,
+                 int64_t c_split_stride, void* stream) {
+    GemmArgs g{};
+    g.A = A; g.a_rs = a_rs; g.a_cs = a_cs; g.B = B; g.b_rs = b_rs; g.b_cs = b_cs; g.C = C; g.c_rs = c_rs;
+    g.bias = bias; g.res = res; g.M = M; g.N = N; g.K = K; g.relu = relu; g.splitk = splitk;
+    g.c_split_stride = c_split_stride;
+    return tdm_launch_gemm(g, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -150,12 +150,16 @@ def p_sample(model, x, t, noise=None):
     add_noise = int(t[0]) != 0
     if add_noise and noise is None:
         noise = torch.randn_like(x)
-    out = torch.empty_like(x)
     B = x.shape[0]
+    # contiguous copies are held in locals until the launch (a temporary would be freed, and its block
+    # possibly re-used by the next argument's copy, before the kernel is enqueued)
+    xc, tc = x.contiguous(), t.contiguous()
+    zc = noise.contiguous() if add_noise else None
+    out = torch.empty_like(xc)
     _lib.check(_lib.lib().tdm_p_sample_update_pert_f32(
-        _lib.ptr(x.contiguous()), _lib.ptr(eps), _lib.ptr(noise.contiguous() if add_noise else None),
+        _lib.ptr(xc), _lib.ptr(eps), _lib.ptr(zc),
         _lib.ptr(tabs["sqrt_recip_alphas"]), _lib.ptr(tabs["eps_coef"]), _lib.ptr(tabs["sigma"]),
-        _lib.ptr(t.contiguous()), 1 if add_noise else 0, _lib.ptr(out), B, x.numel() // B, _lib.stream()),
+        _lib.ptr(tc), 1 if add_noise else 0, _lib.ptr(out), B, xc.numel() // B, _lib.stream()),
         "p_sample_update")
     return out
 

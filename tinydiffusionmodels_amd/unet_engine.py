@@ -126,11 +126,11 @@ def unet_forward(flat: torch.Tensor, x: torch.Tensor, t: torch.Tensor, ws: UNetW
         raise RuntimeError("t must be an int64 tensor of shape (B,)")
     if ws.B != B or (save and not ws.training):
         raise RuntimeError("workspace does not match the batch")
-    x = x.contiguous()
+    x, tc = x.contiguous(), t.contiguous()
     if x.dtype != torch.float32 or flat.dtype != torch.float32:
         raise RuntimeError("the HIP UNet path computes in fp32")
     eps = out if out is not None else torch.empty_like(x)
-    _lib.check(_lib.lib().tdm_unet_fwd_f32(_lib.ptr(flat), _lib.ptr(x), _lib.ptr(t.contiguous()), _lib.ptr(eps),
+    _lib.check(_lib.lib().tdm_unet_fwd_f32(_lib.ptr(flat), _lib.ptr(x), _lib.ptr(tc), _lib.ptr(eps),
                                            _lib.ptr(ws.ws), B, 1 if save else 0, _lib.stream()), "unet_fwd")
     return eps
 
@@ -141,7 +141,8 @@ def unet_backward(flat: torch.Tensor, x: torch.Tensor, deps: torch.Tensor, ws: U
     B = x.shape[0]
     if grads is None:
         grads = torch.empty(NPARAM, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().tdm_unet_bwd_f32(_lib.ptr(flat), _lib.ptr(x.contiguous()), _lib.ptr(deps.contiguous()),
+    xc, dc = x.contiguous(), deps.contiguous()
+    _lib.check(_lib.lib().tdm_unet_bwd_f32(_lib.ptr(flat), _lib.ptr(xc), _lib.ptr(dc),
                                            _lib.ptr(grads), _lib.ptr(ws.ws), _lib.ptr(slabs_for(x.device)), B,
                                            _lib.stream()), "unet_bwd")
     return grads
