@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--sample-steps", type=int, default=20, help="reverse steps timed at B=4096 (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conv-mode", type=int, default=1, choices=[0, 1],
+                    help="UNet conv arithmetic: 1 = bf16x3 split MFMA (default), 0 = exact fp32 MFMA")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,6 +96,7 @@ def main():
     from tinydiffusionmodels_amd.mnist import SimpleUNet, DDPMTrainer, reverse_diffusion
 
     E.check_layout_against_library()
+    _lib.check(_lib.lib().tdm_set_conv_mode(args.conv_mode))
     torch.manual_seed(0)                       # identical default init on every rank (+ broadcast in the trainer)
     model = SimpleUNet().to(dev)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -127,9 +130,11 @@ def main():
         "metric": "DDPM train steps/sec, MNIST UNet b=512/GPU (512-image steps summed over GPUs)",
         "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.conv_mode == 0 else "f32 (convs: bf16x3-split operands on MFMA, fp32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": "MNIST DDPM UNet train step (q_sample+fwd+MSE+bwd+AdamW), batch 512 per GPU, "
-                               "1000-step linear beta schedule, fp32 MFMA conv kernels",
+                               "1000-step linear beta schedule, " +
+                               ("exact fp32 MFMA conv kernels" if args.conv_mode == 0 else "bf16x3 split-MFMA conv kernels"),
                    "batch_per_gpu": B_TRAIN, "global_batch": B_TRAIN * world, "parallelism": f"dp{world}"},
         "images_per_s": round(value * B_TRAIN, 1),
         "final_loss": loss_val,
@@ -154,9 +159,16 @@ def main():
         bias = torch.zeros(cout, device=dev)
         yout = torch.empty(B_TRAIN, hw, hw, cout, device=dev)
 
+        scratch = torch.empty(9 * cin * cout, device=dev)
+
         def run_conv():
-            _lib.check(L.tdm_conv_nhwc_f32(_lib.ptr(xin), _lib.ptr(w), _lib.ptr(bias), None, None, _lib.ptr(yout), None,
-                                           B_TRAIN, hw, cin, cout, 3, 1, _lib.stream()))
+            if args.conv_mode == 0:
+                _lib.check(L.tdm_conv_nhwc_f32(_lib.ptr(xin), _lib.ptr(w), _lib.ptr(bias), None, None, _lib.ptr(yout),
+                                               None, B_TRAIN, hw, cin, cout, 3, 1, _lib.stream()))
+            else:
+                _lib.check(L.tdm_conv_nhwc_bf16x3_f32(_lib.ptr(xin), _lib.ptr(w), _lib.ptr(bias), None, None,
+                                                      _lib.ptr(yout), None, _lib.ptr(scratch), B_TRAIN, hw, cin, cout,
+                                                      3, 1, _lib.stream()))
         ms = time_kernel(run_conv)
         kflop = 2 * 9 * cin * cout * hw * hw * B_TRAIN
         ach = kflop / (ms * 1e-3) / 1e12

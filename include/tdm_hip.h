@@ -128,6 +128,18 @@ int tdm_conv_nhwc_f32(const float* in, const float* w, const float* bias, const 
 int tdm_conv_wgrad_nhwc_f32(const float* in, const float* tb, const float* dout, float* dw, float* db,
                             float* slabs, int64_t B, int HW, int Cin, int Cout, int ksize, void* stream);
 
+/* Arithmetic of the UNet's MFMA convolutions (forward and data gradient):
+ *   0  exact fp32 (v_mfma_f32_32x32x2_f32, bitwise an fp32 fmaf chain)
+ *   1  bf16x3 split operands on v_mfma_f32_32x32x16_bf16 (hi*hi + hi*lo + lo*hi,
+ *      fp32 accumulate; ~1e-5 relative, 3/16 of the fp32 MFMA cycles) — default */
+int tdm_set_conv_mode(int mode);
+int tdm_get_conv_mode(void);
+/* same contract as tdm_conv_nhwc_f32 through the bf16x3 kernel;
+ * scratch >= ksize*ksize*Cin*Cout floats (pre-packed hi/lo weights)          */
+int tdm_conv_nhwc_bf16x3_f32(const float* in, const float* w, const float* bias, const float* res,
+                             const float* tb, float* out, float* aux_relu_out, float* scratch,
+                             int64_t B, int HW, int Cin, int Cout, int ksize, int flags, void* stream);
+
 /* ---- a8-a10: TinyTransformer embedding-space denoiser (src/shakespeare.py:105-120) ----
  * x (B,L,D) fp32, t (B,) int64; post-LN encoder layers (packed in_proj, H heads,
  * ReLU FFN of width ffn, LayerNorm eps 1e-5), no mask, no positional encoding,

@@ -39,6 +39,10 @@ _SIGS = {
     "tdm_unet_p_sample_step_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_i64, c_f], c_int),
     "tdm_conv_nhwc_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int, c_int, c_f], c_int),
     "tdm_conv_wgrad_nhwc_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int, c_f], c_int),
+    "tdm_set_conv_mode": ([c_int], c_int),
+    "tdm_get_conv_mode": ([], c_int),
+    "tdm_conv_nhwc_bf16x3_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int, c_int, c_f],
+                                 c_int),
     "tdm_tt_param_count": ([c_int, c_int, c_int], c_i64),
     "tdm_tt_param_offsets": ([c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int64)], c_int),
     "tdm_tt_workspace_floats": ([c_i64, c_int, c_int, c_int, c_int, c_int, c_int], c_i64),

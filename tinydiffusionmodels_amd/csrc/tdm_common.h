@@ -50,6 +50,9 @@ struct ConvSrc {
     int w_rows;         // rows per tap of w  (fwd: Cin_total; dgrad: Cin_total = N)
     int w_r0;           // fwd: first row of this source inside w
     int w_cols;         // columns of w (fwd: N; dgrad: Cout of the forward conv = K)
+    // bf16x3 path (conv_bf16.hip): weights pre-packed in MFMA B-fragment order
+    const unsigned short* wp;   // packed tensor for this direction (hi/lo planes)
+    int wchunk0;                // first 16-channel K chunk of this source inside wp
 };
 
 struct ConvArgs {
@@ -61,10 +64,18 @@ struct ConvArgs {
     float* aux;         // [M][N] or nullptr: value after relu, before residual
     int relu;
     int B;
+    int ablate;         // diagnostics (bf16x3 kernel): bit0 skip input loads, bit1 skip weight staging, bit2 skip MFMA
 };
 
 // hw in {28,14}; N in {32,64,96}; dgrad: transposed convolution with the forward weights
 int tdm_launch_conv(const ConvArgs& a, int hw, int N, bool dgrad, hipStream_t st);
+
+// bf16x3 split-operand variant (direction-agnostic: the pre-pack encodes fwd / dgrad)
+int tdm_launch_conv_bf16(const ConvArgs& a, int hw, int N, hipStream_t st);
+struct PackDesc { int src_off, cin, cout, taps, dgrad; long dst_off; };
+#define TDM_MAX_PACK 24
+struct PackArgs { PackDesc d[TDM_MAX_PACK]; int n; };
+int tdm_launch_pack(const float* params, const PackArgs& pa, unsigned short* out, hipStream_t st);
 
 struct WgradArgs {
     ConvSrc a;          // activation source (nch = channels covered, multiple of 32)
@@ -79,6 +90,7 @@ struct WgradArgs {
     int nci;            // number of 32-channel ci tiles
 };
 int tdm_launch_wgrad(const WgradArgs& a, int hw, int nslab, hipStream_t st);
+int tdm_launch_wgrad_bf16(const WgradArgs& a, int hw, int nslab, hipStream_t st);   // bf16x3 split operands
 
 // slab reduction: out[off+i] = sum_s slab[s*stride + off + i]
 struct ReduceSec { int off, len, nslab; };

@@ -57,9 +57,43 @@ constexpr Layout make_layout() {
 constexpr Layout kL = make_layout();
 static_assert(kL.total == TDM_UNET_NPARAM, "SimpleUNet parameter count");
 
+// ---- bf16x3 pre-packed weights (conv_bf16.hip) -----------------------------------
+// the nine MFMA convolutions: id, flat offset, Cin, Cout, taps
+enum { W_RB1C2, W_RB2C1, W_RB2C2, W_RB2SK, W_RB3C1, W_RB3C2, W_RB4C1, W_RB4C2, W_RB4SK, W_COUNT };
+struct PackTab {
+    PackArgs pa;
+    long fwd[W_COUNT], dg[W_COUNT];
+    long total_u16;
+};
+PackTab make_pack() {
+    PackTab t{};
+    const int off[W_COUNT] = {kL.rb[0].c2w, kL.rb[1].c1w, kL.rb[1].c2w, kL.rb[1].skw, kL.rb[2].c1w,
+                              kL.rb[2].c2w, kL.rb[3].c1w, kL.rb[3].c2w, kL.rb[3].skw};
+    const int cin[W_COUNT] = {32, 32, 64, 32, 64, 64, 96, 32, 96};
+    const int cout[W_COUNT] = {32, 64, 64, 64, 64, 64, 32, 32, 32};
+    const int taps[W_COUNT] = {9, 9, 9, 1, 9, 9, 9, 9, 1};
+    long o = 0;
+    int n = 0;
+    for (int i = 0; i < W_COUNT; ++i)
+        for (int dir = 0; dir < 2; ++dir) {
+            PackDesc& d = t.pa.d[n++];
+            d.src_off = off[i]; d.cin = cin[i]; d.cout = cout[i]; d.taps = taps[i]; d.dgrad = dir; d.dst_off = o;
+            (dir ? t.dg[i] : t.fwd[i]) = o;
+            o += 2L * cin[i] * cout[i] * taps[i];   // hi + lo planes, one bf16 each
+        }
+    t.pa.n = n;
+    t.total_u16 = o;
+    return t;
+}
+const PackTab kPack = make_pack();
+
+// 0: exact fp32 MFMA (conv_mfma.hip); 1: bf16x3 split operands (conv_bf16.hip)
+int g_conv_mode = 1;
+
 // ------------------------------ workspace --------------------------------------
 struct Ws {
     float *that, *tb, *S, *scratch;
+    unsigned short* wpack;
     float *a1_1, *s1, *a2_1, *h1, *p1;
     float *a1_2, *s2, *a2_2, *h2;
     float *a1_3, *a2_3, *h3;
@@ -79,6 +113,7 @@ Ws carve(float* base, int64_t B, int training) {
     };
     const int64_t M28 = B * 784, M14 = B * 196;
     w.that = take(B); w.tb = take(B * 192); w.S = take(B * 64); w.scratch = take(2048);
+    w.wpack = reinterpret_cast<unsigned short*>(take((kPack.total_u16 + 1) / 2));
     w.a1_1 = take(M28 * 32); w.s1 = take(M28 * 32); w.a2_1 = take(M28 * 32); w.h1 = take(M28 * 32);
     w.p1 = take(M14 * 32);
     w.a1_2 = take(M14 * 64); w.s2 = take(M14 * 64); w.a2_2 = take(M14 * 64); w.h2 = take(M14 * 64);
@@ -96,30 +131,35 @@ Ws carve(float* base, int64_t B, int training) {
 }
 
 ConvSrc mk_src(const float* ptr, int C, int c0, int nch, int up, int taps, const float* w, int w_rows, int w_r0,
-               int w_cols, const float* tb = nullptr) {
+               int w_cols, const float* tb = nullptr, const unsigned short* wp = nullptr, int wchunk0 = 0) {
     ConvSrc s{};
     s.ptr = ptr; s.tb = tb; s.w = w; s.C = C; s.c0 = c0; s.nch = nch; s.up = up; s.taps = taps; s.tb_stride = 192;
-    s.w_rows = w_rows; s.w_r0 = w_r0; s.w_cols = w_cols;
+    s.w_rows = w_rows; s.w_r0 = w_r0; s.w_cols = w_cols; s.wp = wp; s.wchunk0 = wchunk0;
     return s;
 }
 
-// forward conv with one source
-int conv1(hipStream_t st, int hw, int B, const float* in, int Cin, int taps, const float* w, int Cout, const float* bias,
-          int relu, const float* tb, const float* res, float* aux, float* out) {
+int launch_conv_any(const ConvArgs& a, int hw, int N, bool dgrad, hipStream_t st) {
+    if (g_conv_mode == 1) return tdm_launch_conv_bf16(a, hw, N, st);
+    return tdm_launch_conv(a, hw, N, dgrad, st);
+}
+
+// forward conv with one source; wid = index into the pre-packed weights
+int conv1(hipStream_t st, const Ws& ws, int hw, int B, const float* in, int Cin, int taps, const float* w, int wid,
+          int Cout, const float* bias, int relu, const float* tb, const float* res, float* aux, float* out) {
     ConvArgs a{};
     a.nsrc = 1;
-    a.src[0] = mk_src(in, Cin, 0, Cin, 0, taps, w, Cin, 0, Cout, tb);
+    a.src[0] = mk_src(in, Cin, 0, Cin, 0, taps, w, Cin, 0, Cout, tb, ws.wpack + kPack.fwd[wid], 0);
     a.bias = bias; a.res = res; a.out = out; a.aux = aux; a.relu = relu; a.B = B;
-    return tdm_launch_conv(a, hw, Cout, false, st);
+    return launch_conv_any(a, hw, Cout, false, st);
 }
 // transposed conv (dgrad) with one source: in has K channels, out has N channels, w is forward HWIO [taps][N][K]
-int dgrad1(hipStream_t st, int hw, int B, const float* in, int K, int taps, const float* w, int N, const float* res,
-           float* out) {
+int dgrad1(hipStream_t st, const Ws& ws, int hw, int B, const float* in, int K, int taps, const float* w, int wid, int N,
+           const float* res, float* out) {
     ConvArgs a{};
     a.nsrc = 1;
-    a.src[0] = mk_src(in, K, 0, K, 0, taps, w, N, 0, K);
+    a.src[0] = mk_src(in, K, 0, K, 0, taps, w, N, 0, K, nullptr, ws.wpack + kPack.dg[wid], 0);
     a.res = res; a.out = out; a.B = B;
-    return tdm_launch_conv(a, hw, N, true, st);
+    return launch_conv_any(a, hw, N, true, st);
 }
 
 int wgrad(hipStream_t st, int hw, int B, const float* act, int C, int c_used, int up, const float* tb, int taps,
@@ -130,6 +170,7 @@ int wgrad(hipStream_t st, int hw, int B, const float* act, int C, int c_used, in
     const long M = (long)B * hw * hw;
     a.ntiles = (int)((M + 255) / 256);
     a.nci = c_used / 32;
+    if (g_conv_mode == 1) return tdm_launch_wgrad_bf16(a, hw, nslab, st);
     return tdm_launch_wgrad(a, hw, nslab, st);
 }
 
@@ -139,31 +180,36 @@ int unet_forward(const float* P, const float* x, const int64_t* t, float* eps, c
     const int teb[4] = {kL.rb[0].teb, kL.rb[1].teb, kL.rb[2].teb, kL.rb[3].teb};
     TDM_TRY(tdm_launch_timebias(t, P, tew, teb, w.that, w.tb, B, st));
     const BlockOff &r1 = kL.rb[0], &r2 = kL.rb[1], &r3 = kL.rb[2], &r4 = kL.rb[3];
+    if (g_conv_mode == 1) TDM_TRY(tdm_launch_pack(P, kPack.pa, w.wpack, st));
     // rb1 (1 -> 32 @ 28x28)
     TDM_TRY(tdm_launch_conv_first(x, P + r1.c1w, P + r1.c1b, P + r1.skw, P + r1.skb, w.a1_1, w.s1, B, st));
-    TDM_TRY(conv1(st, 28, B, w.a1_1, 32, 9, P + r1.c2w, 32, P + r1.c2b, 1, w.tb + 0, w.s1, save ? w.a2_1 : nullptr, w.h1));
+    TDM_TRY(conv1(st, w, 28, B, w.a1_1, 32, 9, P + r1.c2w, W_RB1C2, 32, P + r1.c2b, 1, w.tb + 0, w.s1,
+                  save ? w.a2_1 : nullptr, w.h1));
     // rb2 (32 -> 64 @ 14x14) on avg_pool2d(h1)
     TDM_TRY(tdm_launch_avgpool(w.h1, w.p1, B, 14, 32, st));
-    TDM_TRY(conv1(st, 14, B, w.p1, 32, 9, P + r2.c1w, 64, P + r2.c1b, 1, nullptr, nullptr, nullptr, w.a1_2));
-    TDM_TRY(conv1(st, 14, B, w.p1, 32, 1, P + r2.skw, 64, P + r2.skb, 0, nullptr, nullptr, nullptr, w.s2));
-    TDM_TRY(conv1(st, 14, B, w.a1_2, 64, 9, P + r2.c2w, 64, P + r2.c2b, 1, w.tb + 32, w.s2, save ? w.a2_2 : nullptr, w.h2));
+    TDM_TRY(conv1(st, w, 14, B, w.p1, 32, 9, P + r2.c1w, W_RB2C1, 64, P + r2.c1b, 1, nullptr, nullptr, nullptr, w.a1_2));
+    TDM_TRY(conv1(st, w, 14, B, w.p1, 32, 1, P + r2.skw, W_RB2SK, 64, P + r2.skb, 0, nullptr, nullptr, nullptr, w.s2));
+    TDM_TRY(conv1(st, w, 14, B, w.a1_2, 64, 9, P + r2.c2w, W_RB2C2, 64, P + r2.c2b, 1, w.tb + 32, w.s2,
+                  save ? w.a2_2 : nullptr, w.h2));
     // rb3 (64 -> 64, identity skip)
-    TDM_TRY(conv1(st, 14, B, w.h2, 64, 9, P + r3.c1w, 64, P + r3.c1b, 1, nullptr, nullptr, nullptr, w.a1_3));
-    TDM_TRY(conv1(st, 14, B, w.a1_3, 64, 9, P + r3.c2w, 64, P + r3.c2b, 1, w.tb + 96, w.h2, save ? w.a2_3 : nullptr, w.h3));
+    TDM_TRY(conv1(st, w, 14, B, w.h2, 64, 9, P + r3.c1w, W_RB3C1, 64, P + r3.c1b, 1, nullptr, nullptr, nullptr, w.a1_3));
+    TDM_TRY(conv1(st, w, 14, B, w.a1_3, 64, 9, P + r3.c2w, W_RB3C2, 64, P + r3.c2b, 1, w.tb + 96, w.h2,
+                  save ? w.a2_3 : nullptr, w.h3));
     // rb4 (96 -> 32 @ 28x28) on cat([up2(h3), h1]) — never materialised
     {
         ConvArgs a{};
         a.nsrc = 2;
-        a.src[0] = mk_src(w.h3, 64, 0, 64, 1, 9, P + r4.c1w, 96, 0, 32);
-        a.src[1] = mk_src(w.h1, 32, 0, 32, 0, 9, P + r4.c1w, 96, 64, 32);
+        a.src[0] = mk_src(w.h3, 64, 0, 64, 1, 9, P + r4.c1w, 96, 0, 32, nullptr, w.wpack + kPack.fwd[W_RB4C1], 0);
+        a.src[1] = mk_src(w.h1, 32, 0, 32, 0, 9, P + r4.c1w, 96, 64, 32, nullptr, w.wpack + kPack.fwd[W_RB4C1], 4);
         a.bias = P + r4.c1b; a.relu = 1; a.out = w.a1_4; a.B = B;
-        TDM_TRY(tdm_launch_conv(a, 28, 32, false, st));
-        a.src[0] = mk_src(w.h3, 64, 0, 64, 1, 1, P + r4.skw, 96, 0, 32);
-        a.src[1] = mk_src(w.h1, 32, 0, 32, 0, 1, P + r4.skw, 96, 64, 32);
+        TDM_TRY(launch_conv_any(a, 28, 32, false, st));
+        a.src[0] = mk_src(w.h3, 64, 0, 64, 1, 1, P + r4.skw, 96, 0, 32, nullptr, w.wpack + kPack.fwd[W_RB4SK], 0);
+        a.src[1] = mk_src(w.h1, 32, 0, 32, 0, 1, P + r4.skw, 96, 64, 32, nullptr, w.wpack + kPack.fwd[W_RB4SK], 4);
         a.bias = P + r4.skb; a.relu = 0; a.out = w.s4;
-        TDM_TRY(tdm_launch_conv(a, 28, 32, false, st));
+        TDM_TRY(launch_conv_any(a, 28, 32, false, st));
     }
-    TDM_TRY(conv1(st, 28, B, w.a1_4, 32, 9, P + r4.c2w, 32, P + r4.c2b, 1, w.tb + 160, w.s4, save ? w.a2_4 : nullptr, w.h4));
+    TDM_TRY(conv1(st, w, 28, B, w.a1_4, 32, 9, P + r4.c2w, W_RB4C2, 32, P + r4.c2b, 1, w.tb + 160, w.s4,
+                  save ? w.a2_4 : nullptr, w.h4));
     TDM_TRY(tdm_launch_conv_out(w.h4, P + kL.outw, P + kL.outb, eps, (int64_t)B * 784, st));
     return 0;
 }
@@ -178,7 +224,7 @@ int unet_backward(const float* P, const float* x, const float* deps, float* G, c
     TDM_TRY(tdm_launch_out_bwd(deps, w.h4, P + kL.outw, w.a2_4, w.dout4, w.dc2_4, slabs, TDM_UNET_NPARAM, kL.outw,
                                kL.outb, M28, NSLAB, st));
     TDM_TRY(wgrad(st, 28, B, w.a1_4, 32, 32, 0, w.tb + 160, 9, w.dc2_4, 32, slabs, r4.c2w, 32, 0, r4.c2b, NSLAB));
-    TDM_TRY(dgrad1(st, 28, B, w.dc2_4, 32, 9, P + r4.c2w, 32, nullptr, w.dh4));
+    TDM_TRY(dgrad1(st, w, 28, B, w.dc2_4, 32, 9, P + r4.c2w, W_RB4C2, 32, nullptr, w.dh4));
     TDM_TRY(tdm_launch_relu_bwd_tb(w.dh4, w.a1_4, w.S, B, 784, 32, st));  // dh4 <- d(conv1 pre-activation)
     TDM_TRY(tdm_launch_time_grad(w.S, w.that, G + r4.tew, G + r4.teb, B, 32, st));
     TDM_TRY(wgrad(st, 28, B, w.h3, 64, 64, 1, nullptr, 9, w.dh4, 32, slabs, r4.c1w, 96, 0, r4.c1b, NSLAB));
@@ -188,24 +234,24 @@ int unet_backward(const float* P, const float* x, const float* deps, float* G, c
     {
         ConvArgs a{};
         a.nsrc = 2;
-        a.src[0] = mk_src(w.dh4, 32, 0, 32, 0, 9, P + r4.c1w, 96, 0, 32);
-        a.src[1] = mk_src(w.dout4, 32, 0, 32, 0, 1, P + r4.skw, 96, 0, 32);
+        a.src[0] = mk_src(w.dh4, 32, 0, 32, 0, 9, P + r4.c1w, 96, 0, 32, nullptr, w.wpack + kPack.dg[W_RB4C1], 0);
+        a.src[1] = mk_src(w.dout4, 32, 0, 32, 0, 1, P + r4.skw, 96, 0, 32, nullptr, w.wpack + kPack.dg[W_RB4SK], 0);
         a.out = w.dcat; a.B = B;
-        TDM_TRY(tdm_launch_conv(a, 28, 96, true, st));
+        TDM_TRY(launch_conv_any(a, 28, 96, true, st));
     }
     TDM_TRY(tdm_launch_split_dcat(w.dcat, w.dout3, B, st));
     // ---- rb3 ----
     TDM_TRY(tdm_launch_relu_mask(w.dout3, w.a2_3, w.dc2_3, M14 * 64, st));
     TDM_TRY(wgrad(st, 14, B, w.a1_3, 64, 64, 0, w.tb + 96, 9, w.dc2_3, 64, slabs, r3.c2w, 64, 0, r3.c2b, NSLAB));
-    TDM_TRY(dgrad1(st, 14, B, w.dc2_3, 64, 9, P + r3.c2w, 64, nullptr, w.dh3));
+    TDM_TRY(dgrad1(st, w, 14, B, w.dc2_3, 64, 9, P + r3.c2w, W_RB3C2, 64, nullptr, w.dh3));
     TDM_TRY(tdm_launch_relu_bwd_tb(w.dh3, w.a1_3, w.S, B, 196, 64, st));
     TDM_TRY(tdm_launch_time_grad(w.S, w.that, G + r3.tew, G + r3.teb, B, 64, st));
     TDM_TRY(wgrad(st, 14, B, w.h2, 64, 64, 0, nullptr, 9, w.dh3, 64, slabs, r3.c1w, 64, 0, r3.c1b, NSLAB));
-    TDM_TRY(dgrad1(st, 14, B, w.dh3, 64, 9, P + r3.c1w, 64, w.dout3, w.dout2));  // + identity skip
+    TDM_TRY(dgrad1(st, w, 14, B, w.dh3, 64, 9, P + r3.c1w, W_RB3C1, 64, w.dout3, w.dout2));  // + identity skip
     // ---- rb2 ----
     TDM_TRY(tdm_launch_relu_mask(w.dout2, w.a2_2, w.dc2_2, M14 * 64, st));
     TDM_TRY(wgrad(st, 14, B, w.a1_2, 64, 64, 0, w.tb + 32, 9, w.dc2_2, 64, slabs, r2.c2w, 64, 0, r2.c2b, NSLAB));
-    TDM_TRY(dgrad1(st, 14, B, w.dc2_2, 64, 9, P + r2.c2w, 64, nullptr, w.dh2));
+    TDM_TRY(dgrad1(st, w, 14, B, w.dc2_2, 64, 9, P + r2.c2w, W_RB2C2, 64, nullptr, w.dh2));
     TDM_TRY(tdm_launch_relu_bwd_tb(w.dh2, w.a1_2, w.S, B, 196, 64, st));
     TDM_TRY(tdm_launch_time_grad(w.S, w.that, G + r2.tew, G + r2.teb, B, 64, st));
     TDM_TRY(wgrad(st, 14, B, w.p1, 32, 32, 0, nullptr, 9, w.dh2, 64, slabs, r2.c1w, 32, 0, r2.c1b, NSLAB));
@@ -213,16 +259,16 @@ int unet_backward(const float* P, const float* x, const float* deps, float* G, c
     {
         ConvArgs a{};
         a.nsrc = 2;
-        a.src[0] = mk_src(w.dh2, 64, 0, 64, 0, 9, P + r2.c1w, 32, 0, 64);
-        a.src[1] = mk_src(w.dout2, 64, 0, 64, 0, 1, P + r2.skw, 32, 0, 64);
+        a.src[0] = mk_src(w.dh2, 64, 0, 64, 0, 9, P + r2.c1w, 32, 0, 64, nullptr, w.wpack + kPack.dg[W_RB2C1], 0);
+        a.src[1] = mk_src(w.dout2, 64, 0, 64, 0, 1, P + r2.skw, 32, 0, 64, nullptr, w.wpack + kPack.dg[W_RB2SK], 0);
         a.out = w.dp1; a.B = B;
-        TDM_TRY(tdm_launch_conv(a, 14, 32, true, st));
+        TDM_TRY(launch_conv_any(a, 14, 32, true, st));
     }
     TDM_TRY(tdm_launch_combine_dh1(w.dcat, w.dp1, w.dout1, B, st));
     // ---- rb1 ----
     TDM_TRY(tdm_launch_relu_mask(w.dout1, w.a2_1, w.dc2_1, M28 * 32, st));
     TDM_TRY(wgrad(st, 28, B, w.a1_1, 32, 32, 0, w.tb + 0, 9, w.dc2_1, 32, slabs, r1.c2w, 32, 0, r1.c2b, NSLAB));
-    TDM_TRY(dgrad1(st, 28, B, w.dc2_1, 32, 9, P + r1.c2w, 32, nullptr, w.dh1));
+    TDM_TRY(dgrad1(st, w, 28, B, w.dc2_1, 32, 9, P + r1.c2w, W_RB1C2, 32, nullptr, w.dh1));
     TDM_TRY(tdm_launch_relu_bwd_tb(w.dh1, w.a1_1, w.S, B, 784, 32, st));
     TDM_TRY(tdm_launch_time_grad(w.S, w.that, G + r1.tew, G + r1.teb, B, 32, st));
     TDM_TRY(tdm_launch_first_wgrad(x, w.dh1, w.dout1, slabs, TDM_UNET_NPARAM, r1.c1w, r1.c1b, r1.skw, r1.skb, B, NSLAB, st));
@@ -311,6 +357,39 @@ int tdm_unet_p_sample_step_f32(const float* params, const float* x, const int64_
                                    B * 784, stream);
 }
 
+int tdm_set_conv_mode(int mode) {
+    TDM_REQUIRE(mode == 0 || mode == 1, "conv mode %d (0 = fp32 MFMA, 1 = bf16x3 split MFMA)", mode);
+    g_conv_mode = mode;
+    return 0;
+}
+int tdm_get_conv_mode(void) { return g_conv_mode; }
+
+// generic conv through the bf16x3 kernel: scratch >= ksize*ksize*Cin*Cout floats (packed hi/lo weights)
+int tdm_conv_nhwc_bf16x3_f32(const float* in, const float* w, const float* bias, const float* res, const float* tb,
+                             float* out, float* aux_relu_out, float* scratch, int64_t B, int HW, int Cin, int Cout,
+                             int ksize, int flags, void* stream) {
+    TDM_CHECK_B(B);
+    TDM_REQUIRE(ksize == 3 || ksize == 1, "conv: ksize %d", ksize);
+    TDM_REQUIRE(scratch != nullptr, "conv_bf16x3: scratch is NULL");
+    const bool dgrad = (flags & 2) != 0;
+    const int taps = ksize * ksize;
+    // forward weight tensor is [taps][wcin][wcout]; for dgrad the call's (Cin, Cout) are (wcout, wcin)
+    const int wcin = dgrad ? Cout : Cin, wcout = dgrad ? Cin : Cout;
+    PackArgs pa{};
+    pa.n = 1;
+    pa.d[0].src_off = 0; pa.d[0].cin = wcin; pa.d[0].cout = wcout; pa.d[0].taps = taps; pa.d[0].dgrad = dgrad ? 1 : 0;
+    pa.d[0].dst_off = 0;
+    unsigned short* wp = reinterpret_cast<unsigned short*>(scratch);
+    TDM_TRY(tdm_launch_pack(w, pa, wp, (hipStream_t)stream));
+    ConvArgs a{};
+    a.nsrc = 1;
+    a.src[0] = mk_src(in, Cin, 0, Cin, 0, taps, w, 0, 0, 0, tb, wp, 0);
+    a.src[0].tb_stride = Cin;
+    a.bias = bias; a.res = res; a.out = out; a.aux = aux_relu_out; a.relu = flags & 1; a.B = (int)B;
+    a.ablate = (flags >> 8) & 15;   // timing diagnostics only (results are wrong when set)
+    return tdm_launch_conv_bf16(a, HW, Cout, (hipStream_t)stream);
+}
+
 // ---- per-layer entry points ----------------------------------------------------
 int tdm_conv_nhwc_f32(const float* in, const float* w, const float* bias, const float* res, const float* tb, float* out,
                       float* aux_relu_out, int64_t B, int HW, int Cin, int Cout, int ksize, int flags, void* stream) {
@@ -342,7 +421,8 @@ int tdm_conv_wgrad_nhwc_f32(const float* in, const float* tb, const float* dout,
     a.g = dout; a.Cout = Cout; a.slab = slabs; a.slab_stride = stride; a.w_off = 0; a.b_off = wlen; a.B = (int)B;
     a.ntiles = (int)(((long)B * HW * HW + 255) / 256);
     a.nci = Cin / 32;
-    TDM_TRY(tdm_launch_wgrad(a, HW, nslab, (hipStream_t)stream));
+    if (g_conv_mode == 1) TDM_TRY(tdm_launch_wgrad_bf16(a, HW, nslab, (hipStream_t)stream));
+    else TDM_TRY(tdm_launch_wgrad(a, HW, nslab, (hipStream_t)stream));
     ReduceArgs ra{};
     ra.nsec = 1;
     ra.sec[0].off = 0; ra.sec[0].len = wlen + Cout; ra.sec[0].nslab = nslab;
