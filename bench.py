@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--sample-steps", type=int, default=20, help="reverse steps timed at B=4096 (0 = skip)")
+    ap.add_argument("--text-steps", type=int, default=10, help="text-denoiser train steps timed (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-mode", type=int, default=1, choices=[0, 1],
                     help="UNet conv arithmetic: 1 = bf16x3 split MFMA (default), 0 = exact fp32 MFMA")
@@ -199,6 +200,35 @@ def main():
                            "imgs_per_s_1000_step": round(world * B_SAMPLE / (ms_rev * 1e-3 * 1000), 2),
                            "tflops": round(FWD_FLOP_PER_SAMPLE * B_SAMPLE / (ms_rev * 1e-3) / 1e12, 2)}
         del xs
+
+    # ---- text denoiser train step (configs[4] shape: B=256/GPU, L=128, D=256; dropout 0) ----
+    if args.text_steps > 0:
+        from tinydiffusionmodels_amd.shakespeare import TinyTransformer, DenoiserTrainer
+        Bt, Lt, Dt = 256, 128, 256
+        torch.manual_seed(0)
+        tmodel = TinyTransformer(Dt, dropout=0.0).to(dev)
+        tmodel.train()
+        xt = torch.randn(Bt, Lt, Dt, device=dev, generator=torch.Generator(device=dev).manual_seed(7 + rank)) * 0.02
+        ttr = DenoiserTrainer(tmodel, Bt, Lt, lr=1e-4, weight_decay=1e-4)
+        for _ in range(3):
+            ttr.step(xt)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.text_steps):
+            ttr.step(xt)
+        sync()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = tt.item()
+        ms_t = 1e3 * el / args.text_steps
+        tflop = 3 * 8_257_536 * Bt * Lt / (ms_t * 1e-3) / 1e12      # 8,257,536 FLOP/token fwd, x3 train
+        out["text_denoiser"] = {"batch_per_gpu": Bt, "seq_len": Lt, "dim": Dt, "ms_per_step": round(ms_t, 3),
+                                "steps_per_s": round(world * 1e3 / ms_t, 2),
+                                "tokens_per_s": round(world * Bt * Lt * 1e3 / ms_t, 0), "tflops": round(tflop, 2),
+                                "arithmetic": "fp32 MFMA GEMMs (exact); dropout 0"}
+        del ttr, tmodel, xt
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -311,3 +311,13 @@ def rel_err(a: torch.Tensor, ref: torch.Tensor) -> float:
     a = a.detach().double().cpu()
     ref = ref.detach().double().cpu()
     return float((a - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def rel_l2(a: torch.Tensor, ref: torch.Tensor) -> float:
+    """||a-ref||_2 / ||ref||_2.  Used for gradients of ReLU networks: a single
+    ReLU-mask flip (a pre-activation within rounding distance of zero, which even
+    the CPU reference does not reproduce run to run under multi-threaded GEMMs)
+    moves a few entries by O(1/sqrt(#samples)) in max-norm but barely in L2."""
+    a = a.detach().double().cpu().reshape(-1)
+    ref = ref.detach().double().cpu().reshape(-1)
+    return float((a - ref).norm() / ref.norm().clamp_min(1e-30))

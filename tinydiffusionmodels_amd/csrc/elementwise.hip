@@ -338,17 +338,28 @@ __global__ __launch_bounds__(EW_BLOCK) void relu_bwd_tb_kernel(float* __restrict
     }
 }
 
-// d_tw[c] = sum_b that[b]*S[b][c]; d_tb[c] = sum_b S[b][c]   (single block)
-__global__ __launch_bounds__(EW_BLOCK) void time_grad_kernel(const float* __restrict__ S, const float* __restrict__ that,
-                                                             float* __restrict__ d_tw, float* __restrict__ d_tb, int B,
-                                                             int C) {
+// d_tw[c] = sum_b that[b]*S[b][c]; d_tb[c] = sum_b S[b][c].  One block per job (layer):
+// 256 threads = (256/C) batch slices x C channels, 8 independent loads in flight per thread.
+struct TimeGradJobs { const float* S[4]; float* d_tw[4]; float* d_tb[4]; int C[4]; int n; };
+__global__ __launch_bounds__(EW_BLOCK) void time_grad_kernel(TimeGradJobs jb, const float* __restrict__ that, int B) {
     __shared__ float shw[EW_BLOCK], shb[EW_BLOCK];
+    const int job = blockIdx.x;
+    const float* __restrict__ S = jb.S[job];
+    const int C = jb.C[job];
     const int c = threadIdx.x % C, g = threadIdx.x / C, ng = EW_BLOCK / C;
     float aw = 0.f, ab = 0.f;
-    for (int b = g; b < B; b += ng) {
-        const float s = S[(int64_t)b * C + c];
-        aw += that[b] * s;
-        ab += s;
+    int b = g;
+    for (; b + 7 * ng < B; b += 8 * ng) {
+        float sv[8], tv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { sv[u] = S[(int64_t)(b + u * ng) * C + c]; tv[u] = that[b + u * ng]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { aw += tv[u] * sv[u]; ab += sv[u]; }
+    }
+    for (; b < B; b += ng) {
+        const float sv = S[(int64_t)b * C + c];
+        aw += that[b] * sv;
+        ab += sv;
     }
     shw[threadIdx.x] = aw;
     shb[threadIdx.x] = ab;
@@ -356,8 +367,8 @@ __global__ __launch_bounds__(EW_BLOCK) void time_grad_kernel(const float* __rest
     if (threadIdx.x < C) {
         float sw = 0.f, sb = 0.f;
         for (int k = 0; k < ng; ++k) { sw += shw[k * C + threadIdx.x]; sb += shb[k * C + threadIdx.x]; }
-        d_tw[threadIdx.x] = sw;
-        d_tb[threadIdx.x] = sb;
+        jb.d_tw[job][threadIdx.x] = sw;
+        jb.d_tb[job][threadIdx.x] = sb;
     }
 }
 
@@ -416,12 +427,10 @@ __global__ __launch_bounds__(EW_BLOCK) void first_wgrad_kernel(const float* __re
     float acc[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = 0.f;
-    for (int64_t p = p0 + g; p < p1; p += 8) {
+    auto one = [&](int64_t p, float d1, float d2) {
         const int b = (int)(p / 784);
         const int rem = (int)(p - (int64_t)b * 784);
         const int y = rem / 28, xx = rem - y * 28;
-        const float d1 = dc1[p * 32 + c];
-        const float d2 = dout1[p * 32 + c];
         float xc = 0.f;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -434,7 +443,16 @@ __global__ __launch_bounds__(EW_BLOCK) void first_wgrad_kernel(const float* __re
         acc[9] += d1;
         acc[10] = fmaf(xc, d2, acc[10]);
         acc[11] += d2;
+    };
+    int64_t p = p0 + g;
+    for (; p + 24 < p1; p += 32) {   // 4 pixels per trip: the 8 gradient loads are independent
+        float d1[4], d2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { d1[u] = dc1[(p + 8 * u) * 32 + c]; d2[u] = dout1[(p + 8 * u) * 32 + c]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(p + 8 * u, d1[u], d2[u]);
     }
+    for (; p < p1; p += 8) one(p, dc1[p * 32 + c], dout1[p * 32 + c]);
 #pragma unroll
     for (int k = 0; k < 12; ++k) sh[g][k][c] = acc[k];
     __syncthreads();
@@ -527,7 +545,22 @@ int tdm_launch_relu_bwd_tb(float* dh, const float* a1, float* S, int B, int HWpi
     return 0;
 }
 int tdm_launch_time_grad(const float* S, const float* that, float* d_tw, float* d_tb, int B, int C, hipStream_t st) {
-    hipLaunchKernelGGL(time_grad_kernel, dim3(1), dim3(EW_BLOCK), 0, st, S, that, d_tw, d_tb, B, C);
+    const float* Sv[1] = {S};
+    float* tw[1] = {d_tw};
+    float* tbv[1] = {d_tb};
+    const int Cv[1] = {C};
+    return tdm_launch_time_grad_multi(Sv, tw, tbv, Cv, 1, that, B, st);
+}
+int tdm_launch_time_grad_multi(const float* const* S, float* const* d_tw, float* const* d_tb, const int* C, int n,
+                               const float* that, int B, hipStream_t st) {
+    TimeGradJobs jb{};
+    TDM_REQUIRE(n >= 1 && n <= 4, "time_grad: %d jobs", n);
+    for (int i = 0; i < n; ++i) {
+        TDM_REQUIRE(C[i] > 0 && EW_BLOCK % C[i] == 0, "time_grad: C=%d must divide %d", C[i], EW_BLOCK);
+        jb.S[i] = S[i]; jb.d_tw[i] = d_tw[i]; jb.d_tb[i] = d_tb[i]; jb.C[i] = C[i];
+    }
+    jb.n = n;
+    hipLaunchKernelGGL(time_grad_kernel, dim3(n), dim3(EW_BLOCK), 0, st, jb, that, B);
     TDM_CHECK_LAUNCH("time_grad");
     return 0;
 }

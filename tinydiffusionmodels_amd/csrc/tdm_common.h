@@ -116,6 +116,8 @@ int tdm_launch_out_bwd(const float* deps, const float* h4, const float* w, const
 int tdm_launch_relu_mask(const float* dout, const float* a, float* dc, int64_t n, hipStream_t st);
 int tdm_launch_relu_bwd_tb(float* dh, const float* a1, float* S, int B, int HWpix, int C, hipStream_t st);
 int tdm_launch_time_grad(const float* S, const float* that, float* d_tw, float* d_tb, int B, int C, hipStream_t st);
+int tdm_launch_time_grad_multi(const float* const* S, float* const* d_tw, float* const* d_tb, const int* C, int n,
+                               const float* that, int B, hipStream_t st);
 int tdm_launch_split_dcat(const float* dcat, float* dout3, int B, hipStream_t st);
 int tdm_launch_combine_dh1(const float* dcat, const float* dp1, float* dout1, int B, hipStream_t st);
 int tdm_launch_first_wgrad(const float* x, const float* dc1, const float* dout1, float* slab, long slab_stride,

@@ -92,7 +92,7 @@ int g_conv_mode = 1;
 
 // ------------------------------ workspace --------------------------------------
 struct Ws {
-    float *that, *tb, *S, *scratch;
+    float *that, *tb, *S[4], *scratch;
     unsigned short* wpack;
     float *a1_1, *s1, *a2_1, *h1, *p1;
     float *a1_2, *s2, *a2_2, *h2;
@@ -112,7 +112,8 @@ Ws carve(float* base, int64_t B, int training) {
         return p;
     };
     const int64_t M28 = B * 784, M14 = B * 196;
-    w.that = take(B); w.tb = take(B * 192); w.S = take(B * 64); w.scratch = take(2048);
+    w.that = take(B); w.tb = take(B * 192); w.scratch = take(2048);
+    for (int i = 0; i < 4; ++i) w.S[i] = take(B * 64);
     w.wpack = reinterpret_cast<unsigned short*>(take((kPack.total_u16 + 1) / 2));
     w.a1_1 = take(M28 * 32); w.s1 = take(M28 * 32); w.a2_1 = take(M28 * 32); w.h1 = take(M28 * 32);
     w.p1 = take(M14 * 32);
@@ -225,8 +226,7 @@ int unet_backward(const float* P, const float* x, const float* deps, float* G, c
                                kL.outb, M28, NSLAB, st));
     TDM_TRY(wgrad(st, 28, B, w.a1_4, 32, 32, 0, w.tb + 160, 9, w.dc2_4, 32, slabs, r4.c2w, 32, 0, r4.c2b, NSLAB));
     TDM_TRY(dgrad1(st, w, 28, B, w.dc2_4, 32, 9, P + r4.c2w, W_RB4C2, 32, nullptr, w.dh4));
-    TDM_TRY(tdm_launch_relu_bwd_tb(w.dh4, w.a1_4, w.S, B, 784, 32, st));  // dh4 <- d(conv1 pre-activation)
-    TDM_TRY(tdm_launch_time_grad(w.S, w.that, G + r4.tew, G + r4.teb, B, 32, st));
+    TDM_TRY(tdm_launch_relu_bwd_tb(w.dh4, w.a1_4, w.S[3], B, 784, 32, st));  // dh4 <- d(conv1 pre-activation)
     TDM_TRY(wgrad(st, 28, B, w.h3, 64, 64, 1, nullptr, 9, w.dh4, 32, slabs, r4.c1w, 96, 0, r4.c1b, NSLAB));
     TDM_TRY(wgrad(st, 28, B, w.h1, 32, 32, 0, nullptr, 9, w.dh4, 32, slabs, r4.c1w, 96, 64, -1, NSLAB));
     TDM_TRY(wgrad(st, 28, B, w.h3, 64, 64, 1, nullptr, 1, w.dout4, 32, slabs, r4.skw, 96, 0, r4.skb, NSLAB));
@@ -244,16 +244,14 @@ int unet_backward(const float* P, const float* x, const float* deps, float* G, c
     TDM_TRY(tdm_launch_relu_mask(w.dout3, w.a2_3, w.dc2_3, M14 * 64, st));
     TDM_TRY(wgrad(st, 14, B, w.a1_3, 64, 64, 0, w.tb + 96, 9, w.dc2_3, 64, slabs, r3.c2w, 64, 0, r3.c2b, NSLAB));
     TDM_TRY(dgrad1(st, w, 14, B, w.dc2_3, 64, 9, P + r3.c2w, W_RB3C2, 64, nullptr, w.dh3));
-    TDM_TRY(tdm_launch_relu_bwd_tb(w.dh3, w.a1_3, w.S, B, 196, 64, st));
-    TDM_TRY(tdm_launch_time_grad(w.S, w.that, G + r3.tew, G + r3.teb, B, 64, st));
+    TDM_TRY(tdm_launch_relu_bwd_tb(w.dh3, w.a1_3, w.S[2], B, 196, 64, st));
     TDM_TRY(wgrad(st, 14, B, w.h2, 64, 64, 0, nullptr, 9, w.dh3, 64, slabs, r3.c1w, 64, 0, r3.c1b, NSLAB));
     TDM_TRY(dgrad1(st, w, 14, B, w.dh3, 64, 9, P + r3.c1w, W_RB3C1, 64, w.dout3, w.dout2));  // + identity skip
     // ---- rb2 ----
     TDM_TRY(tdm_launch_relu_mask(w.dout2, w.a2_2, w.dc2_2, M14 * 64, st));
     TDM_TRY(wgrad(st, 14, B, w.a1_2, 64, 64, 0, w.tb + 32, 9, w.dc2_2, 64, slabs, r2.c2w, 64, 0, r2.c2b, NSLAB));
     TDM_TRY(dgrad1(st, w, 14, B, w.dc2_2, 64, 9, P + r2.c2w, W_RB2C2, 64, nullptr, w.dh2));
-    TDM_TRY(tdm_launch_relu_bwd_tb(w.dh2, w.a1_2, w.S, B, 196, 64, st));
-    TDM_TRY(tdm_launch_time_grad(w.S, w.that, G + r2.tew, G + r2.teb, B, 64, st));
+    TDM_TRY(tdm_launch_relu_bwd_tb(w.dh2, w.a1_2, w.S[1], B, 196, 64, st));
     TDM_TRY(wgrad(st, 14, B, w.p1, 32, 32, 0, nullptr, 9, w.dh2, 64, slabs, r2.c1w, 32, 0, r2.c1b, NSLAB));
     TDM_TRY(wgrad(st, 14, B, w.p1, 32, 32, 0, nullptr, 1, w.dout2, 64, slabs, r2.skw, 32, 0, r2.skb, NSLAB));
     {
@@ -269,8 +267,14 @@ int unet_backward(const float* P, const float* x, const float* deps, float* G, c
     TDM_TRY(tdm_launch_relu_mask(w.dout1, w.a2_1, w.dc2_1, M28 * 32, st));
     TDM_TRY(wgrad(st, 28, B, w.a1_1, 32, 32, 0, w.tb + 0, 9, w.dc2_1, 32, slabs, r1.c2w, 32, 0, r1.c2b, NSLAB));
     TDM_TRY(dgrad1(st, w, 28, B, w.dc2_1, 32, 9, P + r1.c2w, W_RB1C2, 32, nullptr, w.dh1));
-    TDM_TRY(tdm_launch_relu_bwd_tb(w.dh1, w.a1_1, w.S, B, 784, 32, st));
-    TDM_TRY(tdm_launch_time_grad(w.S, w.that, G + r1.tew, G + r1.teb, B, 32, st));
+    TDM_TRY(tdm_launch_relu_bwd_tb(w.dh1, w.a1_1, w.S[0], B, 784, 32, st));
+    {   // gradients of the four time_emb Linear(1,C) layers in one launch
+        const float* Sv[4] = {w.S[0], w.S[1], w.S[2], w.S[3]};
+        float* tw[4] = {G + r1.tew, G + r2.tew, G + r3.tew, G + r4.tew};
+        float* tbv[4] = {G + r1.teb, G + r2.teb, G + r3.teb, G + r4.teb};
+        const int Cv[4] = {32, 64, 64, 32};
+        TDM_TRY(tdm_launch_time_grad_multi(Sv, tw, tbv, Cv, 4, w.that, B, st));
+    }
     TDM_TRY(tdm_launch_first_wgrad(x, w.dh1, w.dout1, slabs, TDM_UNET_NPARAM, r1.c1w, r1.c1b, r1.skw, r1.skb, B, NSLAB, st));
     // ---- sum the slabs into the flat gradient ----
     ReduceArgs ra{};
