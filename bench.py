@@ -78,8 +78,9 @@ def main():
     ap.add_argument("--sample-steps", type=int, default=20, help="reverse steps timed at B=4096 (0 = skip)")
     ap.add_argument("--text-steps", type=int, default=10, help="text-denoiser train steps timed (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--conv-mode", type=int, default=1, choices=[0, 1],
-                    help="UNet conv arithmetic: 1 = bf16x3 split MFMA (default), 0 = exact fp32 MFMA")
+    ap.add_argument("--conv-mode", type=int, default=2, choices=[0, 1, 2],
+                    help="UNet conv arithmetic: 2 = bf16x3 split MFMA over pre-split tensors (default), "
+                         "1 = bf16x3 splitting while staging, 0 = exact fp32 MFMA")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -161,11 +162,16 @@ def main():
         yout = torch.empty(B_TRAIN, hw, hw, cout, device=dev)
 
         scratch = torch.empty(9 * cin * cout, device=dev)
+        scratch2 = torch.empty(9 * cin * cout + B_TRAIN * hw * hw * cin + 128, device=dev)
 
         def run_conv():
             if args.conv_mode == 0:
                 _lib.check(L.tdm_conv_nhwc_f32(_lib.ptr(xin), _lib.ptr(w), _lib.ptr(bias), None, None, _lib.ptr(yout),
                                                None, B_TRAIN, hw, cin, cout, 3, 1, _lib.stream()))
+            elif args.conv_mode == 2:
+                _lib.check(L.tdm_conv_nhwc_s16_f32(_lib.ptr(xin), _lib.ptr(w), _lib.ptr(bias), None, None,
+                                                   _lib.ptr(yout), None, None, None, _lib.ptr(scratch2), B_TRAIN, hw,
+                                                   cin, cout, 3, 1, _lib.stream()))
             else:
                 _lib.check(L.tdm_conv_nhwc_bf16x3_f32(_lib.ptr(xin), _lib.ptr(w), _lib.ptr(bias), None, None,
                                                       _lib.ptr(yout), None, _lib.ptr(scratch), B_TRAIN, hw, cin, cout,

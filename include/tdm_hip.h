@@ -128,10 +128,14 @@ int tdm_conv_nhwc_f32(const float* in, const float* w, const float* bias, const 
 int tdm_conv_wgrad_nhwc_f32(const float* in, const float* tb, const float* dout, float* dw, float* db,
                             float* slabs, int64_t B, int HW, int Cin, int Cout, int ksize, void* stream);
 
-/* Arithmetic of the UNet's MFMA convolutions (forward and data gradient):
+/* Arithmetic of the UNet's MFMA convolutions (forward, data and weight gradient):
  *   0  exact fp32 (v_mfma_f32_32x32x2_f32, bitwise an fp32 fmaf chain)
  *   1  bf16x3 split operands on v_mfma_f32_32x32x16_bf16 (hi*hi + hi*lo + lo*hi,
- *      fp32 accumulate; ~1e-5 relative, 3/16 of the fp32 MFMA cycles) — default */
+ *      fp32 accumulate; ~1e-5 relative, 3/16 of the fp32 MFMA cycles); fp32
+ *      tensors are split while staging
+ *   2  same arithmetic over pre-split "S16" tensors (bf16 hi/lo per 16-channel
+ *      group, same 4 B/element) that the producing kernels write — loaders are
+ *      plain 16-byte copies — default                                          */
 int tdm_set_conv_mode(int mode);
 int tdm_get_conv_mode(void);
 /* same contract as tdm_conv_nhwc_f32 through the bf16x3 kernel;
@@ -139,6 +143,19 @@ int tdm_get_conv_mode(void);
 int tdm_conv_nhwc_bf16x3_f32(const float* in, const float* w, const float* bias, const float* res,
                              const float* tb, float* out, float* aux_relu_out, float* scratch,
                              int64_t B, int HW, int Cin, int Cout, int ksize, int flags, void* stream);
+
+/* per-layer entry points of the S16 pipeline (tests / profiling): the fp32 input is
+ * pre-split into scratch first.  conv: scratch >= k*k*Cin*Cout + B*HW*HW*Cin + 64 floats;
+ * out_s16 (optional, S16 layout: every 16-channel group = 16 bf16 hi then 16 bf16 lo)
+ * receives split(result + tb_out[b][c]).  wgrad: dw only;
+ * scratch >= B*HW*HW*(Cin+Cout) + 65*k*k*Cin*Cout + 128 floats.                         */
+int tdm_conv_nhwc_s16_f32(const float* in, const float* w, const float* bias, const float* res,
+                          const float* tb, float* out, float* aux_relu_out, float* out_s16,
+                          const float* tb_out, float* scratch, int64_t B, int HW, int Cin, int Cout,
+                          int ksize, int flags, void* stream);
+int tdm_conv_wgrad_nhwc_s16_f32(const float* in, const float* tb, const float* dout, float* dw,
+                                float* scratch, int64_t B, int HW, int Cin, int Cout, int ksize,
+                                void* stream);
 
 /* ---- a8-a10: TinyTransformer embedding-space denoiser (src/shakespeare.py:105-120) ----
  * x (B,L,D) fp32, t (B,) int64; post-LN encoder layers (packed in_proj, H heads,

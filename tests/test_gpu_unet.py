@@ -65,14 +65,22 @@ def pinned_tables(golden_tables):
     schedule.set_tables(None)
 
 
-@pytest.fixture(scope="module", autouse=True, params=[1, 0], ids=["bf16x3", "fp32"])
+@pytest.fixture(scope="module", autouse=True, params=[2, 1, 0], ids=["bf16x3-s16", "bf16x3", "fp32"])
 def conv_mode(request):
     """Run every test of this module under both conv arithmetics (include/tdm_hip.h: tdm_set_conv_mode)."""
     from tinydiffusionmodels_amd import _lib
     L = _lib.lib()
     _lib.check(L.tdm_set_conv_mode(request.param))
     yield request.param
-    _lib.check(L.tdm_set_conv_mode(1))
+    _lib.check(L.tdm_set_conv_mode(2))
+
+
+def _s16_decode(t):
+    """S16 tensor (bytes of a float32 tensor [..., C]) -> float32 hi+lo values [..., C]."""
+    C = t.shape[-1]
+    u = t.contiguous().view(torch.int16).view(*t.shape[:-1], C // 16, 2, 16).to(torch.int32)   # [.., group, hi/lo, 16]
+    f = (u.to(torch.int64) << 16).to(torch.int32).view(torch.float32)     # bf16 bits -> fp32
+    return (f[..., 0, :] + f[..., 1, :]).reshape(*t.shape[:-1], C)
 
 
 @pytest.fixture(scope="module")
@@ -134,10 +142,20 @@ def _run_conv(lib, conv_mode, dev, args, scratch_floats, B, hw, cin, cout, k, fl
     from tinydiffusionmodels_amd import _lib
     if conv_mode == 0:
         _lib.check(lib.tdm_conv_nhwc_f32(*[_lib.ptr(a) for a in args], B, hw, cin, cout, k, flags, _lib.stream()))
-    else:
+    elif conv_mode == 1:
         scratch = torch.empty(scratch_floats, device=dev)
         _lib.check(lib.tdm_conv_nhwc_bf16x3_f32(*[_lib.ptr(a) for a in args], _lib.ptr(scratch), B, hw, cin, cout, k,
                                                 flags, _lib.stream()))
+    else:   # S16 pipeline: also returns the pre-split copy of (result + tb_out)
+        scratch = torch.empty(scratch_floats + B * hw * hw * cin + 128, device=dev)
+        out_s16 = torch.zeros(B, hw, hw, cout, device=dev)
+        tb_out = torch.linspace(-1, 1, B * cout, device=dev).view(B, cout).contiguous()
+        _lib.check(lib.tdm_conv_nhwc_s16_f32(*[_lib.ptr(a) for a in args], _lib.ptr(out_s16), _lib.ptr(tb_out),
+                                             _lib.ptr(scratch), B, hw, cin, cout, k, flags, _lib.stream()))
+        torch.cuda.synchronize()
+        dec = _s16_decode(out_s16.cpu())
+        want = args[5].cpu() + tb_out.cpu()[:, None, None, :]
+        assert O.rel_err(dec, want) < 2e-5          # hi+lo keeps 16 mantissa bits: 2^-17 relative
     torch.cuda.synchronize()
 
 
@@ -197,6 +215,13 @@ def test_conv_wgrad_layer(dev, lib, conv_mode, hw, cin, cout, k, B):
     y.backward(dy)
     dw = torch.empty(k, k, cin, cout, device=dev)
     db = torch.empty(cout, device=dev)
+    if conv_mode == 2:
+        scratch = torch.empty(B * hw * hw * (cin + cout) + 65 * k * k * cin * cout + 256, device=dev)
+        args = [_nhwc(x).to(dev), tb.to(dev), _nhwc(dy).to(dev), dw, scratch]
+        _lib.check(lib.tdm_conv_wgrad_nhwc_s16_f32(*[_lib.ptr(a) for a in args], B, hw, cin, cout, k, _lib.stream()))
+        torch.cuda.synchronize()
+        assert O.rel_err(dw.cpu().permute(3, 2, 0, 1), w.grad) < 5e-5
+        return
     slabs = torch.empty(65 * (k * k * cin * cout + cout), device=dev)
     args = [_nhwc(x).to(dev), tb.to(dev), _nhwc(dy).to(dev), dw, db, slabs]
     _lib.check(lib.tdm_conv_wgrad_nhwc_f32(*[_lib.ptr(a) for a in args], B, hw, cin, cout, k, _lib.stream()))

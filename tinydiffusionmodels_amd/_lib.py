@@ -43,6 +43,8 @@ _SIGS = {
     "tdm_get_conv_mode": ([], c_int),
     "tdm_conv_nhwc_bf16x3_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int, c_int, c_f],
                                  c_int),
+    "tdm_conv_nhwc_s16_f32": ([c_f] * 10 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_f], c_int),
+    "tdm_conv_wgrad_nhwc_s16_f32": ([c_f] * 5 + [c_i64, c_int, c_int, c_int, c_int, c_f], c_int),
     "tdm_tt_param_count": ([c_int, c_int, c_int], c_i64),
     "tdm_tt_param_offsets": ([c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int64)], c_int),
     "tdm_tt_workspace_floats": ([c_i64, c_int, c_int, c_int, c_int, c_int, c_int], c_i64),

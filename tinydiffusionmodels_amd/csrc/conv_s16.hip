@@ -1,0 +1,427 @@
+// bf16x3 implicit-GEMM convolution, transposed convolution and weight gradient
+// over PRE-SPLIT ("S16", tdm_s16.h) activations — the loader-light form of
+// conv_bf16.hip.  Same padded-tall tiling, same packed weights
+// (pack_weights_kernel), same arithmetic (hi*hi + hi*lo + lo*hi, fp32
+// accumulate on v_mfma_f32_32x32x16_bf16); what changes:
+//   * staging a K chunk is a 16-byte copy per piece (the S16 group of a pixel is
+//     already [hi 32 B | lo 32 B], exactly the LDS pixel image);
+//   * the MFMA operand roles are swapped (weights = A rows, pixels = B columns),
+//     so each lane ends up with 4 consecutive output channels per register
+//     quad of ITS pixel: float4 epilogue loads/stores and 8-byte S16 stores;
+//   * one MFMA site per tap: a 1x1 source runs through the centre-tap site, so
+//     the accumulators never need moving between alternative code paths;
+//   * bias gradients are no longer the weight-gradient kernel's job (the
+//     producers of the gradient tensors sum them in fp32, elementwise.hip).
+#include "tdm_common.h"
+#include "tdm_s16.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int CK = 16;
+constexpr int PIXB = 80;      // bytes per staged pixel: hi 32 | lo 32 | pad 16
+constexpr int TILE_PX = 256;
+
+template <int HW> struct Geo;
+template <> struct Geo<28> { static constexpr int H = 28, W = 28, HP = 30, WP = 30, NR = 15; };
+template <> struct Geo<14> { static constexpr int H = 14, W = 14, HP = 16, WP = 16, NR = 26; };
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+template <int HW>
+__device__ __forceinline__ int padded_row(int m) {
+    using G = Geo<HW>;
+    const int b = m / (G::H * G::W);
+    const int y = (m - b * (G::H * G::W)) / G::W;
+    return b * G::HP + y + 1;
+}
+
+// float offset of staged position `pos` (padded-tall) in source s, or -1 (zero)
+template <int HW>
+__device__ __forceinline__ int src_offset(const ConvSrc& s, int PR0, int pos, int B) {
+    using G = Geo<HW>;
+    const int lr = pos / G::WP;
+    const int pc = pos - lr * G::WP;
+    const int PR = PR0 + lr;
+    const int b = PR / G::HP;
+    const int py = PR - b * G::HP;
+    if (py >= 1 && py <= G::H && pc >= 1 && pc <= G::W && b < B) {
+        const int up = s.up;
+        const int y = (py - 1) >> up, x = (pc - 1) >> up;
+        return ((b * (G::H >> up) + y) * (G::W >> up) + x) * s.C + s.c0;
+    }
+    return -1;
+}
+
+// ---------------------------------------------------------------------------
+// convolution / transposed convolution
+// ---------------------------------------------------------------------------
+template <int HW, int NT>
+__global__ __launch_bounds__(256) void conv_s16_kernel(ConvArgs a) {
+    using G = Geo<HW>;
+    constexpr int N = NT * 32;
+    constexpr int TILE_B = G::NR * G::WP * PIXB;
+    extern __shared__ float4 smem4[];
+    char* tile = reinterpret_cast<char*>(smem4);
+    char* wl = tile + TILE_B;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int Mtot = a.B * G::H * G::W;
+    const int m0 = t * TILE_PX;
+    const int mlast = min(m0 + TILE_PX - 1, Mtot - 1);
+    const int PR0 = padded_row<HW>(m0) - 1;
+    const int nrows = padded_row<HW>(mlast) - PR0 + 2;
+    const int nelem = nrows * G::WP * 4;      // 16-byte pieces of one chunk
+
+    int aoff[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = min(m0 + (wave * 2 + mt) * 32 + j, Mtot - 1);
+        const int b = m / (G::H * G::W);
+        const int rem = m - b * (G::H * G::W);
+        const int y = rem / G::W, x = rem - y * G::W;
+        aoff[mt] = ((b * G::HP + y + 1 - PR0) * G::WP + x + 1) * PIXB + h * 16;
+    }
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    char* const sdst = tile + (tid >> 2) * PIXB + (tid & 3) * 16;
+    for (int si = 0; si < a.nsrc; ++si) {
+        const ConvSrc s = a.src[si];
+        const int taps = s.taps;
+        const int chunk_u16 = taps * NT * 1024;
+        int goff[8];   // per-thread staging plan: identical for every K chunk of this source
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i;
+            goff[i] = (e < nelem) ? src_offset<HW>(s, PR0, e >> 2, a.B) : -2;
+        }
+        for (int kc = 0; kc < s.nch; kc += CK) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (goff[i] != -2) {
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (goff[i] >= 0) v = reinterpret_cast<const uint4*>(s.ptr + goff[i] + kc)[tid & 3];
+                    *reinterpret_cast<uint4*>(sdst + i * (64 * PIXB)) = v;
+                }
+            }
+            {
+                const uint4* src = reinterpret_cast<const uint4*>(s.wp + (long)(s.wchunk0 + (kc >> 4)) * chunk_u16);
+                uint4* dst = reinterpret_cast<uint4*>(wl);
+                const int n16 = taps * NT * 128;
+                for (int e = tid; e < n16; e += 256) dst[e] = src[e];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                if (taps == 9 || tp == 4) {   // a 1x1 source uses the centre-tap site with packed tap 0
+                    const int toff = ((tp / 3 - 1) * G::WP + (tp % 3 - 1)) * PIXB;
+                    const int wt = (taps == 9) ? tp : 0;
+                    bf16x8 ah[2], al[2];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        ah[mt] = *reinterpret_cast<const bf16x8*>(tile + aoff[mt] + toff);
+                        al[mt] = *reinterpret_cast<const bf16x8*>(tile + aoff[mt] + toff + 32);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const char* wb = wl + ((wt * NT + nt) * 2) * 1024 + lane * 16;
+                        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wb);
+                        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wb + 1024);
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {   // D[co][pixel]: weights are the A operand
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al[mt], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[mt], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[mt], acc[mt][nt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // epilogue: lane = pixel j of its M tile; register quad g of N tile nt = channels nt*32 + 8g + 4h .. +3
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = m0 + (wave * 2 + mt) * 32 + j;
+        if (m < Mtot) {
+            const long row = (long)m * N;
+            const float* tbrow = (a.tb_out != nullptr) ? a.tb_out + (long)(m / (G::H * G::W)) * a.tb_out_stride : nullptr;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = nt * 32 + 8 * g + 4 * h;
+                    float4 v = make_float4(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2],
+                                           acc[mt][nt][4 * g + 3]);
+                    if (a.bias != nullptr) {
+                        const float4 bz = *reinterpret_cast<const float4*>(a.bias + c);
+                        v.x += bz.x; v.y += bz.y; v.z += bz.z; v.w += bz.w;
+                    }
+                    if (a.relu) {
+                        v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y;
+                        v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+                    }
+                    if (a.aux != nullptr) *reinterpret_cast<float4*>(a.aux + row + c) = v;
+                    if (a.res != nullptr) {
+                        const float4 rz = *reinterpret_cast<const float4*>(a.res + row + c);
+                        v.x += rz.x; v.y += rz.y; v.z += rz.z; v.w += rz.w;
+                    }
+                    if (a.out != nullptr) *reinterpret_cast<float4*>(a.out + row + c) = v;
+                    if (a.out_s16 != nullptr) {
+                        if (tbrow != nullptr) {
+                            const float4 tz = *reinterpret_cast<const float4*>(tbrow + c);
+                            v.x += tz.x; v.y += tz.y; v.z += tz.z; v.w += tz.w;
+                        }
+                        tdm_store_s16_4(a.out_s16, m, N, c, v);
+                    }
+                }
+        }
+    }
+}
+
+template <int HW, int NT>
+int launch_conv_t(const ConvArgs& a, hipStream_t st) {
+    using G = Geo<HW>;
+    constexpr size_t lds = (size_t)G::NR * G::WP * PIXB + (size_t)9 * NT * 2048;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<HW, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            tdm_set_error("conv_s16: hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+            return 100 + (int)e;
+        }
+        attr_set = true;
+    }
+    const long Mtot = (long)a.B * G::H * G::W;
+    const int ntiles = (int)((Mtot + TILE_PX - 1) / TILE_PX);
+    hipLaunchKernelGGL((conv_s16_kernel<HW, NT>), dim3(ntiles), dim3(256), lds, st, a);
+    TDM_CHECK_LAUNCH("conv_s16");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient  dW[tap][ci][co] = sum_p A[p + tap][ci] * G[p][co]  (A, G are S16)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
+    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1));
+    s16x8 r;
+    r[0] = lo4[0]; r[1] = lo4[1]; r[2] = lo4[2]; r[3] = lo4[3];
+    r[4] = hi4[0]; r[5] = hi4[1]; r[6] = hi4[2]; r[7] = hi4[3];
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int HW>
+__global__ __launch_bounds__(512) void wgrad_s16_kernel(WgradArgs a) {
+    using G = Geo<HW>;
+    constexpr int NPX = G::NR * G::WP;
+    constexpr int APL = NPX * 64;
+    constexpr int GPL = TILE_PX * 64;
+    extern __shared__ float4 smem4[];
+    char* Ahi = reinterpret_cast<char*>(smem4);
+    char* Alo = Ahi + APL;
+    char* Ghi = Alo + APL;
+    char* Glo = Ghi + GPL;
+    int* pixoff = reinterpret_cast<int*>(Glo + GPL);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ci_tile = blockIdx.y % a.nci, co_tile = blockIdx.y / a.nci;
+    const int ci0 = ci_tile * 32, co0 = co_tile * 32;
+    const int Mtot = a.B * G::H * G::W;
+    const int taps = a.a.taps;
+    const ConvSrc& s = a.a;
+    const int g4 = lane >> 4, cb = g4 & 1, hh = g4 >> 1, q = (lane >> 2) & 3, pcq = lane & 3;
+    const int colb = (cb * 16 + pcq * 4) * 2;
+    // staging role: piece8 = tid & 7 -> 16-channel group (piece8 >> 2), 16-byte piece of the group (piece8 & 3:
+    // 0,1 = hi halves, 2,3 = lo halves); destination plane / offset inside a 64-byte pixel row
+    const int piece8 = tid & 7, grp = piece8 >> 2, pq = piece8 & 3;
+    const int dcol = grp * 32 + (pq & 1) * 16;
+    const bool to_lo = pq >= 2;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+    for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+        const int m0 = t * TILE_PX;
+        const int mlast = min(m0 + TILE_PX - 1, Mtot - 1);
+        const int PR0 = padded_row<HW>(m0) - 1;
+        const int nrows = padded_row<HW>(mlast) - PR0 + 2;
+        __syncthreads();
+        if (tid < TILE_PX) {
+            const int m = min(m0 + tid, Mtot - 1);
+            const int b = m / (G::H * G::W);
+            const int rem = m - b * (G::H * G::W);
+            const int y = rem / G::W, x = rem - y * G::W;
+            pixoff[tid] = (b * G::HP + y + 1 - PR0) * G::WP + x + 1;
+        }
+        {
+            char* const ad = (to_lo ? Alo : Ahi) + dcol;
+            const int nelem = nrows * G::WP * 8;
+#pragma unroll
+            for (int i = 0; i < (NPX * 8 + 511) / 512; ++i) {
+                const int e = tid + 512 * i;
+                if (e < nelem) {
+                    const int pos = e >> 3;
+                    const int go = src_offset<HW>(s, PR0, pos, a.B);
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (go >= 0) v = reinterpret_cast<const uint4*>(s.ptr + go + ci0 + grp * 16)[pq];
+                    *reinterpret_cast<uint4*>(ad + pos * 64) = v;
+                }
+            }
+            char* const gd = (to_lo ? Glo : Ghi) + dcol;
+#pragma unroll
+            for (int i = 0; i < TILE_PX * 8 / 512; ++i) {
+                const int px = (tid + 512 * i) >> 3;
+                const int m = m0 + px;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (m < Mtot) v = reinterpret_cast<const uint4*>(a.g + (long)m * a.Cout + co0 + grp * 16)[pq];
+                *reinterpret_cast<uint4*>(gd + px * 64) = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int p0 = wave * 32 + ks * 16 + hh * 8 + q;
+            const int gb0 = p0 * 64 + colb, gb1 = (p0 + 4) * 64 + colb;
+            const bf16x8 gh = tr_pair(Ghi + gb0, Ghi + gb1);
+            const bf16x8 gl = tr_pair(Glo + gb0, Glo + gb1);
+            const int ab0 = pixoff[p0] * 64 + colb, ab1 = pixoff[p0 + 4] * 64 + colb;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                if (taps == 9 || tp == 4) {
+                    const int to = ((tp / 3 - 1) * G::WP + (tp % 3 - 1)) * 64;
+                    const bf16x8 ah = tr_pair(Ahi + ab0 + to, Ahi + ab1 + to);
+                    const bf16x8 al = tr_pair(Alo + ab0 + to, Alo + ab1 + to);
+                    acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh, acc[tp], 0, 0, 0);
+                    acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl, acc[tp], 0, 0, 0);
+                    acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh, acc[tp], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    float* red = reinterpret_cast<float*>(smem4);   // 8 waves x 1024 floats
+    float* slab = a.slab + (long)blockIdx.x * a.slab_stride;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+        if (taps == 9 || tp == 4) {
+            const int wt = (taps == 9) ? tp : 0;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[tp][r];
+            __syncthreads();
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const int idx = tid + 512 * k2;
+                float sum = 0.f;
+#pragma unroll
+                for (int w8 = 0; w8 < 8; ++w8) sum += red[w8 * 1024 + idx];
+                const int r = idx >> 6, ln = idx & 63;
+                const int ci = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+                const int co = ln & 31;
+                slab[a.w_off + (long)(wt * a.a.w_rows + a.a.w_r0 + ci0 + ci) * a.Cout + co0 + co] = sum;
+            }
+        }
+    }
+}
+
+template <int HW>
+int launch_wgrad_t(const WgradArgs& a, int nslab, hipStream_t st) {
+    using G = Geo<HW>;
+    constexpr size_t lds = (size_t)2 * G::NR * G::WP * 64 + (size_t)2 * TILE_PX * 64 + TILE_PX * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_s16_kernel<HW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            tdm_set_error("wgrad_s16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return 100 + (int)e;
+        }
+        attr_set = true;
+    }
+    const int nco = a.Cout / 32;
+    hipLaunchKernelGGL((wgrad_s16_kernel<HW>), dim3(nslab, a.nci * nco), dim3(512), lds, st, a);
+    TDM_CHECK_LAUNCH("wgrad_s16");
+    return 0;
+}
+
+// out_s16[m][c] = split(in[m][c] + tb[b][c])   (generic entry points / tests)
+__global__ __launch_bounds__(256) void to_s16_kernel(const float* __restrict__ in, const float* __restrict__ tb,
+                                                     int tb_stride, float* __restrict__ out, long M, int HWpix, int C) {
+    const int C4 = C >> 2;
+    const long total = M * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / C4;
+        const int c = (int)(i - m * C4) * 4;
+        float4 v = reinterpret_cast<const float4*>(in)[i];
+        if (tb != nullptr) {
+            const float4 t4 = *reinterpret_cast<const float4*>(tb + (m / HWpix) * tb_stride + c);
+            v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;
+        }
+        tdm_store_s16_4(out, m, C, c, v);
+    }
+}
+
+}  // namespace
+
+int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st) {
+    for (int i = 0; i < a.nsrc; ++i) {
+        TDM_REQUIRE(a.src[i].nch % CK == 0 && a.src[i].nch > 0, "conv_s16: source %d channel count %d", i, a.src[i].nch);
+        TDM_REQUIRE(a.src[i].taps == 9 || a.src[i].taps == 1, "conv_s16: taps must be 9 or 1");
+        TDM_REQUIRE((a.src[i].C % 16) == 0 && (a.src[i].c0 % 16) == 0, "conv_s16: S16 sources need 16-channel groups");
+        TDM_REQUIRE(a.src[i].tb == nullptr, "conv_s16: the time bias is pre-added by the producer of an S16 tensor");
+        TDM_REQUIRE(a.src[i].wp != nullptr && (((uintptr_t)a.src[i].wp) & 15) == 0, "conv_s16: packed weights missing");
+    }
+    TDM_REQUIRE(a.out != nullptr || a.out_s16 != nullptr, "conv_s16: no output");
+    TDM_REQUIRE(a.B > 0 && (long)a.B * hw * hw * 96 < 2147483647L, "conv_s16: batch %d out of range", a.B);
+    if (hw == 28 && N == 32) return launch_conv_t<28, 1>(a, st);
+    if (hw == 28 && N == 64) return launch_conv_t<28, 2>(a, st);
+    if (hw == 28 && N == 96) return launch_conv_t<28, 3>(a, st);
+    if (hw == 14 && N == 32) return launch_conv_t<14, 1>(a, st);
+    if (hw == 14 && N == 64) return launch_conv_t<14, 2>(a, st);
+    tdm_set_error("conv_s16: unsupported geometry hw=%d N=%d", hw, N);
+    return 1;
+}
+
+int tdm_launch_wgrad_s16(const WgradArgs& a, int hw, int nslab, hipStream_t st) {
+    TDM_REQUIRE(a.Cout % 32 == 0 && a.nci >= 1, "wgrad_s16: Cout %d / nci %d", a.Cout, a.nci);
+    TDM_REQUIRE(a.a.taps == 9 || a.a.taps == 1, "wgrad_s16: taps must be 9 or 1");
+    TDM_REQUIRE((a.a.C % 16) == 0 && (a.a.c0 % 16) == 0 && a.a.tb == nullptr, "wgrad_s16: S16 source layout");
+    TDM_REQUIRE(nslab >= 1 && nslab <= TDM_UNET_MAX_SLABS, "wgrad_s16: nslab %d", nslab);
+    TDM_REQUIRE(a.B > 0 && (long)a.B * hw * hw * 96 < 2147483647L, "wgrad_s16: batch %d out of range", a.B);
+    if (hw == 28) return launch_wgrad_t<28>(a, nslab, st);
+    if (hw == 14) return launch_wgrad_t<14>(a, nslab, st);
+    tdm_set_error("wgrad_s16: unsupported hw=%d", hw);
+    return 1;
+}
+
+int tdm_launch_to_s16(const float* in, const float* tb, int tb_stride, float* out, long M, int HWpix, int C,
+                      hipStream_t st) {
+    TDM_REQUIRE(C % 16 == 0, "to_s16: C=%d must be a multiple of 16", C);
+    long g = (M * (C / 4) + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(to_s16_kernel, dim3((unsigned)g), dim3(256), 0, st, in, tb, tb_stride, out, M, HWpix, C);
+    TDM_CHECK_LAUNCH("to_s16");
+    return 0;
+}

@@ -4,6 +4,7 @@
 // with the timestep-bias gradient, AdamW.  All float4-coalesced, 64-lane
 // wavefront reductions, deterministic (no float atomics).
 #include "tdm_common.h"
+#include "tdm_s16.h"
 
 namespace {
 
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(EW_BLOCK) void relu_bwd_tb_kernel(float* __restrict
 
 // d_tw[c] = sum_b that[b]*S[b][c]; d_tb[c] = sum_b S[b][c].  One block per job (layer):
 // 256 threads = (256/C) batch slices x C channels, 8 independent loads in flight per thread.
-struct TimeGradJobs { const float* S[4]; float* d_tw[4]; float* d_tb[4]; int C[4]; int n; };
+struct TimeGradJobs { const float* S[4]; const float* S2[4]; float* d_tw[4]; float* d_tb[4]; float* d_b[4]; int C[4]; int n; };
 __global__ __launch_bounds__(EW_BLOCK) void time_grad_kernel(TimeGradJobs jb, const float* __restrict__ that, int B) {
     __shared__ float shw[EW_BLOCK], shb[EW_BLOCK];
     const int job = blockIdx.x;
@@ -369,6 +370,28 @@ __global__ __launch_bounds__(EW_BLOCK) void time_grad_kernel(TimeGradJobs jb, co
         for (int k = 0; k < ng; ++k) { sw += shw[k * C + threadIdx.x]; sb += shb[k * C + threadIdx.x]; }
         jb.d_tw[job][threadIdx.x] = sw;
         jb.d_tb[job][threadIdx.x] = sb;
+    }
+    // optional: conv1 bias gradient = sum over samples of the per-sample masked sums S2
+    if (jb.S2[job] != nullptr) {
+        const float* __restrict__ S2 = jb.S2[job];
+        float a2 = 0.f;
+        int bb = g;
+        for (; bb + 7 * ng < B; bb += 8 * ng) {
+            float sv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sv[u] = S2[(int64_t)(bb + u * ng) * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a2 += sv[u];
+        }
+        for (; bb < B; bb += ng) a2 += S2[(int64_t)bb * C + c];
+        __syncthreads();
+        shw[threadIdx.x] = a2;
+        __syncthreads();
+        if (threadIdx.x < C) {
+            float sacc = 0.f;
+            for (int k = 0; k < ng; ++k) sacc += shw[k * C + threadIdx.x];
+            jb.d_b[job][threadIdx.x] = sacc;
+        }
     }
 }
 
@@ -500,6 +523,177 @@ __global__ __launch_bounds__(EW_BLOCK) void adamw_kernel(float* __restrict__ p, 
 
 }  // namespace
 
+// ======================= S16-pipeline producers (tdm_s16.h) =======================
+// rb1.conv1 + skip as conv_first_kernel, plus the pre-split copy split(a1 + tb) that rb1.conv2 reads
+__global__ __launch_bounds__(EW_BLOCK) void conv_first_s16_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ w1,
+                                                                  const float* __restrict__ b1,
+                                                                  const float* __restrict__ ws,
+                                                                  const float* __restrict__ bs,
+                                                                  const float* __restrict__ tb, int tb_stride,
+                                                                  float* __restrict__ a1, float* __restrict__ a1_s16,
+                                                                  float* __restrict__ s, int B) {
+    const int64_t total = (int64_t)B * 784 * 8;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c4 = (int)(i & 7);
+        const int64_t m = i >> 3;
+        const int b = (int)(m / 784);
+        const int rem = (int)(m - (int64_t)b * 784);
+        const int y = rem / 28, xx = rem - y * 28;
+        float4 acc = *reinterpret_cast<const float4*>(b1 + c4 * 4);
+        float xc = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xq = xx + tap % 3 - 1;
+            float xv = 0.f;
+            if (yy >= 0 && yy < 28 && xq >= 0 && xq < 28) xv = x[(int64_t)b * 784 + yy * 28 + xq];
+            if (tap == 4) xc = xv;
+            const float4 wv = *reinterpret_cast<const float4*>(w1 + tap * 32 + c4 * 4);
+            acc.x = fmaf(xv, wv.x, acc.x); acc.y = fmaf(xv, wv.y, acc.y);
+            acc.z = fmaf(xv, wv.z, acc.z); acc.w = fmaf(xv, wv.w, acc.w);
+        }
+        acc.x = acc.x < 0.f ? 0.f : acc.x; acc.y = acc.y < 0.f ? 0.f : acc.y;
+        acc.z = acc.z < 0.f ? 0.f : acc.z; acc.w = acc.w < 0.f ? 0.f : acc.w;
+        *reinterpret_cast<float4*>(a1 + m * 32 + c4 * 4) = acc;
+        const float4 t4 = *reinterpret_cast<const float4*>(tb + (int64_t)b * tb_stride + c4 * 4);
+        tdm_store_s16_4(a1_s16, m, 32, c4 * 4, make_float4(acc.x + t4.x, acc.y + t4.y, acc.z + t4.z, acc.w + t4.w));
+        const float4 wsv = *reinterpret_cast<const float4*>(ws + c4 * 4);
+        const float4 bsv = *reinterpret_cast<const float4*>(bs + c4 * 4);
+        float4 sv;
+        sv.x = fmaf(xc, wsv.x, bsv.x); sv.y = fmaf(xc, wsv.y, bsv.y);
+        sv.z = fmaf(xc, wsv.z, bsv.z); sv.w = fmaf(xc, wsv.w, bsv.w);
+        *reinterpret_cast<float4*>(s + m * 32 + c4 * 4) = sv;
+    }
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void avgpool_s16_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                               float* __restrict__ out_s16, int B, int Ho, int C) {
+    const int C4 = C >> 2, Wo = Ho, Wi = 2 * Ho;
+    const int64_t total = (int64_t)B * Ho * Wo * C4;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c4 = (int)(i % C4);
+        const int64_t p = i / C4;
+        const int xo = (int)(p % Wo);
+        const int64_t q = p / Wo;
+        const int yo = (int)(q % Ho);
+        const int64_t b = q / Ho;
+        const float4* src = reinterpret_cast<const float4*>(in) + ((b * Wi + 2 * yo) * Wi + 2 * xo) * C4 + c4;
+        const float4 v00 = src[0], v01 = src[C4], v10 = src[(int64_t)Wi * C4], v11 = src[(int64_t)Wi * C4 + C4];
+        float4 o;
+        o.x = (((v00.x + v01.x) + v10.x) + v11.x) * 0.25f;
+        o.y = (((v00.y + v01.y) + v10.y) + v11.y) * 0.25f;
+        o.z = (((v00.z + v01.z) + v10.z) + v11.z) * 0.25f;
+        o.w = (((v00.w + v01.w) + v10.w) + v11.w) * 0.25f;
+        if (out != nullptr) reinterpret_cast<float4*>(out)[i] = o;
+        tdm_store_s16_4(out_s16, p, C, c4 * 4, o);
+    }
+}
+
+// block-level per-channel-quad reduction: threads with equal (tid % C4) hold partial sums of the same 4 channels
+__device__ __forceinline__ void quad_reduce_store(float4 v, float4* sh, int C4, float* dst /* slab + off, or nullptr */) {
+    __syncthreads();
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    if (dst != nullptr && threadIdx.x < C4) {
+        float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = threadIdx.x; k < EW_BLOCK; k += C4) {
+            const float4 t = sh[k];
+            sacc.x += t.x; sacc.y += t.y; sacc.z += t.z; sacc.w += t.w;
+        }
+        *reinterpret_cast<float4*>(dst + threadIdx.x * 4) = sacc;
+    }
+}
+
+// out_bwd_kernel + S16 copies of dout / dc2 + bias gradients of rb4.conv2 (sum dc2) and rb4.skip (sum dout)
+__global__ __launch_bounds__(EW_BLOCK) void out_bwd_s16_kernel(const float* __restrict__ deps,
+                                                               const float* __restrict__ h4, const float* __restrict__ w,
+                                                               const float* __restrict__ a2, float* __restrict__ dout,
+                                                               float* __restrict__ dout_s16, float* __restrict__ dc2_s16,
+                                                               float* __restrict__ slab, long slab_stride, int w_off,
+                                                               int b_off, int c2b_off, int skb_off, int64_t M) {
+    __shared__ float4 shw[EW_BLOCK];
+    __shared__ float shb[4];
+    const int c4 = threadIdx.x & 7;
+    const float4 wv = *reinterpret_cast<const float4*>(w + c4 * 4);
+    float4 gw = make_float4(0.f, 0.f, 0.f, 0.f), g_c2 = gw, g_sk = gw;
+    float gb = 0.f;
+    const int64_t total = M * 8;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int64_t m = i >> 3;
+        const float d = deps[m];
+        const float4 hv = reinterpret_cast<const float4*>(h4)[i];
+        const float4 av = reinterpret_cast<const float4*>(a2)[i];
+        float4 o;
+        o.x = d * wv.x; o.y = d * wv.y; o.z = d * wv.z; o.w = d * wv.w;
+        reinterpret_cast<float4*>(dout)[i] = o;
+        tdm_store_s16_4(dout_s16, m, 32, c4 * 4, o);
+        float4 mk;
+        mk.x = av.x > 0.f ? o.x : 0.f; mk.y = av.y > 0.f ? o.y : 0.f;
+        mk.z = av.z > 0.f ? o.z : 0.f; mk.w = av.w > 0.f ? o.w : 0.f;
+        tdm_store_s16_4(dc2_s16, m, 32, c4 * 4, mk);
+        gw.x += d * hv.x; gw.y += d * hv.y; gw.z += d * hv.z; gw.w += d * hv.w;
+        g_c2.x += mk.x; g_c2.y += mk.y; g_c2.z += mk.z; g_c2.w += mk.w;
+        g_sk.x += o.x; g_sk.y += o.y; g_sk.z += o.z; g_sk.w += o.w;
+        if (c4 == 0) gb += d;
+    }
+    float* dst = slab + (long)blockIdx.x * slab_stride;
+    const float sb = block_sum(gb, shb);
+    quad_reduce_store(gw, shw, 8, dst + w_off);
+    quad_reduce_store(g_c2, shw, 8, dst + c2b_off);
+    quad_reduce_store(g_sk, shw, 8, dst + skb_off);
+    if (threadIdx.x == 0) dst[b_off] = sb;
+}
+
+// dc_s16 = split(dout * (a > 0)); per-channel slab partials of the masked (and unmasked) gradient
+__global__ __launch_bounds__(EW_BLOCK) void relu_mask_s16_kernel(const float* __restrict__ dout,
+                                                                 const float* __restrict__ a, float* __restrict__ dc_s16,
+                                                                 float* __restrict__ slab, long slab_stride,
+                                                                 int b_masked_off, int b_unmasked_off, int64_t M, int C) {
+    __shared__ float4 sh[EW_BLOCK];
+    const int C4 = C >> 2;
+    const int c4 = threadIdx.x % C4;             // fixed per thread: the grid stride is a multiple of C4
+    float4 gm = make_float4(0.f, 0.f, 0.f, 0.f), gu = gm;
+    const int64_t total = M * C4;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const float4 d = reinterpret_cast<const float4*>(dout)[i];
+        const float4 av = reinterpret_cast<const float4*>(a)[i];
+        float4 o;
+        o.x = av.x > 0.f ? d.x : 0.f; o.y = av.y > 0.f ? d.y : 0.f;
+        o.z = av.z > 0.f ? d.z : 0.f; o.w = av.w > 0.f ? d.w : 0.f;
+        tdm_store_s16_4(dc_s16, i / C4, C, c4 * 4, o);
+        gm.x += o.x; gm.y += o.y; gm.z += o.z; gm.w += o.w;
+        gu.x += d.x; gu.y += d.y; gu.z += d.z; gu.w += d.w;
+    }
+    float* dst = slab + (long)blockIdx.x * slab_stride;
+    quad_reduce_store(gm, sh, C4, dst + b_masked_off);
+    quad_reduce_store(gu, sh, C4, b_unmasked_off >= 0 ? dst + b_unmasked_off : nullptr);
+}
+
+// relu_bwd_tb_kernel + S16 copy of the masked gradient + per-sample masked sums S2
+__global__ __launch_bounds__(EW_BLOCK) void relu_bwd_tb_s16_kernel(float* __restrict__ dh, const float* __restrict__ a1,
+                                                                   float* __restrict__ dc1_s16, float* __restrict__ S,
+                                                                   float* __restrict__ S2, int HWpix, int C) {
+    __shared__ float4 sh[EW_BLOCK];
+    const int C4 = C >> 2;
+    const int c4 = threadIdx.x % C4, pg = threadIdx.x / C4, npg = EW_BLOCK / C4;
+    const int64_t pix0 = (int64_t)blockIdx.x * HWpix;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accm = acc;
+    for (int p = pg; p < HWpix; p += npg) {
+        const int64_t i = (pix0 + p) * C4 + c4;
+        const float4 d = reinterpret_cast<const float4*>(dh)[i];
+        const float4 av = reinterpret_cast<const float4*>(a1)[i];
+        acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+        float4 o;
+        o.x = av.x > 0.f ? d.x : 0.f; o.y = av.y > 0.f ? d.y : 0.f;
+        o.z = av.z > 0.f ? d.z : 0.f; o.w = av.w > 0.f ? d.w : 0.f;
+        accm.x += o.x; accm.y += o.y; accm.z += o.z; accm.w += o.w;
+        reinterpret_cast<float4*>(dh)[i] = o;
+        tdm_store_s16_4(dc1_s16, pix0 + p, C, c4 * 4, o);
+    }
+    quad_reduce_store(acc, sh, C4, S + (int64_t)blockIdx.x * C);
+    quad_reduce_store(accm, sh, C4, S2 + (int64_t)blockIdx.x * C);
+}
+
 // ------------------------------- launchers -----------------------------------
 int tdm_launch_timebias(const int64_t* t, const float* params, const int* te_w_off, const int* te_b_off, float* that,
                         float* tb, int B, hipStream_t st) {
@@ -553,11 +747,17 @@ int tdm_launch_time_grad(const float* S, const float* that, float* d_tw, float* 
 }
 int tdm_launch_time_grad_multi(const float* const* S, float* const* d_tw, float* const* d_tb, const int* C, int n,
                                const float* that, int B, hipStream_t st) {
+    return tdm_launch_time_grad_multi2(S, nullptr, d_tw, d_tb, nullptr, C, n, that, B, st);
+}
+int tdm_launch_time_grad_multi2(const float* const* S, const float* const* S2, float* const* d_tw, float* const* d_tb,
+                                float* const* d_b, const int* C, int n, const float* that, int B, hipStream_t st) {
     TimeGradJobs jb{};
     TDM_REQUIRE(n >= 1 && n <= 4, "time_grad: %d jobs", n);
     for (int i = 0; i < n; ++i) {
         TDM_REQUIRE(C[i] > 0 && EW_BLOCK % C[i] == 0, "time_grad: C=%d must divide %d", C[i], EW_BLOCK);
         jb.S[i] = S[i]; jb.d_tw[i] = d_tw[i]; jb.d_tb[i] = d_tb[i]; jb.C[i] = C[i];
+        jb.S2[i] = (S2 != nullptr) ? S2[i] : nullptr;
+        jb.d_b[i] = (d_b != nullptr) ? d_b[i] : nullptr;
     }
     jb.n = n;
     hipLaunchKernelGGL(time_grad_kernel, dim3(n), dim3(EW_BLOCK), 0, st, jb, that, B);
@@ -585,6 +785,42 @@ int tdm_launch_nhwc_to_nchw(const float* in, float* out, int B, int HWpix, int C
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_grid((int64_t)B * HWpix * C)), dim3(EW_BLOCK), 0, st, in, out, B,
                        HWpix, C);
     TDM_CHECK_LAUNCH("nhwc_to_nchw");
+    return 0;
+}
+
+int tdm_launch_conv_first_s16(const float* x, const float* w1, const float* b1, const float* ws, const float* bs,
+                              const float* tb, int tb_stride, float* a1, float* a1_s16, float* s, int B, hipStream_t st) {
+    hipLaunchKernelGGL(conv_first_s16_kernel, dim3(ew_grid((int64_t)B * 784 * 8)), dim3(EW_BLOCK), 0, st, x, w1, b1, ws, bs,
+                       tb, tb_stride, a1, a1_s16, s, B);
+    TDM_CHECK_LAUNCH("conv_first_s16");
+    return 0;
+}
+int tdm_launch_avgpool_s16(const float* in, float* out, float* out_s16, int B, int Hout, int C, hipStream_t st) {
+    hipLaunchKernelGGL(avgpool_s16_kernel, dim3(ew_grid((int64_t)B * Hout * Hout * (C / 4))), dim3(EW_BLOCK), 0, st, in,
+                       out, out_s16, B, Hout, C);
+    TDM_CHECK_LAUNCH("avgpool_s16");
+    return 0;
+}
+int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, const float* a2, float* dout,
+                           float* dout_s16, float* dc2_s16, float* slab, long slab_stride, int w_off, int b_off,
+                           int c2b_off, int skb_off, int64_t M, int nslab, hipStream_t st) {
+    hipLaunchKernelGGL(out_bwd_s16_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, deps, h4, w, a2, dout, dout_s16, dc2_s16,
+                       slab, slab_stride, w_off, b_off, c2b_off, skb_off, M);
+    TDM_CHECK_LAUNCH("out_bwd_s16");
+    return 0;
+}
+int tdm_launch_relu_mask_s16(const float* dout, const float* a, float* dc_s16, float* slab, long slab_stride,
+                             int b_masked_off, int b_unmasked_off, int64_t M, int C, int nslab, hipStream_t st) {
+    TDM_REQUIRE(C % 16 == 0 && EW_BLOCK % (C / 4) == 0, "relu_mask_s16: C=%d", C);
+    hipLaunchKernelGGL(relu_mask_s16_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, dout, a, dc_s16, slab, slab_stride,
+                       b_masked_off, b_unmasked_off, M, C);
+    TDM_CHECK_LAUNCH("relu_mask_s16");
+    return 0;
+}
+int tdm_launch_relu_bwd_tb_s16(float* dh, const float* a1, float* dc1_s16, float* S, float* S2, int B, int HWpix, int C,
+                               hipStream_t st) {
+    hipLaunchKernelGGL(relu_bwd_tb_s16_kernel, dim3(B), dim3(EW_BLOCK), 0, st, dh, a1, dc1_s16, S, S2, HWpix, C);
+    TDM_CHECK_LAUNCH("relu_bwd_tb_s16");
     return 0;
 }
 

@@ -65,6 +65,10 @@ struct ConvArgs {
     int relu;
     int B;
     int ablate;         // diagnostics (bf16x3 kernel): bit0 skip input loads, bit1 skip weight staging, bit2 skip MFMA
+    // S16 pipeline (conv_s16.hip): sources are S16 tensors; optional extra pre-split output
+    float* out_s16;           // [M][N] S16 copy of the result (+ tb_out), or nullptr
+    const float* tb_out;      // [B][tb_out_stride]: per-(sample, channel) bias folded into out_s16 only
+    int tb_out_stride;
 };
 
 // hw in {28,14}; N in {32,64,96}; dgrad: transposed convolution with the forward weights
@@ -76,6 +80,11 @@ struct PackDesc { int src_off, cin, cout, taps, dgrad; long dst_off; };
 #define TDM_MAX_PACK 24
 struct PackArgs { PackDesc d[TDM_MAX_PACK]; int n; };
 int tdm_launch_pack(const float* params, const PackArgs& pa, unsigned short* out, hipStream_t st);
+
+// S16 pipeline: pre-split sources, float4 epilogue (conv_s16.hip)
+int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st);
+int tdm_launch_to_s16(const float* in, const float* tb, int tb_stride, float* out, long M, int HWpix, int C,
+                      hipStream_t st);
 
 struct WgradArgs {
     ConvSrc a;          // activation source (nch = channels covered, multiple of 32)
@@ -91,6 +100,7 @@ struct WgradArgs {
 };
 int tdm_launch_wgrad(const WgradArgs& a, int hw, int nslab, hipStream_t st);
 int tdm_launch_wgrad_bf16(const WgradArgs& a, int hw, int nslab, hipStream_t st);   // bf16x3 split operands
+int tdm_launch_wgrad_s16(const WgradArgs& a, int hw, int nslab, hipStream_t st);    // a.a.ptr and a.g are S16; no bias
 
 // slab reduction: out[off+i] = sum_s slab[s*stride + off + i]
 struct ReduceSec { int off, len, nslab; };
@@ -122,4 +132,19 @@ int tdm_launch_split_dcat(const float* dcat, float* dout3, int B, hipStream_t st
 int tdm_launch_combine_dh1(const float* dcat, const float* dp1, float* dout1, int B, hipStream_t st);
 int tdm_launch_first_wgrad(const float* x, const float* dc1, const float* dout1, float* slab, long slab_stride,
                            int w1_off, int b1_off, int ws_off, int bs_off, int B, int nslab, hipStream_t st);
+// S16-pipeline producers (optional extra outputs; nullptr = not written)
+int tdm_launch_conv_first_s16(const float* x, const float* w1, const float* b1, const float* ws, const float* bs,
+                              const float* tb, int tb_stride, float* a1, float* a1_s16, float* s, int B, hipStream_t st);
+int tdm_launch_avgpool_s16(const float* in, float* out, float* out_s16, int B, int Hout, int C, hipStream_t st);
+int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, const float* a2, float* dout,
+                           float* dout_s16, float* dc2_s16, float* slab, long slab_stride, int w_off, int b_off,
+                           int c2b_off, int skb_off, int64_t M, int nslab, hipStream_t st);
+// dc_s16 = split(dout * (a > 0)); slab partial sums of the masked (and optionally unmasked) gradient per channel
+int tdm_launch_relu_mask_s16(const float* dout, const float* a, float* dc_s16, float* slab, long slab_stride,
+                             int b_masked_off, int b_unmasked_off, int64_t M, int C, int nslab, hipStream_t st);
+// dh <- dh * (a1 > 0) in place (fp32) + S16 copy; S[b][c] = sum dh (unmasked), S2[b][c] = sum of the masked values
+int tdm_launch_relu_bwd_tb_s16(float* dh, const float* a1, float* dc1_s16, float* S, float* S2, int B, int HWpix, int C,
+                               hipStream_t st);
+int tdm_launch_time_grad_multi2(const float* const* S, const float* const* S2, float* const* d_tw, float* const* d_tb,
+                                float* const* d_b, const int* C, int n, const float* that, int B, hipStream_t st);
 int tdm_launch_nhwc_to_nchw(const float* in, float* out, int B, int HWpix, int C, hipStream_t st);

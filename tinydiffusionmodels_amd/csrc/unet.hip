@@ -87,8 +87,9 @@ PackTab make_pack() {
 }
 const PackTab kPack = make_pack();
 
-// 0: exact fp32 MFMA (conv_mfma.hip); 1: bf16x3 split operands (conv_bf16.hip)
-int g_conv_mode = 1;
+// 0: exact fp32 MFMA (conv_mfma.hip); 1: bf16x3, fp32 tensors split while staging (conv_bf16.hip);
+// 2: bf16x3 over pre-split "S16" tensors written by the producers (conv_s16.hip) — same arithmetic as 1
+int g_conv_mode = 2;
 
 // ------------------------------ workspace --------------------------------------
 struct Ws {
@@ -100,6 +101,9 @@ struct Ws {
     float *a1_4, *s4, *a2_4, *h4;
     // backward temporaries
     float *dout4, *dc2_4, *dh4, *dcat, *dout3, *dc2_3, *dh3, *dout2, *dc2_2, *dh2, *dp1, *dout1, *dc2_1, *dh1;
+    // S16 pipeline (mode 2): pre-split copies read by the conv / wgrad loaders
+    float *a1s_1, *h1s, *p1s, *a1s_2, *h2s, *a1s_3, *h3s, *a1s_4;
+    float *dout4s, *dc2s_4, *dh4s, *dc2s_3, *dh3s, *dc2s_2, *dh2s, *dout2s, *dc2s_1, *S2[4];
     int64_t total;
 };
 
@@ -120,12 +124,18 @@ Ws carve(float* base, int64_t B, int training) {
     w.a1_2 = take(M14 * 64); w.s2 = take(M14 * 64); w.a2_2 = take(M14 * 64); w.h2 = take(M14 * 64);
     w.a1_3 = take(M14 * 64); w.a2_3 = take(M14 * 64); w.h3 = take(M14 * 64);
     w.a1_4 = take(M28 * 32); w.s4 = take(M28 * 32); w.a2_4 = take(M28 * 32); w.h4 = take(M28 * 32);
+    w.a1s_1 = take(M28 * 32); w.h1s = take(M28 * 32); w.p1s = take(M14 * 32); w.a1s_2 = take(M14 * 64);
+    w.h2s = take(M14 * 64); w.a1s_3 = take(M14 * 64); w.h3s = take(M14 * 64); w.a1s_4 = take(M28 * 32);
     if (training) {
         w.dout4 = take(M28 * 32); w.dc2_4 = take(M28 * 32); w.dh4 = take(M28 * 32); w.dcat = take(M28 * 96);
         w.dout3 = take(M14 * 64); w.dc2_3 = take(M14 * 64); w.dh3 = take(M14 * 64);
         w.dout2 = take(M14 * 64); w.dc2_2 = take(M14 * 64); w.dh2 = take(M14 * 64);
         w.dp1 = take(M14 * 32);
         w.dout1 = take(M28 * 32); w.dc2_1 = take(M28 * 32); w.dh1 = take(M28 * 32);
+        w.dout4s = take(M28 * 32); w.dc2s_4 = take(M28 * 32); w.dh4s = take(M28 * 32);
+        w.dc2s_3 = take(M14 * 64); w.dh3s = take(M14 * 64); w.dc2s_2 = take(M14 * 64); w.dh2s = take(M14 * 64);
+        w.dout2s = take(M14 * 64); w.dc2s_1 = take(M28 * 32);
+        for (int i = 0; i < 4; ++i) w.S2[i] = take(B * 64);
     }
     w.total = off;
     return w;
@@ -175,8 +185,14 @@ int wgrad(hipStream_t st, int hw, int B, const float* act, int C, int c_used, in
     return tdm_launch_wgrad(a, hw, nslab, st);
 }
 
+int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* eps, const Ws& w, int B, int save,
+                     hipStream_t st);
+int unet_backward_s16(const float* P, const float* x, const float* deps, float* G, const Ws& w, float* slabs, int B,
+                      hipStream_t st);
+
 int unet_forward(const float* P, const float* x, const int64_t* t, float* eps, const Ws& w, int B, int save,
                  hipStream_t st) {
+    if (g_conv_mode == 2) return unet_forward_s16(P, x, t, eps, w, B, save, st);
     const int tew[4] = {kL.rb[0].tew, kL.rb[1].tew, kL.rb[2].tew, kL.rb[3].tew};
     const int teb[4] = {kL.rb[0].teb, kL.rb[1].teb, kL.rb[2].teb, kL.rb[3].teb};
     TDM_TRY(tdm_launch_timebias(t, P, tew, teb, w.that, w.tb, B, st));
@@ -215,10 +231,165 @@ int unet_forward(const float* P, const float* x, const int64_t* t, float* eps, c
     return 0;
 }
 
+// ------------------------- S16 pipeline (mode 2) -----------------------------------
+ConvSrc s16_src(const float* ptr, int C, int nch, int up, int taps, const unsigned short* wp, int wchunk0) {
+    ConvSrc s{};
+    s.ptr = ptr; s.C = C; s.c0 = 0; s.nch = nch; s.up = up; s.taps = taps; s.wp = wp; s.wchunk0 = wchunk0;
+    return s;
+}
+struct S16Out { float* out; float* aux; const float* res; float* out_s16; const float* tb_out; };
+int conv_s16_1(hipStream_t st, const Ws& ws, int hw, int B, const float* in_s16, int Cin, int taps, long wpoff, int N,
+               const float* bias, int relu, const S16Out& o) {
+    ConvArgs a{};
+    a.nsrc = 1;
+    a.src[0] = s16_src(in_s16, Cin, Cin, 0, taps, ws.wpack + wpoff, 0);
+    a.bias = bias; a.relu = relu; a.B = B;
+    a.out = o.out; a.aux = o.aux; a.res = o.res; a.out_s16 = o.out_s16; a.tb_out = o.tb_out; a.tb_out_stride = 192;
+    return tdm_launch_conv_s16(a, hw, N, st);
+}
+int wgrad_s16(hipStream_t st, int hw, int B, const float* act_s16, int C, int c_used, int up, int taps,
+              const float* g_s16, int Cout, float* slabs, int w_off, int w_rows, int w_r0, int nslab) {
+    WgradArgs a{};
+    a.a = s16_src(act_s16, C, c_used, up, taps, nullptr, 0);
+    a.a.w_rows = w_rows; a.a.w_r0 = w_r0;
+    a.g = g_s16; a.Cout = Cout; a.slab = slabs; a.slab_stride = TDM_UNET_NPARAM; a.w_off = w_off; a.b_off = -1; a.B = B;
+    a.ntiles = (int)(((long)B * hw * hw + 255) / 256);
+    a.nci = c_used / 32;
+    return tdm_launch_wgrad_s16(a, hw, nslab, st);
+}
+
+int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* eps, const Ws& w, int B, int save,
+                     hipStream_t st) {
+    const int tew[4] = {kL.rb[0].tew, kL.rb[1].tew, kL.rb[2].tew, kL.rb[3].tew};
+    const int teb[4] = {kL.rb[0].teb, kL.rb[1].teb, kL.rb[2].teb, kL.rb[3].teb};
+    TDM_TRY(tdm_launch_timebias(t, P, tew, teb, w.that, w.tb, B, st));
+    TDM_TRY(tdm_launch_pack(P, kPack.pa, w.wpack, st));
+    const BlockOff &r1 = kL.rb[0], &r2 = kL.rb[1], &r3 = kL.rb[2], &r4 = kL.rb[3];
+    // rb1: conv1 (Cin = 1) writes a1 (mask) and split(a1 + tb) for conv2
+    TDM_TRY(tdm_launch_conv_first_s16(x, P + r1.c1w, P + r1.c1b, P + r1.skw, P + r1.skb, w.tb + 0, 192, w.a1_1, w.a1s_1,
+                                      w.s1, B, st));
+    TDM_TRY(conv_s16_1(st, w, 28, B, w.a1s_1, 32, 9, kPack.fwd[W_RB1C2], 32, P + r1.c2b, 1,
+                       S16Out{w.h1, save ? w.a2_1 : nullptr, w.s1, w.h1s, nullptr}));
+    // rb2 on avg_pool2d(h1)
+    TDM_TRY(tdm_launch_avgpool_s16(w.h1, nullptr, w.p1s, B, 14, 32, st));
+    TDM_TRY(conv_s16_1(st, w, 14, B, w.p1s, 32, 9, kPack.fwd[W_RB2C1], 64, P + r2.c1b, 1,
+                       S16Out{save ? w.a1_2 : nullptr, nullptr, nullptr, w.a1s_2, w.tb + 32}));
+    TDM_TRY(conv_s16_1(st, w, 14, B, w.p1s, 32, 1, kPack.fwd[W_RB2SK], 64, P + r2.skb, 0,
+                       S16Out{w.s2, nullptr, nullptr, nullptr, nullptr}));
+    TDM_TRY(conv_s16_1(st, w, 14, B, w.a1s_2, 64, 9, kPack.fwd[W_RB2C2], 64, P + r2.c2b, 1,
+                       S16Out{w.h2, save ? w.a2_2 : nullptr, w.s2, w.h2s, nullptr}));
+    // rb3 (identity skip)
+    TDM_TRY(conv_s16_1(st, w, 14, B, w.h2s, 64, 9, kPack.fwd[W_RB3C1], 64, P + r3.c1b, 1,
+                       S16Out{save ? w.a1_3 : nullptr, nullptr, nullptr, w.a1s_3, w.tb + 96}));
+    TDM_TRY(conv_s16_1(st, w, 14, B, w.a1s_3, 64, 9, kPack.fwd[W_RB3C2], 64, P + r3.c2b, 1,
+                       S16Out{w.h3, save ? w.a2_3 : nullptr, w.h2, w.h3s, nullptr}));
+    // rb4 on cat([up2(h3), h1])
+    {
+        ConvArgs a{};
+        a.nsrc = 2;
+        a.src[0] = s16_src(w.h3s, 64, 64, 1, 9, w.wpack + kPack.fwd[W_RB4C1], 0);
+        a.src[1] = s16_src(w.h1s, 32, 32, 0, 9, w.wpack + kPack.fwd[W_RB4C1], 4);
+        a.bias = P + r4.c1b; a.relu = 1; a.B = B;
+        a.out = save ? w.a1_4 : nullptr; a.out_s16 = w.a1s_4; a.tb_out = w.tb + 160; a.tb_out_stride = 192;
+        TDM_TRY(tdm_launch_conv_s16(a, 28, 32, st));
+        ConvArgs k{};
+        k.nsrc = 2;
+        k.src[0] = s16_src(w.h3s, 64, 64, 1, 1, w.wpack + kPack.fwd[W_RB4SK], 0);
+        k.src[1] = s16_src(w.h1s, 32, 32, 0, 1, w.wpack + kPack.fwd[W_RB4SK], 4);
+        k.bias = P + r4.skb; k.relu = 0; k.B = B; k.out = w.s4;
+        TDM_TRY(tdm_launch_conv_s16(k, 28, 32, st));
+    }
+    TDM_TRY(conv_s16_1(st, w, 28, B, w.a1s_4, 32, 9, kPack.fwd[W_RB4C2], 32, P + r4.c2b, 1,
+                       S16Out{w.h4, save ? w.a2_4 : nullptr, w.s4, nullptr, nullptr}));
+    TDM_TRY(tdm_launch_conv_out(w.h4, P + kL.outw, P + kL.outb, eps, (int64_t)B * 784, st));
+    return 0;
+}
+
+int unet_backward_s16(const float* P, const float* x, const float* deps, float* G, const Ws& w, float* slabs, int B,
+                      hipStream_t st) {
+    constexpr int NS = 256;
+    const BlockOff &r1 = kL.rb[0], &r2 = kL.rb[1], &r3 = kL.rb[2], &r4 = kL.rb[3];
+    const int64_t M28 = (int64_t)B * 784, M14 = (int64_t)B * 196;
+    const long NP = TDM_UNET_NPARAM;
+    // ---- out conv + rb4 ----
+    TDM_TRY(tdm_launch_out_bwd_s16(deps, w.h4, P + kL.outw, w.a2_4, w.dout4, w.dout4s, w.dc2s_4, slabs, NP, kL.outw,
+                                   kL.outb, r4.c2b, r4.skb, M28, NS, st));
+    TDM_TRY(wgrad_s16(st, 28, B, w.a1s_4, 32, 32, 0, 9, w.dc2s_4, 32, slabs, r4.c2w, 32, 0, NS));
+    TDM_TRY(conv_s16_1(st, w, 28, B, w.dc2s_4, 32, 9, kPack.dg[W_RB4C2], 32, nullptr, 0,
+                       S16Out{w.dh4, nullptr, nullptr, nullptr, nullptr}));
+    TDM_TRY(tdm_launch_relu_bwd_tb_s16(w.dh4, w.a1_4, w.dh4s, w.S[3], w.S2[3], B, 784, 32, st));
+    TDM_TRY(wgrad_s16(st, 28, B, w.h3s, 64, 64, 1, 9, w.dh4s, 32, slabs, r4.c1w, 96, 0, NS));
+    TDM_TRY(wgrad_s16(st, 28, B, w.h1s, 32, 32, 0, 9, w.dh4s, 32, slabs, r4.c1w, 96, 64, NS));
+    TDM_TRY(wgrad_s16(st, 28, B, w.h3s, 64, 64, 1, 1, w.dout4s, 32, slabs, r4.skw, 96, 0, NS));
+    TDM_TRY(wgrad_s16(st, 28, B, w.h1s, 32, 32, 0, 1, w.dout4s, 32, slabs, r4.skw, 96, 64, NS));
+    {
+        ConvArgs a{};
+        a.nsrc = 2;
+        a.src[0] = s16_src(w.dh4s, 32, 32, 0, 9, w.wpack + kPack.dg[W_RB4C1], 0);
+        a.src[1] = s16_src(w.dout4s, 32, 32, 0, 1, w.wpack + kPack.dg[W_RB4SK], 0);
+        a.out = w.dcat; a.B = B;
+        TDM_TRY(tdm_launch_conv_s16(a, 28, 96, st));
+    }
+    TDM_TRY(tdm_launch_split_dcat(w.dcat, w.dout3, B, st));
+    // ---- rb3 ----
+    TDM_TRY(tdm_launch_relu_mask_s16(w.dout3, w.a2_3, w.dc2s_3, slabs, NP, r3.c2b, -1, M14, 64, NS, st));
+    TDM_TRY(wgrad_s16(st, 14, B, w.a1s_3, 64, 64, 0, 9, w.dc2s_3, 64, slabs, r3.c2w, 64, 0, NS));
+    TDM_TRY(conv_s16_1(st, w, 14, B, w.dc2s_3, 64, 9, kPack.dg[W_RB3C2], 64, nullptr, 0,
+                       S16Out{w.dh3, nullptr, nullptr, nullptr, nullptr}));
+    TDM_TRY(tdm_launch_relu_bwd_tb_s16(w.dh3, w.a1_3, w.dh3s, w.S[2], w.S2[2], B, 196, 64, st));
+    TDM_TRY(wgrad_s16(st, 14, B, w.h2s, 64, 64, 0, 9, w.dh3s, 64, slabs, r3.c1w, 64, 0, NS));
+    TDM_TRY(conv_s16_1(st, w, 14, B, w.dh3s, 64, 9, kPack.dg[W_RB3C1], 64, nullptr, 0,
+                       S16Out{w.dout2, nullptr, w.dout3, w.dout2s, nullptr}));   // + identity skip
+    // ---- rb2 ----
+    TDM_TRY(tdm_launch_relu_mask_s16(w.dout2, w.a2_2, w.dc2s_2, slabs, NP, r2.c2b, r2.skb, M14, 64, NS, st));
+    TDM_TRY(wgrad_s16(st, 14, B, w.a1s_2, 64, 64, 0, 9, w.dc2s_2, 64, slabs, r2.c2w, 64, 0, NS));
+    TDM_TRY(conv_s16_1(st, w, 14, B, w.dc2s_2, 64, 9, kPack.dg[W_RB2C2], 64, nullptr, 0,
+                       S16Out{w.dh2, nullptr, nullptr, nullptr, nullptr}));
+    TDM_TRY(tdm_launch_relu_bwd_tb_s16(w.dh2, w.a1_2, w.dh2s, w.S[1], w.S2[1], B, 196, 64, st));
+    TDM_TRY(wgrad_s16(st, 14, B, w.p1s, 32, 32, 0, 9, w.dh2s, 64, slabs, r2.c1w, 32, 0, NS));
+    TDM_TRY(wgrad_s16(st, 14, B, w.p1s, 32, 32, 0, 1, w.dout2s, 64, slabs, r2.skw, 32, 0, NS));
+    {
+        ConvArgs a{};
+        a.nsrc = 2;
+        a.src[0] = s16_src(w.dh2s, 64, 64, 0, 9, w.wpack + kPack.dg[W_RB2C1], 0);
+        a.src[1] = s16_src(w.dout2s, 64, 64, 0, 1, w.wpack + kPack.dg[W_RB2SK], 0);
+        a.out = w.dp1; a.B = B;
+        TDM_TRY(tdm_launch_conv_s16(a, 14, 32, st));
+    }
+    TDM_TRY(tdm_launch_combine_dh1(w.dcat, w.dp1, w.dout1, B, st));
+    // ---- rb1 ----
+    TDM_TRY(tdm_launch_relu_mask_s16(w.dout1, w.a2_1, w.dc2s_1, slabs, NP, r1.c2b, -1, M28, 32, NS, st));
+    TDM_TRY(wgrad_s16(st, 28, B, w.a1s_1, 32, 32, 0, 9, w.dc2s_1, 32, slabs, r1.c2w, 32, 0, NS));
+    TDM_TRY(conv_s16_1(st, w, 28, B, w.dc2s_1, 32, 9, kPack.dg[W_RB1C2], 32, nullptr, 0,
+                       S16Out{w.dh1, nullptr, nullptr, nullptr, nullptr}));
+    TDM_TRY(tdm_launch_relu_bwd_tb(w.dh1, w.a1_1, w.S[0], B, 784, 32, st));
+    {   // time_emb gradients of all four blocks + conv1 bias gradients of rb2..rb4, one launch
+        const float* Sv[4] = {w.S[0], w.S[1], w.S[2], w.S[3]};
+        const float* S2v[4] = {nullptr, w.S2[1], w.S2[2], w.S2[3]};
+        float* tw[4] = {G + r1.tew, G + r2.tew, G + r3.tew, G + r4.tew};
+        float* tbv[4] = {G + r1.teb, G + r2.teb, G + r3.teb, G + r4.teb};
+        float* dbv[4] = {nullptr, G + r2.c1b, G + r3.c1b, G + r4.c1b};
+        const int Cv[4] = {32, 64, 64, 32};
+        TDM_TRY(tdm_launch_time_grad_multi2(Sv, S2v, tw, tbv, dbv, Cv, 4, w.that, B, st));
+    }
+    TDM_TRY(tdm_launch_first_wgrad(x, w.dh1, w.dout1, slabs, NP, r1.c1w, r1.c1b, r1.skw, r1.skb, B, NS, st));
+    ReduceArgs ra{};
+    int n = 0;
+    auto sec = [&](int off, int len) { ra.sec[n].off = off; ra.sec[n].len = len; ra.sec[n].nslab = NS; ++n; };
+    sec(r1.c1w, 288 + 32); sec(r1.c2w, 9216 + 32); sec(r1.skw, 32 + 32);
+    sec(r2.c1w, 18432); sec(r2.c2w, 36864 + 64); sec(r2.skw, 2048 + 64);
+    sec(r3.c1w, 36864); sec(r3.c2w, 36864 + 64);
+    sec(r4.c1w, 27648); sec(r4.c2w, 9216 + 32); sec(r4.skw, 3072 + 32);
+    sec(kL.outw, 33);
+    ra.nsec = n;
+    return tdm_launch_reduce(slabs, NP, ra, G, st);
+}
+
 constexpr int NSLAB = 256;
 
 int unet_backward(const float* P, const float* x, const float* deps, float* G, const Ws& w, float* slabs, int B,
                   hipStream_t st) {
+    if (g_conv_mode == 2) return unet_backward_s16(P, x, deps, G, w, slabs, B, st);
     const BlockOff &r1 = kL.rb[0], &r2 = kL.rb[1], &r3 = kL.rb[2], &r4 = kL.rb[3];
     const int64_t M28 = (int64_t)B * 784, M14 = (int64_t)B * 196;
     // ---- out conv + rb4 ----
@@ -362,7 +533,7 @@ int tdm_unet_p_sample_step_f32(const float* params, const float* x, const int64_
 }
 
 int tdm_set_conv_mode(int mode) {
-    TDM_REQUIRE(mode == 0 || mode == 1, "conv mode %d (0 = fp32 MFMA, 1 = bf16x3 split MFMA)", mode);
+    TDM_REQUIRE(mode >= 0 && mode <= 2, "conv mode %d (0 = fp32 MFMA, 1 = bf16x3, 2 = bf16x3 over pre-split tensors)", mode);
     g_conv_mode = mode;
     return 0;
 }
@@ -392,6 +563,64 @@ int tdm_conv_nhwc_bf16x3_f32(const float* in, const float* w, const float* bias,
     a.bias = bias; a.res = res; a.out = out; a.aux = aux_relu_out; a.relu = flags & 1; a.B = (int)B;
     a.ablate = (flags >> 8) & 15;   // timing diagnostics only (results are wrong when set)
     return tdm_launch_conv_bf16(a, HW, Cout, (hipStream_t)stream);
+}
+
+// generic conv through the S16 pipeline: the fp32 input (+tb) is pre-split into scratch, then conv_s16 runs.
+// scratch >= ksize^2*Cin*Cout + B*HW*HW*Cin floats.  out_s16 (optional) receives split(result + tb_out).
+int tdm_conv_nhwc_s16_f32(const float* in, const float* w, const float* bias, const float* res, const float* tb,
+                          float* out, float* aux_relu_out, float* out_s16, const float* tb_out, float* scratch,
+                          int64_t B, int HW, int Cin, int Cout, int ksize, int flags, void* stream) {
+    TDM_CHECK_B(B);
+    TDM_REQUIRE(ksize == 3 || ksize == 1, "conv: ksize %d", ksize);
+    TDM_REQUIRE(scratch != nullptr, "conv_s16: scratch is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    const bool dgrad = (flags & 2) != 0;
+    const int taps = ksize * ksize;
+    const int wcin = dgrad ? Cout : Cin, wcout = dgrad ? Cin : Cout;
+    PackArgs pa{};
+    pa.n = 1;
+    pa.d[0].src_off = 0; pa.d[0].cin = wcin; pa.d[0].cout = wcout; pa.d[0].taps = taps; pa.d[0].dgrad = dgrad ? 1 : 0;
+    pa.d[0].dst_off = 0;
+    unsigned short* wp = reinterpret_cast<unsigned short*>(scratch);
+    float* in_s16 = scratch + (((long)taps * Cin * Cout + 63) & ~63L);
+    TDM_TRY(tdm_launch_pack(w, pa, wp, st));
+    TDM_TRY(tdm_launch_to_s16(in, tb, Cin, in_s16, (long)B * HW * HW, HW * HW, Cin, st));
+    ConvArgs a{};
+    a.nsrc = 1;
+    a.src[0] = s16_src(in_s16, Cin, Cin, 0, taps, wp, 0);
+    a.bias = bias; a.res = res; a.out = out; a.aux = aux_relu_out; a.relu = flags & 1; a.B = (int)B;
+    a.out_s16 = out_s16; a.tb_out = tb_out; a.tb_out_stride = Cout;
+    return tdm_launch_conv_s16(a, HW, Cout, st);
+}
+
+// weight gradient through the S16 pipeline (dw only; bias gradients belong to the producers of dout).
+// scratch >= B*HW*HW*(Cin + Cout) + 65 * ksize^2*Cin*Cout floats.
+int tdm_conv_wgrad_nhwc_s16_f32(const float* in, const float* tb, const float* dout, float* dw, float* scratch,
+                                int64_t B, int HW, int Cin, int Cout, int ksize, void* stream) {
+    TDM_CHECK_B(B);
+    TDM_REQUIRE(ksize == 3 || ksize == 1, "wgrad: ksize %d", ksize);
+    TDM_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "wgrad_s16: Cin %d / Cout %d must be multiples of 32", Cin, Cout);
+    hipStream_t st = (hipStream_t)stream;
+    const int taps = ksize * ksize;
+    const long M = (long)B * HW * HW;
+    const long wlen = (long)taps * Cin * Cout;
+    float* in_s16 = scratch;
+    float* g_s16 = in_s16 + ((M * Cin + 63) & ~63L);
+    float* slabs = g_s16 + ((M * Cout + 63) & ~63L);
+    const int nslab = 64;
+    TDM_TRY(tdm_launch_to_s16(in, tb, Cin, in_s16, M, HW * HW, Cin, st));
+    TDM_TRY(tdm_launch_to_s16(dout, nullptr, 0, g_s16, M, HW * HW, Cout, st));
+    WgradArgs a{};
+    a.a = s16_src(in_s16, Cin, Cin, 0, taps, nullptr, 0);
+    a.a.w_rows = Cin; a.a.w_r0 = 0;
+    a.g = g_s16; a.Cout = Cout; a.slab = slabs; a.slab_stride = wlen; a.w_off = 0; a.b_off = -1; a.B = (int)B;
+    a.ntiles = (int)((M + 255) / 256);
+    a.nci = Cin / 32;
+    TDM_TRY(tdm_launch_wgrad_s16(a, HW, nslab, st));
+    ReduceArgs ra{};
+    ra.nsec = 1;
+    ra.sec[0].off = 0; ra.sec[0].len = (int)wlen; ra.sec[0].nslab = nslab;
+    return tdm_launch_reduce(slabs, wlen, ra, dw, st);
 }
 
 // ---- per-layer entry points ----------------------------------------------------
