@@ -88,11 +88,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X; there is no CPU path")
+    # TDM_DIST_BACKEND=gloo + TDM_SHARE_GPU=1: rehearsal of the multi-rank path on a one-GPU box
+    backend = os.environ.get("TDM_DIST_BACKEND", "nccl")
+    if os.environ.get("TDM_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from tinydiffusionmodels_amd import _lib, unet_engine as E
     from tinydiffusionmodels_amd.mnist import SimpleUNet, DDPMTrainer, reverse_diffusion

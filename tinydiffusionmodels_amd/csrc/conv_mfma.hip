@@ -365,8 +365,9 @@ int launch_wgrad_t(const WgradArgs& a, int nslab, hipStream_t st) {
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, long stride,
                                                            ReduceArgs ra, float* __restrict__ out) {
     const ReduceSec s = ra.sec[blockIdx.y];
+    if (s.stride_override != 0) stride = s.stride_override;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < s.len; i += gridDim.x * 256) {
-        const float* p = slabs + s.off + i;
+        const float* p = slabs + s.off + s.src_delta + i;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int k = 0;
         for (; k + 4 <= s.nslab; k += 4) {

@@ -103,7 +103,11 @@ int tdm_launch_wgrad_bf16(const WgradArgs& a, int hw, int nslab, hipStream_t st)
 int tdm_launch_wgrad_s16(const WgradArgs& a, int hw, int nslab, hipStream_t st);    // a.a.ptr and a.g are S16; no bias
 
 // slab reduction: out[off+i] = sum_s slab[s*stride + off + i]
-struct ReduceSec { int off, len, nslab; };
+struct ReduceSec {
+    int off, len, nslab;
+    long src_delta;        // slab 0 of this section starts at slabs + off + src_delta (default 0)
+    long stride_override;  // distance between this section's slabs; 0 = the launch's common stride
+};
 #define TDM_MAX_SECS 40
 struct ReduceArgs {
     ReduceSec sec[TDM_MAX_SECS];

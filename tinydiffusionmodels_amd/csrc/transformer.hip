@@ -12,9 +12,30 @@
 
 namespace {
 
-constexpr int SPLITK = 8;      // weight-gradient GEMMs: split of the token (contraction) dimension
 constexpr int LN_SLABS = 256;  // per-wave partials of the LayerNorm affine gradients
-constexpr int CS_SLABS = 128;  // row-block partials of the bias gradients
+constexpr int CS_SLABS = 512;  // row-block partials of the bias gradients
+
+// Weight-gradient GEMMs contract over tokens (K = B*L, tens of thousands) into small [N][K] outputs:
+// each tensor gets its own split-K factor so that tiles x splits ~ 1024 workgroups fill the chip.
+inline int wgrad_splitk(int N, int K) {
+    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    int sk = (1024 + tiles - 1) / tiles;
+    if (sk < 1) sk = 1;
+    if (sk > 128) sk = 128;
+    return sk;
+}
+// slab regions (floats) of the 4 weight matrices of one layer, in order in_w, out_w, l1_w, l2_w
+struct SlabPlan { long base[8][4]; int sk[4]; long len[4]; long total; };
+SlabPlan slab_plan(int D, int depth, int F) {
+    SlabPlan p{};
+    const int Ns[4] = {3 * D, D, F, D}, Ks[4] = {D, D, D, F};
+    long off = 0;
+    for (int k = 0; k < 4; ++k) { p.sk[k] = wgrad_splitk(Ns[k], Ks[k]); p.len[k] = (long)Ns[k] * Ks[k]; }
+    for (int l = 0; l < depth; ++l)
+        for (int k = 0; k < 4; ++k) { p.base[l][k] = off; off += p.sk[k] * p.len[k]; }
+    p.total = off;
+    return p;
+}
 
 // ----------------------------- parameter layout ---------------------------------
 struct LayerOff { long in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b; };
@@ -423,22 +444,50 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
-// column sums over row blocks: part[blockIdx.x][n] = sum_{rows of block} a[row][n]   (N <= 2048)
+// column sums over row blocks: part[blockIdx.x][n] = sum_{rows of block} a[row][n]   (N % 4 == 0, N <= 4096)
+// 256 threads = (256 / C4) row lanes x C4 float4 columns (or 1 row x up to 4 column passes when C4 > 256)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, float* __restrict__ part, long M, int N) {
-    float acc[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-    for (long row = blockIdx.x; row < M; row += gridDim.x) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int c = threadIdx.x + 256 * q;
-            if (c < N) acc[q] += a[row * N + c];
+    __shared__ float4 sh[256];
+    const int C4 = N >> 2;
+    if (C4 <= 256) {
+        const int rpp = 256 / C4;
+        const int c4 = threadIdx.x % C4, rg = threadIdx.x / C4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rg < rpp) {
+            for (long row = (long)blockIdx.x * rpp + rg; row < M; row += (long)gridDim.x * rpp) {
+                const float4 v = reinterpret_cast<const float4*>(a + row * N)[c4];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
         }
-    }
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        if (threadIdx.x < C4) {
+            float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < rpp; ++k) {
+                const float4 t = sh[k * C4 + threadIdx.x];
+                sacc.x += t.x; sacc.y += t.y; sacc.z += t.z; sacc.w += t.w;
+            }
+            reinterpret_cast<float4*>(part + (long)blockIdx.x * N)[threadIdx.x] = sacc;
+        }
+    } else {
+        float4 acc[4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int c = threadIdx.x + 256 * q;
-        if (c < N) part[(long)blockIdx.x * N + c] = acc[q];
+        for (int q = 0; q < 4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (long row = blockIdx.x; row < M; row += gridDim.x) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c4 = threadIdx.x + 256 * q;
+                if (c4 < C4) {
+                    const float4 v = reinterpret_cast<const float4*>(a + row * N)[c4];
+                    acc[q].x += v.x; acc[q].y += v.y; acc[q].z += v.z; acc[q].w += v.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c4 = threadIdx.x + 256 * q;
+            if (c4 < C4) reinterpret_cast<float4*>(part + (long)blockIdx.x * N)[c4] = acc[q];
+        }
     }
 }
 
@@ -519,17 +568,19 @@ int linear_dgrad(const float* dY, const float* W, const float* res, float* dX, l
     return tdm_launch_gemm(g, st);
 }
 // dW[N][K] partials = dY[M][N]^T X[M][K], split over M into SPLITK slabs at slabs + w_off
-int linear_wgrad(const float* dY, const float* X, float* slabs, long slab_stride, long w_off, long M, int N, int K,
-                 hipStream_t st) {
+int linear_wgrad(const float* dY, const float* X, float* slab_region, long M, int N, int K, hipStream_t st) {
     GemmArgs g{};
     g.A = dY; g.a_rs = 1; g.a_cs = N;
     g.B = X; g.b_rs = K; g.b_cs = 1;
-    g.C = slabs + w_off; g.c_rs = K; g.M = N; g.N = K; g.K = (int)M; g.splitk = SPLITK; g.c_split_stride = slab_stride;
+    g.C = slab_region; g.c_rs = K; g.M = N; g.N = K; g.K = (int)M; g.splitk = wgrad_splitk(N, K);
+    g.c_split_stride = (long)N * K;
     return tdm_launch_gemm(g, st);
 }
 // bias gradient: db[N] = colsum(dY) via partials + reduce
 int bias_grad(const float* dY, float* part, float* db, long M, int N, hipStream_t st) {
-    const int nb = (int)(M < CS_SLABS ? M : CS_SLABS);
+    const int C4 = N / 4;
+    const long rowblocks = (C4 <= 256) ? (M + (256 / C4) - 1) / (256 / C4) : M;
+    const int nb = (int)(rowblocks < CS_SLABS ? rowblocks : CS_SLABS);
     hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, dY, part, M, N);
     TDM_CHECK_LAUNCH("colsum");
     ReduceArgs ra{};
@@ -593,7 +644,7 @@ int tt_forward(const float* P, const TTLayout& lay, const float* x, const int64_
 int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G, float* dx, const TTWs& w, float* slabs,
                 long B, int L, int D, int H, int depth, int F, hipStream_t st) {
     const long M = B * L;
-    const long NP = lay.total;
+    const SlabPlan sp = slab_plan(D, depth, F);
     const float* gh = dout;  // gradient w.r.t. the current layer's output
     for (int l = depth - 1; l >= 0; --l) {
         const LayerOff& o = lay.L[l];
@@ -602,26 +653,26 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
         TDM_TRY(ln_bwd(gh, nullptr, a.s2, a.mean2, a.rstd2, P + o.n2_w, w.g_s, w.part, G + o.n2_w, M, D, st));
         // f2 = f1 W2^T + b2
         TDM_TRY(bias_grad(w.g_s, w.part, G + o.l2_b, M, D, st));
-        TDM_TRY(linear_wgrad(w.g_s, a.f1, slabs, NP, o.l2_w, M, D, F, st));
+        TDM_TRY(linear_wgrad(w.g_s, a.f1, slabs + sp.base[l][3], M, D, F, st));
         TDM_TRY(linear_dgrad(w.g_s, P + o.l2_w, nullptr, w.g_f, M, D, F, st));
         // relu
         TDM_TRY(tdm_launch_relu_mask(w.g_f, a.f1, w.g_f, M * F, st));
         // z1 = h1 W1^T + b1
         TDM_TRY(bias_grad(w.g_f, w.part, G + o.l1_b, M, F, st));
-        TDM_TRY(linear_wgrad(w.g_f, a.h1, slabs, NP, o.l1_w, M, F, D, st));
+        TDM_TRY(linear_wgrad(w.g_f, a.h1, slabs + sp.base[l][2], M, F, D, st));
         TDM_TRY(linear_dgrad(w.g_f, P + o.l1_w, nullptr, w.g_h1, M, F, D, st));
         // LayerNorm 1: h1 = LN(hin + a); d(h1) = g_h1 (FFN path) + g_s (residual)
         TDM_TRY(ln_bwd(w.g_h1, w.g_s, a.s1, a.mean1, a.rstd1, P + o.n1_w, w.g_s1, w.part, G + o.n1_w, M, D, st));
         // a = o Wout^T + bout
         TDM_TRY(bias_grad(w.g_s1, w.part, G + o.out_b, M, D, st));
-        TDM_TRY(linear_wgrad(w.g_s1, a.o, slabs, NP, o.out_w, M, D, D, st));
+        TDM_TRY(linear_wgrad(w.g_s1, a.o, slabs + sp.base[l][1], M, D, D, st));
         TDM_TRY(linear_dgrad(w.g_s1, P + o.out_w, nullptr, w.g_o, M, D, D, st));
         // attention
         TDM_TRY(attn_dispatch(1, D / H, a.qkv, a.o, a.lse, w.g_o, w.g_qkv, w.Dvec, B, L, D, H, st));
         TDM_TRY(attn_dispatch(2, D / H, a.qkv, nullptr, a.lse, w.g_o, w.g_qkv, w.Dvec, B, L, D, H, st));
         // qkv = hin Win^T + bin ; d(hin) = g_qkv Win + g_s1 (residual)
         TDM_TRY(bias_grad(w.g_qkv, w.part, G + o.in_b, M, 3 * D, st));
-        TDM_TRY(linear_wgrad(w.g_qkv, a.hin, slabs, NP, o.in_w, M, 3 * D, D, st));
+        TDM_TRY(linear_wgrad(w.g_qkv, a.hin, slabs + sp.base[l][0], M, 3 * D, D, st));
         float* gout = (l == 0 && dx != nullptr) ? dx : w.g_h;   // layer 0: this is d(loss)/d(x)
         TDM_TRY(linear_dgrad(w.g_qkv, P + o.in_w, w.g_s1, gout, M, 3 * D, D, st));
         gh = gout;
@@ -643,11 +694,14 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
         const long offs[4] = {o.in_w, o.out_w, o.l1_w, o.l2_w};
         const long lens[4] = {3L * D * D, (long)D * D, (long)F * D, (long)D * F};
         for (int k = 0; k < 4; ++k) {
-            ra.sec[n].off = (int)offs[k]; ra.sec[n].len = (int)lens[k]; ra.sec[n].nslab = SPLITK; ++n;
+            ra.sec[n].off = (int)offs[k]; ra.sec[n].len = (int)lens[k]; ra.sec[n].nslab = sp.sk[k];
+            ra.sec[n].src_delta = sp.base[l][k] - offs[k];
+            ra.sec[n].stride_override = sp.len[k];
+            ++n;
         }
     }
     ra.nsec = n;
-    return tdm_launch_reduce(slabs, NP, ra, G, st);
+    return tdm_launch_reduce(slabs, 0, ra, G, st);
 }
 
 }  // namespace
@@ -670,7 +724,7 @@ int64_t tdm_tt_workspace_floats(int64_t B, int L, int D, int H, int depth, int f
 
 int64_t tdm_tt_slab_floats(int D, int depth, int ffn) {
     if (depth < 1 || depth > 8) return -1;
-    return (int64_t)SPLITK * tt_layout(D, depth, ffn).total;
+    return slab_plan(D, depth, ffn).total;
 }
 
 int tdm_tt_fwd_f32(const float* params, const float* x, const int64_t* t, float* out, float* ws, int64_t B, int L, int D,
