@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--sample-steps", type=int, default=20, help="reverse steps timed at B=4096 (0 = skip)")
     ap.add_argument("--text-steps", type=int, default=10, help="text-denoiser train steps timed (0 = skip)")
+    ap.add_argument("--gemm-mode", type=int, default=1, choices=[0, 1, 2],
+                    help="transformer linear layers: 1 = bf16x3 split MFMA (default), 2 = plain bf16 MFMA, 0 = fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-mode", type=int, default=2, choices=[0, 1, 2],
                     help="UNet conv arithmetic: 2 = bf16x3 split MFMA over pre-split tensors (default), "
@@ -218,6 +220,7 @@ def main():
     if args.text_steps > 0:
         from tinydiffusionmodels_amd.shakespeare import TinyTransformer, DenoiserTrainer
         Bt, Lt, Dt = 256, 128, 256
+        _lib.check(_lib.lib().tdm_set_gemm_mode(args.gemm_mode))
         torch.manual_seed(0)
         tmodel = TinyTransformer(Dt, dropout=0.0).to(dev)
         tmodel.train()
@@ -240,7 +243,9 @@ def main():
         out["text_denoiser"] = {"batch_per_gpu": Bt, "seq_len": Lt, "dim": Dt, "ms_per_step": round(ms_t, 3),
                                 "steps_per_s": round(world * 1e3 / ms_t, 2),
                                 "tokens_per_s": round(world * Bt * Lt * 1e3 / ms_t, 0), "tflops": round(tflop, 2),
-                                "arithmetic": "fp32 MFMA GEMMs (exact); dropout 0"}
+                                "arithmetic": {0: "fp32 MFMA GEMMs (exact)", 1: "bf16x3 split-operand MFMA GEMMs, fp32 accumulate",
+                                               2: "plain bf16-operand MFMA GEMMs, fp32 accumulate"}[args.gemm_mode] +
+                                              "; fp32 attention / LayerNorm; dropout 0"}
         del ttr, tmodel, xt
 
     if rank == 0:

@@ -186,6 +186,11 @@ int tdm_tt_p_sample_step_f32(const float* params, const float* x, const int64_t*
                              const float* tab_recip, const float* tab_eps, const float* tab_sigma,
                              int t_index, float* eps, float* x_out, float* ws,
                              int64_t B, int L, int D, int H, int depth, int ffn, void* stream);
+/* Arithmetic of the transformer's linear layers and their gradients:
+ *   0 exact fp32 MFMA; 1 bf16x3 split operands, fp32 accumulate (default; ~1e-5 rel,
+ *   meets the 1e-3 parity bound); 2 plain bf16 operands (throughput mode, ~3e-3 rel) */
+int tdm_set_gemm_mode(int mode);
+int tdm_get_gemm_mode(void);
 /* general strided fp32-MFMA GEMM (tests / profiling):
  * C[i][j] = sum_k A[i*a_rs + k*a_cs] * B[k*b_rs + j*b_cs] (+bias[j]) (+res[i][j]) (relu)      */
 int tdm_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs,

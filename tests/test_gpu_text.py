@@ -34,6 +34,22 @@ def pinned_tables(golden_tables):
     schedule.set_tables(None)
 
 
+@pytest.fixture(scope="module", autouse=True, params=[1, 0, 2], ids=["bf16x3", "fp32", "bf16"])
+def gemm_mode(request):
+    """Every test of this module under the three linear-layer arithmetics (tdm_set_gemm_mode)."""
+    from tinydiffusionmodels_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.tdm_set_gemm_mode(request.param))
+    yield request.param
+    _lib.check(L.tdm_set_gemm_mode(1))
+
+
+def _ftol(gemm_mode, base=TOL):
+    """fp32: base; bf16x3: 16 mantissa bits per operand (~1e-5 per GEMM, 3 layers x 4 GEMMs);
+    plain bf16 operands: ~3e-3 per GEMM — reported, held to 3e-2."""
+    return {0: base, 1: max(base, 3e-4), 2: 3e-2}[gemm_mode]
+
+
 def _model(dim, dev):
     from tinydiffusionmodels_amd.shakespeare import TinyTransformer
     from tinydiffusionmodels_amd import transformer_engine as TE
@@ -51,7 +67,7 @@ GEMM_CASES = [  # (M, N, K, mode)
 
 
 @pytest.mark.parametrize("M,N,K,mode", GEMM_CASES)
-def test_gemm(dev, M, N, K, mode):
+def test_gemm(dev, gemm_mode, M, N, K, mode):
     from tinydiffusionmodels_amd import _lib
     L = _lib.lib()
     g = torch.Generator().manual_seed(M + N + K)
@@ -81,11 +97,13 @@ def test_gemm(dev, M, N, K, mode):
                                   M * N, _lib.stream()))
         out = C.sum(0).cpu()
     torch.cuda.synchronize()
-    assert O.rel_err(out, ref) < 1e-5
+    # NN has no bf16 kernel (the transformer uses NT on a transposed weight instead): it stays exact fp32
+    tol = 1e-5 if (gemm_mode == 0 or mode == "nn") else (5e-5 if gemm_mode == 1 else 2e-2)
+    assert O.rel_err(out, ref) < tol
 
 
 @pytest.mark.parametrize("tag,dim", [("d32", 32), ("d256", 256)])
-def test_transformer_forward_and_grads_golden(dev, golden_dir, golden_tables, tag, dim):
+def test_transformer_forward_and_grads_golden(dev, golden_dir, golden_tables, gemm_mode, tag, dim):
     from tinydiffusionmodels_amd import transformer_engine as TE
     from tinydiffusionmodels_amd.shakespeare import q_sample
     g = _load(golden_dir, "text_denoiser.npz")
@@ -96,23 +114,28 @@ def test_transformer_forward_and_grads_golden(dev, golden_dir, golden_tables, ta
     m.eval()
     with torch.no_grad():
         pred = m(xq, t)
-    assert O.rel_err(pred.cpu(), g[f"{tag}.pred"]) < TOL
+    err = O.rel_err(pred.cpu(), g[f"{tag}.pred"])
+    print(f"[parity] TinyTransformer({dim}) forward rel err, gemm mode {gemm_mode}: {err:.2e}")
+    assert err < _ftol(gemm_mode)
     # fused loss + gradients
     st = TE.TTTrainState(m.cfg, m.flat.detach(), x0.shape[0], x0.shape[1])
     loss = TE.tt_loss_and_grad(m.flat.detach(), st, x0, noise, t)
-    assert abs(loss.item() - g[f"{tag}.loss"].item()) < 1e-5 * abs(g[f"{tag}.loss"].item())
+    assert abs(loss.item() - g[f"{tag}.loss"].item()) < max(1e-5, 10 * _ftol(gemm_mode)) * abs(g[f"{tag}.loss"].item())
     got = TE.state_dict_from_flat(st.grads, dim)
     n_checked = 0
     for k, v in g.items():
         if k.startswith(f"{tag}.grad.") or k.startswith(f"{tag}.gradall."):
             name = k.split(".", 2)[2]
-            assert O.rel_err(got[name].cpu(), v) < 1e-4, name
+            if gemm_mode == 0:
+                assert O.rel_err(got[name].cpu(), v) < 1e-4, name
+            else:   # ReLU-mask flips: L2 metric (see O.rel_l2)
+                assert O.rel_l2(got[name].cpu(), v) < (2e-3 if gemm_mode == 1 else 1e-1), name
             n_checked += 1
     assert n_checked >= 6
 
 
 @pytest.mark.parametrize("B,L,dim", [(2, 37, 64), (1, 130, 128), (3, 128, 256)])
-def test_transformer_oracle_shapes_and_autograd_bridge(dev, golden_tables, B, L, dim):
+def test_transformer_oracle_shapes_and_autograd_bridge(dev, golden_tables, gemm_mode, B, L, dim):
     """Ragged sequence lengths (not multiples of 128), other widths, and the
     nn.Module surface: loss.backward() fills model.flat.grad AND x.grad."""
     from tinydiffusionmodels_amd import transformer_engine as TE
@@ -135,13 +158,17 @@ def test_transformer_oracle_shapes_and_autograd_bridge(dev, golden_tables, B, L,
     # (multi-threaded GEMM summation order), so a near-zero pre-activation may flip its mask
     # on either side; one flip moves a row of linear1.weight's gradient by O(1/sqrt(tokens)).
     # Hence: tight relative-L2 bound + loose max-norm sanity bound (see O.rel_l2).
+    # bf16x3: forward differences of ~3e-6 flip ~1e-5 of the FFN ReLU masks; with only B*L = 74..384 tokens
+    # the relative L2 effect on linear1.weight's gradient is sqrt(flips / (tokens*2048)) ~ 5e-3
+    l2tol = {0: 1e-3, 1: 1e-2, 2: 1e-1}[gemm_mode]
     for k, v in leaf.items():
-        assert O.rel_l2(got[k].cpu(), v.grad) < 1e-3, k
-        assert O.rel_err(got[k].cpu(), v.grad) < 3e-2, k
-    assert O.rel_l2(xd.grad.cpu(), xr.grad) < 1e-3
+        assert O.rel_l2(got[k].cpu(), v.grad) < l2tol, k
+        if gemm_mode == 0:
+            assert O.rel_err(got[k].cpu(), v.grad) < 3e-2, k
+    assert O.rel_l2(xd.grad.cpu(), xr.grad) < l2tol
 
 
-def test_text_p_sample_and_chain(dev, golden_dir, golden_tables):
+def test_text_p_sample_and_chain(dev, golden_dir, golden_tables, gemm_mode):
     from tinydiffusionmodels_amd.shakespeare import p_sample, reverse_diffusion
     g = _load(golden_dir, "text_denoiser.npz")
     for tag, dim, tts in (("d256", 256, (999,)), ("d32", 32, (999, 0))):
@@ -151,7 +178,7 @@ def test_text_p_sample_and_chain(dev, golden_dir, golden_tables):
                 x = g[f"{tag}.ps{tt}.x"].to(dev)
                 t = torch.full((x.shape[0],), tt, dtype=torch.long, device=dev)
                 y = p_sample(m, x, t, noise=g[f"{tag}.ps{tt}.z"].to(dev))
-                assert O.rel_err(y.cpu(), g[f"{tag}.ps{tt}.y"]) < TOL, (tag, tt)
+                assert O.rel_err(y.cpu(), g[f"{tag}.ps{tt}.y"]) < _ftol(gemm_mode), (tag, tt)
     # short chain vs oracle with shared noise
     dim, B, L = 32, 2, 16
     m = _model(dim, dev).eval()
@@ -163,10 +190,10 @@ def test_text_p_sample_and_chain(dev, golden_dir, golden_tables):
     for k, i in enumerate(range(5, -1, -1)):
         ref = O.text_p_sample(p, ref, torch.full((B,), i, dtype=torch.long), zs[k], golden_tables)
     out = reverse_diffusion(m, x.to(dev), noises=[z.to(dev) for z in zs], t_start=5)
-    assert O.rel_err(out.cpu(), ref) < 1e-4
+    assert O.rel_err(out.cpu(), ref) < _ftol(gemm_mode, 1e-4)
 
 
-def test_denoiser_trainer_step_matches_oracle_adamw(dev, golden_tables):
+def test_denoiser_trainer_step_matches_oracle_adamw(dev, golden_tables, gemm_mode):
     from tinydiffusionmodels_amd import transformer_engine as TE
     from tinydiffusionmodels_amd.shakespeare import DenoiserTrainer
     dim, B, L = 64, 4, 24
@@ -185,7 +212,7 @@ def test_denoiser_trainer_step_matches_oracle_adamw(dev, golden_tables):
     for k in p:
         ref, _, _ = O.adamw_step(p[k], grads[k], torch.zeros_like(p[k]), torch.zeros_like(p[k]), 1, lr=lr,
                                  weight_decay=1e-4)
-        assert (sd[k].cpu() - ref).abs().max().item() < 0.05 * lr, k
+        assert (sd[k].cpu() - ref).abs().max().item() < (0.05 if gemm_mode == 0 else 2.1) * lr, k
 
 
 def test_train_mode_dropout_refused(dev):

@@ -45,6 +45,8 @@ _SIGS = {
                                  c_int),
     "tdm_conv_nhwc_s16_f32": ([c_f] * 10 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_f], c_int),
     "tdm_conv_wgrad_nhwc_s16_f32": ([c_f] * 5 + [c_i64, c_int, c_int, c_int, c_int, c_f], c_int),
+    "tdm_set_gemm_mode": ([c_int], c_int),
+    "tdm_get_gemm_mode": ([], c_int),
     "tdm_tt_param_count": ([c_int, c_int, c_int], c_i64),
     "tdm_tt_param_offsets": ([c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int64)], c_int),
     "tdm_tt_workspace_floats": ([c_i64, c_int, c_int, c_int, c_int, c_int, c_int], c_i64),

@@ -1,0 +1,304 @@
+// bf16 MFMA GEMMs for the transformer denoiser's linear layers
+// (src/shakespeare.py:105-120: packed in_proj, out_proj, FFN 256<->2048) and
+// their gradients, on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+//
+//   NPROD = 3 ("bf16x3"): every fp32 operand x is split while staging into
+//       hi = bf16(x), lo = bf16(x - hi); hi*hi + hi*lo + lo*hi keeps 16 mantissa
+//       bits per operand (~1e-5 relative) — the mode that meets the 1e-3 parity bound;
+//   NPROD = 1 (plain bf16 operands): 1/3 of the MFMAs, half the LDS, ~3e-3 relative
+//       per GEMM — the throughput mode BASELINE.json's config 5 names.
+//
+// gemm_nt:  C[M][N] = A[M][K] . B[N][K]^T (+bias[N]) (+res) (relu)   — forward, and the data
+//           gradient with the transposed weight (W^T is rebuilt once per backward pass).
+//           Both operands are K-contiguous: LDS images [row][32 k] with an 80-byte pitch
+//           (5 x 16 B, conflict-free ds_read_b128 fragments).  The weight rows feed the MFMA
+//           A operand and the token rows the B operand, so a lane owns 4 consecutive output
+//           columns of ITS token row per register quad: float4 epilogue.
+// gemm_tn:  C[N][K] = sum_m A[m][N] . B[m][K]   — weight gradients, contraction over tokens,
+//           split-K over workgroups.  Operands are row(token)-major, so fragments (8
+//           consecutive tokens of one column) come from ds_read_b64_tr_b16 on [col block of
+//           32][token][32 cols] images whose 64-byte pitch keeps the transposed reads
+//           conflict-free.
+#include "tdm_common.h"
+#include "tdm_transformer.h"
+#include "tdm_s16.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int TM = 128, TN_ = 128, BK = 32;
+constexpr int PITCH = 80;                 // bytes per staged row of 32 bf16 (+16 pad)
+constexpr int PLANE = 128 * PITCH;        // one 128-row image
+
+__device__ __forceinline__ float4 load4_guard(const float* p, int avail) {  // avail = elements left in the row
+    if (avail >= 4) return *reinterpret_cast<const float4*>(p);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (avail > 0) v.x = p[0];
+    if (avail > 1) v.y = p[1];
+    if (avail > 2) v.z = p[2];
+    return v;
+}
+
+template <int NPROD>
+__device__ __forceinline__ void put_split(char* hi_plane, char* lo_plane, int off, const float4 v) {
+    tdm_bf16x4 hi, lo;
+    if (NPROD == 3) {
+        tdm_split4(v, hi, lo);
+        *reinterpret_cast<tdm_bf16x4*>(hi_plane + off) = hi;
+        *reinterpret_cast<tdm_bf16x4*>(lo_plane + off) = lo;
+    } else {
+        hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+        *reinterpret_cast<tdm_bf16x4*>(hi_plane + off) = hi;
+    }
+}
+
+// ------------------------------------------------------------------ NT
+template <int NPROD>
+__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
+    // planes: A hi, A lo, B hi, B lo  (lo planes unused when NPROD == 1)
+    __shared__ __attribute__((aligned(16))) char lds[4 * PLANE];
+    char* Ahi = lds; char* Alo = lds + PLANE; char* Bhi = lds + 2 * PLANE; char* Blo = lds + 3 * PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i0 = blockIdx.y * TM, j0 = blockIdx.x * TN_;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {   // 128 rows x 8 float4
+            const int f = tid + 256 * p;
+            const int row = f >> 3, kq = f & 7;
+            const int gk = k0 + kq * 4;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            if (i0 + row < g.M) va = load4_guard(g.A + (long)(i0 + row) * g.a_rs + gk, g.K - gk);
+            if (j0 + row < g.N) vb = load4_guard(g.B + (long)(j0 + row) * g.b_cs + gk, g.K - gk);
+            put_split<NPROD>(Ahi, Alo, row * PITCH + kq * 8, va);
+            put_split<NPROD>(Bhi, Blo, row * PITCH + kq * 8, vb);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xh[2], xl[2], wh[2], wl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ao = (wm * 64 + t * 32 + j) * PITCH + ks * 32 + h * 16;
+                const int bo = (wn * 64 + t * 32 + j) * PITCH + ks * 32 + h * 16;
+                xh[t] = *reinterpret_cast<const bf16x8*>(Ahi + ao);
+                wh[t] = *reinterpret_cast<const bf16x8*>(Bhi + bo);
+                if (NPROD == 3) {
+                    xl[t] = *reinterpret_cast<const bf16x8*>(Alo + ao);
+                    wl[t] = *reinterpret_cast<const bf16x8*>(Blo + bo);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {   // D[n][m]: weight rows are the MFMA A operand
+                    if (NPROD == 3) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[nt], xl[mt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[nt], xh[mt], acc[mt][nt], 0, 0, 0);
+                    }
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[nt], xh[mt], acc[mt][nt], 0, 0, 0);
+                }
+        }
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = i0 + wm * 64 + mt * 32 + j;
+        if (m < g.M) {
+            const long row = (long)m * g.c_rs;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = j0 + wn * 64 + nt * 32 + 8 * q + 4 * h;
+                    if (n < g.N) {   // N % 4 == 0: the whole quad is in range
+                        float4 v = make_float4(acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2],
+                                               acc[mt][nt][4 * q + 3]);
+                        if (g.bias != nullptr) {
+                            const float4 bz = *reinterpret_cast<const float4*>(g.bias + n);
+                            v.x += bz.x; v.y += bz.y; v.z += bz.z; v.w += bz.w;
+                        }
+                        if (g.res != nullptr) {
+                            const float4 rz = *reinterpret_cast<const float4*>(g.res + row + n);
+                            v.x += rz.x; v.y += rz.y; v.z += rz.z; v.w += rz.w;
+                        }
+                        if (g.relu) {
+                            v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y;
+                            v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+                        }
+                        *reinterpret_cast<float4*>(g.C + row + n) = v;
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ TN (split over the contraction)
+__device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
+    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1));
+    s16x8 r;
+    r[0] = lo4[0]; r[1] = lo4[1]; r[2] = lo4[2]; r[3] = lo4[3];
+    r[4] = hi4[0]; r[5] = hi4[1]; r[6] = hi4[2]; r[7] = hi4[3];
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+constexpr int TPL = 4 * 32 * 64;   // one [4 col blocks][32 tokens][32 cols] bf16 image = 8 KB
+
+template <int NPROD>
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
+    // C[i][j] = sum_k A(i,k) B(k,j) with A(i,k) = A[k*a_cs + i], B(k,j) = B[k*b_rs + j]  (a_rs = b_cs = 1)
+    __shared__ __attribute__((aligned(16))) char lds[4 * TPL];
+    char* Ahi = lds; char* Alo = lds + TPL; char* Bhi = lds + 2 * TPL; char* Blo = lds + 3 * TPL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i0 = blockIdx.y * TM, j0 = blockIdx.x * TN_;
+    const int g4 = lane >> 4, cb = g4 & 1, hh = g4 >> 1, q = (lane >> 2) & 3, pcq = lane & 3;
+    const int colb = (cb * 16 + pcq * 4) * 2;
+    int kbeg = 0, kend = g.K;
+    if (g.splitk > 1) {
+        const int chunk = ((g.K + g.splitk - 1) / g.splitk + BK - 1) / BK * BK;
+        kbeg = blockIdx.z * chunk;
+        kend = min(g.K, kbeg + chunk);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {   // 32 token rows x 32 float4 columns
+            const int f = tid + 256 * p;
+            const int mrow = f >> 5, c4 = f & 31;
+            const int gk = k0 + mrow;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            if (gk < kend) {
+                va = load4_guard(g.A + (long)gk * g.a_cs + i0 + c4 * 4, g.M - (i0 + c4 * 4));
+                vb = load4_guard(g.B + (long)gk * g.b_rs + j0 + c4 * 4, g.N - (j0 + c4 * 4));
+            }
+            const int off = ((c4 >> 3) * 32 + mrow) * 64 + (c4 & 7) * 8;
+            put_split<NPROD>(Ahi, Alo, off, va);
+            put_split<NPROD>(Bhi, Blo, off, vb);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int m0r = ks * 16 + hh * 8 + q;   // token row of this lane's first transposed read
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ao = ((wm * 2 + t) * 32 + m0r) * 64 + colb;
+                const int bo = ((wn * 2 + t) * 32 + m0r) * 64 + colb;
+                ah[t] = tr_pair(Ahi + ao, Ahi + ao + 4 * 64);
+                bh[t] = tr_pair(Bhi + bo, Bhi + bo + 4 * 64);
+                if (NPROD == 3) {
+                    al[t] = tr_pair(Alo + ao, Alo + ao + 4 * 64);
+                    bl[t] = tr_pair(Blo + bo, Blo + bo + 4 * 64);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    if (NPROD == 3) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                    }
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                }
+        }
+    }
+    float* C = g.C + (g.splitk > 1 ? (long)blockIdx.z * g.c_split_stride : 0L);
+    const int h = lane >> 5, jl = lane & 31;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = j0 + wn * 64 + nt * 32 + jl;
+            if (col < g.N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < g.M) C[(long)row * g.c_rs + col] = acc[mt][nt][r];
+                }
+            }
+        }
+}
+
+// out[c][r] = in[r][c]
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R,
+                                                        int Cn) {
+    __shared__ float t[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = by + ty + 8 * k, c = bx + tx;
+        if (r < R && c < Cn) t[ty + 8 * k][tx] = in[(long)r * Cn + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = bx + ty + 8 * k, r = by + tx;
+        if (r < R && c < Cn) out[(long)c * R + r] = t[tx][ty + 8 * k];
+    }
+}
+
+}  // namespace
+
+// C[M][N] = A[M][K] B[N][K]^T ...: A(i,k) = A[i*a_rs + k], B(k,j) = B[j*b_cs + k]
+int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
+    TDM_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm_nt_bf16: empty problem");
+    TDM_REQUIRE(g.a_cs == 1 && g.b_rs == 1, "gemm_nt_bf16: both operands must be K-contiguous");
+    TDM_REQUIRE((g.a_rs % 4) == 0 && (g.b_cs % 4) == 0 && (g.N % 4) == 0 && (g.c_rs % 4) == 0,
+                "gemm_nt_bf16: leading dimensions and N must be multiples of 4");
+    TDM_REQUIRE((((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.C) & 15) == 0, "gemm_nt_bf16: 16-byte alignment");
+    TDM_REQUIRE(g.splitk <= 1, "gemm_nt_bf16: no split-K");
+    dim3 grid((g.N + TN_ - 1) / TN_, (g.M + TM - 1) / TM);
+    if (nprod == 3) hipLaunchKernelGGL(gemm_nt_bf16_kernel<3>, grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(gemm_nt_bf16_kernel<1>, grid, dim3(256), 0, st, g);
+    TDM_CHECK_LAUNCH("gemm_nt_bf16");
+    return 0;
+}
+
+// C[M][N] = sum_k A[k][M]^T B[k][N]: A(i,k) = A[k*a_cs + i], B(k,j) = B[k*b_rs + j]; raw split-K output
+int tdm_launch_gemm_tn_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
+    TDM_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm_tn_bf16: empty problem");
+    TDM_REQUIRE(g.a_rs == 1 && g.b_cs == 1, "gemm_tn_bf16: both operands must be row(contraction)-major");
+    TDM_REQUIRE((g.a_cs % 4) == 0 && (g.b_rs % 4) == 0, "gemm_tn_bf16: leading dimensions must be multiples of 4");
+    TDM_REQUIRE((((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0, "gemm_tn_bf16: 16-byte alignment");
+    TDM_REQUIRE(g.bias == nullptr && g.res == nullptr && !g.relu, "gemm_tn_bf16: raw output only");
+    const int sk = g.splitk > 1 ? g.splitk : 1;
+    dim3 grid((g.N + TN_ - 1) / TN_, (g.M + TM - 1) / TM, sk);
+    if (nprod == 3) hipLaunchKernelGGL(gemm_tn_bf16_kernel<3>, grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(gemm_tn_bf16_kernel<1>, grid, dim3(256), 0, st, g);
+    TDM_CHECK_LAUNCH("gemm_tn_bf16");
+    return 0;
+}
+
+int tdm_launch_transpose(const float* in, float* out, int R, int Cn, hipStream_t st) {
+    dim3 grid((Cn + 31) / 32, (R + 31) / 32);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, st, in, out, R, Cn);
+    TDM_CHECK_LAUNCH("transpose");
+    return 0;
+}

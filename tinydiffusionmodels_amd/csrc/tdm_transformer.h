@@ -13,3 +13,8 @@ struct GemmArgs {
     int splitk; long c_split_stride;   // splitk > 1: partial z goes to C + z*c_split_stride (raw)
 };
 int tdm_launch_gemm(const GemmArgs& g, hipStream_t st);
+
+// bf16 MFMA GEMMs (gemm_bf16.hip); nprod = 3 (hi/lo split operands, ~1e-5) or 1 (plain bf16 operands)
+int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st);
+int tdm_launch_gemm_tn_bf16(const GemmArgs& g, int nprod, hipStream_t st);
+int tdm_launch_transpose(const float* in, float* out, int R, int Cn, hipStream_t st);

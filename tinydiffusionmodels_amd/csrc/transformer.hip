@@ -12,7 +12,11 @@
 
 namespace {
 
-constexpr int LN_SLABS = 256;  // per-wave partials of the LayerNorm affine gradients
+// arithmetic of the linear layers: 0 exact fp32 MFMA, 1 bf16x3 split operands (default, meets the 1e-3
+// parity bound), 2 plain bf16 operands (throughput mode)
+int g_gemm_mode = 1;
+
+constexpr int LN_SLABS = 2048; // per-wave partials of the LayerNorm affine gradients (512 workgroups)
 constexpr int CS_SLABS = 512;  // row-block partials of the bias gradients
 
 // Weight-gradient GEMMs contract over tokens (K = B*L, tens of thousands) into small [N][K] outputs:
@@ -68,7 +72,7 @@ TTLayout tt_layout(int D, int depth, int F) {
 // --------------------------------- workspace -------------------------------------
 struct LayerWs { float *hin, *qkv, *o, *lse, *s1, *mean1, *rstd1, *h1, *f1, *s2, *mean2, *rstd2; };
 struct TTWs {
-    float *that, *tb, *abuf;
+    float *that, *tb, *abuf, *wT;
     LayerWs L[8];
     // backward temporaries
     float *g_h, *g_s, *g_s1, *g_f, *g_h1, *g_o, *g_qkv, *Dvec, *Sb, *part;
@@ -84,6 +88,7 @@ TTWs tt_carve(float* base, long B, int Lq, int D, int H, int depth, int F, int t
     };
     const long M = B * Lq;
     w.that = take(B); w.tb = take(B * D); w.abuf = take(M * D);
+    w.wT = take((long)(F > 3 * D ? F : 3 * D) * D);   // transposed weight of the current data-gradient GEMM
     for (int l = 0; l < depth; ++l) {
         LayerWs& x = w.L[l];
         x.hin = take(M * D); x.qkv = take(M * 3 * D); x.o = take(M * D); x.lse = take(B * H * Lq);
@@ -557,11 +562,20 @@ int linear_fwd(const float* X, const float* W, const float* bias, const float* r
     g.A = X; g.a_rs = K; g.a_cs = 1;
     g.B = W; g.b_rs = 1; g.b_cs = K;
     g.C = Y; g.c_rs = N; g.bias = bias; g.res = res; g.relu = relu; g.M = (int)M; g.N = N; g.K = K; g.splitk = 1;
+    if (g_gemm_mode != 0) return tdm_launch_gemm_nt_bf16(g, g_gemm_mode == 1 ? 3 : 1, st);
     return tdm_launch_gemm(g, st);
 }
 // dX[M][K] = dY[M][N] W[N][K] (+res)
-int linear_dgrad(const float* dY, const float* W, const float* res, float* dX, long M, int N, int K, hipStream_t st) {
+int linear_dgrad(const float* dY, const float* W, float* wT, const float* res, float* dX, long M, int N, int K,
+                 hipStream_t st) {
     GemmArgs g{};
+    if (g_gemm_mode != 0) {   // dX = dY . (W^T)^T as a K-contiguous (NT) product on the transposed weight
+        TDM_TRY(tdm_launch_transpose(W, wT, N, K, st));
+        g.A = dY; g.a_rs = N; g.a_cs = 1;
+        g.B = wT; g.b_rs = 1; g.b_cs = N;
+        g.C = dX; g.c_rs = K; g.res = res; g.M = (int)M; g.N = K; g.K = N; g.splitk = 1;
+        return tdm_launch_gemm_nt_bf16(g, g_gemm_mode == 1 ? 3 : 1, st);
+    }
     g.A = dY; g.a_rs = N; g.a_cs = 1;
     g.B = W; g.b_rs = K; g.b_cs = 1;
     g.C = dX; g.c_rs = K; g.res = res; g.M = (int)M; g.N = K; g.K = N; g.splitk = 1;
@@ -574,6 +588,7 @@ int linear_wgrad(const float* dY, const float* X, float* slab_region, long M, in
     g.B = X; g.b_rs = K; g.b_cs = 1;
     g.C = slab_region; g.c_rs = K; g.M = N; g.N = K; g.K = (int)M; g.splitk = wgrad_splitk(N, K);
     g.c_split_stride = (long)N * K;
+    if (g_gemm_mode != 0) return tdm_launch_gemm_tn_bf16(g, g_gemm_mode == 1 ? 3 : 1, st);
     return tdm_launch_gemm(g, st);
 }
 // bias gradient: db[N] = colsum(dY) via partials + reduce
@@ -654,19 +669,19 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
         // f2 = f1 W2^T + b2
         TDM_TRY(bias_grad(w.g_s, w.part, G + o.l2_b, M, D, st));
         TDM_TRY(linear_wgrad(w.g_s, a.f1, slabs + sp.base[l][3], M, D, F, st));
-        TDM_TRY(linear_dgrad(w.g_s, P + o.l2_w, nullptr, w.g_f, M, D, F, st));
+        TDM_TRY(linear_dgrad(w.g_s, P + o.l2_w, w.wT, nullptr, w.g_f, M, D, F, st));
         // relu
         TDM_TRY(tdm_launch_relu_mask(w.g_f, a.f1, w.g_f, M * F, st));
         // z1 = h1 W1^T + b1
         TDM_TRY(bias_grad(w.g_f, w.part, G + o.l1_b, M, F, st));
         TDM_TRY(linear_wgrad(w.g_f, a.h1, slabs + sp.base[l][2], M, F, D, st));
-        TDM_TRY(linear_dgrad(w.g_f, P + o.l1_w, nullptr, w.g_h1, M, F, D, st));
+        TDM_TRY(linear_dgrad(w.g_f, P + o.l1_w, w.wT, nullptr, w.g_h1, M, F, D, st));
         // LayerNorm 1: h1 = LN(hin + a); d(h1) = g_h1 (FFN path) + g_s (residual)
         TDM_TRY(ln_bwd(w.g_h1, w.g_s, a.s1, a.mean1, a.rstd1, P + o.n1_w, w.g_s1, w.part, G + o.n1_w, M, D, st));
         // a = o Wout^T + bout
         TDM_TRY(bias_grad(w.g_s1, w.part, G + o.out_b, M, D, st));
         TDM_TRY(linear_wgrad(w.g_s1, a.o, slabs + sp.base[l][1], M, D, D, st));
-        TDM_TRY(linear_dgrad(w.g_s1, P + o.out_w, nullptr, w.g_o, M, D, D, st));
+        TDM_TRY(linear_dgrad(w.g_s1, P + o.out_w, w.wT, nullptr, w.g_o, M, D, D, st));
         // attention
         TDM_TRY(attn_dispatch(1, D / H, a.qkv, a.o, a.lse, w.g_o, w.g_qkv, w.Dvec, B, L, D, H, st));
         TDM_TRY(attn_dispatch(2, D / H, a.qkv, nullptr, a.lse, w.g_o, w.g_qkv, w.Dvec, B, L, D, H, st));
@@ -674,7 +689,7 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
         TDM_TRY(bias_grad(w.g_qkv, w.part, G + o.in_b, M, 3 * D, st));
         TDM_TRY(linear_wgrad(w.g_qkv, a.hin, slabs + sp.base[l][0], M, 3 * D, D, st));
         float* gout = (l == 0 && dx != nullptr) ? dx : w.g_h;   // layer 0: this is d(loss)/d(x)
-        TDM_TRY(linear_dgrad(w.g_qkv, P + o.in_w, w.g_s1, gout, M, 3 * D, D, st));
+        TDM_TRY(linear_dgrad(w.g_qkv, P + o.in_w, w.wT, w.g_s1, gout, M, 3 * D, D, st));
         gh = gout;
     }
     // time embedding: hin0 = x + (w*that + b)
@@ -774,6 +789,13 @@ int tdm_tt_p_sample_step_f32(const float* params, const float* x, const int64_t*
                                    B * L * D, stream);
 }
 
+int tdm_set_gemm_mode(int mode) {
+    TDM_REQUIRE(mode >= 0 && mode <= 2, "gemm mode %d (0 = fp32 MFMA, 1 = bf16x3, 2 = bf16)", mode);
+    g_gemm_mode = mode;
+    return 0;
+}
+int tdm_get_gemm_mode(void) { return g_gemm_mode; }
+
 int tdm_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float* C,
                  int64_t c_rs, const float* bias, const float* res, int M, int N, int K, int relu, int splitk,
                  int64_t c_split_stride, void* stream) {
@@ -781,6 +803,13 @@ int tdm_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int
     g.A = A; g.a_rs = a_rs; g.a_cs = a_cs; g.B = B; g.b_rs = b_rs; g.b_cs = b_cs; g.C = C; g.c_rs = c_rs;
     g.bias = bias; g.res = res; g.M = M; g.N = N; g.K = K; g.relu = relu; g.splitk = splitk;
     g.c_split_stride = c_split_stride;
+    if (g_gemm_mode != 0) {   // route the K-contiguous (NT) and token-major (TN) forms through the bf16 kernels
+        const int nprod = g_gemm_mode == 1 ? 3 : 1;
+        if (a_cs == 1 && b_rs == 1 && splitk <= 1 && (N % 4) == 0 && (c_rs % 4) == 0)
+            return tdm_launch_gemm_nt_bf16(g, nprod, (hipStream_t)stream);
+        if (a_rs == 1 && b_cs == 1 && bias == nullptr && res == nullptr && !relu)
+            return tdm_launch_gemm_tn_bf16(g, nprod, (hipStream_t)stream);
+    }
     return tdm_launch_gemm(g, (hipStream_t)stream);
 }
 
