@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--sample-steps", type=int, default=20, help="reverse steps timed at B=4096 (0 = skip)")
+    ap.add_argument("--sample-steps", type=int, default=40, help="reverse steps timed at B=4096 (0 = skip)")
     ap.add_argument("--text-steps", type=int, default=10, help="text-denoiser train steps timed (0 = skip)")
     ap.add_argument("--gemm-mode", type=int, default=1, choices=[0, 1, 2],
                     help="transformer linear layers: 1 = bf16x3 split MFMA (default), 2 = plain bf16 MFMA, 0 = fp32 MFMA")
@@ -199,7 +199,7 @@ def main():
     if args.sample_steps > 0:
         xs = torch.randn(B_SAMPLE, 1, 28, 28, device=dev, generator=torch.Generator(device=dev).manual_seed(99 + rank))
         with torch.no_grad():
-            reverse_diffusion(model, xs, t_start=2)      # warm-up (3 steps)
+            reverse_diffusion(model, xs, t_start=args.sample_steps - 1)   # warm-up: captures the two-step hipGraph
             sync()
             t0 = time.perf_counter()
             reverse_diffusion(model, xs, t_start=args.sample_steps - 1)
@@ -211,7 +211,7 @@ def main():
             el = tt.item()
         ms_rev = 1e3 * el / args.sample_steps
         out["sampling"] = {"batch_per_gpu": B_SAMPLE, "ms_per_reverse_step": round(ms_rev, 3),
-                           "reverse_steps_timed": args.sample_steps,
+                           "reverse_steps_timed": args.sample_steps, "hipgraph": args.sample_steps >= 16,
                            "imgs_per_s_1000_step": round(world * B_SAMPLE / (ms_rev * 1e-3 * 1000), 2),
                            "tflops": round(FWD_FLOP_PER_SAMPLE * B_SAMPLE / (ms_rev * 1e-3) / 1e12, 2)}
         del xs

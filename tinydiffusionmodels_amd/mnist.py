@@ -98,6 +98,7 @@ class SimpleUNet(nn.Module):
         sd["out.weight"], sd["out.bias"] = out.weight.detach(), out.bias.detach()
         self.flat = nn.Parameter(E.flat_from_state_dict(sd))
         self._infer_ws = None
+        self._samplers = {}
 
     # ---- reference-compatible checkpoint ABI ---------------------------------
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
@@ -119,6 +120,13 @@ class SimpleUNet(nn.Module):
         if ws is None or ws.B != B or ws.ws.device != device:
             ws = self._infer_ws = E.UNetWorkspace(B, device, training=False)
         return ws
+
+    def _graph_sampler(self, n, device):
+        key = (n, str(device), self.flat.data_ptr())
+        if key not in self._samplers:
+            self._samplers.clear()                          # one resident sampler (buffers + graph) at a time
+            self._samplers[key] = _GraphSampler(self, n, device)
+        return self._samplers[key]
 
     def forward(self, x, t):
         """x (B,1,28,28) fp32 on the GPU, t (B,) int64 raw step indices (src/mnist.py:76-87)."""
@@ -164,31 +172,122 @@ def p_sample(model, x, t, noise=None):
     return out
 
 
+def _reverse_step_device_t(flat, ws, cur, t_vec, z, eps, nxt, sigma_tab, tabs):
+    """x_{t-1} from x_t with the step index held in DEVICE memory (t_vec): UNet forward, then the
+    update of src/mnist.py:173-180 gathered by t; sigma_tab[0] = 0 makes the t == 0 step return the
+    mean exactly as the reference's `if t[0] == 0` branch does, with no host-side branch."""
+    E.unet_forward(flat, cur, t_vec, ws, save=False, out=eps)
+    B = cur.shape[0]
+    _lib.check(_lib.lib().tdm_p_sample_update_pert_f32(
+        _lib.ptr(cur), _lib.ptr(eps), _lib.ptr(z), _lib.ptr(tabs["sqrt_recip_alphas"]), _lib.ptr(tabs["eps_coef"]),
+        _lib.ptr(sigma_tab), _lib.ptr(t_vec), 1, _lib.ptr(nxt), B, cur.numel() // B, _lib.stream()), "p_sample_update")
+
+
 @torch.no_grad()
 def reverse_diffusion(model: "SimpleUNet", x: torch.Tensor, noises=None, t_start: int = timesteps - 1,
-                      use_graph: bool = False) -> torch.Tensor:
-    """The reverse loop of src/mnist.py:190-193 (`for i in reversed(range(T))`)
-    without any host sync: the step index is a host integer, so the t[0]==0
-    test of the reference never touches the device.  noises: optional sequence
-    of z tensors (teacher forcing), noises[k] used at t = t_start-k."""
+                      use_graph: Optional[bool] = None) -> torch.Tensor:
+    """The reverse loop of src/mnist.py:190-193 (`for i in reversed(range(T))`) with no host sync.
+
+    use_graph (default: on when the noise is drawn on the device and the chain is long): two reverse
+    steps (x ping-pong) are captured ONCE into a hipGraph — noise draw, 13 UNet launches, update,
+    t -= 1 each — and the graph is replayed (t_start+1)/2 times; the step index lives in device
+    memory.  noises: optional sequence of z tensors (teacher forcing), noises[k] used at
+    t = t_start-k; that path runs eagerly with a host-side step index."""
     E._need_cuda(x)
     n = x.shape[0]
     dev = x.device
     flat = model.flat.detach()
     ws = model._workspace(n, dev)
     eps = torch.empty_like(x)
+    nsteps = t_start + 1
+    if use_graph is None:
+        use_graph = noises is None and nsteps >= 16
     cur, nxt = x.contiguous().clone(), torch.empty_like(x)
-    # one int64 (n,) tensor per step would be 1000 tiny fills; keep a single
-    # table of all step vectors resident instead (8 MB at n = 1000... sized n*T)
-    t_all = torch.arange(t_start, -1, -1, device=dev, dtype=torch.long).view(-1, 1).expand(-1, n).contiguous()
-    for k, i in enumerate(range(t_start, -1, -1)):
-        if i > 0:
-            z = noises[k].contiguous() if noises is not None else torch.randn_like(cur)
+    if not use_graph:
+        # one (n,) int64 vector per step would be 1000 tiny fills: keep all of them resident instead
+        t_all = torch.arange(t_start, -1, -1, device=dev, dtype=torch.long).view(-1, 1).expand(-1, n).contiguous()
+        for k, i in enumerate(range(t_start, -1, -1)):
+            if i > 0:
+                z = noises[k].contiguous() if noises is not None else torch.randn_like(cur)
+            else:
+                z = None
+            E.p_sample_step(flat, ws, cur, t_all[k], i, z, eps, nxt)
+            cur, nxt = nxt, cur
+        return cur
+
+    sampler = model._graph_sampler(n, dev)
+    return sampler.run(cur, nsteps, t_start, noises)
+
+
+class _GraphSampler:
+    """Persistent buffers + one captured two-step hipGraph for a (model, batch size) pair."""
+
+    def __init__(self, model: "SimpleUNet", n: int, dev):
+        self.model, self.n, self.dev = model, n, dev
+        self.tabs = device_tables(dev)
+        self.sigma0 = self.tabs["sigma"].clone()
+        self.sigma0[0] = 0.0                               # t == 0: x = mean (src/mnist.py:176-177)
+        self.xa = torch.empty(n, 1, 28, 28, device=dev)
+        self.xb = torch.empty_like(self.xa)
+        self.eps = torch.empty_like(self.xa)
+        self.z = torch.empty_like(self.xa)
+        self.t_vec = torch.zeros(n, device=dev, dtype=torch.long)
+        self.kidx = torch.zeros(1, device=dev, dtype=torch.long)
+        self.ws = E.UNetWorkspace(n, dev, training=False)  # owned here: the graph holds its address
+        self.bank = None
+        self.graph = None
+        self.graph_has_bank = None
+
+    def _one(self, a, b):
+        if self.bank is None:
+            self.z.normal_()
+        else:   # teacher forcing inside the graph: z gathered from a resident bank by a device-side counter
+            torch.index_select(self.bank, 0, self.kidx, out=self.z.view(1, -1))
+            self.kidx.add_(1).clamp_(max=self.bank.shape[0] - 1)
+        _reverse_step_device_t(self.model.flat.detach(), self.ws, a, self.t_vec, self.z, self.eps, b, self.sigma0,
+                               self.tabs)
+        self.t_vec.sub_(1)
+
+    def _capture(self):
+        saved = (self.xa.clone(), self.t_vec.clone(), self.kidx.clone())
+        side = torch.cuda.Stream(device=self.dev)          # warm-up off the capture stream, then restore
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            self._one(self.xa, self.xb)
+            self._one(self.xb, self.xa)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        self.xa.copy_(saved[0]); self.t_vec.copy_(saved[1]); self.kidx.copy_(saved[2])
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._one(self.xa, self.xb)
+            self._one(self.xb, self.xa)
+        self.graph_has_bank = self.bank is not None
+
+    def run(self, x, nsteps, t_start, noises):
+        bank = None
+        if noises is not None:
+            bank = torch.stack([zz.contiguous() for zz in noises[:nsteps]]).view(-1, x.numel())
+        if self.graph is not None and (self.graph_has_bank != (bank is not None) or
+                                       (bank is not None and (self.bank is None or bank.shape != self.bank.shape))):
+            self.graph = None                               # the captured bank address / shape changed
+        if bank is not None and self.graph is not None:
+            self.bank.copy_(bank)
         else:
-            z = None
-        E.p_sample_step(flat, ws, cur, t_all[k], i, z, eps, nxt)
-        cur, nxt = nxt, cur
-    return cur
+            self.bank = bank
+        self.xa.copy_(x)
+        self.t_vec.fill_(t_start)
+        self.kidx.zero_()
+        left = nsteps
+        if left % 2 == 1:                                   # odd chain: first step eagerly (a -> b), then move b to a
+            self._one(self.xa, self.xb)
+            self.xa.copy_(self.xb)
+            left -= 1
+        if left > 0:
+            if self.graph is None:
+                self._capture()
+            for _ in range(left // 2):
+                self.graph.replay()
+        return self.xa.clone()
 
 
 def to_image_range(x: torch.Tensor):
