@@ -160,39 +160,53 @@ def main():
                                 "frac_f32_mfma": round(flops / step_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                                 "gbs": round(byts / step_s / 1e9, 1),
                                 "frac_hbm": round(byts / step_s / 1e9 / PEAK_HBM_GBS, 4)}
-        # ---- dominant kernel: conv_mfma_kernel<28,1,fwd> on the rb4.conv1 shape ----
-        # (96->32 3x3 @28x28, B=512: 43,352,064 FLOP/sample),
-        # timed live with events on the launch stream.
+        # ---- dominant kernel (26 % of the step): the implicit-GEMM conv kernel, timed ALONE with events on
+        # the launch stream on the rb4.conv1 shape (96->32 3x3 @28x28, B=512: 43,352,064 FLOP and
+        # (96+32)*4*784 = 401,408 B per sample).  In the default arithmetic (bf16x3
+        # split MFMA over pre-split tensors) its binding roof is HBM (MFMA floor 26.6 us = HBM floor 25.7 us).
         L = _lib.lib()
         cin, cout, hw = 96, 32, 28
         xin = torch.randn(B_TRAIN, hw, hw, cin, device=dev)
         w = torch.randn(3, 3, cin, cout, device=dev) * 0.05
         bias = torch.zeros(cout, device=dev)
         yout = torch.empty(B_TRAIN, hw, hw, cout, device=dev)
+        woff = (9 * cin * cout + 63) & ~63
+        scratch = torch.empty(woff + B_TRAIN * hw * hw * cin + 128, device=dev)
+        kname = {0: "conv_mfma_kernel<28,1,fwd>", 1: "conv_bf16x3_kernel<28,1>", 2: "conv_s16_kernel<28,1>"}[args.conv_mode]
 
-        scratch = torch.empty(9 * cin * cout, device=dev)
-        scratch2 = torch.empty(9 * cin * cout + B_TRAIN * hw * hw * cin + 128, device=dev)
-
-        def run_conv():
+        def conv_call(inp, flags):
             if args.conv_mode == 0:
                 _lib.check(L.tdm_conv_nhwc_f32(_lib.ptr(xin), _lib.ptr(w), _lib.ptr(bias), None, None, _lib.ptr(yout),
                                                None, B_TRAIN, hw, cin, cout, 3, 1, _lib.stream()))
-            elif args.conv_mode == 2:
-                _lib.check(L.tdm_conv_nhwc_s16_f32(_lib.ptr(xin), _lib.ptr(w), _lib.ptr(bias), None, None,
-                                                   _lib.ptr(yout), None, None, None, _lib.ptr(scratch2), B_TRAIN, hw,
-                                                   cin, cout, 3, 1, _lib.stream()))
-            else:
+            elif args.conv_mode == 1:
                 _lib.check(L.tdm_conv_nhwc_bf16x3_f32(_lib.ptr(xin), _lib.ptr(w), _lib.ptr(bias), None, None,
                                                       _lib.ptr(yout), None, _lib.ptr(scratch), B_TRAIN, hw, cin, cout,
                                                       3, 1, _lib.stream()))
-        ms = time_kernel(run_conv)
+            else:
+                _lib.check(L.tdm_conv_nhwc_s16_f32(_lib.ptr(inp), _lib.ptr(w), _lib.ptr(bias), None, None,
+                                                   _lib.ptr(yout), None, None, None, _lib.ptr(scratch), B_TRAIN, hw,
+                                                   cin, cout, 3, flags, _lib.stream()))
+        conv_call(xin, 1)                                   # mode 2: packs weights + pre-splits the input once
+        xs16 = scratch[woff:woff + B_TRAIN * hw * hw * cin]
+        ms = time_kernel(lambda: conv_call(xs16, 1 | 4 | 8))
         kflop = 2 * 9 * cin * cout * hw * hw * B_TRAIN
-        ach = kflop / (ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                           "kernel": "conv_mfma_kernel<28,1,fwd> (rb4.conv1 shape 96->32 3x3 @28x28, B=512)",
-                           "ms_per_launch": round(ms, 4), "flop_per_launch": kflop,
-                           "algorithmic_bytes_per_launch": (cin + cout) * 4 * hw * hw * B_TRAIN}
+        kbytes = (cin + cout) * 4 * hw * hw * B_TRAIN
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")     # PMC FETCH_SIZE/WRITE_SIZE, see file
+        if args.conv_mode == 2 and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        if args.conv_mode == 0:
+            ach = kflop / (ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic}
+        else:
+            ach = kbytes / (ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
+                               "mfma_tflops_bf16": round(3 * kflop / (ms * 1e-3) / 1e12, 1), "mfma_peak_bf16": 2500.0}
+        out["roofline"].update({"kernel": kname + " (rb4.conv1 shape 96->32 3x3 @28x28, B=512)",
+                                "ms_per_launch": round(ms, 4), "flop_per_launch": kflop,
+                                "algorithmic_bytes_per_launch": kbytes})
         del xin, yout
 
     # ---- 1000-step sampling rate at B=4096 (configs[3]); sharded over ranks, no collectives ----

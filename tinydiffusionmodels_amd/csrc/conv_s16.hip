@@ -100,56 +100,77 @@ __global__ __launch_bounds__(256) void conv_s16_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
+    // Software pipeline over K chunks: the 16-byte pieces of chunk c+1 (8 input pieces + WN weight pieces per
+    // thread) are loaded into registers BEFORE the MFMAs of chunk c and written to LDS after them, so only the
+    // first chunk of a tile exposes a memory latency; input and weight loads are always in flight together.
+    constexpr int WN = (9 * NT * 128 + 255) / 256;
     char* const sdst = tile + (tid >> 2) * PIXB + (tid & 3) * 16;
-    for (int si = 0; si < a.nsrc; ++si) {
-        const ConvSrc s = a.src[si];
-        const int taps = s.taps;
-        const int chunk_u16 = taps * NT * 1024;
-        int goff[8];   // per-thread staging plan: identical for every K chunk of this source
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int e = tid + 256 * i;
-            goff[i] = (e < nelem) ? src_offset<HW>(s, PR0, e >> 2, a.B) : -2;
-        }
-        for (int kc = 0; kc < s.nch; kc += CK) {
-            __syncthreads();
+    const int nc0 = a.src[0].nch >> 4;
+    const int nchunks = nc0 + (a.nsrc > 1 ? (a.src[1].nch >> 4) : 0);
+    int goff[8];        // staging plan of the source being prefetched
+    int plan_src = -1;
+    uint4 pin[8], pwt[WN];
+
+    auto prefetch = [&](int c) {
+        const int si = (c >= nc0) ? 1 : 0;
+        const int ch = si ? c - nc0 : c;
+        const ConvSrc& s = a.src[si];
+        if (plan_src != si) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                if (goff[i] != -2) {
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (goff[i] >= 0) v = reinterpret_cast<const uint4*>(s.ptr + goff[i] + kc)[tid & 3];
-                    *reinterpret_cast<uint4*>(sdst + i * (64 * PIXB)) = v;
+                const int e = tid + 256 * i;
+                goff[i] = (e < nelem) ? src_offset<HW>(s, PR0, e >> 2, a.B) : -2;
+            }
+            plan_src = si;
+        }
+        const int kc = ch << 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            pin[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (goff[i] >= 0) pin[i] = reinterpret_cast<const uint4*>(s.ptr + goff[i] + kc)[tid & 3];
+        }
+        const int n16 = s.taps * NT * 128;
+        const uint4* wsrc = reinterpret_cast<const uint4*>(s.wp + (long)(s.wchunk0 + ch) * (s.taps * NT * 1024));
+#pragma unroll
+        for (int i = 0; i < WN; ++i) {
+            const int e = tid + 256 * i;
+            pwt[i] = (e < n16) ? wsrc[e] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+
+    prefetch(0);
+    for (int c = 0; c < nchunks; ++c) {
+        const int taps = a.src[(c >= nc0) ? 1 : 0].taps;
+        __syncthreads();      // everyone finished reading the previous chunk's LDS image
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (tid + 256 * i < nelem) *reinterpret_cast<uint4*>(sdst + i * (64 * PIXB)) = pin[i];
+#pragma unroll
+        for (int i = 0; i < WN; ++i)
+            if (tid + 256 * i < 9 * NT * 128) reinterpret_cast<uint4*>(wl)[tid + 256 * i] = pwt[i];
+        __syncthreads();
+        if (c + 1 < nchunks) prefetch(c + 1);
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            if (taps == 9 || tp == 4) {   // a 1x1 source uses the centre-tap site with packed tap 0
+                const int toff = ((tp / 3 - 1) * G::WP + (tp % 3 - 1)) * PIXB;
+                const int wt = (taps == 9) ? tp : 0;
+                bf16x8 ah[2], al[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    ah[mt] = *reinterpret_cast<const bf16x8*>(tile + aoff[mt] + toff);
+                    al[mt] = *reinterpret_cast<const bf16x8*>(tile + aoff[mt] + toff + 32);
                 }
-            }
-            {
-                const uint4* src = reinterpret_cast<const uint4*>(s.wp + (long)(s.wchunk0 + (kc >> 4)) * chunk_u16);
-                uint4* dst = reinterpret_cast<uint4*>(wl);
-                const int n16 = taps * NT * 128;
-                for (int e = tid; e < n16; e += 256) dst[e] = src[e];
-            }
-            __syncthreads();
 #pragma unroll
-            for (int tp = 0; tp < 9; ++tp) {
-                if (taps == 9 || tp == 4) {   // a 1x1 source uses the centre-tap site with packed tap 0
-                    const int toff = ((tp / 3 - 1) * G::WP + (tp % 3 - 1)) * PIXB;
-                    const int wt = (taps == 9) ? tp : 0;
-                    bf16x8 ah[2], al[2];
+                for (int nt = 0; nt < NT; ++nt) {
+                    const char* wb = wl + ((wt * NT + nt) * 2) * 1024 + lane * 16;
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wb);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wb + 1024);
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        ah[mt] = *reinterpret_cast<const bf16x8*>(tile + aoff[mt] + toff);
-                        al[mt] = *reinterpret_cast<const bf16x8*>(tile + aoff[mt] + toff + 32);
-                    }
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const char* wb = wl + ((wt * NT + nt) * 2) * 1024 + lane * 16;
-                        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wb);
-                        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wb + 1024);
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) {   // D[co][pixel]: weights are the A operand
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al[mt], acc[mt][nt], 0, 0, 0);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[mt], acc[mt][nt], 0, 0, 0);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[mt], acc[mt][nt], 0, 0, 0);
-                        }
+                    for (int mt = 0; mt < 2; ++mt) {   // D[co][pixel]: weights are the A operand
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al[mt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[mt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[mt], acc[mt][nt], 0, 0, 0);
                     }
                 }
             }
@@ -262,44 +283,58 @@ __global__ __launch_bounds__(512) void wgrad_s16_kernel(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
-    for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+    // Software pipeline over pixel tiles: the 16-byte pieces of tile t+1 (NA activation + NG gradient pieces per
+    // thread) are loaded into registers before the MFMAs of tile t and written to LDS after them.
+    constexpr int NA = (NPX * 8 + 511) / 512;
+    constexpr int NG = TILE_PX * 8 / 512;
+    uint4 pa[NA], pg[NG];
+    int p_pix = 0;     // staged-pixel index of tile pixel `tid` (threads < TILE_PX)
+    int p_nelem = 0;
+    auto prefetch = [&](int t) {
         const int m0 = t * TILE_PX;
         const int mlast = min(m0 + TILE_PX - 1, Mtot - 1);
         const int PR0 = padded_row<HW>(m0) - 1;
         const int nrows = padded_row<HW>(mlast) - PR0 + 2;
-        __syncthreads();
+        p_nelem = nrows * G::WP * 8;
         if (tid < TILE_PX) {
             const int m = min(m0 + tid, Mtot - 1);
             const int b = m / (G::H * G::W);
             const int rem = m - b * (G::H * G::W);
             const int y = rem / G::W, x = rem - y * G::W;
-            pixoff[tid] = (b * G::HP + y + 1 - PR0) * G::WP + x + 1;
+            p_pix = (b * G::HP + y + 1 - PR0) * G::WP + x + 1;
         }
-        {
-            char* const ad = (to_lo ? Alo : Ahi) + dcol;
-            const int nelem = nrows * G::WP * 8;
 #pragma unroll
-            for (int i = 0; i < (NPX * 8 + 511) / 512; ++i) {
-                const int e = tid + 512 * i;
-                if (e < nelem) {
-                    const int pos = e >> 3;
-                    const int go = src_offset<HW>(s, PR0, pos, a.B);
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (go >= 0) v = reinterpret_cast<const uint4*>(s.ptr + go + ci0 + grp * 16)[pq];
-                    *reinterpret_cast<uint4*>(ad + pos * 64) = v;
-                }
-            }
-            char* const gd = (to_lo ? Glo : Ghi) + dcol;
-#pragma unroll
-            for (int i = 0; i < TILE_PX * 8 / 512; ++i) {
-                const int px = (tid + 512 * i) >> 3;
-                const int m = m0 + px;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (m < Mtot) v = reinterpret_cast<const uint4*>(a.g + (long)m * a.Cout + co0 + grp * 16)[pq];
-                *reinterpret_cast<uint4*>(gd + px * 64) = v;
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + 512 * i;
+            pa[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (e < p_nelem) {
+                const int go = src_offset<HW>(s, PR0, e >> 3, a.B);
+                if (go >= 0) pa[i] = reinterpret_cast<const uint4*>(s.ptr + go + ci0 + grp * 16)[pq];
             }
         }
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int m = m0 + ((tid + 512 * i) >> 3);
+            pg[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (m < Mtot) pg[i] = reinterpret_cast<const uint4*>(a.g + (long)m * a.Cout + co0 + grp * 16)[pq];
+        }
+    };
+
+    char* const ad = (to_lo ? Alo : Ahi) + dcol;
+    char* const gd = (to_lo ? Glo : Ghi) + dcol;
+    if ((int)blockIdx.x < a.ntiles) prefetch(blockIdx.x);
+    for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+        __syncthreads();   // previous tile fully consumed
+        if (tid < TILE_PX) pixoff[tid] = p_pix;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + 512 * i;
+            if (e < p_nelem) *reinterpret_cast<uint4*>(ad + (e >> 3) * 64) = pa[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NG; ++i) *reinterpret_cast<uint4*>(gd + ((tid + 512 * i) >> 3) * 64) = pg[i];
         __syncthreads();
+        if (t + (int)gridDim.x < a.ntiles) prefetch(t + gridDim.x);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int p0 = wave * 32 + ks * 16 + hh * 8 + q;

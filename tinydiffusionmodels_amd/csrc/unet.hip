@@ -583,8 +583,10 @@ int tdm_conv_nhwc_s16_f32(const float* in, const float* w, const float* bias, co
     pa.d[0].dst_off = 0;
     unsigned short* wp = reinterpret_cast<unsigned short*>(scratch);
     float* in_s16 = scratch + (((long)taps * Cin * Cout + 63) & ~63L);
-    TDM_TRY(tdm_launch_pack(w, pa, wp, st));
-    TDM_TRY(tdm_launch_to_s16(in, tb, Cin, in_s16, (long)B * HW * HW, HW * HW, Cin, st));
+    // flags bit2: `in` is already an S16 tensor; bit3: scratch already holds the packed weights (profiling)
+    if (!(flags & 8)) TDM_TRY(tdm_launch_pack(w, pa, wp, st));
+    if (flags & 4) in_s16 = const_cast<float*>(in);
+    else TDM_TRY(tdm_launch_to_s16(in, tb, Cin, in_s16, (long)B * HW * HW, HW * HW, Cin, st));
     ConvArgs a{};
     a.nsrc = 1;
     a.src[0] = s16_src(in_s16, Cin, Cin, 0, taps, wp, 0);
