@@ -159,8 +159,12 @@ int tdm_conv_wgrad_nhwc_s16_f32(const float* in, const float* tb, const float* d
 
 /* ---- a8-a10: TinyTransformer embedding-space denoiser (src/shakespeare.py:105-120) ----
  * x (B,L,D) fp32, t (B,) int64; post-LN encoder layers (packed in_proj, H heads,
- * ReLU FFN of width ffn, LayerNorm eps 1e-5), no mask, no positional encoding,
- * eval / dropout 0.  Parameters: ONE flat fp32 buffer in the reference's
+ * ReLU FFN of width ffn, LayerNorm eps 1e-5), no mask, no positional encoding.
+ * p_drop = 0: eval mode.  p_drop > 0: train mode of the reference (model.train(),
+ * src/shakespeare.py:210) with its 1 + 4*depth dropout sites; the masks are a pure
+ * function of (seed, site, element index) — tdm_dropout_keep_u8 — regenerated in
+ * registers by forward and backward, so a backward call must receive the p_drop and
+ * seed of its forward.  Parameters: ONE flat fp32 buffer in the reference's
  * state_dict order and native layouts (tdm_tt_param_offsets: 12 tensors per
  * layer, then time_emb.weight, time_emb.bias; last entry = total).          */
 int64_t tdm_tt_param_count(int D, int depth, int ffn);
@@ -169,18 +173,21 @@ int64_t tdm_tt_workspace_floats(int64_t B, int L, int D, int H, int depth, int f
 int64_t tdm_tt_slab_floats(int D, int depth, int ffn);
 /* out = TinyTransformer(x, t)  (src/shakespeare.py:115-120) */
 int tdm_tt_fwd_f32(const float* params, const float* x, const int64_t* t, float* out, float* ws,
-                   int64_t B, int L, int D, int H, int depth, int ffn, int save, void* stream);
+                   int64_t B, int L, int D, int H, int depth, int ffn, int save, float p_drop,
+                   uint64_t seed, void* stream);
 /* parameter gradients given d(loss)/d(out); needs ws of a save != 0 forward;
  * dx (B,L,D), may be NULL: d(loss)/d(x) (needed by learned embeddings,
  * src/shakespeare.py:225-226)                                                 */
 int tdm_tt_bwd_f32(const float* params, const float* dout, float* grads, float* dx, float* ws, float* slabs,
-                   int64_t B, int L, int D, int H, int depth, int ffn, void* stream);
+                   int64_t B, int L, int D, int H, int depth, int ffn, float p_drop, uint64_t seed,
+                   void* stream);
 /* denoiser part of the text train step (src/shakespeare.py:230-236): q_sample ->
  * forward -> MSE -> backward; flat gradient in grads, loss in loss_out[0]     */
 int tdm_tt_loss_grad_f32(const float* params, const float* x0, const float* noise, const int64_t* t,
                          const float* sqrt_acp, const float* sqrt_1m_acp, float* x_noisy, float* pred,
                          float* dpred, float* loss_out, float* grads, float* ws, float* slabs,
-                         int64_t B, int L, int D, int H, int depth, int ffn, void* stream);
+                         int64_t B, int L, int D, int H, int depth, int ffn, float p_drop, uint64_t seed,
+                         void* stream);
 /* one reverse step of src/shakespeare.py:382-385 / :343-352 for a uniform t_index */
 int tdm_tt_p_sample_step_f32(const float* params, const float* x, const int64_t* t, const float* noise,
                              const float* tab_recip, const float* tab_eps, const float* tab_sigma,
@@ -191,6 +198,15 @@ int tdm_tt_p_sample_step_f32(const float* params, const float* x, const int64_t*
  *   meets the 1e-3 parity bound); 2 plain bf16 operands (throughput mode, ~3e-3 rel) */
 int tdm_set_gemm_mode(int mode);
 int tdm_get_gemm_mode(void);
+/* Attention kernels: 0 scalar fp32 (one thread per row), 1 fp32 MFMA (default). Both are
+ * exact fp32 arithmetic; mode 0 is the cross-check for mode 1.                          */
+int tdm_set_attn_mode(int mode);
+int tdm_get_attn_mode(void);
+/* Host-side evaluation of the dropout mask (tests, oracle cross-check): keep_host[i] = 1 iff
+ * flat element idx0 + i of dropout site `site` survives.  Sites in the order the reference's
+ * forward reaches them: 0 input dropout (src/shakespeare.py:119); layer l: 1+4l attention
+ * probabilities (B,H,L,L), 2+4l dropout1 (B,L,D), 3+4l FFN dropout (B,L,ffn), 4+4l dropout2. */
+int tdm_dropout_keep_u8(float p_drop, uint64_t seed, int site, int64_t idx0, int64_t n, uint8_t* keep_host);
 /* general strided fp32-MFMA GEMM (tests / profiling):
  * C[i][j] = sum_k A[i*a_rs + k*a_cs] * B[k*b_rs + j*b_cs] (+bias[j]) (+res[i][j]) (relu)      */
 int tdm_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs,

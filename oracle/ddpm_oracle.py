@@ -260,17 +260,63 @@ def transformer_init_params(dim: int, depth: int = 3, ffn: int = 2048, seed: int
     return p
 
 
+# Dropout (train mode, src/shakespeare.py:106-119, :210).  torch draws dropout masks from its
+# generator; the product replaces that stream by a counter-based hash so that forward and
+# backward (and this oracle) can regenerate a mask from (seed, site, element index) alone:
+#   key  = hash32(seed_lo ^ hash32(seed_hi + 0x9E3779B9 * (site + 1)))
+#   u    = hash32(hash32(idx_lo ^ key) + idx_hi);  keep = u >= round(p * 2^32)
+#   y    = x * (keep * (1 / (1 - p)))            -- torch's x * (mask / (1 - p))
+# with hash32 = the "lowbias32" finaliser.  Sites, in the order the reference's forward reaches
+# them: 0 input dropout; layer l: 1+4l attention probabilities (B,H,L,L), 2+4l dropout1 (B,L,D),
+# 3+4l FFN dropout (B,L,ffn), 4+4l dropout2 (B,L,D).
+def _hash32(x):
+    import numpy as np
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d)
+    x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def dropout_keep(p: float, seed: int, site: int, shape) -> torch.Tensor:
+    """Boolean keep-mask of one dropout site (all True for p = 0)."""
+    import numpy as np
+    n = int(np.prod(shape))
+    if not p > 0.0:
+        return torch.ones(shape, dtype=torch.bool)
+    thr = min(4294967295, int(float(np.float32(p)) * 4294967296.0 + 0.5))
+    thr = max(thr, 1)
+    with np.errstate(over="ignore"):
+        seed_lo = np.array([seed & 0xFFFFFFFF], dtype=np.uint32)
+        seed_hi = np.array([(seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
+        key = _hash32(seed_lo ^ _hash32(seed_hi + np.uint32((0x9E3779B9 * (site + 1)) & 0xFFFFFFFF)))
+        idx = np.arange(n, dtype=np.uint64)
+        lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        hi = (idx >> np.uint64(32)).astype(np.uint32)
+        u = _hash32(_hash32(lo ^ key) + hi)
+    return torch.from_numpy(u >= np.uint32(thr)).view(*shape)
+
+
+def _dropout(x: torch.Tensor, p: float, seed: int, site: int) -> torch.Tensor:
+    if not p > 0.0:
+        return x
+    import numpy as np
+    scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+    return x * (dropout_keep(p, seed, site, tuple(x.shape)).to(x.dtype) * scale)
+
+
 def transformer_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor,
-                        n_heads: int = 4, depth: int = 3, eps: float = 1e-5) -> torch.Tensor:
-    """src/shakespeare.py:115-120 in eval mode (dropout = identity), with
-    nn.TransformerEncoderLayer's defaults written out: post-LN, ReLU FFN,
-    LayerNorm eps 1e-5, no mask, no positional encoding, no final norm.
+                        n_heads: int = 4, depth: int = 3, eps: float = 1e-5,
+                        p_drop: float = 0.0, seed: int = 0) -> torch.Tensor:
+    """src/shakespeare.py:115-120 with nn.TransformerEncoderLayer's defaults written out:
+    post-LN, ReLU FFN, LayerNorm eps 1e-5, no mask, no positional encoding, no final
+    norm.  p_drop = 0: eval mode; p_drop > 0: train mode with the hash-defined masks above.
     x (B,L,D) fp32, t (B,) int64."""
     B, L, D = x.shape
     hd = D // n_heads
     ts = (t.float() / TIMESTEPS).unsqueeze(-1)                               # (B,1)
     tb = F.linear(ts, p["time_emb.weight"], p["time_emb.bias"]).unsqueeze(1)  # (B,1,D)
-    x = x + tb
+    x = _dropout(x + tb, p_drop, seed, 0)
     for l in range(depth):
         pre = f"encoder.layers.{l}."
         qkv = F.linear(x, p[pre + "self_attn.in_proj_weight"], p[pre + "self_attn.in_proj_bias"])
@@ -279,23 +325,30 @@ def transformer_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.Te
         k = k.view(B, L, n_heads, hd).transpose(1, 2)
         v = v.view(B, L, n_heads, hd).transpose(1, 2)
         att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd), dim=-1)
+        att = _dropout(att, p_drop, seed, 1 + 4 * l)
         o = (att @ v).transpose(1, 2).reshape(B, L, D)
         o = F.linear(o, p[pre + "self_attn.out_proj.weight"], p[pre + "self_attn.out_proj.bias"])
-        x = F.layer_norm(x + o, (D,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], eps)
-        f = F.linear(F.relu(F.linear(x, p[pre + "linear1.weight"], p[pre + "linear1.bias"])),
-                     p[pre + "linear2.weight"], p[pre + "linear2.bias"])
-        x = F.layer_norm(x + f, (D,), p[pre + "norm2.weight"], p[pre + "norm2.bias"], eps)
+        x = F.layer_norm(x + _dropout(o, p_drop, seed, 2 + 4 * l), (D,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], eps)
+        f = F.relu(F.linear(x, p[pre + "linear1.weight"], p[pre + "linear1.bias"]))
+        f = F.linear(_dropout(f, p_drop, seed, 3 + 4 * l), p[pre + "linear2.weight"], p[pre + "linear2.bias"])
+        x = F.layer_norm(x + _dropout(f, p_drop, seed, 4 + 4 * l), (D,), p[pre + "norm2.weight"], p[pre + "norm2.bias"], eps)
     return x
 
 
-def transformer_loss_and_grads(p, x0, t, noise, tables, n_heads: int = 4, depth: int = 3):
-    """Denoiser part of src/shakespeare.py:230-236 with dropout 0."""
+def transformer_loss_and_grads(p, x0, t, noise, tables, n_heads: int = 4, depth: int = 3,
+                               p_drop: float = 0.0, seed: int = 0, want_dx: bool = False):
+    """Denoiser part of src/shakespeare.py:230-236 (p_drop = 0: the eval-mode network)."""
     leaf = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
     x_noisy = q_sample(x0, t, noise, tables)
-    pred = transformer_forward(leaf, x_noisy, t, n_heads, depth)
+    if want_dx:
+        x_noisy = x_noisy.detach().requires_grad_(True)
+    pred = transformer_forward(leaf, x_noisy, t, n_heads, depth, p_drop=p_drop, seed=seed)
     loss = F.mse_loss(pred, noise)
     loss.backward()
-    return loss.detach(), {k: v.grad.detach() for k, v in leaf.items()}
+    grads = {k: v.grad.detach() for k, v in leaf.items()}
+    if want_dx:
+        grads["__dx"] = x_noisy.grad.detach()
+    return loss.detach(), grads
 
 
 def text_p_sample(p, x, t, noise, tables, n_heads: int = 4, depth: int = 3):

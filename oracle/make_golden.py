@@ -215,7 +215,73 @@ def gen_text():
     print("text goldens written to", GOLD)
 
 
+def gen_text_dropout():
+    """Train-mode (dropout 0.1, the reference's default) forward + gradients of the REFERENCE
+    TinyTransformer with torch's two dropout entry points replaced by the counter-hash masks
+    the product uses (oracle.dropout_keep): F.dropout (nn.Dropout modules: input dropout,
+    dropout1, FFN dropout, dropout2) and F.scaled_dot_product_attention (the attention-
+    probability dropout inside nn.MultiheadAttention, written out as softmax -> dropout -> @V).
+    Call order of the reference's own forward defines the site numbers; this pins site order,
+    scaling and placement of every mask against the real module code."""
+    _install_stubs(with_torchvision=False)
+    sys.path.insert(0, REF)
+    import math
+    import src.shakespeare as S
+    import torch.nn.functional as F
+    from oracle import ddpm_oracle as O
+
+    P_DROP, SEED = 0.1, 0x5EEDC0FFEE1234
+    state = {"site": 0}
+
+    def hashed_dropout(x, p=0.5, training=True, inplace=False):
+        site = state["site"]; state["site"] += 1
+        if not training or p == 0.0:
+            return x
+        return O._dropout(x, p, SEED, site)
+
+    def hashed_sdpa(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, scale=None, **kw):
+        assert attn_mask is None and not is_causal
+        site = state["site"]; state["site"] += 1
+        att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(q.shape[-1]), dim=-1)
+        if dropout_p > 0.0:
+            att = O._dropout(att, dropout_p, SEED, site)
+        return att @ v
+
+    real_dropout, real_sdpa = F.dropout, F.scaled_dot_product_attention
+    out = {"p_drop": torch.tensor([P_DROP]), "seed": torch.tensor([SEED], dtype=torch.int64)}
+    try:
+        F.dropout, F.scaled_dot_product_attention = hashed_dropout, hashed_sdpa
+        for dim, B, L, tag in ((256, 2, 128, "d256"), (32, 3, 16, "d32")):
+            params = O.transformer_init_params(dim, seed=11)
+            net = S.TinyTransformer(dim, dropout=P_DROP)
+            net.load_state_dict(params, strict=True)
+            g = torch.Generator().manual_seed(77 + dim)
+            x0 = torch.randn(B, L, dim, generator=g) * 0.5
+            t = torch.randint(0, S.T, (B,), generator=g)
+            noise = torch.randn(B, L, dim, generator=g)
+            xq = S.q_sample(x0, t, noise).requires_grad_(True)
+            net.train()
+            state["site"] = 0
+            pred = net(xq, t)
+            assert state["site"] == 13, state
+            loss = F.mse_loss(pred, noise)
+            loss.backward()
+            out[f"{tag}.x0"] = x0; out[f"{tag}.t"] = t; out[f"{tag}.noise"] = noise
+            out[f"{tag}.pred"] = pred.detach(); out[f"{tag}.loss"] = loss.detach().reshape(1)
+            out[f"{tag}.dx"] = xq.grad.detach().clone()
+            named = dict(net.named_parameters())
+            gsel = ["time_emb.weight", "time_emb.bias", "encoder.layers.0.self_attn.in_proj_bias",
+                    "encoder.layers.2.norm2.weight", "encoder.layers.1.linear2.bias", "encoder.layers.1.linear1.bias",
+                    "encoder.layers.0.self_attn.out_proj.weight", "encoder.layers.2.self_attn.out_proj.bias"]
+            for k in (named if dim == 32 else gsel):
+                out[f"{tag}.grad.{k}"] = named[k].grad.detach().clone()
+    finally:
+        F.dropout, F.scaled_dot_product_attention = real_dropout, real_sdpa
+    np.savez(os.path.join(GOLD, "text_dropout.npz"), **_np(out))
+    print("text dropout goldens written to", GOLD)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "mnist"
     torch.set_num_threads(8)
-    {"mnist": gen_mnist, "text": gen_text}[which]()
+    {"mnist": gen_mnist, "text": gen_text, "text_dropout": gen_text_dropout}[which]()

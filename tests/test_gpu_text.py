@@ -44,6 +44,16 @@ def gemm_mode(request):
     _lib.check(L.tdm_set_gemm_mode(1))
 
 
+@pytest.fixture(params=[1, 0], ids=["attn-mfma", "attn-scalar"])
+def attn_mode(request):
+    """Attention kernels: fp32 MFMA (default) and the scalar fp32 cross-check (tdm_set_attn_mode)."""
+    from tinydiffusionmodels_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.tdm_set_attn_mode(request.param))
+    yield request.param
+    _lib.check(L.tdm_set_attn_mode(1))
+
+
 def _ftol(gemm_mode, base=TOL):
     """fp32: base; bf16x3: 16 mantissa bits per operand (~1e-5 per GEMM, 3 layers x 4 GEMMs);
     plain bf16 operands: ~3e-3 per GEMM — reported, held to 3e-2."""
@@ -103,7 +113,7 @@ def test_gemm(dev, gemm_mode, M, N, K, mode):
 
 
 @pytest.mark.parametrize("tag,dim", [("d32", 32), ("d256", 256)])
-def test_transformer_forward_and_grads_golden(dev, golden_dir, golden_tables, gemm_mode, tag, dim):
+def test_transformer_forward_and_grads_golden(dev, golden_dir, golden_tables, gemm_mode, attn_mode, tag, dim):
     from tinydiffusionmodels_amd import transformer_engine as TE
     from tinydiffusionmodels_amd.shakespeare import q_sample
     g = _load(golden_dir, "text_denoiser.npz")
@@ -134,8 +144,111 @@ def test_transformer_forward_and_grads_golden(dev, golden_dir, golden_tables, ge
     assert n_checked >= 6
 
 
+@pytest.mark.parametrize("tag,dim", [("d32", 32), ("d256", 256)])
+def test_transformer_train_mode_dropout_golden(dev, golden_dir, golden_tables, gemm_mode, attn_mode, tag, dim):
+    """model.train() with the reference's default dropout 0.1 (src/shakespeare.py:106, :210): forward,
+    loss, parameter gradients and d(loss)/d(x) against the REFERENCE module run with the same
+    hash-defined masks (oracle/make_golden.py:gen_text_dropout), through the fused C-ABI train call
+    and through the nn.Module / autograd surface."""
+    from tinydiffusionmodels_amd import transformer_engine as TE
+    from tinydiffusionmodels_amd.shakespeare import TinyTransformer, q_sample
+    g = _load(golden_dir, "text_dropout.npz")
+    p_drop, seed = float(g["p_drop"][0]), int(g["seed"][0])
+    m = TinyTransformer(dim, dropout=p_drop)
+    m.load_state_dict(O.transformer_init_params(dim, seed=11))
+    m = m.to(dev)
+    x0, t, noise = g[f"{tag}.x0"].to(dev), g[f"{tag}.t"].to(dev), g[f"{tag}.noise"].to(dev)
+    m.train()
+    m.dropout_seed = seed
+    xq = q_sample(x0, t, noise).requires_grad_(True)
+    pred = m(xq, t)
+    err = O.rel_err(pred.detach().cpu(), g[f"{tag}.pred"])
+    print(f"[parity] TinyTransformer({dim}) train-mode (dropout {p_drop}) forward rel err, gemm {gemm_mode} attn {attn_mode}: {err:.2e}")
+    assert err < _ftol(gemm_mode)
+    m.zero_grad()
+    F.mse_loss(pred, noise).backward()
+    l2 = {0: 2e-4, 1: 5e-3, 2: 1e-1}[gemm_mode]
+    assert O.rel_l2(xq.grad.cpu(), g[f"{tag}.dx"]) < l2
+    got = TE.state_dict_from_flat(m.flat.grad, dim)
+    # fused train call with the same seed
+    st = TE.TTTrainState(m.cfg, m.flat.detach(), x0.shape[0], x0.shape[1])
+    loss = TE.tt_loss_and_grad(m.flat.detach(), st, x0, noise, t, p_drop=p_drop, seed=seed)
+    assert abs(loss.item() - g[f"{tag}.loss"].item()) < max(1e-5, 10 * _ftol(gemm_mode)) * abs(g[f"{tag}.loss"].item())
+    got2 = TE.state_dict_from_flat(st.grads, dim)
+    n = 0
+    for k, v in g.items():
+        if k.startswith(f"{tag}.grad."):
+            name = k.split(".", 2)[2]
+            for which in (got, got2):
+                if gemm_mode == 0:
+                    assert O.rel_err(which[name].cpu(), v) < 2e-4, name
+                else:
+                    assert O.rel_l2(which[name].cpu(), v) < l2, name
+            n += 1
+    assert n >= 8
+    # eval mode ignores dropout; a different seed gives a different train-mode output
+    m.eval()
+    with torch.no_grad():
+        ev = m(xq.detach(), t)
+    assert O.rel_err(ev.cpu(), O.transformer_forward(O.transformer_init_params(dim, seed=11), xq.detach().cpu(), t.cpu())) < _ftol(gemm_mode)
+    m.train()
+    m.dropout_seed = seed + 1
+    with torch.no_grad():
+        other = m(xq.detach(), t)
+    assert O.rel_err(other.cpu(), g[f"{tag}.pred"]) > 1e-2
+    m.dropout_seed = None
+    torch.manual_seed(5)
+    with torch.no_grad():
+        a = m(xq.detach(), t)
+    s1 = m.last_dropout_seed
+    torch.manual_seed(5)
+    with torch.no_grad():
+        b = m(xq.detach(), t)
+    assert m.last_dropout_seed == s1 and torch.equal(a, b)      # torch.manual_seed makes train mode repeatable
+
+
+@pytest.mark.parametrize("B,L,dim,p_drop", [(2, 37, 64, 0.3), (1, 130, 128, 0.1), (2, 200, 32, 0.5)])
+def test_dropout_ragged_shapes_vs_oracle(dev, golden_tables, gemm_mode, attn_mode, B, L, dim, p_drop):
+    """Ragged lengths (not multiples of 32 / 128; more than one key block), head dims 16 / 32 / 8, other rates."""
+    from tinydiffusionmodels_amd import transformer_engine as TE
+    from tinydiffusionmodels_amd.shakespeare import TinyTransformer
+    p = O.transformer_init_params(dim, seed=3)
+    m = TinyTransformer(dim, dropout=p_drop)
+    m.load_state_dict(p)
+    m = m.to(dev).train()
+    seed = (B << 40) + L * 977 + dim
+    m.dropout_seed = seed
+    g = torch.Generator().manual_seed(L)
+    x = torch.randn(B, L, dim, generator=g) * 0.7
+    t = torch.randint(0, 1000, (B,), generator=g)
+    target = torch.randn(B, L, dim, generator=g)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xr = x.clone().requires_grad_(True)
+    ref = O.transformer_forward(leaf, xr, t, p_drop=p_drop, seed=seed)
+    F.mse_loss(ref, target).backward()
+    xd = x.to(dev).requires_grad_(True)
+    out = m(xd, t.to(dev))
+    assert O.rel_err(out.detach().cpu(), ref.detach()) < _ftol(gemm_mode)
+    m.zero_grad()
+    F.mse_loss(out, target.to(dev)).backward()
+    got = TE.state_dict_from_flat(m.flat.grad, dim)
+    l2tol = {0: 1e-3, 1: 1e-2, 2: 1e-1}[gemm_mode]
+    for k, v in leaf.items():
+        assert O.rel_l2(got[k].cpu(), v.grad) < l2tol, k
+    assert O.rel_l2(xd.grad.cpu(), xr.grad) < l2tol
+
+
+def test_dropout_mask_host_function_matches_oracle():
+    import ctypes
+    from tinydiffusionmodels_amd import _lib
+    for p_drop, seed, site, n in [(0.1, 12345, 0, 100000), (0.5, (7 << 40) + 99, 7, 50000), (0.25, 2 ** 62 - 1, 12, 12345)]:
+        buf = np.zeros(n, dtype=np.uint8)
+        _lib.check(_lib.lib().tdm_dropout_keep_u8(p_drop, seed, site, 0, n, buf.ctypes.data), "dropout_keep")
+        assert np.array_equal(buf.astype(bool), O.dropout_keep(p_drop, seed, site, (n,)).numpy())
+
+
 @pytest.mark.parametrize("B,L,dim", [(2, 37, 64), (1, 130, 128), (3, 128, 256)])
-def test_transformer_oracle_shapes_and_autograd_bridge(dev, golden_tables, gemm_mode, B, L, dim):
+def test_transformer_oracle_shapes_and_autograd_bridge(dev, golden_tables, gemm_mode, attn_mode, B, L, dim):
     """Ragged sequence lengths (not multiples of 128), other widths, and the
     nn.Module surface: loss.backward() fills model.flat.grad AND x.grad."""
     from tinydiffusionmodels_amd import transformer_engine as TE
@@ -215,12 +328,19 @@ def test_denoiser_trainer_step_matches_oracle_adamw(dev, golden_tables, gemm_mod
         assert (sd[k].cpu() - ref).abs().max().item() < (0.05 if gemm_mode == 0 else 2.1) * lr, k
 
 
-def test_train_mode_dropout_refused(dev):
+def test_train_mode_default_dropout_and_bad_rate(dev):
     from tinydiffusionmodels_amd.shakespeare import TinyTransformer
-    m = TinyTransformer(32).to(dev)          # default dropout 0.1
+    m = TinyTransformer(32).to(dev)          # default dropout 0.1, like the reference
+    x, t = torch.ones(1, 4, 32, device=dev), torch.zeros(1, dtype=torch.long, device=dev)
     m.train()
-    with pytest.raises(RuntimeError, match="dropout"):
-        m(torch.zeros(1, 4, 32, device=dev), torch.zeros(1, dtype=torch.long, device=dev))
+    with torch.no_grad():
+        a = m(x, t)
     m.eval()
     with torch.no_grad():
-        assert m(torch.zeros(1, 4, 32, device=dev), torch.zeros(1, dtype=torch.long, device=dev)).shape == (1, 4, 32)
+        b = m(x, t)
+    assert a.shape == b.shape == (1, 4, 32) and not torch.equal(a, b)
+    bad = TinyTransformer(32, dropout=0.0).to(dev)
+    bad.p_drop = 1.0                          # torch accepts p = 1; the native path refuses it loudly
+    bad.train()
+    with pytest.raises(RuntimeError, match="dropout probability"):
+        bad(x, t)

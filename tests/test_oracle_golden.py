@@ -112,6 +112,32 @@ def test_transformer(golden_dir, golden_tables, tag, dim):
         assert O.rel_err(y, g[f"{tag}.ps{tt}.y"]) < 2e-6
 
 
+@pytest.mark.parametrize("tag,dim", [("d32", 32), ("d256", 256)])
+def test_transformer_train_mode_dropout(golden_dir, golden_tables, tag, dim):
+    """Train mode (dropout 0.1): the oracle's placement / scaling / site numbering of the 13
+    dropout masks against the REFERENCE module run with the same hash-defined masks
+    (oracle/make_golden.py:gen_text_dropout)."""
+    g = _load(golden_dir, "text_dropout.npz")
+    p_drop, seed = float(g["p_drop"][0]), int(g["seed"][0])
+    p = O.transformer_init_params(dim, seed=11)
+    x0, t, noise = g[f"{tag}.x0"], g[f"{tag}.t"], g[f"{tag}.noise"]
+    pred = O.transformer_forward(p, O.q_sample(x0, t, noise, golden_tables), t, p_drop=p_drop, seed=seed)
+    assert O.rel_err(pred, g[f"{tag}.pred"]) < 2e-6
+    # the masks matter: eval-mode output is far away
+    assert O.rel_err(O.transformer_forward(p, O.q_sample(x0, t, noise, golden_tables), t), g[f"{tag}.pred"]) > 1e-2
+    loss, grads = O.transformer_loss_and_grads(p, x0, t, noise, golden_tables, p_drop=p_drop, seed=seed, want_dx=True)
+    assert abs(loss.item() - g[f"{tag}.loss"].item()) < 1e-5 * abs(g[f"{tag}.loss"].item())
+    assert O.rel_err(grads["__dx"], g[f"{tag}.dx"]) < 5e-5
+    n = 0
+    for k, v in g.items():
+        if k.startswith(f"{tag}.grad."):
+            assert O.rel_err(grads[k.split(".", 2)[2]], v) < 5e-5, k
+            n += 1
+    assert n >= 8
+    keep = O.dropout_keep(p_drop, seed, 3, (200000,))
+    assert abs(keep.float().mean().item() - (1 - p_drop)) < 5e-3
+
+
 def test_host_schedules(golden_dir):
     g = _load(golden_dir, "text_denoiser.npz")
     assert g["cosine_warmup_10_100"].shape[0] == 100 and g["cosine_warmup_10_100"][0] == 0.0

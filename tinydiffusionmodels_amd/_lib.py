@@ -18,6 +18,7 @@ c_f = ctypes.c_void_p      # device pointers travel as void*
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int
 c_float = ctypes.c_float
+c_u64 = ctypes.c_uint64
 
 _SIGS = {
     "tdm_version": ([], c_int),
@@ -51,9 +52,12 @@ _SIGS = {
     "tdm_tt_param_offsets": ([c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int64)], c_int),
     "tdm_tt_workspace_floats": ([c_i64, c_int, c_int, c_int, c_int, c_int, c_int], c_i64),
     "tdm_tt_slab_floats": ([c_int, c_int, c_int], c_i64),
-    "tdm_tt_fwd_f32": ([c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_f], c_int),
-    "tdm_tt_bwd_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int, c_int, c_f], c_int),
-    "tdm_tt_loss_grad_f32": ([c_f] * 13 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_f], c_int),
+    "tdm_tt_fwd_f32": ([c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_u64, c_f], c_int),
+    "tdm_tt_bwd_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int, c_int, c_float, c_u64, c_f], c_int),
+    "tdm_tt_loss_grad_f32": ([c_f] * 13 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_float, c_u64, c_f], c_int),
+    "tdm_set_attn_mode": ([c_int], c_int),
+    "tdm_get_attn_mode": ([], c_int),
+    "tdm_dropout_keep_u8": ([c_float, c_u64, c_int, c_i64, c_i64, c_f], c_int),
     "tdm_tt_p_sample_step_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_i64, c_int, c_int, c_int,
                                   c_int, c_int, c_f], c_int),
     "tdm_gemm_f32": ([c_f, c_i64, c_i64, c_f, c_i64, c_i64, c_f, c_i64, c_f, c_f, c_int, c_int, c_int, c_int, c_int,

@@ -75,20 +75,32 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
-        __syncthreads();
+    // software pipeline: the global loads of K-chunk k+1 are in flight (registers) while chunk k is multiplied
+    float4 pa[4], pb[4];
+    auto gload = [&](int k0) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {   // 128 rows x 8 float4
             const int f = tid + 256 * p;
             const int row = f >> 3, kq = f & 7;
             const int gk = k0 + kq * 4;
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-            if (i0 + row < g.M) va = load4_guard(g.A + (long)(i0 + row) * g.a_rs + gk, g.K - gk);
-            if (j0 + row < g.N) vb = load4_guard(g.B + (long)(j0 + row) * g.b_cs + gk, g.K - gk);
-            put_split<NPROD>(Ahi, Alo, row * PITCH + kq * 8, va);
-            put_split<NPROD>(Bhi, Blo, row * PITCH + kq * 8, vb);
+            pa[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            pb[p] = pa[p];
+            if (i0 + row < g.M) pa[p] = load4_guard(g.A + (long)(i0 + row) * g.a_rs + gk, g.K - gk);
+            if (j0 + row < g.N) pb[p] = load4_guard(g.B + (long)(j0 + row) * g.b_cs + gk, g.K - gk);
+        }
+    };
+    gload(0);
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int f = tid + 256 * p;
+            const int row = f >> 3, kq = f & 7;
+            put_split<NPROD>(Ahi, Alo, row * PITCH + kq * 8, pa[p]);
+            put_split<NPROD>(Bhi, Blo, row * PITCH + kq * 8, pb[p]);
         }
         __syncthreads();
+        if (k0 + BK < g.K) gload(k0 + BK);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 xh[2], xl[2], wh[2], wl[2];
@@ -141,6 +153,18 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
                             v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y;
                             v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
                         }
+                        if (g.gate != nullptr) {
+                            const float4 gz = *reinterpret_cast<const float4*>(g.gate + row + n);
+                            v.x = gz.x > 0.f ? v.x * g.gate_scale : 0.f; v.y = gz.y > 0.f ? v.y * g.gate_scale : 0.f;
+                            v.z = gz.z > 0.f ? v.z * g.gate_scale : 0.f; v.w = gz.w > 0.f ? v.w * g.gate_scale : 0.f;
+                        }
+                        if (g.drop.thr != 0u) {
+                            const unsigned long long e = (unsigned long long)m * (unsigned)g.N + (unsigned)n;
+                            v.x = tdm_keep(g.drop, e) ? v.x * g.drop.scale : 0.f;
+                            v.y = tdm_keep(g.drop, e + 1) ? v.y * g.drop.scale : 0.f;
+                            v.z = tdm_keep(g.drop, e + 2) ? v.z * g.drop.scale : 0.f;
+                            v.w = tdm_keep(g.drop, e + 3) ? v.w * g.drop.scale : 0.f;
+                        }
                         *reinterpret_cast<float4*>(g.C + row + n) = v;
                     }
                 }
@@ -184,23 +208,37 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        __syncthreads();
+    float4 pa[4], pb[4];   // next chunk's global loads, in flight during the MFMAs of the current one
+    auto gload = [&](int k0) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {   // 32 token rows x 32 float4 columns
             const int f = tid + 256 * p;
             const int mrow = f >> 5, c4 = f & 31;
             const int gk = k0 + mrow;
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            pa[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            pb[p] = pa[p];
             if (gk < kend) {
-                va = load4_guard(g.A + (long)gk * g.a_cs + i0 + c4 * 4, g.M - (i0 + c4 * 4));
-                vb = load4_guard(g.B + (long)gk * g.b_rs + j0 + c4 * 4, g.N - (j0 + c4 * 4));
+                pa[p] = load4_guard(g.A + (long)gk * g.a_cs + i0 + c4 * 4, g.M - (i0 + c4 * 4));
+                pb[p] = load4_guard(g.B + (long)gk * g.b_rs + j0 + c4 * 4, g.N - (j0 + c4 * 4));
             }
+        }
+    };
+    if (kbeg < kend) gload(kbeg);
+    const bool do_cs = g.colsum != nullptr && blockIdx.x == 0;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);   // this thread's 4 A columns (c4 = tid & 31), rows tid>>5 (+8p)
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int f = tid + 256 * p;
+            const int mrow = f >> 5, c4 = f & 31;
             const int off = ((c4 >> 3) * 32 + mrow) * 64 + (c4 & 7) * 8;
-            put_split<NPROD>(Ahi, Alo, off, va);
-            put_split<NPROD>(Bhi, Blo, off, vb);
+            put_split<NPROD>(Ahi, Alo, off, pa[p]);
+            put_split<NPROD>(Bhi, Blo, off, pb[p]);
+            if (do_cs) { csum.x += pa[p].x; csum.y += pa[p].y; csum.z += pa[p].z; csum.w += pa[p].w; }
         }
         __syncthreads();
+        if (k0 + BK < kend) gload(k0 + BK);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int m0r = ks * 16 + hh * 8 + q;   // token row of this lane's first transposed read
@@ -226,6 +264,26 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
                     }
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
                 }
+        }
+    }
+    if (do_cs) {   // 8 row groups -> one sum per column, fixed order
+        __syncthreads();
+        float4* red = reinterpret_cast<float4*>(lds);
+        red[tid] = csum;
+        __syncthreads();
+        if (tid < 32) {
+            float4 a = red[tid];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {
+                const float4 b = red[tid + 32 * k];
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            float* dst = g.colsum + (long)blockIdx.z * g.colsum_stride;
+            const int i = i0 + tid * 4;
+            if (i + 0 < g.M) dst[i + 0] = a.x;
+            if (i + 1 < g.M) dst[i + 1] = a.y;
+            if (i + 2 < g.M) dst[i + 2] = a.z;
+            if (i + 3 < g.M) dst[i + 3] = a.w;
         }
     }
     float* C = g.C + (g.splitk > 1 ? (long)blockIdx.z * g.c_split_stride : 0L);
@@ -287,7 +345,8 @@ int tdm_launch_gemm_tn_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
     TDM_REQUIRE(g.a_rs == 1 && g.b_cs == 1, "gemm_tn_bf16: both operands must be row(contraction)-major");
     TDM_REQUIRE((g.a_cs % 4) == 0 && (g.b_rs % 4) == 0, "gemm_tn_bf16: leading dimensions must be multiples of 4");
     TDM_REQUIRE((((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0, "gemm_tn_bf16: 16-byte alignment");
-    TDM_REQUIRE(g.bias == nullptr && g.res == nullptr && !g.relu, "gemm_tn_bf16: raw output only");
+    TDM_REQUIRE(g.bias == nullptr && g.res == nullptr && !g.relu && g.gate == nullptr && g.drop.thr == 0u,
+                "gemm_tn_bf16: raw output only");
     const int sk = g.splitk > 1 ? g.splitk : 1;
     dim3 grid((g.N + TN_ - 1) / TN_, (g.M + TM - 1) / TM, sk);
     if (nprod == 3) hipLaunchKernelGGL(gemm_tn_bf16_kernel<3>, grid, dim3(256), 0, st, g);

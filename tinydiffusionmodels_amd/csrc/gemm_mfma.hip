@@ -122,6 +122,9 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
                         const long o = (long)row * g.c_rs + col;
                         if (g.res != nullptr) v += g.res[o];
                         if (g.relu) v = (v < 0.f) ? 0.f : v;
+                        if (g.gate != nullptr) v = g.gate[o] > 0.f ? v * g.gate_scale : 0.f;
+                        if (g.drop.thr != 0u)
+                            v = tdm_keep(g.drop, (unsigned long long)row * (unsigned)g.N + (unsigned)col) ? v * g.drop.scale : 0.f;
                         C[o] = v;
                     }
                 }
@@ -139,8 +142,10 @@ int tdm_launch_gemm(const GemmArgs& g, hipStream_t st) {
     TDM_REQUIRE(((g.a_cs == 1 ? g.a_rs : g.a_cs) % 4) == 0 && ((g.b_cs == 1 ? g.b_rs : g.b_cs) % 4) == 0,
                 "gemm: leading dimensions must be multiples of 4 floats");
     TDM_REQUIRE((((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0, "gemm: operands must be 16-byte aligned");
+    TDM_REQUIRE(g.colsum == nullptr, "gemm: fused column sums exist in the bf16 TN kernel only");
     const int sk = g.splitk > 1 ? g.splitk : 1;
-    TDM_REQUIRE(sk == 1 || (g.bias == nullptr && !g.relu && g.res == nullptr), "gemm: split-K output must be raw");
+    TDM_REQUIRE(sk == 1 || (g.bias == nullptr && !g.relu && g.res == nullptr && g.gate == nullptr && g.drop.thr == 0u),
+                "gemm: split-K output must be raw");
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, sk);
     hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), 0, st, g);
     TDM_CHECK_LAUNCH("gemm_mfma");

@@ -108,7 +108,7 @@ struct ReduceSec {
     long src_delta;        // slab 0 of this section starts at slabs + off + src_delta (default 0)
     long stride_override;  // distance between this section's slabs; 0 = the launch's common stride
 };
-#define TDM_MAX_SECS 40
+#define TDM_MAX_SECS 64
 struct ReduceArgs {
     ReduceSec sec[TDM_MAX_SECS];
     int nsec;

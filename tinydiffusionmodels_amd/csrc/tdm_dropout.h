@@ -1,0 +1,47 @@
+// Counter-based dropout masks for the transformer denoiser's train mode
+// (src/shakespeare.py:106-119 builds nn.TransformerEncoderLayer(dropout=p) and an
+// nn.Dropout(p) on the input; torch draws the masks from its Philox stream, which no
+// other implementation can replay).  Here a mask is a pure function of
+//   (seed, site, flat element index)
+// so forward and backward regenerate it in registers (nothing is stored) and the
+// CPU oracle recomputes the identical mask with integer arithmetic:
+//   key  = hash32(seed_lo ^ hash32(seed_hi + 0x9E3779B9 * (site + 1)))
+//   u    = hash32(hash32(idx_lo ^ key) + idx_hi)
+//   keep = u >= thr,  thr = round(p * 2^32)  =>  P(keep) = 1 - p
+//   y    = keep ? x * (1 / (1 - p)) : 0                (torch: x * (mask / (1 - p)))
+// hash32 is the "lowbias32" integer finaliser.  Sites are numbered in the order the
+// reference's forward reaches them: 0 = input dropout; for layer l: 1+4l attention
+// probabilities (B,H,L,L), 2+4l dropout1 (B,L,D), 3+4l FFN dropout (B,L,F), 4+4l dropout2.
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+struct DropArgs {
+    uint32_t thr;   // 0 = dropout off
+    uint32_t key;
+    float scale;    // 1 / (1 - p)
+};
+
+__host__ __device__ __forceinline__ uint32_t tdm_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+__host__ __device__ __forceinline__ bool tdm_keep(const DropArgs& d, unsigned long long idx) {
+    const uint32_t u = tdm_hash32(tdm_hash32((uint32_t)idx ^ d.key) + (uint32_t)(idx >> 32));
+    return u >= d.thr;
+}
+
+inline DropArgs tdm_drop_site(float p, uint64_t seed, int site) {
+    DropArgs d{};
+    if (!(p > 0.f)) return d;
+    double t = (double)p * 4294967296.0 + 0.5;
+    if (t > 4294967295.0) t = 4294967295.0;
+    d.thr = (uint32_t)t;
+    if (d.thr == 0) d.thr = 1;
+    d.key = tdm_hash32((uint32_t)seed ^ tdm_hash32((uint32_t)(seed >> 32) + 0x9E3779B9U * (uint32_t)(site + 1)));
+    d.scale = 1.0f / (1.0f - p);
+    return d;
+}

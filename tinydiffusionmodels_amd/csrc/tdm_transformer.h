@@ -1,6 +1,7 @@
 // Internal declarations for the transformer-denoiser kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "tdm_dropout.h"
 
 struct GemmArgs {
     const float* A; long a_rs, a_cs;   // A(i,k) = A[i*a_rs + k*a_cs]
@@ -11,6 +12,12 @@ struct GemmArgs {
     const float* res;                  // [M][c_rs] residual added before relu, may alias C; or nullptr
     int relu;
     int splitk; long c_split_stride;   // splitk > 1: partial z goes to C + z*c_split_stride (raw)
+    // epilogue extras, applied after bias / residual / relu, in this order:
+    const float* gate; float gate_scale;   // v = gate[i*c_rs + j] > 0 ? v * gate_scale : 0   (ReLU (+dropout) backward)
+    DropArgs drop;                         // dropout over the flat index i*N + j
+    // TN form only: colsum[z*colsum_stride + i] = sum over this split's k of A(i,k) (exact fp32; the bias gradient
+    // when A = dY), written by the workgroups of tile column 0
+    float* colsum; long colsum_stride;
 };
 int tdm_launch_gemm(const GemmArgs& g, hipStream_t st);
 
@@ -18,3 +25,8 @@ int tdm_launch_gemm(const GemmArgs& g, hipStream_t st);
 int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st);
 int tdm_launch_gemm_tn_bf16(const GemmArgs& g, int nprod, hipStream_t st);
 int tdm_launch_transpose(const float* in, float* out, int R, int Cn, hipStream_t st);
+
+// fp32-MFMA attention (attn_mfma.hip). which: 0 forward (out = O, aux = lse), 1 dQ (out = dqkv, aux = D written),
+// 2 dK/dV (out = dqkv, aux = D read)
+int tdm_launch_attn_mfma(int which, int hd, const float* qkv, const float* o, const float* lse, const float* dO, float* out,
+                         float* aux, long B, int L, int D, int H, DropArgs dr, hipStream_t st);

@@ -1,11 +1,13 @@
 // TinyTransformer embedding-space denoiser (src/shakespeare.py:105-120):
 //   x + Linear(1,D)(t/1000)  ->  depth x post-LN nn.TransformerEncoderLayer
 //   (packed in_proj, n_heads-way softmax attention without mask, out_proj,
-//    residual + LayerNorm, ReLU FFN, residual + LayerNorm), eval / dropout 0.
+//    residual + LayerNorm, ReLU FFN, residual + LayerNorm); eval, or train mode
+//   with the 1 + 4*depth dropout sites of the reference (masks: tdm_dropout.h).
 // Forward, backward and the text reverse step, as launches on one stream.
-// Linear layers and their gradients run on the fp32 MFMA GEMM (gemm_mfma.hip);
-// attention (5 % of the FLOPs at L=128) is an fp32 kernel with K/V (or Q/dO)
-// tiles broadcast from LDS; LayerNorm is one wavefront per token row.
+// Linear layers and their gradients run on the MFMA GEMMs (gemm_bf16.hip /
+// gemm_mfma.hip); attention on the fp32 matrix cores (attn_mfma.hip; the scalar
+// fp32 kernels below are kept as attention mode 0, the cross-check); LayerNorm is
+// one wavefront per token row.
 #include <math.h>
 #include "tdm_common.h"
 #include "tdm_transformer.h"
@@ -15,9 +17,17 @@ namespace {
 // arithmetic of the linear layers: 0 exact fp32 MFMA, 1 bf16x3 split operands (default, meets the 1e-3
 // parity bound), 2 plain bf16 operands (throughput mode)
 int g_gemm_mode = 1;
+// attention: 0 scalar fp32 kernels (this file), 1 fp32 MFMA (attn_mfma.hip, default)
+int g_attn_mode = 1;
 
-constexpr int LN_SLABS = 2048; // per-wave partials of the LayerNorm affine gradients (512 workgroups)
-constexpr int CS_SLABS = 512;  // row-block partials of the bias gradients
+// train-mode dropout of one call: p = 0 -> off
+struct Drop {
+    float p; uint64_t seed;
+    DropArgs site(int s) const { return tdm_drop_site(p, seed, s); }
+};
+
+constexpr int LN_SLABS = 256;  // workgroup partials of the LayerNorm affine / bias gradients (one workgroup per CU)
+constexpr int CS_SLABS = 256;  // row-block partials of the bias gradients
 
 // Weight-gradient GEMMs contract over tokens (K = B*L, tens of thousands) into small [N][K] outputs:
 // each tensor gets its own split-K factor so that tiles x splits ~ 1024 workgroups fill the chip.
@@ -29,14 +39,17 @@ inline int wgrad_splitk(int N, int K) {
     return sk;
 }
 // slab regions (floats) of the 4 weight matrices of one layer, in order in_w, out_w, l1_w, l2_w
-struct SlabPlan { long base[8][4]; int sk[4]; long len[4]; long total; };
+struct SlabPlan { long base[8][4]; long bias_base[8][4]; int sk[4]; long len[4]; int nout[4]; long total; };
 SlabPlan slab_plan(int D, int depth, int F) {
     SlabPlan p{};
     const int Ns[4] = {3 * D, D, F, D}, Ks[4] = {D, D, D, F};
     long off = 0;
-    for (int k = 0; k < 4; ++k) { p.sk[k] = wgrad_splitk(Ns[k], Ks[k]); p.len[k] = (long)Ns[k] * Ks[k]; }
+    for (int k = 0; k < 4; ++k) { p.sk[k] = wgrad_splitk(Ns[k], Ks[k]); p.len[k] = (long)Ns[k] * Ks[k]; p.nout[k] = Ns[k]; }
     for (int l = 0; l < depth; ++l)
         for (int k = 0; k < 4; ++k) { p.base[l][k] = off; off += p.sk[k] * p.len[k]; }
+    // per-split partial bias gradients written by the weight-gradient GEMMs (bf16 modes)
+    for (int l = 0; l < depth; ++l)
+        for (int k = 0; k < 4; ++k) { p.bias_base[l][k] = off; off += (long)p.sk[k] * ((Ns[k] + 63) & ~63); }
     p.total = off;
     return p;
 }
@@ -75,7 +88,7 @@ struct TTWs {
     float *that, *tb, *abuf, *wT;
     LayerWs L[8];
     // backward temporaries
-    float *g_h, *g_s, *g_s1, *g_f, *g_h1, *g_o, *g_qkv, *Dvec, *Sb, *part;
+    float *g_h, *g_s, *g_s1, *g_d, *g_f, *g_h1, *g_o, *g_qkv, *Dvec, *Sb, *part;
     long total;
 };
 TTWs tt_carve(float* base, long B, int Lq, int D, int H, int depth, int F, int training) {
@@ -96,9 +109,9 @@ TTWs tt_carve(float* base, long B, int Lq, int D, int H, int depth, int F, int t
         x.s2 = take(M * D); x.mean2 = take(M); x.rstd2 = take(M);
     }
     if (training) {
-        w.g_h = take(M * D); w.g_s = take(M * D); w.g_s1 = take(M * D); w.g_f = take(M * F); w.g_h1 = take(M * D);
+        w.g_h = take(M * D); w.g_s = take(M * D); w.g_s1 = take(M * D); w.g_d = take(M * D); w.g_f = take(M * F); w.g_h1 = take(M * D);
         w.g_o = take(M * D); w.g_qkv = take(M * 3 * D); w.Dvec = take(B * H * Lq); w.Sb = take(B * D);
-        long pmax = (long)LN_SLABS * 2 * D;
+        long pmax = (long)LN_SLABS * 3 * D;
         const long c1 = (long)CS_SLABS * (F > 3 * D ? F : 3 * D);
         if (c1 > pmax) pmax = c1;
         w.part = take(pmax + (F > 3 * D ? F : 3 * D));
@@ -117,7 +130,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ __launch_bounds__(256) void add_timebias_kernel(const float* __restrict__ x, const int64_t* __restrict__ t,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
                                                            float* __restrict__ that, float* __restrict__ tb,
-                                                           float* __restrict__ h0, long B, int L, int D) {
+                                                           float* __restrict__ h0, long B, int L, int D, DropArgs dr) {
     const long total = B * L * D;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int d = (int)(i % D);
@@ -125,7 +138,9 @@ __global__ __launch_bounds__(256) void add_timebias_kernel(const float* __restri
         const long b = m / L;
         const float th = __fdiv_rn((float)t[b], 1000.f);
         const float tv = fmaf(w[d], th, bias[d]);
-        h0[i] = x[i] + tv;
+        float v = x[i] + tv;
+        if (dr.thr != 0u) v = tdm_keep(dr, (unsigned long long)i) ? v * dr.scale : 0.f;
+        h0[i] = v;
         if (m - b * L == 0) {
             tb[b * D + d] = tv;
             if (d == 0) that[b] = th;
@@ -138,7 +153,8 @@ __global__ __launch_bounds__(256) void add_timebias_kernel(const float* __restri
 // in chunks of 128 (all lanes read the same K/V row: LDS broadcast).
 template <int HD>
 __global__ __launch_bounds__(128) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o,
-                                                       float* __restrict__ lse, int L, int D, int H, float scale) {
+                                                       float* __restrict__ lse, int L, int D, int H, float scale,
+                                                       DropArgs dr) {
     extern __shared__ float4 sm4[];
     float* Ks = reinterpret_cast<float*>(sm4);
     float* Vs = Ks + 128 * HD;
@@ -188,8 +204,10 @@ __global__ __launch_bounds__(128) void attn_fwd_kernel(const float* __restrict__
             }
             const float p = expf(s - m);
             l += p;
+            float pd = p;
+            if (dr.thr != 0u) pd = tdm_keep(dr, ((unsigned long long)bh * L + i) * L + j0 + jj) ? p * dr.scale : 0.f;
 #pragma unroll
-            for (int d = 0; d < HD; ++d) acc[d] = fmaf(p, Vs[jj * HD + d], acc[d]);
+            for (int d = 0; d < HD; ++d) acc[d] = fmaf(pd, Vs[jj * HD + d], acc[d]);
         }
     }
     if (valid) {
@@ -208,7 +226,7 @@ template <int HD>
 __global__ __launch_bounds__(128) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                           const float* __restrict__ lse, const float* __restrict__ dO,
                                                           float* __restrict__ dqkv, float* __restrict__ Dvec, int L,
-                                                          int D, int H, float scale) {
+                                                          int D, int H, float scale, DropArgs dr) {
     extern __shared__ float4 sm4[];
     float* Ks = reinterpret_cast<float*>(sm4);
     float* Vs = Ks + 128 * HD;
@@ -256,6 +274,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dq_kernel(const float* __restric
                 dp = fmaf(dov[d], Vs[jj * HD + d], dp);
             }
             const float p = expf(s * scale - lse_i);
+            if (dr.thr != 0u) dp = tdm_keep(dr, ((unsigned long long)bh * L + i) * L + j0 + jj) ? dp * dr.scale : 0.f;
             const float dsv = p * (dp - Di);
 #pragma unroll
             for (int d = 0; d < HD; ++d) dq[d] = fmaf(dsv, Ks[jj * HD + d], dq[d]);
@@ -273,7 +292,8 @@ __global__ __launch_bounds__(128) void attn_bwd_dq_kernel(const float* __restric
 template <int HD>
 __global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ lse,
                                                            const float* __restrict__ dO, const float* __restrict__ Dvec,
-                                                           float* __restrict__ dqkv, int L, int D, int H, float scale) {
+                                                           float* __restrict__ dqkv, int L, int D, int H, float scale,
+                                                           DropArgs dr) {
     extern __shared__ float4 sm4[];
     float* Qs = reinterpret_cast<float*>(sm4);
     float* Os = Qs + 128 * HD;
@@ -319,10 +339,16 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(const float* __restri
                 dp = fmaf(Os[ii * HD + d], v[d], dp);
             }
             const float p = expf(s * scale - Ls[ii]);
+            float pd = p;
+            if (dr.thr != 0u) {
+                const bool keep = tdm_keep(dr, ((unsigned long long)bh * L + i0 + ii) * L + jg);
+                pd = keep ? p * dr.scale : 0.f;
+                dp = keep ? dp * dr.scale : 0.f;
+            }
             const float dsv = p * (dp - Ds[ii]);
 #pragma unroll
             for (int d = 0; d < HD; ++d) {
-                dv[d] = fmaf(p, Os[ii * HD + d], dv[d]);
+                dv[d] = fmaf(pd, Os[ii * HD + d], dv[d]);
                 dk[d] = fmaf(dsv, Qs[ii * HD + d], dk[d]);
             }
         }
@@ -387,65 +413,148 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (lane == 0 && mean_out != nullptr) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
 
-// ds = rstd * (g - mean(g) - xhat*mean(g*xhat)), g = (dy + dy2) * gamma;
-// per-wave partials of dgamma = sum dy*xhat and dbeta = sum dy -> part[(block*4+wave)][2][D]
+// ds = rstd * (g - mean(g) - xhat*mean(g*xhat)), g = (dy + dy2) * gamma.
+// s = x + a is the LayerNorm input, so ds is the gradient of both the residual x and
+// the sub-layer output a; in train mode a = dropout(linear(...)) and the gradient the
+// linear layer sees is ds_drop = mask * ds / (1 - p), written next to ds.
+// Per-workgroup partials -> part[block][3][D]: dgamma = sum dy*xhat, dbeta = sum dy and
+// the column sums of ds_drop (= the bias gradient of that linear layer).
+// NQ float4 per lane cover a row (D <= 256*NQ); a wave keeps 4/NQ rows in flight.
+template <int NQ>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dy2,
                                                      const float* __restrict__ s, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                     float* __restrict__ ds, float* __restrict__ part, long M, int D) {
+                                                     float* __restrict__ ds, float* __restrict__ ds_drop,
+                                                     float* __restrict__ part, long M, int D, DropArgs dr) {
+    constexpr int R = 4 / NQ;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int D4 = D >> 2;
-    float4 gacc[4], bacc[4];
+    const float invD = 1.f / (float)D;
+    float4 gacc[NQ], bacc[NQ], cacc[NQ], gm[NQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { gacc[q] = make_float4(0.f, 0.f, 0.f, 0.f); bacc[q] = gacc[q]; }
-    for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
-        float4 g[4], xh[4];
-        float c1 = 0.f, c2 = 0.f;
+    for (int q = 0; q < NQ; ++q) {
+        gacc[q] = make_float4(0.f, 0.f, 0.f, 0.f); bacc[q] = gacc[q]; cacc[q] = gacc[q];
+        const int c4 = lane + 64 * q;
+        gm[q] = c4 < D4 ? reinterpret_cast<const float4*>(gamma)[c4] : gacc[q];
+    }
+    const long wid = (long)blockIdx.x * 4 + wave, nw = (long)gridDim.x * 4;
+    for (long row0 = wid * R; row0 < M; row0 += nw * R) {
+        float4 d[R][NQ], xh[R][NQ];
+        float mu[R], rs[R];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c4 = lane + 64 * q;
-            g[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            xh[q] = g[q];
-            if (c4 < D4) {
-                float4 d = reinterpret_cast<const float4*>(dy + row * D)[c4];
-                if (dy2 != nullptr) {
-                    const float4 d2 = reinterpret_cast<const float4*>(dy2 + row * D)[c4];
-                    d.x += d2.x; d.y += d2.y; d.z += d2.z; d.w += d2.w;
+        for (int rr = 0; rr < R; ++rr) {
+            const long row = row0 + rr;
+            const bool rv = row < M;
+            mu[rr] = rv ? mean[row] : 0.f;
+            rs[rr] = rv ? rstd[row] : 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int c4 = lane + 64 * q;
+                d[rr][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                xh[rr][q] = d[rr][q];
+                if (rv && c4 < D4) {
+                    d[rr][q] = reinterpret_cast<const float4*>(dy + row * D)[c4];
+                    if (dy2 != nullptr) {
+                        const float4 d2 = reinterpret_cast<const float4*>(dy2 + row * D)[c4];
+                        d[rr][q].x += d2.x; d[rr][q].y += d2.y; d[rr][q].z += d2.z; d[rr][q].w += d2.w;
+                    }
+                    xh[rr][q] = reinterpret_cast<const float4*>(s + row * D)[c4];
                 }
-                const float4 sv = reinterpret_cast<const float4*>(s + row * D)[c4];
-                const float4 gm = reinterpret_cast<const float4*>(gamma)[c4];
-                xh[q] = make_float4((sv.x - mu) * rs, (sv.y - mu) * rs, (sv.z - mu) * rs, (sv.w - mu) * rs);
-                g[q] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
-                c1 += (g[q].x + g[q].y) + (g[q].z + g[q].w);
-                c2 += (g[q].x * xh[q].x + g[q].y * xh[q].y) + (g[q].z * xh[q].z + g[q].w * xh[q].w);
-                gacc[q].x += d.x * xh[q].x; gacc[q].y += d.y * xh[q].y; gacc[q].z += d.z * xh[q].z; gacc[q].w += d.w * xh[q].w;
-                bacc[q].x += d.x; bacc[q].y += d.y; bacc[q].z += d.z; bacc[q].w += d.w;
             }
         }
-        c1 = wave_sum(c1) / (float)D;
-        c2 = wave_sum(c2) / (float)D;
+        float c1[R], c2[R];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c4 = lane + 64 * q;
-            if (c4 < D4) {
-                float4 o;
-                o.x = rs * (g[q].x - c1 - xh[q].x * c2);
-                o.y = rs * (g[q].y - c1 - xh[q].y * c2);
-                o.z = rs * (g[q].z - c1 - xh[q].z * c2);
-                o.w = rs * (g[q].w - c1 - xh[q].w * c2);
-                reinterpret_cast<float4*>(ds + row * D)[c4] = o;
+        for (int rr = 0; rr < R; ++rr) {
+            c1[rr] = 0.f; c2[rr] = 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int c4 = lane + 64 * q;
+                if (c4 < D4) {
+                    const float4 sv = xh[rr][q], dd = d[rr][q];
+                    const float4 x = make_float4((sv.x - mu[rr]) * rs[rr], (sv.y - mu[rr]) * rs[rr], (sv.z - mu[rr]) * rs[rr],
+                                                 (sv.w - mu[rr]) * rs[rr]);
+                    xh[rr][q] = x;
+                    const float4 g = make_float4(dd.x * gm[q].x, dd.y * gm[q].y, dd.z * gm[q].z, dd.w * gm[q].w);
+                    c1[rr] += (g.x + g.y) + (g.z + g.w);
+                    c2[rr] += (g.x * x.x + g.y * x.y) + (g.z * x.z + g.w * x.w);
+                    gacc[q].x += dd.x * x.x; gacc[q].y += dd.y * x.y; gacc[q].z += dd.z * x.z; gacc[q].w += dd.w * x.w;
+                    bacc[q].x += dd.x; bacc[q].y += dd.y; bacc[q].z += dd.z; bacc[q].w += dd.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) { c1[rr] = wave_sum(c1[rr]) * invD; c2[rr] = wave_sum(c2[rr]) * invD; }
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const long row = row0 + rr;
+            if (row >= M) continue;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int c4 = lane + 64 * q;
+                if (c4 < D4) {
+                    const float4 dd = d[rr][q], x = xh[rr][q];
+                    float4 o;
+                    o.x = rs[rr] * (dd.x * gm[q].x - c1[rr] - x.x * c2[rr]);
+                    o.y = rs[rr] * (dd.y * gm[q].y - c1[rr] - x.y * c2[rr]);
+                    o.z = rs[rr] * (dd.z * gm[q].z - c1[rr] - x.z * c2[rr]);
+                    o.w = rs[rr] * (dd.w * gm[q].w - c1[rr] - x.w * c2[rr]);
+                    reinterpret_cast<float4*>(ds + row * D)[c4] = o;
+                    if (ds_drop != nullptr) {
+                        const unsigned long long e = (unsigned long long)row * D + c4 * 4;
+                        o.x = tdm_keep(dr, e) ? o.x * dr.scale : 0.f;
+                        o.y = tdm_keep(dr, e + 1) ? o.y * dr.scale : 0.f;
+                        o.z = tdm_keep(dr, e + 2) ? o.z * dr.scale : 0.f;
+                        o.w = tdm_keep(dr, e + 3) ? o.w * dr.scale : 0.f;
+                        reinterpret_cast<float4*>(ds_drop + row * D)[c4] = o;
+                    }
+                    cacc[q].x += o.x; cacc[q].y += o.y; cacc[q].z += o.z; cacc[q].w += o.w;
+                }
             }
         }
     }
-    float* dst = part + ((long)blockIdx.x * 4 + wave) * 2 * D;
+    // the 4 waves' partial sums are added in fixed order through LDS: one partial per workgroup
+    __shared__ float4 red[3][3][64 * NQ];
+    float* dst = part + (long)blockIdx.x * 3 * D;
+    if (wave > 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int c4 = lane + 64 * q;
-        if (c4 < D4) {
-            reinterpret_cast<float4*>(dst)[c4] = gacc[q];
-            reinterpret_cast<float4*>(dst + D)[c4] = bacc[q];
+        for (int q = 0; q < NQ; ++q) {
+            red[wave - 1][0][lane + 64 * q] = gacc[q];
+            red[wave - 1][1][lane + 64 * q] = bacc[q];
+            red[wave - 1][2][lane + 64 * q] = cacc[q];
         }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c4 = lane + 64 * q;
+            if (c4 < D4) {
+                float4 a = gacc[q], b = bacc[q], c = cacc[q];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    const float4 x = red[w][0][c4], y = red[w][1][c4], z = red[w][2][c4];
+                    a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+                    b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
+                    c.x += z.x; c.y += z.y; c.z += z.z; c.w += z.w;
+                }
+                reinterpret_cast<float4*>(dst)[c4] = a;
+                reinterpret_cast<float4*>(dst + D)[c4] = b;
+                reinterpret_cast<float4*>(dst + 2 * D)[c4] = c;
+            }
+        }
+    }
+}
+
+// in-place dropout backward: g = mask * g / (1 - p)
+__global__ __launch_bounds__(256) void drop_apply_kernel(float* __restrict__ g, long n4, DropArgs dr) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 v = reinterpret_cast<float4*>(g)[i];
+        const unsigned long long e = (unsigned long long)i * 4;
+        v.x = tdm_keep(dr, e) ? v.x * dr.scale : 0.f;
+        v.y = tdm_keep(dr, e + 1) ? v.y * dr.scale : 0.f;
+        v.z = tdm_keep(dr, e + 2) ? v.z * dr.scale : 0.f;
+        v.w = tdm_keep(dr, e + 3) ? v.w * dr.scale : 0.f;
+        reinterpret_cast<float4*>(g)[i] = v;
     }
 }
 
@@ -509,7 +618,7 @@ __global__ __launch_bounds__(256) void seqsum_kernel(const float* __restrict__ g
 // ----------------------------------- launchers -----------------------------------
 template <int HD>
 int attn_launch(int which, const float* qkv, const float* o, const float* lse, const float* dO, float* out, float* aux,
-                long B, int L, int D, int H, hipStream_t st) {
+                long B, int L, int D, int H, DropArgs dr, hipStream_t st) {
     const float scale = 1.0f / sqrtf((float)HD);
     dim3 grid((unsigned)(B * H), (L + 127) / 128);
     const size_t lds2 = (size_t)2 * 128 * HD * sizeof(float);
@@ -531,44 +640,48 @@ int attn_launch(int which, const float* qkv, const float* o, const float* lse, c
         attr_set = true;
     }
     if (which == 0) {
-        hipLaunchKernelGGL((attn_fwd_kernel<HD>), grid, dim3(128), lds2, st, qkv, out, aux, L, D, H, scale);
+        hipLaunchKernelGGL((attn_fwd_kernel<HD>), grid, dim3(128), lds2, st, qkv, out, aux, L, D, H, scale, dr);
         TDM_CHECK_LAUNCH("attn_fwd");
     } else if (which == 1) {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), grid, dim3(128), lds2, st, qkv, o, lse, dO, out, aux, L, D, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), grid, dim3(128), lds2, st, qkv, o, lse, dO, out, aux, L, D, H, scale,
+                           dr);
         TDM_CHECK_LAUNCH("attn_bwd_dq");
     } else {
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD>), grid, dim3(128), lds2 + 256 * sizeof(float), st, qkv, lse, dO, aux,
-                           out, L, D, H, scale);
+                           out, L, D, H, scale, dr);
         TDM_CHECK_LAUNCH("attn_bwd_dkv");
     }
     return 0;
 }
 int attn_dispatch(int which, int hd, const float* qkv, const float* o, const float* lse, const float* dO, float* out,
-                  float* aux, long B, int L, int D, int H, hipStream_t st) {
+                  float* aux, long B, int L, int D, int H, DropArgs dr, hipStream_t st) {
+    if (g_attn_mode == 1) return tdm_launch_attn_mfma(which, hd, qkv, o, lse, dO, out, aux, B, L, D, H, dr, st);
     switch (hd) {
-        case 8: return attn_launch<8>(which, qkv, o, lse, dO, out, aux, B, L, D, H, st);
-        case 16: return attn_launch<16>(which, qkv, o, lse, dO, out, aux, B, L, D, H, st);
-        case 32: return attn_launch<32>(which, qkv, o, lse, dO, out, aux, B, L, D, H, st);
-        case 64: return attn_launch<64>(which, qkv, o, lse, dO, out, aux, B, L, D, H, st);
+        case 8: return attn_launch<8>(which, qkv, o, lse, dO, out, aux, B, L, D, H, dr, st);
+        case 16: return attn_launch<16>(which, qkv, o, lse, dO, out, aux, B, L, D, H, dr, st);
+        case 32: return attn_launch<32>(which, qkv, o, lse, dO, out, aux, B, L, D, H, dr, st);
+        case 64: return attn_launch<64>(which, qkv, o, lse, dO, out, aux, B, L, D, H, dr, st);
     }
     tdm_set_error("attention: head_dim %d not supported (8, 16, 32, 64)", hd);
     return 1;
 }
 
-// Y[M][N] = X[M][K] W[N][K]^T + bias (+res) (relu)
+// Y[M][N] = dropout(relu(X[M][K] W[N][K]^T + bias (+res)))
 int linear_fwd(const float* X, const float* W, const float* bias, const float* res, float* Y, long M, int N, int K,
-               int relu, hipStream_t st) {
+               int relu, DropArgs dr, hipStream_t st) {
     GemmArgs g{};
     g.A = X; g.a_rs = K; g.a_cs = 1;
     g.B = W; g.b_rs = 1; g.b_cs = K;
     g.C = Y; g.c_rs = N; g.bias = bias; g.res = res; g.relu = relu; g.M = (int)M; g.N = N; g.K = K; g.splitk = 1;
+    g.drop = dr;
     if (g_gemm_mode != 0) return tdm_launch_gemm_nt_bf16(g, g_gemm_mode == 1 ? 3 : 1, st);
     return tdm_launch_gemm(g, st);
 }
-// dX[M][K] = dY[M][N] W[N][K] (+res)
-int linear_dgrad(const float* dY, const float* W, float* wT, const float* res, float* dX, long M, int N, int K,
-                 hipStream_t st) {
+// dX[M][K] = dY[M][N] W[N][K] (+res), then dX = gate > 0 ? dX * gate_scale : 0 (ReLU / FFN-dropout backward)
+int linear_dgrad(const float* dY, const float* W, float* wT, const float* res, const float* gate, float gate_scale,
+                 float* dX, long M, int N, int K, hipStream_t st) {
     GemmArgs g{};
+    g.gate = gate; g.gate_scale = gate_scale;
     if (g_gemm_mode != 0) {   // dX = dY . (W^T)^T as a K-contiguous (NT) product on the transposed weight
         TDM_TRY(tdm_launch_transpose(W, wT, N, K, st));
         g.A = dY; g.a_rs = N; g.a_cs = 1;
@@ -581,14 +694,19 @@ int linear_dgrad(const float* dY, const float* W, float* wT, const float* res, f
     g.C = dX; g.c_rs = K; g.res = res; g.M = (int)M; g.N = K; g.K = N; g.splitk = 1;
     return tdm_launch_gemm(g, st);
 }
-// dW[N][K] partials = dY[M][N]^T X[M][K], split over M into SPLITK slabs at slabs + w_off
-int linear_wgrad(const float* dY, const float* X, float* slab_region, long M, int N, int K, hipStream_t st) {
+// dW[N][K] partials = dY[M][N]^T X[M][K], split over M into SPLITK slabs at slab_region; bias_region != nullptr
+// (bf16 modes): the same kernel also writes db partials = per-split column sums of dY, [SPLITK][N]
+int linear_wgrad(const float* dY, const float* X, float* slab_region, float* bias_region, long M, int N, int K,
+                 hipStream_t st) {
     GemmArgs g{};
     g.A = dY; g.a_rs = 1; g.a_cs = N;
     g.B = X; g.b_rs = K; g.b_cs = 1;
     g.C = slab_region; g.c_rs = K; g.M = N; g.N = K; g.K = (int)M; g.splitk = wgrad_splitk(N, K);
     g.c_split_stride = (long)N * K;
-    if (g_gemm_mode != 0) return tdm_launch_gemm_tn_bf16(g, g_gemm_mode == 1 ? 3 : 1, st);
+    if (g_gemm_mode != 0) {
+        g.colsum = bias_region; g.colsum_stride = (N + 63) & ~63;
+        return tdm_launch_gemm_tn_bf16(g, g_gemm_mode == 1 ? 3 : 1, st);
+    }
     return tdm_launch_gemm(g, st);
 }
 // bias gradient: db[N] = colsum(dY) via partials + reduce
@@ -602,15 +720,28 @@ int bias_grad(const float* dY, float* part, float* db, long M, int N, hipStream_
     ra.nsec = 1; ra.sec[0].off = 0; ra.sec[0].len = N; ra.sec[0].nslab = nb;
     return tdm_launch_reduce(part, N, ra, db, st);
 }
+// LayerNorm backward; G = gradient buffer base: dgamma/dbeta go to G[gamma_off .. +2D), the column sums of the
+// (dropped) input gradient to G[bias_off .. +D) (the bias gradient of the linear layer feeding the residual add)
 int ln_bwd(const float* dy, const float* dy2, const float* s, const float* mean, const float* rstd, const float* gamma,
-           float* ds, float* part, float* dgamma_dbeta /* [2D] contiguous */, long M, int D, hipStream_t st) {
-    long nb = (M + 3) / 4;
-    if (nb > LN_SLABS / 4) nb = LN_SLABS / 4;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, dy2, s, mean, rstd, gamma, ds, part, M, D);
+           float* ds, float* ds_drop, DropArgs dr, float* part, float* G, long gamma_off, long bias_off, long M, int D,
+           hipStream_t st) {
+    const int NQ = D <= 256 ? 1 : (D <= 512 ? 2 : 4);
+    const int R = 4 / NQ;
+    long nb = (M + 4 * R - 1) / (4 * R);
+    if (nb > LN_SLABS) nb = LN_SLABS;
+    if (ds_drop == nullptr) dr = DropArgs{};
+    if (NQ == 1)
+        hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, dy, dy2, s, mean, rstd, gamma, ds, ds_drop, part, M, D, dr);
+    else if (NQ == 2)
+        hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3((unsigned)nb), dim3(256), 0, st, dy, dy2, s, mean, rstd, gamma, ds, ds_drop, part, M, D, dr);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3((unsigned)nb), dim3(256), 0, st, dy, dy2, s, mean, rstd, gamma, ds, ds_drop, part, M, D, dr);
     TDM_CHECK_LAUNCH("ln_bwd");
     ReduceArgs ra{};
-    ra.nsec = 1; ra.sec[0].off = 0; ra.sec[0].len = 2 * D; ra.sec[0].nslab = (int)nb * 4;
-    return tdm_launch_reduce(part, 2L * D, ra, dgamma_dbeta, st);
+    ra.nsec = 2;
+    ra.sec[0].off = (int)gamma_off; ra.sec[0].len = 2 * D; ra.sec[0].nslab = (int)nb; ra.sec[0].src_delta = -gamma_off;
+    ra.sec[1].off = (int)bias_off; ra.sec[1].len = D; ra.sec[1].nslab = (int)nb; ra.sec[1].src_delta = 2L * D - bias_off;
+    return tdm_launch_reduce(part, 3L * D, ra, G, st);
 }
 int ln_fwd(const float* x, const float* r, const float* gamma, const float* beta, float* y, float* s, float* mean,
            float* rstd, long M, int D, hipStream_t st) {
@@ -632,65 +763,79 @@ int tt_check(long B, int L, int D, int H, int depth, int F) {
 }
 
 int tt_forward(const float* P, const TTLayout& lay, const float* x, const int64_t* t, float* out, const TTWs& w, long B,
-               int L, int D, int H, int depth, int F, hipStream_t st) {
+               int L, int D, int H, int depth, int F, Drop drop, hipStream_t st) {
     const long M = B * L;
+    const DropArgs none{};
     {
         long n = M * D;
         int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
         hipLaunchKernelGGL(add_timebias_kernel, dim3(grid), dim3(256), 0, st, x, t, P + lay.te_w, P + lay.te_b, w.that,
-                           w.tb, w.L[0].hin, B, L, D);
+                           w.tb, w.L[0].hin, B, L, D, drop.site(0));
         TDM_CHECK_LAUNCH("add_timebias");
     }
     for (int l = 0; l < depth; ++l) {
         const LayerOff& o = lay.L[l];
         const LayerWs& a = w.L[l];
         float* hout = (l + 1 < depth) ? w.L[l + 1].hin : out;
-        TDM_TRY(linear_fwd(a.hin, P + o.in_w, P + o.in_b, nullptr, a.qkv, M, 3 * D, D, 0, st));
-        TDM_TRY(attn_dispatch(0, D / H, a.qkv, nullptr, nullptr, nullptr, a.o, a.lse, B, L, D, H, st));
-        TDM_TRY(linear_fwd(a.o, P + o.out_w, P + o.out_b, nullptr, w.abuf, M, D, D, 0, st));
+        TDM_TRY(linear_fwd(a.hin, P + o.in_w, P + o.in_b, nullptr, a.qkv, M, 3 * D, D, 0, none, st));
+        TDM_TRY(attn_dispatch(0, D / H, a.qkv, nullptr, nullptr, nullptr, a.o, a.lse, B, L, D, H, drop.site(1 + 4 * l), st));
+        TDM_TRY(linear_fwd(a.o, P + o.out_w, P + o.out_b, nullptr, w.abuf, M, D, D, 0, drop.site(2 + 4 * l), st));
         TDM_TRY(ln_fwd(a.hin, w.abuf, P + o.n1_w, P + o.n1_b, a.h1, a.s1, a.mean1, a.rstd1, M, D, st));
-        TDM_TRY(linear_fwd(a.h1, P + o.l1_w, P + o.l1_b, nullptr, a.f1, M, F, D, 1, st));
-        TDM_TRY(linear_fwd(a.f1, P + o.l2_w, P + o.l2_b, nullptr, w.abuf, M, D, F, 0, st));
+        TDM_TRY(linear_fwd(a.h1, P + o.l1_w, P + o.l1_b, nullptr, a.f1, M, F, D, 1, drop.site(3 + 4 * l), st));
+        TDM_TRY(linear_fwd(a.f1, P + o.l2_w, P + o.l2_b, nullptr, w.abuf, M, D, F, 0, drop.site(4 + 4 * l), st));
         TDM_TRY(ln_fwd(a.h1, w.abuf, P + o.n2_w, P + o.n2_b, hout, a.s2, a.mean2, a.rstd2, M, D, st));
     }
     return 0;
 }
 
 int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G, float* dx, const TTWs& w, float* slabs,
-                long B, int L, int D, int H, int depth, int F, hipStream_t st) {
+                long B, int L, int D, int H, int depth, int F, Drop drop, hipStream_t st) {
     const long M = B * L;
     const SlabPlan sp = slab_plan(D, depth, F);
+    const bool dropping = drop.p > 0.f;
+    const bool fused_bias = g_gemm_mode != 0;   // in_proj / linear1 bias gradients come out of the bf16 wgrad GEMM
     const float* gh = dout;  // gradient w.r.t. the current layer's output
+    float* gout = nullptr;
     for (int l = depth - 1; l >= 0; --l) {
         const LayerOff& o = lay.L[l];
         const LayerWs& a = w.L[l];
-        // LayerNorm 2: hout = LN(h1 + f2)
-        TDM_TRY(ln_bwd(gh, nullptr, a.s2, a.mean2, a.rstd2, P + o.n2_w, w.g_s, w.part, G + o.n2_w, M, D, st));
-        // f2 = f1 W2^T + b2
-        TDM_TRY(bias_grad(w.g_s, w.part, G + o.l2_b, M, D, st));
-        TDM_TRY(linear_wgrad(w.g_s, a.f1, slabs + sp.base[l][3], M, D, F, st));
-        TDM_TRY(linear_dgrad(w.g_s, P + o.l2_w, w.wT, nullptr, w.g_f, M, D, F, st));
-        // relu
-        TDM_TRY(tdm_launch_relu_mask(w.g_f, a.f1, w.g_f, M * F, st));
+        // LayerNorm 2: hout = LN(h1 + dropout2(f2)); g_s = d(h1) residual part, g2 = d(f2); db2 = colsum(g2)
+        TDM_TRY(ln_bwd(gh, nullptr, a.s2, a.mean2, a.rstd2, P + o.n2_w, w.g_s, dropping ? w.g_d : nullptr,
+                       drop.site(4 + 4 * l), w.part, G, o.n2_w, o.l2_b, M, D, st));
+        const float* g2 = dropping ? w.g_d : w.g_s;
+        // f2 = f1 W2^T + b2, f1 = dropout(relu(z1)): d(z1) = (g2 W2) * [f1 > 0] / (1 - p) in the GEMM epilogue
+        TDM_TRY(linear_wgrad(g2, a.f1, slabs + sp.base[l][3], nullptr, M, D, F, st));
+        TDM_TRY(linear_dgrad(g2, P + o.l2_w, w.wT, nullptr, a.f1, dropping ? drop.site(3 + 4 * l).scale : 1.f, w.g_f, M, D,
+                             F, st));
         // z1 = h1 W1^T + b1
-        TDM_TRY(bias_grad(w.g_f, w.part, G + o.l1_b, M, F, st));
-        TDM_TRY(linear_wgrad(w.g_f, a.h1, slabs + sp.base[l][2], M, F, D, st));
-        TDM_TRY(linear_dgrad(w.g_f, P + o.l1_w, w.wT, nullptr, w.g_h1, M, F, D, st));
-        // LayerNorm 1: h1 = LN(hin + a); d(h1) = g_h1 (FFN path) + g_s (residual)
-        TDM_TRY(ln_bwd(w.g_h1, w.g_s, a.s1, a.mean1, a.rstd1, P + o.n1_w, w.g_s1, w.part, G + o.n1_w, M, D, st));
+        if (!fused_bias) TDM_TRY(bias_grad(w.g_f, w.part, G + o.l1_b, M, F, st));
+        TDM_TRY(linear_wgrad(w.g_f, a.h1, slabs + sp.base[l][2], fused_bias ? slabs + sp.bias_base[l][2] : nullptr, M, F, D,
+                             st));
+        TDM_TRY(linear_dgrad(w.g_f, P + o.l1_w, w.wT, nullptr, nullptr, 1.f, w.g_h1, M, F, D, st));
+        // LayerNorm 1: h1 = LN(hin + dropout1(a)); d(h1) = g_h1 (FFN path) + g_s (residual)
+        TDM_TRY(ln_bwd(w.g_h1, w.g_s, a.s1, a.mean1, a.rstd1, P + o.n1_w, w.g_s1, dropping ? w.g_d : nullptr,
+                       drop.site(2 + 4 * l), w.part, G, o.n1_w, o.out_b, M, D, st));
+        const float* g1 = dropping ? w.g_d : w.g_s1;
         // a = o Wout^T + bout
-        TDM_TRY(bias_grad(w.g_s1, w.part, G + o.out_b, M, D, st));
-        TDM_TRY(linear_wgrad(w.g_s1, a.o, slabs + sp.base[l][1], M, D, D, st));
-        TDM_TRY(linear_dgrad(w.g_s1, P + o.out_w, w.wT, nullptr, w.g_o, M, D, D, st));
+        TDM_TRY(linear_wgrad(g1, a.o, slabs + sp.base[l][1], nullptr, M, D, D, st));
+        TDM_TRY(linear_dgrad(g1, P + o.out_w, w.wT, nullptr, nullptr, 1.f, w.g_o, M, D, D, st));
         // attention
-        TDM_TRY(attn_dispatch(1, D / H, a.qkv, a.o, a.lse, w.g_o, w.g_qkv, w.Dvec, B, L, D, H, st));
-        TDM_TRY(attn_dispatch(2, D / H, a.qkv, nullptr, a.lse, w.g_o, w.g_qkv, w.Dvec, B, L, D, H, st));
+        const DropArgs da = drop.site(1 + 4 * l);
+        TDM_TRY(attn_dispatch(1, D / H, a.qkv, a.o, a.lse, w.g_o, w.g_qkv, w.Dvec, B, L, D, H, da, st));
+        TDM_TRY(attn_dispatch(2, D / H, a.qkv, nullptr, a.lse, w.g_o, w.g_qkv, w.Dvec, B, L, D, H, da, st));
         // qkv = hin Win^T + bin ; d(hin) = g_qkv Win + g_s1 (residual)
-        TDM_TRY(bias_grad(w.g_qkv, w.part, G + o.in_b, M, 3 * D, st));
-        TDM_TRY(linear_wgrad(w.g_qkv, a.hin, slabs + sp.base[l][0], M, 3 * D, D, st));
-        float* gout = (l == 0 && dx != nullptr) ? dx : w.g_h;   // layer 0: this is d(loss)/d(x)
-        TDM_TRY(linear_dgrad(w.g_qkv, P + o.in_w, w.wT, w.g_s1, gout, M, 3 * D, D, st));
+        if (!fused_bias) TDM_TRY(bias_grad(w.g_qkv, w.part, G + o.in_b, M, 3 * D, st));
+        TDM_TRY(linear_wgrad(w.g_qkv, a.hin, slabs + sp.base[l][0], fused_bias ? slabs + sp.bias_base[l][0] : nullptr, M,
+                             3 * D, D, st));
+        gout = (l == 0 && dx != nullptr) ? dx : w.g_h;   // layer 0: this is d(loss)/d(dropout0(x + time bias))
+        TDM_TRY(linear_dgrad(w.g_qkv, P + o.in_w, w.wT, w.g_s1, nullptr, 1.f, gout, M, 3 * D, D, st));
         gh = gout;
+    }
+    if (dropping) {   // input dropout: d(x + time bias) = mask * g / (1 - p)
+        const long n4 = M * D / 4;
+        int grid = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+        hipLaunchKernelGGL(drop_apply_kernel, dim3(grid), dim3(256), 0, st, gout, n4, drop.site(0));
+        TDM_CHECK_LAUNCH("drop_apply");
     }
     // time embedding: hin0 = x + (w*that + b)
     hipLaunchKernelGGL(seqsum_kernel, dim3((unsigned)B), dim3(256), 0, st, gh, w.Sb, L, D);
@@ -713,6 +858,17 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
             ra.sec[n].src_delta = sp.base[l][k] - offs[k];
             ra.sec[n].stride_override = sp.len[k];
             ++n;
+        }
+        if (fused_bias) {
+            const long boffs[2] = {o.in_b, o.l1_b};
+            const int ks[2] = {0, 2};
+            for (int q = 0; q < 2; ++q) {
+                const int k = ks[q];
+                ra.sec[n].off = (int)boffs[q]; ra.sec[n].len = sp.nout[k]; ra.sec[n].nslab = sp.sk[k];
+                ra.sec[n].src_delta = sp.bias_base[l][k] - boffs[q];
+                ra.sec[n].stride_override = (sp.nout[k] + 63) & ~63;
+                ++n;
+            }
         }
     }
     ra.nsec = n;
@@ -743,37 +899,42 @@ int64_t tdm_tt_slab_floats(int D, int depth, int ffn) {
 }
 
 int tdm_tt_fwd_f32(const float* params, const float* x, const int64_t* t, float* out, float* ws, int64_t B, int L, int D,
-                   int H, int depth, int ffn, int save, void* stream) {
+                   int H, int depth, int ffn, int save, float p_drop, uint64_t seed, void* stream) {
     TDM_TRY(tt_check(B, L, D, H, depth, ffn));
     TDM_REQUIRE(params && x && t && out && ws, "tt_fwd: NULL pointer");
+    TDM_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "tt_fwd: dropout probability %g outside [0, 1)", (double)p_drop);
     const TTLayout lay = tt_layout(D, depth, ffn);
     const TTWs w = tt_carve(ws, B, L, D, H, depth, ffn, save);
-    return tt_forward(params, lay, x, t, out, w, B, L, D, H, depth, ffn, (hipStream_t)stream);
+    return tt_forward(params, lay, x, t, out, w, B, L, D, H, depth, ffn, Drop{p_drop, seed}, (hipStream_t)stream);
 }
 
 int tdm_tt_bwd_f32(const float* params, const float* dout, float* grads, float* dx, float* ws, float* slabs, int64_t B,
-                   int L, int D, int H, int depth, int ffn, void* stream) {
+                   int L, int D, int H, int depth, int ffn, float p_drop, uint64_t seed, void* stream) {
     TDM_TRY(tt_check(B, L, D, H, depth, ffn));
+    TDM_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "tt_bwd: dropout probability %g outside [0, 1)", (double)p_drop);
     TDM_REQUIRE(params && dout && grads && ws && slabs, "tt_bwd: NULL pointer");
     const TTLayout lay = tt_layout(D, depth, ffn);
     const TTWs w = tt_carve(ws, B, L, D, H, depth, ffn, 1);
-    return tt_backward(params, lay, dout, grads, dx, w, slabs, B, L, D, H, depth, ffn, (hipStream_t)stream);
+    return tt_backward(params, lay, dout, grads, dx, w, slabs, B, L, D, H, depth, ffn, Drop{p_drop, seed},
+                       (hipStream_t)stream);
 }
 
 int tdm_tt_loss_grad_f32(const float* params, const float* x0, const float* noise, const int64_t* t,
                          const float* sqrt_acp, const float* sqrt_1m_acp, float* x_noisy, float* pred, float* dpred,
                          float* loss_out, float* grads, float* ws, float* slabs, int64_t B, int L, int D, int H,
-                         int depth, int ffn, void* stream) {
+                         int depth, int ffn, float p_drop, uint64_t seed, void* stream) {
     TDM_TRY(tt_check(B, L, D, H, depth, ffn));
+    TDM_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "tt_loss_grad: dropout probability %g outside [0, 1)", (double)p_drop);
+    const Drop drop{p_drop, seed};
     TDM_REQUIRE(params && x0 && noise && t && x_noisy && pred && dpred && loss_out && grads && ws && slabs,
                 "tt_loss_grad: NULL pointer");
     const TTLayout lay = tt_layout(D, depth, ffn);
     const TTWs w = tt_carve(ws, B, L, D, H, depth, ffn, 1);
     hipStream_t st = (hipStream_t)stream;
     TDM_TRY(tdm_q_sample_f32(x0, noise, t, sqrt_acp, sqrt_1m_acp, x_noisy, B, (int64_t)L * D, stream));
-    TDM_TRY(tt_forward(params, lay, x_noisy, t, pred, w, B, L, D, H, depth, ffn, st));
+    TDM_TRY(tt_forward(params, lay, x_noisy, t, pred, w, B, L, D, H, depth, ffn, drop, st));
     TDM_TRY(tdm_mse_fwd_bwd_f32(pred, noise, loss_out, dpred, w.part, B * L * D, stream));
-    return tt_backward(params, lay, dpred, grads, nullptr, w, slabs, B, L, D, H, depth, ffn, st);
+    return tt_backward(params, lay, dpred, grads, nullptr, w, slabs, B, L, D, H, depth, ffn, drop, st);
 }
 
 int tdm_tt_p_sample_step_f32(const float* params, const float* x, const int64_t* t, const float* noise,
@@ -784,7 +945,7 @@ int tdm_tt_p_sample_step_f32(const float* params, const float* x, const int64_t*
     TDM_REQUIRE(params && x && t && eps && x_out && ws, "tt_p_sample_step: NULL pointer");
     const TTLayout lay = tt_layout(D, depth, ffn);
     const TTWs w = tt_carve(ws, B, L, D, H, depth, ffn, 0);
-    TDM_TRY(tt_forward(params, lay, x, t, eps, w, B, L, D, H, depth, ffn, (hipStream_t)stream));
+    TDM_TRY(tt_forward(params, lay, x, t, eps, w, B, L, D, H, depth, ffn, Drop{0.f, 0}, (hipStream_t)stream));
     return tdm_p_sample_update_f32(x, eps, t_index == 0 ? nullptr : noise, tab_recip, tab_eps, tab_sigma, t_index, x_out,
                                    B * L * D, stream);
 }
@@ -795,6 +956,21 @@ int tdm_set_gemm_mode(int mode) {
     return 0;
 }
 int tdm_get_gemm_mode(void) { return g_gemm_mode; }
+
+int tdm_set_attn_mode(int mode) {
+    TDM_REQUIRE(mode == 0 || mode == 1, "attention mode %d (0 = scalar fp32, 1 = fp32 MFMA)", mode);
+    g_attn_mode = mode;
+    return 0;
+}
+int tdm_get_attn_mode(void) { return g_attn_mode; }
+
+// keep[i] = 1 if element idx0 + i of dropout site `site` survives (the mask the kernels regenerate in registers)
+int tdm_dropout_keep_u8(float p_drop, uint64_t seed, int site, int64_t idx0, int64_t n, uint8_t* keep_host) {
+    TDM_REQUIRE(p_drop >= 0.f && p_drop < 1.f && keep_host != nullptr && n >= 0, "dropout_keep: bad arguments");
+    const DropArgs d = tdm_drop_site(p_drop, seed, site);
+    for (int64_t i = 0; i < n; ++i) keep_host[i] = (d.thr == 0u || tdm_keep(d, (unsigned long long)(idx0 + i))) ? 1 : 0;
+    return 0;
+}
 
 int tdm_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float* C,
                  int64_t c_rs, const float* bias, const float* res, int M, int N, int K, int relu, int splitk,

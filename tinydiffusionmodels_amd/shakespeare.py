@@ -8,8 +8,10 @@ embedding table and rounding head (src/shakespeare.py:46-102) are row N1
 ("next") and are still plain torch modules here, used through autograd around
 the native denoiser; tokenizer / Gemma / dataset loading needs network and is
 out of scope (synthetic vocabularies are used for tests and benchmarks).
-Dropout: the native path implements eval / dropout = 0; calling a module with
-dropout > 0 in train mode raises."""
+Dropout: train mode applies the reference's 1 + 4*depth dropout sites natively;
+the masks come from a counter-based hash of (seed, site, element index) — torch's
+Philox stream cannot be replayed by anyone else — with one 64-bit seed per forward
+drawn from torch's CPU generator (so `torch.manual_seed` makes runs repeatable)."""
 import math
 import os
 from collections import OrderedDict
@@ -82,14 +84,14 @@ class LearnedRounding(nn.Module):
 
 class _TTFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, t, flat, cfg):
+    def forward(ctx, x, t, flat, cfg, p_drop=0.0, seed=0):
         need_w = bool(ctx.needs_input_grad[2])
         need_x = bool(ctx.needs_input_grad[0])
         save = need_w or need_x
         ws = TE.TTWorkspace(cfg, x.shape[0], x.shape[1], x.device, training=save)
-        y = TE.tt_forward(cfg, flat.detach(), x.detach(), t, ws, save=save)
+        y = TE.tt_forward(cfg, flat.detach(), x.detach(), t, ws, save=save, p_drop=p_drop, seed=seed)
         if save:
-            ctx.ws, ctx.cfg, ctx.need_x = ws, cfg, need_x
+            ctx.ws, ctx.cfg, ctx.need_x, ctx.drop = ws, cfg, need_x, (p_drop, seed)
             ctx.save_for_backward(flat)
         return y
 
@@ -97,9 +99,10 @@ class _TTFunction(torch.autograd.Function):
     def backward(ctx, dout):
         (flat,) = ctx.saved_tensors
         dx = torch.empty_like(dout, memory_format=torch.contiguous_format) if ctx.need_x else None
-        grads = TE.tt_backward(ctx.cfg, flat.detach(), dout.contiguous(), ctx.ws, dx=dx)
+        grads = TE.tt_backward(ctx.cfg, flat.detach(), dout.contiguous(), ctx.ws, dx=dx, p_drop=ctx.drop[0],
+                               seed=ctx.drop[1])
         ctx.ws = None
-        return dx, None, grads, None
+        return dx, None, grads, None, None, None
 
 
 class TinyTransformer(nn.Module):
@@ -121,6 +124,14 @@ class TinyTransformer(nn.Module):
         sd["time_emb.weight"], sd["time_emb.bias"] = te.weight.detach(), te.bias.detach()
         self.flat = nn.Parameter(TE.flat_from_state_dict(sd, dim, depth, TE.FFN))
         self._infer_ws = None
+        self.dropout_seed = None   # set to an int to force the seed of the next train-mode forwards (tests)
+        self.last_dropout_seed = None
+
+    def next_dropout_seed(self) -> int:
+        """Seed of one train-mode forward: forced, or 62 bits from torch's CPU generator (no device sync)."""
+        seed = self.dropout_seed if self.dropout_seed is not None else int(torch.randint(0, 1 << 62, (1,)).item())
+        self.last_dropout_seed = seed
+        return seed
 
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
         out = destination if destination is not None else OrderedDict()
@@ -142,12 +153,12 @@ class TinyTransformer(nn.Module):
 
     def forward(self, x: torch.Tensor, t: torch.Tensor):
         E._need_cuda(x, t, self.flat)
-        if self.training and self.p_drop > 0.0:
-            raise RuntimeError("TinyTransformer (HIP): dropout > 0 in train mode is not implemented on the native path "
-                               "yet; construct with dropout=0.0 or call .eval()")
+        p_drop = self.p_drop if self.training else 0.0
+        seed = self.next_dropout_seed() if p_drop > 0.0 else 0
         if torch.is_grad_enabled() and (self.flat.requires_grad or x.requires_grad):
-            return _TTFunction.apply(x, t, self.flat, self.cfg)
-        return TE.tt_forward(self.cfg, self.flat.detach(), x, t, self._workspace(x.shape[0], x.shape[1], x.device), False)
+            return _TTFunction.apply(x, t, self.flat, self.cfg, p_drop, seed)
+        return TE.tt_forward(self.cfg, self.flat.detach(), x, t, self._workspace(x.shape[0], x.shape[1], x.device), False,
+                             p_drop=p_drop, seed=seed)
 
 
 def get_cosine_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps, eta_min=0):
@@ -173,8 +184,6 @@ class DenoiserTrainer:
 
     def __init__(self, model: TinyTransformer, batch_size: int, seq_len: int, lr: float = 1e-4,
                  weight_decay: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8):
-        if model.p_drop > 0.0 and model.training:
-            raise RuntimeError("DenoiserTrainer: native path implements dropout = 0 only")
         self.model, self.lr, self.wd, self.betas, self.eps = model, lr, weight_decay, betas, eps
         self.flat = model.flat.detach()
         E._need_cuda(self.flat)
@@ -188,7 +197,9 @@ class DenoiserTrainer:
             t = torch.randint(0, T, (x0.shape[0],), device=x0.device)
         if noise is None:
             noise = torch.randn_like(x0)
-        loss = TE.tt_loss_and_grad(self.flat, st, x0, noise, t)
+        p_drop = self.model.p_drop if self.model.training else 0.0   # model.train() -> the reference's dropout
+        seed = self.model.next_dropout_seed() if p_drop > 0.0 else 0
+        loss = TE.tt_loss_and_grad(self.flat, st, x0, noise, t, p_drop=p_drop, seed=seed)
         scale = dp.allreduce_grads_(st.grads)
         st.step += 1
         E.adamw_step(self.flat, st.grads, st.m, st.v, st.step, self.lr if lr is None else lr, self.betas, self.eps,

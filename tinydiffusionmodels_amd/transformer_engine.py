@@ -97,6 +97,9 @@ class TTWorkspace:
 _slabs: Dict[str, torch.Tensor] = {}
 
 
+_U64 = (1 << 64) - 1
+
+
 def slabs_for(cfg: TTConfig, device) -> torch.Tensor:
     key = f"{device}:{cfg.dim}:{cfg.depth}:{cfg.ffn}"
     if key not in _slabs:
@@ -115,7 +118,9 @@ def _check_x(cfg, x, t):
         raise RuntimeError("the HIP transformer path takes fp32 tensors")
 
 
-def tt_forward(cfg: TTConfig, flat, x, t, ws: TTWorkspace, save: bool, out: Optional[torch.Tensor] = None):
+def tt_forward(cfg: TTConfig, flat, x, t, ws: TTWorkspace, save: bool, out: Optional[torch.Tensor] = None,
+               p_drop: float = 0.0, seed: int = 0):
+    """p_drop > 0 = train mode of the reference (dropout masks from (seed, site, index), include/tdm_hip.h)."""
     _check_x(cfg, x, t)
     B, L, D = x.shape
     if ws.B != B or ws.L != L or (save and not ws.training):
@@ -124,12 +129,12 @@ def tt_forward(cfg: TTConfig, flat, x, t, ws: TTWorkspace, save: bool, out: Opti
     y = out if out is not None else torch.empty_like(x)
     _lib.check(_lib.lib().tdm_tt_fwd_f32(_lib.ptr(flat), _lib.ptr(x), _lib.ptr(tc), _lib.ptr(y),
                                          _lib.ptr(ws.ws), B, L, D, cfg.n_heads, cfg.depth, cfg.ffn, 1 if save else 0,
-                                         _lib.stream()), "tt_fwd")
+                                         float(p_drop), int(seed) & _U64, _lib.stream()), "tt_fwd")
     return y
 
 
 def tt_backward(cfg: TTConfig, flat, dout, ws: TTWorkspace, grads: Optional[torch.Tensor] = None,
-                dx: Optional[torch.Tensor] = None):
+                dx: Optional[torch.Tensor] = None, p_drop: float = 0.0, seed: int = 0):
     _need_cuda(flat, dout)
     B, L, D = dout.shape
     if grads is None:
@@ -138,7 +143,7 @@ def tt_backward(cfg: TTConfig, flat, dout, ws: TTWorkspace, grads: Optional[torc
     _lib.check(_lib.lib().tdm_tt_bwd_f32(_lib.ptr(flat), _lib.ptr(doutc), _lib.ptr(grads), _lib.ptr(dx),
                                          _lib.ptr(ws.ws),
                                          _lib.ptr(slabs_for(cfg, dout.device)), B, L, D, cfg.n_heads, cfg.depth, cfg.ffn,
-                                         _lib.stream()), "tt_bwd")
+                                         float(p_drop), int(seed) & _U64, _lib.stream()), "tt_bwd")
     return grads
 
 
@@ -157,7 +162,7 @@ class TTTrainState:
         self.step = 0
 
 
-def tt_loss_and_grad(flat, st: TTTrainState, x0, noise, t):
+def tt_loss_and_grad(flat, st: TTTrainState, x0, noise, t, p_drop: float = 0.0, seed: int = 0):
     """Denoiser part of src/shakespeare.py:230-236: q_sample -> forward -> mse -> backward."""
     _need_cuda(flat, x0, noise, t)
     cfg = st.cfg
@@ -169,7 +174,7 @@ def tt_loss_and_grad(flat, st: TTTrainState, x0, noise, t):
             tabs["sqrt_one_minus_alphas_cumprod"], st.x_noisy, st.pred, st.dpred, st.loss, st.grads, st.ws.ws,
             slabs_for(cfg, x0.device)]
     _lib.check(_lib.lib().tdm_tt_loss_grad_f32(*[_lib.ptr(a) for a in args], B, L, D, cfg.n_heads, cfg.depth, cfg.ffn,
-                                               _lib.stream()), "tt_loss_grad")
+                                               float(p_drop), int(seed) & _U64, _lib.stream()), "tt_loss_grad")
     return st.loss
 
 
