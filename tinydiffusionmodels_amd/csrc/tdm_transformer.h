@@ -18,6 +18,8 @@ struct GemmArgs {
     // TN form only: colsum[z*colsum_stride + i] = sum over this split's k of A(i,k) (exact fp32; the bias gradient
     // when A = dY), written by the workgroups of tile column 0
     float* colsum; long colsum_stride;
+    int ablate;   // timing diagnostics (NT bf16 kernel; results are wrong when set): 1 no global loads after the first
+                  // chunk, 2 no MFMA, 4 no epilogue stores, 8 no split / LDS stores after the first chunk
 };
 int tdm_launch_gemm(const GemmArgs& g, hipStream_t st);
 

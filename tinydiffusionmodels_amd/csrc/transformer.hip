@@ -30,7 +30,7 @@ constexpr int LN_SLABS = 256;  // workgroup partials of the LayerNorm affine / b
 constexpr int CS_SLABS = 256;  // row-block partials of the bias gradients
 
 // Weight-gradient GEMMs contract over tokens (K = B*L, tens of thousands) into small [N][K] outputs:
-// each tensor gets its own split-K factor so that tiles x splits ~ 1024 workgroups fill the chip.
+// each tensor gets its own split-K factor so that tiles x splits ~ 1024 workgroups fill the chip (512 measured slower).
 inline int wgrad_splitk(int N, int K) {
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
     int sk = (1024 + tiles - 1) / tiles;
@@ -977,7 +977,8 @@ int tdm_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int
                  int64_t c_split_stride, void* stream) {
     GemmArgs g{};
     g.A = A; g.a_rs = a_rs; g.a_cs = a_cs; g.B = B; g.b_rs = b_rs; g.b_cs = b_cs; g.C = C; g.c_rs = c_rs;
-    g.bias = bias; g.res = res; g.M = M; g.N = N; g.K = K; g.relu = relu; g.splitk = splitk;
+    g.bias = bias; g.res = res; g.M = M; g.N = N; g.K = K; g.relu = relu & 1; g.splitk = splitk;
+    g.ablate = (relu >> 8) & 15;   // timing diagnostics only
     g.c_split_stride = c_split_stride;
     if (g_gemm_mode != 0) {   // route the K-contiguous (NT) and token-major (TN) forms through the bf16 kernels
         const int nprod = g_gemm_mode == 1 ? 3 : 1;
