@@ -177,42 +177,54 @@ __global__ __launch_bounds__(256) void conv_s16_kernel(ConvArgs a) {
         }
     }
 
-    // epilogue: lane = pixel j of its M tile; register quad g of N tile nt = channels nt*32 + 8g + 4h .. +3
+    // Epilogue through LDS.  In the accumulator layout lane = pixel j of its M tile and register quad g of N tile
+    // nt = channels nt*32 + 8g + 4h .. +3: storing from there writes 32-byte pieces of 32 different pixel rows per
+    // instruction.  Each wave instead transposes 32 pixels x N channels through a private LDS block and walks it
+    // row-major — 32 pixels x N floats are ONE contiguous range of every NHWC tensor involved — so each load / store
+    // instruction of the epilogue (residual in; out, saved post-ReLU copy, S16 twin out) covers 1 KB of consecutive
+    // addresses.
+    constexpr int EPI = N + 4;   // floats per staged pixel row: (N/4 + 1) x 16 B, an odd slot count
+    __syncthreads();             // every wave is done with the operand images
+    float* T = reinterpret_cast<float*>(smem4) + wave * (32 * EPI);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        const int m = m0 + (wave * 2 + mt) * 32 + j;
-        if (m < Mtot) {
-            const long row = (long)m * N;
-            const float* tbrow = (a.tb_out != nullptr) ? a.tb_out + (long)(m / (G::H * G::W)) * a.tb_out_stride : nullptr;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = nt * 32 + 8 * g + 4 * h;
-                    float4 v = make_float4(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2],
-                                           acc[mt][nt][4 * g + 3]);
-                    if (a.bias != nullptr) {
-                        const float4 bz = *reinterpret_cast<const float4*>(a.bias + c);
-                        v.x += bz.x; v.y += bz.y; v.z += bz.z; v.w += bz.w;
-                    }
-                    if (a.relu) {
-                        v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y;
-                        v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
-                    }
-                    if (a.aux != nullptr) *reinterpret_cast<float4*>(a.aux + row + c) = v;
-                    if (a.res != nullptr) {
-                        const float4 rz = *reinterpret_cast<const float4*>(a.res + row + c);
-                        v.x += rz.x; v.y += rz.y; v.z += rz.z; v.w += rz.w;
-                    }
-                    if (a.out != nullptr) *reinterpret_cast<float4*>(a.out + row + c) = v;
-                    if (a.out_s16 != nullptr) {
-                        if (tbrow != nullptr) {
-                            const float4 tz = *reinterpret_cast<const float4*>(tbrow + c);
-                            v.x += tz.x; v.y += tz.y; v.z += tz.z; v.w += tz.w;
-                        }
-                        tdm_store_s16_4(a.out_s16, m, N, c, v);
-                    }
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(T + j * EPI + nt * 32 + 8 * g + 4 * h) =
+                    make_float4(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
+        const int mbase = m0 + (wave * 2 + mt) * 32;
+#pragma unroll
+        for (int it = 0; it < N / 8; ++it) {   // 32 * N/4 float4 per pass, 64 per instruction
+            const int e = it * 64 + lane;
+            const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
+            const int m = mbase + px;
+            float4 v = *reinterpret_cast<const float4*>(T + px * EPI + c);
+            if (m < Mtot) {
+                const long o = (long)m * N + c;
+                if (a.bias != nullptr) {
+                    const float4 bz = *reinterpret_cast<const float4*>(a.bias + c);
+                    v.x += bz.x; v.y += bz.y; v.z += bz.z; v.w += bz.w;
                 }
+                if (a.relu) {
+                    v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y;
+                    v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+                }
+                if (a.aux != nullptr) *reinterpret_cast<float4*>(a.aux + o) = v;
+                if (a.res != nullptr) {
+                    const float4 rz = *reinterpret_cast<const float4*>(a.res + o);
+                    v.x += rz.x; v.y += rz.y; v.z += rz.z; v.w += rz.w;
+                }
+                if (a.out != nullptr) *reinterpret_cast<float4*>(a.out + o) = v;
+                if (a.out_s16 != nullptr) {
+                    if (a.tb_out != nullptr) {
+                        const float4 tz = *reinterpret_cast<const float4*>(a.tb_out + (long)(m / (G::H * G::W)) * a.tb_out_stride + c);
+                        v.x += tz.x; v.y += tz.y; v.z += tz.z; v.w += tz.w;
+                    }
+                    tdm_store_s16_4(a.out_s16, m, N, c, v);
+                }
+            }
         }
     }
 }
