@@ -64,7 +64,7 @@ __device__ __forceinline__ int src_offset(const ConvSrc& s, int PR0, int pos, in
 // convolution / transposed convolution
 // ---------------------------------------------------------------------------
 template <int HW, int NT>
-__global__ __launch_bounds__(256) void conv_s16_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvArgs a) {
     using G = Geo<HW>;
     constexpr int N = NT * 32;
     constexpr int TILE_B = G::NR * G::WP * PIXB;
@@ -100,18 +100,19 @@ __global__ __launch_bounds__(256) void conv_s16_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    // Software pipeline over K chunks: the 16-byte pieces of chunk c+1 (8 input pieces + WN weight pieces per
-    // thread) are loaded into registers BEFORE the MFMAs of chunk c and written to LDS after them, so only the
-    // first chunk of a tile exposes a memory latency; input and weight loads are always in flight together.
+    // Software pipeline over K chunks, register-staged.  Input pieces are prefetched TWO chunks ahead (two register
+    // sets, 8 x 16 B per thread each), the L2-resident packed weights one chunk ahead: with a single chunk of
+    // distance a workgroup's MFMA phase (~0.8 us) is shorter than the HBM latency under load and every chunk
+    // stalled (ablation: K loop without global loads 73-86 us vs ~30 us of MFMA / LDS time for the 96->32 layer).
     constexpr int WN = (9 * NT * 128 + 255) / 256;
     char* const sdst = tile + (tid >> 2) * PIXB + (tid & 3) * 16;
     const int nc0 = a.src[0].nch >> 4;
     const int nchunks = nc0 + (a.nsrc > 1 ? (a.src[1].nch >> 4) : 0);
-    int goff[8];        // staging plan of the source being prefetched
-    int plan_src = -1;
-    uint4 pin[8], pwt[WN];
+    int goffA[8], goffB[8];   // staging plans of the sources the two input sets were loaded from
+    int planA = -1, planB = -1;
+    uint4 pinA[8], pinB[8], pwt[WN];
 
-    auto prefetch = [&](int c) {
+    auto prefetch_in = [&](uint4 (&pin)[8], int (&goff)[8], int& plan_src, int c) {
         const int si = (c >= nc0) ? 1 : 0;
         const int ch = si ? c - nc0 : c;
         const ConvSrc& s = a.src[si];
@@ -129,6 +130,11 @@ __global__ __launch_bounds__(256) void conv_s16_kernel(ConvArgs a) {
             pin[i] = make_uint4(0u, 0u, 0u, 0u);
             if (goff[i] >= 0) pin[i] = reinterpret_cast<const uint4*>(s.ptr + goff[i] + kc)[tid & 3];
         }
+    };
+    auto prefetch_w = [&](int c) {
+        const int si = (c >= nc0) ? 1 : 0;
+        const int ch = si ? c - nc0 : c;
+        const ConvSrc& s = a.src[si];
         const int n16 = s.taps * NT * 128;
         const uint4* wsrc = reinterpret_cast<const uint4*>(s.wp + (long)(s.wchunk0 + ch) * (s.taps * NT * 1024));
 #pragma unroll
@@ -137,10 +143,7 @@ __global__ __launch_bounds__(256) void conv_s16_kernel(ConvArgs a) {
             pwt[i] = (e < n16) ? wsrc[e] : make_uint4(0u, 0u, 0u, 0u);
         }
     };
-
-    prefetch(0);
-    for (int c = 0; c < nchunks; ++c) {
-        const int taps = a.src[(c >= nc0) ? 1 : 0].taps;
+    auto stage = [&](const uint4 (&pin)[8]) {
         __syncthreads();      // everyone finished reading the previous chunk's LDS image
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -149,7 +152,10 @@ __global__ __launch_bounds__(256) void conv_s16_kernel(ConvArgs a) {
         for (int i = 0; i < WN; ++i)
             if (tid + 256 * i < 9 * NT * 128) reinterpret_cast<uint4*>(wl)[tid + 256 * i] = pwt[i];
         __syncthreads();
-        if (c + 1 < nchunks) prefetch(c + 1);
+    };
+    auto compute = [&](int c) {
+        if (a.ablate & 4) return;
+        const int taps = a.src[(c >= nc0) ? 1 : 0].taps;
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
             if (taps == 9 || tp == 4) {   // a 1x1 source uses the centre-tap site with packed tap 0
@@ -175,6 +181,22 @@ __global__ __launch_bounds__(256) void conv_s16_kernel(ConvArgs a) {
                 }
             }
         }
+    };
+
+    const bool pf = !(a.ablate & 1);
+    prefetch_in(pinA, goffA, planA, 0);
+    prefetch_w(0);
+    if (nchunks > 1) prefetch_in(pinB, goffB, planB, 1);
+    for (int c = 0; c < nchunks; c += 2) {
+        stage(pinA);                                                  // chunk c
+        if (c + 2 < nchunks && pf) prefetch_in(pinA, goffA, planA, c + 2);
+        if (c + 1 < nchunks && pf) prefetch_w(c + 1);
+        compute(c);
+        if (c + 1 >= nchunks) break;
+        stage(pinB);                                                  // chunk c + 1
+        if (c + 3 < nchunks && pf) prefetch_in(pinB, goffB, planB, c + 3);
+        if (c + 2 < nchunks && pf) prefetch_w(c + 2);
+        compute(c + 1);
     }
 
     // Epilogue through LDS.  In the accumulator layout lane = pixel j of its M tile and register quad g of N tile
@@ -183,6 +205,7 @@ __global__ __launch_bounds__(256) void conv_s16_kernel(ConvArgs a) {
     // row-major — 32 pixels x N floats are ONE contiguous range of every NHWC tensor involved — so each load / store
     // instruction of the epilogue (residual in; out, saved post-ReLU copy, S16 twin out) covers 1 KB of consecutive
     // addresses.
+    if (a.ablate & 8) return;
     constexpr int EPI = N + 4;   // floats per staged pixel row: (N/4 + 1) x 16 B, an odd slot count
     __syncthreads();             // every wave is done with the operand images
     float* T = reinterpret_cast<float*>(smem4) + wave * (32 * EPI);

@@ -64,7 +64,8 @@ struct ConvArgs {
     float* aux;         // [M][N] or nullptr: value after relu, before residual
     int relu;
     int B;
-    int ablate;         // diagnostics (bf16x3 kernel): bit0 skip input loads, bit1 skip weight staging, bit2 skip MFMA
+    int ablate;         // diagnostics: bit0 skip input loads (s16: all prefetches after chunk 0), bit1 skip weight staging
+                        // (bf16x3 kernel), bit2 skip MFMA, bit3 skip the epilogue (s16 kernel)
     // S16 pipeline (conv_s16.hip): sources are S16 tensors; optional extra pre-split output
     float* out_s16;           // [M][N] S16 copy of the result (+ tb_out), or nullptr
     const float* tb_out;      // [B][tb_out_stride]: per-(sample, channel) bias folded into out_s16 only
