@@ -3,7 +3,7 @@
  * The reference (LiamConnell/TinyDiffusionModels) has no FFI: its hot path is
  * plain Python over ATen ops.  Each entry point below replaces the ATen work
  * behind one reference function; the citation names the reference lines it
- * stands in for.  Python host code (tinydiffusionmodels_amd/*.py) re-creates
+ * stands in for.  Python host code (the modules of tinydiffusionmodels_amd) re-creates
  * the reference's Python surface on top of these.
  *
  * Conventions

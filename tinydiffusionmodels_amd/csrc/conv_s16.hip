@@ -19,6 +19,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // a 16-byte piece held in registers
 
 namespace {
 
@@ -285,6 +286,12 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
+// 8 waves = 2 tap groups (waves 0-3: taps 0..4, waves 4-7: taps 5..8) x 4 pixel quarters of the 256-pixel tile.
+// A wave keeps 5 tap accumulators (80 registers, not 144), which leaves room for TWO register sets of prefetched
+// tiles without spilling: the loads of tile t+2 are in flight while tile t is multiplied.  (With 9 accumulators per
+// wave the prefetch base pointer spilled; every prefetch load was then preceded by a scratch reload and an
+// s_waitcnt vmcnt(0), i.e. the loads of a tile were serialised and the kernel ran 5-6x off its MFMA time.)
+// A 1x1 source has one tap: the 8 waves split the tile's 16 K-steps instead.
 template <int HW>
 __global__ __launch_bounds__(512) void wgrad_s16_kernel(WgradArgs a) {
     using G = Geo<HW>;
@@ -306,112 +313,162 @@ __global__ __launch_bounds__(512) void wgrad_s16_kernel(WgradArgs a) {
     const ConvSrc& s = a.a;
     const int g4 = lane >> 4, cb = g4 & 1, hh = g4 >> 1, q = (lane >> 2) & 3, pcq = lane & 3;
     const int colb = (cb * 16 + pcq * 4) * 2;
+    const int tgrp = wave >> 2, wq = wave & 3;
+    const int tp0 = tgrp * 5, ntap = tgrp ? 4 : 5;
     // staging role: piece8 = tid & 7 -> 16-channel group (piece8 >> 2), 16-byte piece of the group (piece8 & 3:
     // 0,1 = hi halves, 2,3 = lo halves); destination plane / offset inside a 64-byte pixel row
     const int piece8 = tid & 7, grp = piece8 >> 2, pq = piece8 & 3;
     const int dcol = grp * 32 + (pq & 1) * 16;
     const bool to_lo = pq >= 2;
 
-    f32x16 acc[9];
+    f32x16 acc[5];
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+    for (int k = 0; k < 5; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
-    // Software pipeline over pixel tiles: the 16-byte pieces of tile t+1 (NA activation + NG gradient pieces per
-    // thread) are loaded into registers before the MFMAs of tile t and written to LDS after them.
     constexpr int NA = (NPX * 8 + 511) / 512;
     constexpr int NG = TILE_PX * 8 / 512;
-    uint4 pa[NA], pg[NG];
-    int p_pix = 0;     // staged-pixel index of tile pixel `tid` (threads < TILE_PX)
-    int p_nelem = 0;
-    auto prefetch = [&](int t) {
+    // Every prefetch issues exactly NA + NG loads, unconditionally (invalid pieces read offset 0 and are zeroed from
+    // `ok` when they are written to LDS): with a static load count the compiler can wait for the OLDER register set
+    // only (s_waitcnt vmcnt(NA + NG)) instead of draining both sets with vmcnt(0).
+    struct Stage { u32x4 pa[NA]; u32x4 pg[NG]; int pix; int nelem; unsigned ok; };
+    Stage s0, s1;
+    auto prefetch = [&](Stage& st, int t) {
         const int m0 = t * TILE_PX;
         const int mlast = min(m0 + TILE_PX - 1, Mtot - 1);
         const int PR0 = padded_row<HW>(m0) - 1;
         const int nrows = padded_row<HW>(mlast) - PR0 + 2;
-        p_nelem = nrows * G::WP * 8;
-        if (tid < TILE_PX) {
+        st.nelem = nrows * G::WP * 8;
+        st.pix = 0;
+        st.ok = 0u;
+        if (tid < TILE_PX) {   // staged-pixel index of tile pixel `tid`
             const int m = min(m0 + tid, Mtot - 1);
             const int b = m / (G::H * G::W);
             const int rem = m - b * (G::H * G::W);
             const int y = rem / G::W, x = rem - y * G::W;
-            p_pix = (b * G::HP + y + 1 - PR0) * G::WP + x + 1;
+            st.pix = (b * G::HP + y + 1 - PR0) * G::WP + x + 1;
         }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int e = tid + 512 * i;
-            pa[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (e < p_nelem) {
-                const int go = src_offset<HW>(s, PR0, e >> 3, a.B);
-                if (go >= 0) pa[i] = reinterpret_cast<const uint4*>(s.ptr + go + ci0 + grp * 16)[pq];
-            }
+            int e = tid + 512 * i;
+            // opaque to the optimiser: otherwise the tile-invariant parts of src_offset (row / column of each piece,
+            // partial addresses) are hoisted out of the tile loop, kept in 24+ registers and spilled
+            asm volatile("" : "+v"(e));
+            const int go = (e < st.nelem) ? src_offset<HW>(s, PR0, e >> 3, a.B) : -1;
+            const bool ok = go >= 0;
+            st.ok |= ok ? (1u << i) : 0u;
+            st.pa[i] = reinterpret_cast<const u32x4*>(s.ptr + (ok ? go : 0) + ci0 + grp * 16)[pq];
         }
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int m = m0 + ((tid + 512 * i) >> 3);
-            pg[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (m < Mtot) pg[i] = reinterpret_cast<const uint4*>(a.g + (long)m * a.Cout + co0 + grp * 16)[pq];
+            const bool ok = m < Mtot;
+            st.ok |= ok ? (1u << (16 + i)) : 0u;
+            st.pg[i] = reinterpret_cast<const u32x4*>(a.g + (long)(ok ? m : 0) * a.Cout + co0 + grp * 16)[pq];
         }
     };
-
     char* const ad = (to_lo ? Alo : Ahi) + dcol;
     char* const gd = (to_lo ? Glo : Ghi) + dcol;
-    if ((int)blockIdx.x < a.ntiles) prefetch(blockIdx.x);
-    for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    auto stage = [&](const Stage& st) {
         __syncthreads();   // previous tile fully consumed
-        if (tid < TILE_PX) pixoff[tid] = p_pix;
+        if (tid < TILE_PX) pixoff[tid] = st.pix;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int e = tid + 512 * i;
-            if (e < p_nelem) *reinterpret_cast<uint4*>(ad + (e >> 3) * 64) = pa[i];
+            if (e < st.nelem) *reinterpret_cast<u32x4*>(ad + (e >> 3) * 64) = ((st.ok >> i) & 1u) ? st.pa[i] : zero4;
         }
 #pragma unroll
-        for (int i = 0; i < NG; ++i) *reinterpret_cast<uint4*>(gd + ((tid + 512 * i) >> 3) * 64) = pg[i];
+        for (int i = 0; i < NG; ++i)
+            *reinterpret_cast<u32x4*>(gd + ((tid + 512 * i) >> 3) * 64) = ((st.ok >> (16 + i)) & 1u) ? st.pg[i] : zero4;
         __syncthreads();
-        if (t + (int)gridDim.x < a.ntiles) prefetch(t + gridDim.x);
+    };
+    auto kstep = [&](int ks, int t0, int nt) {   // 16 pixels ks*16.., taps t0 .. t0+nt-1 -> acc[0..nt-1]
+        const int p0 = ks * 16 + hh * 8 + q;
+        const int gb0 = p0 * 64 + colb, gb1 = (p0 + 4) * 64 + colb;
+        const bf16x8 gh = tr_pair(Ghi + gb0, Ghi + gb1);
+        const bf16x8 gl = tr_pair(Glo + gb0, Glo + gb1);
+        const int ab0 = pixoff[p0] * 64 + colb, ab1 = pixoff[p0 + 4] * 64 + colb;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int p0 = wave * 32 + ks * 16 + hh * 8 + q;
-            const int gb0 = p0 * 64 + colb, gb1 = (p0 + 4) * 64 + colb;
-            const bf16x8 gh = tr_pair(Ghi + gb0, Ghi + gb1);
-            const bf16x8 gl = tr_pair(Glo + gb0, Glo + gb1);
-            const int ab0 = pixoff[p0] * 64 + colb, ab1 = pixoff[p0 + 4] * 64 + colb;
+        for (int d = 0; d < 5; ++d) {
+            if (d < nt) {
+                const int tp = t0 + d;
+                const int to = ((tp / 3 - 1) * G::WP + (tp % 3 - 1)) * 64;
+                const bf16x8 ah = tr_pair(Ahi + ab0 + to, Ahi + ab1 + to);
+                const bf16x8 al = tr_pair(Alo + ab0 + to, Alo + ab1 + to);
+                acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh, acc[d], 0, 0, 0);
+                acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl, acc[d], 0, 0, 0);
+                acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh, acc[d], 0, 0, 0);
+            }
+        }
+    };
+    auto compute = [&]() {
+        if (taps == 9) {
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) kstep(wq * 4 + k, tp0, ntap);
+        } else {   // one tap, the centre of the padded-tall image: 2 K-steps per wave
+            kstep(wave * 2, 4, 1);
+            kstep(wave * 2 + 1, 4, 1);
+        }
+    };
+
+    // (prefetches past the last tile re-read tile ntiles-1: never staged, keeps the load count static)
+    const int step = gridDim.x, tlast = a.ntiles - 1;
+    int t = blockIdx.x;
+    prefetch(s0, min(t, tlast));
+    prefetch(s1, min(t + step, tlast));
+    for (; t < a.ntiles; t += 2 * step) {
+        stage(s0);
+        prefetch(s0, min(t + 2 * step, tlast));
+        compute();
+        if (t + step >= a.ntiles) break;
+        stage(s1);
+        prefetch(s1, min(t + 3 * step, tlast));
+        compute();
+    }
+
+    // partial sums of the waves that share a tap -> LDS -> fixed-order sum -> this workgroup's slab
+    float* red = reinterpret_cast<float*>(smem4);   // 8 waves x 1024 floats
+    float* slab = a.slab + (long)blockIdx.x * a.slab_stride;
+    if (taps == 9) {
 #pragma unroll
-            for (int tp = 0; tp < 9; ++tp) {
-                if (taps == 9 || tp == 4) {
-                    const int to = ((tp / 3 - 1) * G::WP + (tp % 3 - 1)) * 64;
-                    const bf16x8 ah = tr_pair(Ahi + ab0 + to, Ahi + ab1 + to);
-                    const bf16x8 al = tr_pair(Alo + ab0 + to, Alo + ab1 + to);
-                    acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh, acc[tp], 0, 0, 0);
-                    acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl, acc[tp], 0, 0, 0);
-                    acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh, acc[tp], 0, 0, 0);
+        for (int d = 0; d < 5; ++d) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[d][r];
+            __syncthreads();
+            // tap d of group 0 (waves 0-3) and tap 5 + d of group 1 (waves 4-7; d < 4): 2 x 1024 outputs
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+                const int o = tid + 512 * k2;
+                const int grp2 = o >> 10, idx = o & 1023;
+                if (grp2 == 0 || d < 4) {
+                    const float* rb = red + grp2 * 4096 + idx;
+                    const float sum = (rb[0] + rb[1024]) + (rb[2048] + rb[3072]);
+                    const int r = idx >> 6, ln = idx & 63;
+                    const int ci = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+                    const int co = ln & 31;
+                    const int wt = grp2 * 5 + d;
+                    slab[a.w_off + (long)(wt * a.a.w_rows + a.a.w_r0 + ci0 + ci) * a.Cout + co0 + co] = sum;
                 }
             }
         }
-    }
-
-    float* red = reinterpret_cast<float*>(smem4);   // 8 waves x 1024 floats
-    float* slab = a.slab + (long)blockIdx.x * a.slab_stride;
+    } else {
+        __syncthreads();
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
-        if (taps == 9 || tp == 4) {
-            const int wt = (taps == 9) ? tp : 0;
-            __syncthreads();
+        for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[0][r];
+        __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[tp][r];
-            __syncthreads();
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int idx = tid + 512 * k2;
+            float sum = 0.f;
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                const int idx = tid + 512 * k2;
-                float sum = 0.f;
-#pragma unroll
-                for (int w8 = 0; w8 < 8; ++w8) sum += red[w8 * 1024 + idx];
-                const int r = idx >> 6, ln = idx & 63;
-                const int ci = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
-                const int co = ln & 31;
-                slab[a.w_off + (long)(wt * a.a.w_rows + a.a.w_r0 + ci0 + ci) * a.Cout + co0 + co] = sum;
-            }
+            for (int w8 = 0; w8 < 8; ++w8) sum += red[w8 * 1024 + idx];
+            const int r = idx >> 6, ln = idx & 63;
+            const int ci = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+            const int co = ln & 31;
+            slab[a.w_off + (long)(a.a.w_r0 + ci0 + ci) * a.Cout + co0 + co] = sum;
         }
     }
 }

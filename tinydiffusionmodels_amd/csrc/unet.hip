@@ -308,6 +308,9 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
 int unet_backward_s16(const float* P, const float* x, const float* deps, float* G, const Ws& w, float* slabs, int B,
                       hipStream_t st) {
     constexpr int NS = 256;
+    // weight-gradient slabs of the 14x14 layers: with 2 / 4 (ci, co) channel-tile combinations per layer, 128 / 64
+    // slabs make one round of 256 workgroups that each pipeline ~6 pixel tiles (256 slabs = 512-1024 workgroups of 1-3)
+    constexpr int NS2 = 128, NS4 = 64;
     const BlockOff &r1 = kL.rb[0], &r2 = kL.rb[1], &r3 = kL.rb[2], &r4 = kL.rb[3];
     const int64_t M28 = (int64_t)B * 784, M14 = (int64_t)B * 196;
     const long NP = TDM_UNET_NPARAM;
@@ -333,21 +336,21 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     TDM_TRY(tdm_launch_split_dcat(w.dcat, w.dout3, B, st));
     // ---- rb3 ----
     TDM_TRY(tdm_launch_relu_mask_s16(w.dout3, w.a2_3, w.dc2s_3, slabs, NP, r3.c2b, -1, M14, 64, NS, st));
-    TDM_TRY(wgrad_s16(st, 14, B, w.a1s_3, 64, 64, 0, 9, w.dc2s_3, 64, slabs, r3.c2w, 64, 0, NS));
+    TDM_TRY(wgrad_s16(st, 14, B, w.a1s_3, 64, 64, 0, 9, w.dc2s_3, 64, slabs, r3.c2w, 64, 0, NS4));
     TDM_TRY(conv_s16_1(st, w, 14, B, w.dc2s_3, 64, 9, kPack.dg[W_RB3C2], 64, nullptr, 0,
                        S16Out{w.dh3, nullptr, nullptr, nullptr, nullptr}));
     TDM_TRY(tdm_launch_relu_bwd_tb_s16(w.dh3, w.a1_3, w.dh3s, w.S[2], w.S2[2], B, 196, 64, st));
-    TDM_TRY(wgrad_s16(st, 14, B, w.h2s, 64, 64, 0, 9, w.dh3s, 64, slabs, r3.c1w, 64, 0, NS));
+    TDM_TRY(wgrad_s16(st, 14, B, w.h2s, 64, 64, 0, 9, w.dh3s, 64, slabs, r3.c1w, 64, 0, NS4));
     TDM_TRY(conv_s16_1(st, w, 14, B, w.dh3s, 64, 9, kPack.dg[W_RB3C1], 64, nullptr, 0,
                        S16Out{w.dout2, nullptr, w.dout3, w.dout2s, nullptr}));   // + identity skip
     // ---- rb2 ----
     TDM_TRY(tdm_launch_relu_mask_s16(w.dout2, w.a2_2, w.dc2s_2, slabs, NP, r2.c2b, r2.skb, M14, 64, NS, st));
-    TDM_TRY(wgrad_s16(st, 14, B, w.a1s_2, 64, 64, 0, 9, w.dc2s_2, 64, slabs, r2.c2w, 64, 0, NS));
+    TDM_TRY(wgrad_s16(st, 14, B, w.a1s_2, 64, 64, 0, 9, w.dc2s_2, 64, slabs, r2.c2w, 64, 0, NS4));
     TDM_TRY(conv_s16_1(st, w, 14, B, w.dc2s_2, 64, 9, kPack.dg[W_RB2C2], 64, nullptr, 0,
                        S16Out{w.dh2, nullptr, nullptr, nullptr, nullptr}));
     TDM_TRY(tdm_launch_relu_bwd_tb_s16(w.dh2, w.a1_2, w.dh2s, w.S[1], w.S2[1], B, 196, 64, st));
-    TDM_TRY(wgrad_s16(st, 14, B, w.p1s, 32, 32, 0, 9, w.dh2s, 64, slabs, r2.c1w, 32, 0, NS));
-    TDM_TRY(wgrad_s16(st, 14, B, w.p1s, 32, 32, 0, 1, w.dout2s, 64, slabs, r2.skw, 32, 0, NS));
+    TDM_TRY(wgrad_s16(st, 14, B, w.p1s, 32, 32, 0, 9, w.dh2s, 64, slabs, r2.c1w, 32, 0, NS2));
+    TDM_TRY(wgrad_s16(st, 14, B, w.p1s, 32, 32, 0, 1, w.dout2s, 64, slabs, r2.skw, 32, 0, NS2));
     {
         ConvArgs a{};
         a.nsrc = 2;
@@ -375,12 +378,13 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     TDM_TRY(tdm_launch_first_wgrad(x, w.dh1, w.dout1, slabs, NP, r1.c1w, r1.c1b, r1.skw, r1.skb, B, NS, st));
     ReduceArgs ra{};
     int n = 0;
-    auto sec = [&](int off, int len) { ra.sec[n].off = off; ra.sec[n].len = len; ra.sec[n].nslab = NS; ++n; };
-    sec(r1.c1w, 288 + 32); sec(r1.c2w, 9216 + 32); sec(r1.skw, 32 + 32);
-    sec(r2.c1w, 18432); sec(r2.c2w, 36864 + 64); sec(r2.skw, 2048 + 64);
-    sec(r3.c1w, 36864); sec(r3.c2w, 36864 + 64);
-    sec(r4.c1w, 27648); sec(r4.c2w, 9216 + 32); sec(r4.skw, 3072 + 32);
-    sec(kL.outw, 33);
+    auto sec = [&](int off, int len, int ns) { ra.sec[n].off = off; ra.sec[n].len = len; ra.sec[n].nslab = ns; ++n; };
+    sec(r1.c1w, 288 + 32, NS); sec(r1.c2w, 9216 + 32, NS); sec(r1.skw, 32 + 32, NS);
+    sec(r2.c1w, 18432, NS2); sec(r2.c2w, 36864, NS4); sec(r2.c2w + 36864, 64, NS);   // weights | bias (elementwise producers)
+    sec(r2.skw, 2048, NS2); sec(r2.skw + 2048, 64, NS);
+    sec(r3.c1w, 36864, NS4); sec(r3.c2w, 36864, NS4); sec(r3.c2w + 36864, 64, NS);
+    sec(r4.c1w, 27648, NS); sec(r4.c2w, 9216 + 32, NS); sec(r4.skw, 3072 + 32, NS);
+    sec(kL.outw, 33, NS);
     ra.nsec = n;
     return tdm_launch_reduce(slabs, NP, ra, G, st);
 }
