@@ -437,20 +437,27 @@ __global__ __launch_bounds__(EW_BLOCK) void combine_dh1_kernel(const float* __re
 }
 
 // weight gradients of rb1.conv1 (Cin = 1, 3x3) and rb1.skip (1x1), per-block slabs.
-// thread (c = tid&31, g = tid>>5): channel c over pixels g, g+8, ... of the block's range.
-__global__ __launch_bounds__(EW_BLOCK) void first_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dc1,
+// 1024 threads (16 waves per CU: the kernel is latency-bound, one workgroup per slab); thread (c4 = tid & 7,
+// g = tid >> 3) owns channels 4*c4 .. +3 of pixels g, g + 128, ... of the block's range (float4 gradient loads, two
+// pixels in flight); partial sums: lanes of a wave by shuffles, the 16 waves through LDS, fixed order.
+constexpr int FW_BLOCK = 1024;
+__global__ __launch_bounds__(FW_BLOCK) void first_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dc1,
                                                                const float* __restrict__ dout1, float* __restrict__ slab,
                                                                long slab_stride, int w1_off, int b1_off, int ws_off,
                                                                int bs_off, int B) {
-    __shared__ float sh[8][12][32];
-    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    __shared__ float sh[16][12][32];
+    const int c4 = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t M = (int64_t)B * 784;
     const int64_t per = (M + gridDim.x - 1) / gridDim.x;
     const int64_t p0 = (int64_t)blockIdx.x * per, p1 = min(p0 + per, M);
-    float acc[12];
+    float4 acc[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
-    auto one = [&](int64_t p, float d1, float d2) {
+    for (int k = 0; k < 12; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fma4 = [](float a, const float4& d, float4& r) {
+        r.x = fmaf(a, d.x, r.x); r.y = fmaf(a, d.y, r.y); r.z = fmaf(a, d.z, r.z); r.w = fmaf(a, d.w, r.w);
+    };
+    auto one = [&](int64_t p, const float4& d1, const float4& d2) {
         const int b = (int)(p / 784);
         const int rem = (int)(p - (int64_t)b * 784);
         const int y = rem / 28, xx = rem - y * 28;
@@ -461,30 +468,40 @@ __global__ __launch_bounds__(EW_BLOCK) void first_wgrad_kernel(const float* __re
             float xv = 0.f;
             if (yy >= 0 && yy < 28 && xq >= 0 && xq < 28) xv = x[(int64_t)b * 784 + yy * 28 + xq];
             if (tap == 4) xc = xv;
-            acc[tap] = fmaf(xv, d1, acc[tap]);
+            fma4(xv, d1, acc[tap]);
         }
-        acc[9] += d1;
-        acc[10] = fmaf(xc, d2, acc[10]);
-        acc[11] += d2;
+        acc[9].x += d1.x; acc[9].y += d1.y; acc[9].z += d1.z; acc[9].w += d1.w;
+        fma4(xc, d2, acc[10]);
+        acc[11].x += d2.x; acc[11].y += d2.y; acc[11].z += d2.z; acc[11].w += d2.w;
     };
     int64_t p = p0 + g;
-    for (; p + 24 < p1; p += 32) {   // 4 pixels per trip: the 8 gradient loads are independent
-        float d1[4], d2[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { d1[u] = dc1[(p + 8 * u) * 32 + c]; d2[u] = dout1[(p + 8 * u) * 32 + c]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) one(p + 8 * u, d1[u], d2[u]);
+    for (; p + 128 < p1; p += 256) {   // 2 pixels per trip: the 4 gradient loads are independent
+        const float4 a0 = reinterpret_cast<const float4*>(dc1 + p * 32)[c4];
+        const float4 b0 = reinterpret_cast<const float4*>(dout1 + p * 32)[c4];
+        const float4 a1 = reinterpret_cast<const float4*>(dc1 + (p + 128) * 32)[c4];
+        const float4 b1 = reinterpret_cast<const float4*>(dout1 + (p + 128) * 32)[c4];
+        one(p, a0, b0);
+        one(p + 128, a1, b1);
     }
-    for (; p < p1; p += 8) one(p, dc1[p * 32 + c], dout1[p * 32 + c]);
+    for (; p < p1; p += 128)
+        one(p, reinterpret_cast<const float4*>(dc1 + p * 32)[c4], reinterpret_cast<const float4*>(dout1 + p * 32)[c4]);
+    // lanes with the same c4 (lane & 7) hold different pixels: sum over lane bits 3..5
 #pragma unroll
-    for (int k = 0; k < 12; ++k) sh[g][k][c] = acc[k];
+    for (int k = 0; k < 12; ++k) {
+#pragma unroll
+        for (int o = 8; o <= 32; o <<= 1) {
+            acc[k].x += __shfl_xor(acc[k].x, o); acc[k].y += __shfl_xor(acc[k].y, o);
+            acc[k].z += __shfl_xor(acc[k].z, o); acc[k].w += __shfl_xor(acc[k].w, o);
+        }
+        if (lane < 8) *reinterpret_cast<float4*>(&sh[wave][k][lane * 4]) = acc[k];
+    }
     __syncthreads();
     float* dst = slab + (long)blockIdx.x * slab_stride;
-    for (int e = threadIdx.x; e < 12 * 32; e += EW_BLOCK) {
+    for (int e = threadIdx.x; e < 12 * 32; e += FW_BLOCK) {
         const int k = e >> 5, cc = e & 31;
         float s = 0.f;
 #pragma unroll
-        for (int gg = 0; gg < 8; ++gg) s += sh[gg][k][cc];
+        for (int w = 0; w < 16; ++w) s += sh[w][k][cc];
         if (k < 9) dst[w1_off + k * 32 + cc] = s;
         else if (k == 9) dst[b1_off + cc] = s;
         else if (k == 10) dst[ws_off + cc] = s;
@@ -776,7 +793,7 @@ int tdm_launch_combine_dh1(const float* dcat, const float* dp1, float* dout1, in
 }
 int tdm_launch_first_wgrad(const float* x, const float* dc1, const float* dout1, float* slab, long slab_stride,
                            int w1_off, int b1_off, int ws_off, int bs_off, int B, int nslab, hipStream_t st) {
-    hipLaunchKernelGGL(first_wgrad_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, x, dc1, dout1, slab, slab_stride, w1_off,
+    hipLaunchKernelGGL(first_wgrad_kernel, dim3(nslab), dim3(FW_BLOCK), 0, st, x, dc1, dout1, slab, slab_stride, w1_off,
                        b1_off, ws_off, bs_off, B);
     TDM_CHECK_LAUNCH("first_wgrad");
     return 0;
