@@ -27,6 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // a 16-byte piece held in registers
 
 namespace {
 
@@ -45,7 +46,8 @@ __device__ __forceinline__ float4 load4_guard(const float* p, int avail) {  // a
 }
 
 template <int NPROD>
-__device__ __forceinline__ void put_split(char* hi_plane, char* lo_plane, int off, const float4 v) {
+__device__ __forceinline__ void put_split(char* hi_plane, char* lo_plane, int off, const f32x4 v4) {
+    const float4 v = make_float4(v4[0], v4[1], v4[2], v4[3]);
     tdm_bf16x4 hi, lo;
     if (NPROD == 3) {
         tdm_split4(v, hi, lo);
@@ -67,7 +69,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 template <int NPROD>
-__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g, int ntx, int ntiles) {
+__global__ __launch_bounds__(256, 3) void gemm_nt_bf16_kernel(GemmArgs g, int ntx, int ntiles) {
     // planes: A hi, A lo, B hi, B lo  (lo planes unused when NPROD == 1)
     __shared__ __attribute__((aligned(16))) char lds[4 * PLANE];
     char* Ahi = lds; char* Alo = lds + PLANE; char* Bhi = lds + 2 * PLANE; char* Blo = lds + 3 * PLANE;
@@ -81,18 +83,28 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g, int ntx, 
     const int t_end = t_beg + per + (slot < rem ? 1 : 0);
     const int nchunk = (g.K + BK - 1) / BK;
 
-    float4 pa[4], pb[4];   // the next K-chunk's global loads, in flight while the current chunk is multiplied
+    // The next K-chunk's global loads, in flight while the current chunk is multiplied.  All 8 loads of a chunk are
+    // issued unconditionally and back to back: out-of-range pieces read a clamped address and are zeroed from the
+    // `ok` bits when they are split into LDS.  (Guarded loads with scalar tail paths compiled to branches with an
+    // s_waitcnt vmcnt(0) between consecutive loads, i.e. the loads of a chunk were serialised.)  K % 4 == 0.
+    f32x4 pa[4], pb[4];
+    unsigned ok = 0u;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto gload = [&](int tile, int k0) {
         const int i0 = (tile / ntx) * TM, j0 = (tile % ntx) * TN_;
+        ok = 0u;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {   // 128 rows x 8 float4
             const int f = tid + 256 * p;
             const int row = f >> 3, kq = f & 7;
             const int gk = k0 + kq * 4;
-            pa[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            pb[p] = pa[p];
-            if (i0 + row < g.M) pa[p] = load4_guard(g.A + (long)(i0 + row) * g.a_rs + gk, g.K - gk);
-            if (j0 + row < g.N) pb[p] = load4_guard(g.B + (long)(j0 + row) * g.b_cs + gk, g.K - gk);
+            const bool kin = gk < g.K;
+            const bool oa = kin && (i0 + row < g.M), ob = kin && (j0 + row < g.N);
+            ok |= (oa ? 1u : 0u) << p;
+            ok |= (ob ? 1u : 0u) << (4 + p);
+            const int gkc = kin ? gk : 0;
+            pa[p] = *reinterpret_cast<const f32x4*>(g.A + (long)min(i0 + row, g.M - 1) * g.a_rs + gkc);
+            pb[p] = *reinterpret_cast<const f32x4*>(g.B + (long)min(j0 + row, g.N - 1) * g.b_cs + gkc);
         }
     };
     if (t_beg < t_end) gload(t_beg, 0);
@@ -114,8 +126,8 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g, int ntx, 
                 for (int p = 0; p < 4; ++p) {
                     const int f = tid + 256 * p;
                     const int row = f >> 3, kq = f & 7;
-                    put_split<NPROD>(Ahi, Alo, row * PITCH + kq * 8, pa[p]);
-                    put_split<NPROD>(Bhi, Blo, row * PITCH + kq * 8, pb[p]);
+                    put_split<NPROD>(Ahi, Alo, row * PITCH + kq * 8, ((ok >> p) & 1u) ? pa[p] : zero4);
+                    put_split<NPROD>(Bhi, Blo, row * PITCH + kq * 8, ((ok >> (4 + p)) & 1u) ? pb[p] : zero4);
                 }
             }
             __syncthreads();
@@ -241,19 +253,26 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    float4 pa[4], pb[4];   // next chunk's global loads, in flight during the MFMAs of the current one
+    // next chunk's global loads, in flight during the MFMAs of the current one; unconditional and back to back
+    // (out-of-range pieces read a clamped address, zeroed from `ok` at the LDS store); M % 4 == N % 4 == 0
+    f32x4 pa[4], pb[4];
+    unsigned ok = 0u;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto gload = [&](int k0) {
+        ok = 0u;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {   // 32 token rows x 32 float4 columns
             const int f = tid + 256 * p;
             const int mrow = f >> 5, c4 = f & 31;
             const int gk = k0 + mrow;
-            pa[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            pb[p] = pa[p];
-            if (gk < kend) {
-                pa[p] = load4_guard(g.A + (long)gk * g.a_cs + i0 + c4 * 4, g.M - (i0 + c4 * 4));
-                pb[p] = load4_guard(g.B + (long)gk * g.b_rs + j0 + c4 * 4, g.N - (j0 + c4 * 4));
-            }
+            const bool kin = gk < kend;
+            const int ia = i0 + c4 * 4, ib = j0 + c4 * 4;
+            const bool oa = kin && ia < g.M, ob = kin && ib < g.N;
+            ok |= (oa ? 1u : 0u) << p;
+            ok |= (ob ? 1u : 0u) << (4 + p);
+            const long gkc = kin ? gk : kbeg;
+            pa[p] = *reinterpret_cast<const f32x4*>(g.A + gkc * g.a_cs + (oa ? ia : 0));
+            pb[p] = *reinterpret_cast<const f32x4*>(g.B + gkc * g.b_rs + (ob ? ib : 0));
         }
     };
     if (kbeg < kend) gload(kbeg);
@@ -266,9 +285,10 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
             const int f = tid + 256 * p;
             const int mrow = f >> 5, c4 = f & 31;
             const int off = ((c4 >> 3) * 32 + mrow) * 64 + (c4 & 7) * 8;
-            put_split<NPROD>(Ahi, Alo, off, pa[p]);
-            put_split<NPROD>(Bhi, Blo, off, pb[p]);
-            if (do_cs) { csum.x += pa[p].x; csum.y += pa[p].y; csum.z += pa[p].z; csum.w += pa[p].w; }
+            const f32x4 va = ((ok >> p) & 1u) ? pa[p] : zero4;
+            put_split<NPROD>(Ahi, Alo, off, va);
+            put_split<NPROD>(Bhi, Blo, off, ((ok >> (4 + p)) & 1u) ? pb[p] : zero4);
+            if (do_cs) { csum.x += va[0]; csum.y += va[1]; csum.z += va[2]; csum.w += va[3]; }
         }
         __syncthreads();
         if (k0 + BK < kend) gload(k0 + BK);
@@ -361,8 +381,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
     TDM_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm_nt_bf16: empty problem");
     TDM_REQUIRE(g.a_cs == 1 && g.b_rs == 1, "gemm_nt_bf16: both operands must be K-contiguous");
-    TDM_REQUIRE((g.a_rs % 4) == 0 && (g.b_cs % 4) == 0 && (g.N % 4) == 0 && (g.c_rs % 4) == 0,
-                "gemm_nt_bf16: leading dimensions and N must be multiples of 4");
+    TDM_REQUIRE((g.a_rs % 4) == 0 && (g.b_cs % 4) == 0 && (g.N % 4) == 0 && (g.c_rs % 4) == 0 && (g.K % 4) == 0,
+                "gemm_nt_bf16: leading dimensions, N and K must be multiples of 4");
     TDM_REQUIRE((((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.C) & 15) == 0, "gemm_nt_bf16: 16-byte alignment");
     TDM_REQUIRE(g.splitk <= 1, "gemm_nt_bf16: no split-K");
     const int ntx = (g.N + TN_ - 1) / TN_, ntiles = ntx * ((g.M + TM - 1) / TM);
@@ -391,7 +411,8 @@ int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
 int tdm_launch_gemm_tn_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
     TDM_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm_tn_bf16: empty problem");
     TDM_REQUIRE(g.a_rs == 1 && g.b_cs == 1, "gemm_tn_bf16: both operands must be row(contraction)-major");
-    TDM_REQUIRE((g.a_cs % 4) == 0 && (g.b_rs % 4) == 0, "gemm_tn_bf16: leading dimensions must be multiples of 4");
+    TDM_REQUIRE((g.a_cs % 4) == 0 && (g.b_rs % 4) == 0 && (g.M % 4) == 0 && (g.N % 4) == 0,
+                "gemm_tn_bf16: leading dimensions, M and N must be multiples of 4");
     TDM_REQUIRE((((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0, "gemm_tn_bf16: 16-byte alignment");
     TDM_REQUIRE(g.bias == nullptr && g.res == nullptr && !g.relu && g.gate == nullptr && g.drop.thr == 0u,
                 "gemm_tn_bf16: raw output only");
