@@ -268,6 +268,36 @@ def main():
                                                2: "plain bf16-operand MFMA GEMMs, fp32 accumulate"}[args.gemm_mode] +
                                               "; fp32-MFMA attention, fp32 LayerNorm; counter-hash dropout masks"}
         del xt
+        # rounding head of the same train step (row N1): logits + cross-entropy + the three gradients for the
+        # 32,768 tokens of the batch against a GPT-2-sized vocabulary (synthetic table; V is not a multiple of 4)
+        Vh = 50257
+        Mh = Bt * Lt
+        gh = torch.Generator(device=dev).manual_seed(11 + rank)
+        xh = torch.randn(Mh, Dt, device=dev, generator=gh) * 0.5
+        Wh = torch.randn(Vh, Dt, device=dev, generator=gh) * (1.0 / Dt ** 0.5)
+        bh = torch.zeros(Vh, device=dev)
+        idh = torch.randint(0, Vh, (Mh,), device=dev, generator=gh)
+        L_ = _lib.lib()
+        wsh = torch.empty(L_.tdm_round_workspace_floats(Mh, Vh, Dt), device=dev)
+        lossh, dxh, dWh, dbh = torch.empty(1, device=dev), torch.empty_like(xh), torch.empty_like(Wh), torch.empty_like(bh)
+
+        def head():
+            _lib.check(L_.tdm_round_ce_loss_grad_f32(_lib.ptr(xh), _lib.ptr(Wh), _lib.ptr(bh), _lib.ptr(idh), 1.0, _lib.ptr(lossh),
+                                                     _lib.ptr(dxh), _lib.ptr(dWh), _lib.ptr(dbh), _lib.ptr(wsh), Mh, Vh, Dt,
+                                                     _lib.stream()), "round_ce")
+        head()
+        sync()
+        nh = max(1, args.text_steps // 3)
+        t0 = time.perf_counter()
+        for _ in range(nh):
+            head()
+        sync()
+        ms_h = 1e3 * (time.perf_counter() - t0) / nh
+        out["text_denoiser"]["rounding_head"] = {"vocab": Vh, "tokens": Mh, "ms": round(ms_h, 3),
+                                                 "tflops": round(3 * 2.0 * Mh * Vh * Dt / (ms_h * 1e-3) / 1e12, 1),
+                                                 "logits_gb": round(Mh * 4.0 * ((Vh + 3) // 4 * 4) / 1e9, 2),
+                                                 "loss": round(float(lossh.item()), 4)}
+        del xh, Wh, bh, idh, wsh, dxh, dWh, dbh
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

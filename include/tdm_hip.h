@@ -207,6 +207,30 @@ int tdm_get_attn_mode(void);
  * forward reaches them: 0 input dropout (src/shakespeare.py:119); layer l: 1+4l attention
  * probabilities (B,H,L,L), 2+4l dropout1 (B,L,D), 3+4l FFN dropout (B,L,ffn), 4+4l dropout2. */
 int tdm_dropout_keep_u8(float p_drop, uint64_t seed, int site, int64_t idx0, int64_t n, uint8_t* keep_host);
+/* ---- N1: learned embedding table and rounding head of the text train step
+ *      (src/shakespeare.py:46-102 modules, :225-243 train step, :387-390 decode) ----
+ * table (V,D) fp32, ids (M,) int64 token ids in [0,V), W (V,D) / b (V,) = LearnedRounding.decoder.  */
+/* out[m] = table[ids[m]]   (LearnedEmbedding.forward, src/shakespeare.py:67) */
+int tdm_embed_gather_f32(const float* table, const int64_t* ids, float* out, int64_t M, int V, int D,
+                         void* stream);
+/* dtable[ids[m]] += scale * g[m]   (its gradient; dtable must be zeroed / hold the running sum;
+ * float atomics: summation order over repeated ids is not fixed, like torch's GPU embedding backward) */
+int tdm_embed_scatter_add_f32(const float* g, const int64_t* ids, float* dtable, int64_t M, int V, int D,
+                              float scale, void* stream);
+int64_t tdm_round_workspace_floats(int64_t M, int V, int D);
+/* rounding loss of src/shakespeare.py:239-240 and its gradients in one call:
+ *   loss_out[0] = cross_entropy(x W^T + b, ids)  (mean over the M tokens, unweighted)
+ *   dx (M,D; may be NULL), dW (V,D), db (V) = gradients of  grad_scale * loss  (grad_scale = the
+ *   rounding weight of :243); all three are overwritten.  ws: tdm_round_workspace_floats(M,V,D).  */
+int tdm_round_ce_loss_grad_f32(const float* x, const float* W, const float* b, const int64_t* ids,
+                               float grad_scale, float* loss_out, float* dx, float* dW, float* db,
+                               float* ws, int64_t M, int V, int D, void* stream);
+/* logits (M, ld >= V, ld % 4 == 0) = x W^T + b   (LearnedRounding.forward, src/shakespeare.py:101) */
+int tdm_round_logits_f32(const float* x, const float* W, const float* b, float* logits, int64_t ld,
+                         int64_t M, int V, int D, void* stream);
+/* out_ids[m] = argmax_v (x W^T + b)[m][v]   (decode, src/shakespeare.py:389-390) */
+int tdm_round_argmax_f32(const float* x, const float* W, const float* b, int64_t* out_ids, float* ws,
+                         int64_t M, int V, int D, void* stream);
 /* general strided fp32-MFMA GEMM (tests / profiling):
  * C[i][j] = sum_k A[i*a_rs + k*a_cs] * B[k*b_rs + j*b_cs] (+bias[j]) (+res[i][j]) (relu)      */
 int tdm_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs,

@@ -351,6 +351,26 @@ def transformer_loss_and_grads(p, x0, t, noise, tables, n_heads: int = 4, depth:
     return loss.detach(), grads
 
 
+def embed(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    """LearnedEmbedding.forward (src/shakespeare.py:67): rows of the table."""
+    return table[ids]
+
+
+def rounding_logits(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """LearnedRounding.forward (src/shakespeare.py:101)."""
+    return F.linear(x, W, b)
+
+
+def rounding_ce_and_grads(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, ids: torch.Tensor):
+    """Rounding loss of the text train step (src/shakespeare.py:239-240) and its gradients
+    w.r.t. the embeddings, the decoder weight and bias."""
+    xl, Wl, bl = (v.detach().clone().requires_grad_(True) for v in (x, W, b))
+    logits = F.linear(xl, Wl, bl)
+    loss = F.cross_entropy(logits.reshape(-1, logits.size(-1)), ids.reshape(-1))
+    loss.backward()
+    return loss.detach(), xl.grad, Wl.grad, bl.grad
+
+
 def text_p_sample(p, x, t, noise, tables, n_heads: int = 4, depth: int = 3):
     """src/shakespeare.py:343-352."""
     return p_sample_from_eps(x, t, transformer_forward(p, x, t, n_heads, depth), noise, tables)

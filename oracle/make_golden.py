@@ -281,7 +281,45 @@ def gen_text_dropout():
     print("text dropout goldens written to", GOLD)
 
 
+def gen_text_head():
+    """Row N1: the reference's LearnedEmbedding / LearnedRounding modules and the rounding-loss part of
+    its train step (src/shakespeare.py:46-102, :225-243): x0 = embedding_fn(ids); logits = rounding_fn(x0);
+    loss = cross_entropy(logits, ids); plus a diffusion-like second use of x0 so that d(loss)/d(table)
+    mixes both paths, and the argmax decode (:389-390)."""
+    _install_stubs(with_torchvision=False)
+    sys.path.insert(0, REF)
+    import src.shakespeare as S
+    import torch.nn.functional as F
+
+    out = {}
+    for V, D, B, L, tag in ((1003, 32, 3, 16, "v1003"), (2048, 64, 2, 64, "v2048")):
+        torch.manual_seed(100 + V)
+        emb = S.LearnedEmbedding(V, D)
+        rnd = S.LearnedRounding(D, V)
+        with torch.no_grad():
+            emb.embeddings.weight.mul_(25.0)      # std 0.5: logits with a real spread (default init 0.02 gives ~uniform softmax)
+        g = torch.Generator().manual_seed(V)
+        ids = torch.randint(0, V, (B, L), generator=g)
+        ids[0, :4] = ids[0, 0]                    # repeated ids: the embedding gradient accumulates
+        target = torch.randn(B, L, D, generator=g)
+        x0 = emb(ids)
+        logits = rnd(x0)
+        ce = F.cross_entropy(logits.reshape(-1, V), ids.reshape(-1))
+        total = F.mse_loss(x0, target) + 0.7 * ce
+        total.backward()
+        out[f"{tag}.table"] = emb.embeddings.weight.detach().clone()
+        out[f"{tag}.W"] = rnd.decoder.weight.detach().clone(); out[f"{tag}.b"] = rnd.decoder.bias.detach().clone()
+        out[f"{tag}.ids"] = ids; out[f"{tag}.target"] = target
+        out[f"{tag}.x0"] = x0.detach(); out[f"{tag}.ce"] = ce.detach().reshape(1)
+        out[f"{tag}.argmax"] = logits.detach().argmax(dim=-1)
+        out[f"{tag}.logits_head"] = logits.detach()[0, :2].clone()
+        out[f"{tag}.dtable"] = emb.embeddings.weight.grad.clone()
+        out[f"{tag}.dW"] = rnd.decoder.weight.grad.clone(); out[f"{tag}.db"] = rnd.decoder.bias.grad.clone()
+    np.savez(os.path.join(GOLD, "text_head.npz"), **_np(out))
+    print("text head goldens written to", GOLD)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "mnist"
     torch.set_num_threads(8)
-    {"mnist": gen_mnist, "text": gen_text, "text_dropout": gen_text_dropout}[which]()
+    {"mnist": gen_mnist, "text": gen_text, "text_dropout": gen_text_dropout, "text_head": gen_text_head}[which]()

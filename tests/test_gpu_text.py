@@ -344,3 +344,75 @@ def test_train_mode_default_dropout_and_bad_rate(dev):
     bad.train()
     with pytest.raises(RuntimeError, match="dropout probability"):
         bad(x, t)
+
+
+# ---------------------------------------------------------------------------------------------
+# Row N1: learned embedding + rounding head (src/shakespeare.py:46-102, :225-243, :387-390)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["v1003", "v2048"])
+def test_text_head_golden(dev, golden_dir, gemm_mode, tag):
+    """Native gather / fused rounding cross-entropy / argmax through the module surface, against the
+    reference's own modules (tests/golden/text_head.npz).  The head's GEMMs always run bf16x3."""
+    if gemm_mode != 1:
+        pytest.skip("the rounding head has one arithmetic (bf16x3)")
+    from tinydiffusionmodels_amd.shakespeare import LearnedEmbedding, LearnedRounding
+    g = _load(golden_dir, "text_head.npz")
+    table, W, b, ids, target = (g[f"{tag}.{k}"] for k in ("table", "W", "b", "ids", "target"))
+    V, D = table.shape
+    emb, rnd = LearnedEmbedding(V, D), LearnedRounding(D, V)
+    emb.load_state_dict({"embeddings.weight": table})
+    rnd.load_state_dict({"decoder.weight": W, "decoder.bias": b})
+    emb, rnd = emb.to(dev), rnd.to(dev)
+    idd = ids.to(dev)
+    x0 = emb(idd)
+    assert torch.equal(x0.detach().cpu(), g[f"{tag}.x0"])                      # gather: bit-exact
+    ce = rnd.cross_entropy(x0, idd)
+    assert abs(ce.item() - g[f"{tag}.ce"].item()) < 2e-5 * abs(g[f"{tag}.ce"].item())
+    total = F.mse_loss(x0, target.to(dev)) + 0.7 * ce
+    total.backward()
+    assert O.rel_err(rnd.decoder.weight.grad.cpu(), g[f"{tag}.dW"]) < 1e-4
+    assert O.rel_err(rnd.decoder.bias.grad.cpu(), g[f"{tag}.db"]) < 1e-4
+    assert O.rel_err(emb.embeddings.weight.grad.cpu(), g[f"{tag}.dtable"]) < 1e-4
+    # decode
+    with torch.no_grad():
+        logits = rnd(x0.detach())
+        assert logits.shape == (*ids.shape, V)
+        assert O.rel_err(logits[0, :2].cpu(), g[f"{tag}.logits_head"]) < 3e-5
+        am = rnd.argmax(x0.detach()).cpu()
+    ref_logits = O.rounding_logits(g[f"{tag}.x0"], W, b)
+    agree = (am == g[f"{tag}.argmax"])
+    # a disagreement is only acceptable on a numerical tie of the two top logits
+    top2 = ref_logits.topk(2, dim=-1).values
+    assert bool((agree | ((top2[..., 0] - top2[..., 1]).abs() < 1e-4 * top2[..., 0].abs())).all())
+    assert agree.float().mean().item() > 0.99
+
+
+@pytest.mark.parametrize("M,V,D", [(384, 5000, 256), (100, 777, 64), (1, 6, 8)])
+def test_rounding_ce_c_abi_vs_oracle(dev, gemm_mode, M, V, D):
+    """tdm_round_ce_loss_grad_f32 directly: ragged vocabulary sizes (not multiples of 4 / 128), a single row,
+    the grad_scale argument, dx = NULL."""
+    if gemm_mode != 1:
+        pytest.skip("the rounding head has one arithmetic (bf16x3)")
+    from tinydiffusionmodels_amd import _lib
+    L = _lib.lib()
+    gen = torch.Generator().manual_seed(M + V)
+    x = torch.randn(M, D, generator=gen) * 0.8
+    W = torch.randn(V, D, generator=gen) * (2.0 / D ** 0.5)
+    b = torch.randn(V, generator=gen) * 0.1
+    ids = torch.randint(0, V, (M,), generator=gen)
+    loss_ref, dx_ref, dW_ref, db_ref = O.rounding_ce_and_grads(x, W, b, ids)
+    xd, Wd, bd, idd = x.to(dev), W.to(dev), b.to(dev), ids.to(dev)
+    ws = torch.empty(L.tdm_round_workspace_floats(M, V, D), device=dev)
+    loss, dx, dW, db = torch.empty(1, device=dev), torch.empty(M, D, device=dev), torch.empty(V, D, device=dev), torch.empty(V, device=dev)
+    _lib.check(L.tdm_round_ce_loss_grad_f32(_lib.ptr(xd), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(idd), 0.25, _lib.ptr(loss),
+                                            _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db), _lib.ptr(ws), M, V, D, _lib.stream()))
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_ref.item()) < 2e-5 * abs(loss_ref.item())
+    assert O.rel_err(dx.cpu(), 0.25 * dx_ref) < 1e-4
+    assert O.rel_err(dW.cpu(), 0.25 * dW_ref) < 1e-4
+    assert O.rel_err(db.cpu(), 0.25 * db_ref) < 1e-4
+    dW2, db2 = torch.empty_like(dW), torch.empty_like(db)
+    _lib.check(L.tdm_round_ce_loss_grad_f32(_lib.ptr(xd), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(idd), 0.25, _lib.ptr(loss),
+                                            None, _lib.ptr(dW2), _lib.ptr(db2), _lib.ptr(ws), M, V, D, _lib.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(dW2, dW) and torch.equal(db2, db)      # deterministic (fixed-order slab sums)

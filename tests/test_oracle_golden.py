@@ -138,6 +138,26 @@ def test_transformer_train_mode_dropout(golden_dir, golden_tables, tag, dim):
     assert abs(keep.float().mean().item() - (1 - p_drop)) < 5e-3
 
 
+@pytest.mark.parametrize("tag", ["v1003", "v2048"])
+def test_text_head_oracle(golden_dir, tag):
+    """Row N1: embedding lookup, rounding logits / cross-entropy / gradients / argmax of the oracle against
+    the reference's own LearnedEmbedding + LearnedRounding modules (oracle/make_golden.py:gen_text_head)."""
+    g = _load(golden_dir, "text_head.npz")
+    table, W, b, ids, target = (g[f"{tag}.{k}"] for k in ("table", "W", "b", "ids", "target"))
+    x0 = O.embed(table, ids)
+    assert torch.equal(x0, g[f"{tag}.x0"])
+    logits = O.rounding_logits(x0, W, b)
+    assert O.rel_err(logits[0, :2], g[f"{tag}.logits_head"]) < 2e-6
+    assert torch.equal(logits.argmax(dim=-1), g[f"{tag}.argmax"])
+    ce, dx, dW, db = O.rounding_ce_and_grads(x0, W, b, ids)
+    assert abs(ce.item() - g[f"{tag}.ce"].item()) < 1e-6 * abs(g[f"{tag}.ce"].item())
+    assert O.rel_err(0.7 * dW, g[f"{tag}.dW"]) < 1e-5 and O.rel_err(0.7 * db, g[f"{tag}.db"]) < 1e-5
+    # d(total)/d(table) = scatter-add over ids of (mse part + 0.7 * rounding part)
+    dx_tot = 2.0 * (x0 - target) / x0.numel() + 0.7 * dx
+    dtab = torch.zeros_like(table).index_add_(0, ids.reshape(-1), dx_tot.reshape(-1, table.shape[1]))
+    assert O.rel_err(dtab, g[f"{tag}.dtable"]) < 1e-5
+
+
 def test_host_schedules(golden_dir):
     g = _load(golden_dir, "text_denoiser.npz")
     assert g["cosine_warmup_10_100"].shape[0] == 100 and g["cosine_warmup_10_100"][0] == 0.0

@@ -180,14 +180,30 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_kernel(GemmArgs g, int nt
             // (wave-private region: no barrier needed between this wave's writes and reads)
             const int c4 = lane & 15;
             const int n = j0 + wn * 64 + c4 * 4;
+            const int nq = g.N - n;   // columns of this quad inside the matrix (>= 4: whole quad)
             float4 bz = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g.bias != nullptr && n < g.N) bz = *reinterpret_cast<const float4*>(g.bias + n);
+            if (g.bias != nullptr && nq > 0) {
+                if (nq >= 4) bz = *reinterpret_cast<const float4*>(g.bias + n);
+                else { bz.x = g.bias[n]; if (nq > 1) bz.y = g.bias[n + 1]; if (nq > 2) bz.z = g.bias[n + 2]; }
+            }
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int rr = it * 4 + (lane >> 4);
                 const int m = i0 + wm * 64 + mt * 32 + rr;
                 float4 v = *reinterpret_cast<const float4*>(T + rr * EP + c4 * 4);
-                if (m < g.M && n < g.N && !(g.ablate & 4)) {   // N % 4 == 0: the whole quad is in range
+                if (m < g.M && nq > 0 && nq < 4 && !(g.ablate & 4)) {   // ragged last quad (N % 4 != 0): plain epilogue
+                    const long o = (long)m * g.c_rs + n;
+                    const float vv[3] = {v.x + bz.x, v.y + bz.y, v.z + bz.z};
+                    for (int e = 0; e < nq; ++e) {
+                        float u = vv[e];
+                        if (g.res != nullptr) u += g.res[o + e];
+                        if (g.relu) u = u < 0.f ? 0.f : u;
+                        if (g.gate != nullptr) u = g.gate[o + e] > 0.f ? u * g.gate_scale : 0.f;
+                        if (g.drop.thr != 0u)
+                            u = tdm_keep(g.drop, (unsigned long long)m * (unsigned)g.N + (unsigned)(n + e)) ? u * g.drop.scale : 0.f;
+                        g.C[o + e] = u;
+                    }
+                } else if (m < g.M && nq >= 4 && !(g.ablate & 4)) {
                     const long o = (long)m * g.c_rs + n;
                     v.x += bz.x; v.y += bz.y; v.z += bz.z; v.w += bz.w;
                     if (g.res != nullptr) {
@@ -381,8 +397,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
     TDM_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm_nt_bf16: empty problem");
     TDM_REQUIRE(g.a_cs == 1 && g.b_rs == 1, "gemm_nt_bf16: both operands must be K-contiguous");
-    TDM_REQUIRE((g.a_rs % 4) == 0 && (g.b_cs % 4) == 0 && (g.N % 4) == 0 && (g.c_rs % 4) == 0 && (g.K % 4) == 0,
-                "gemm_nt_bf16: leading dimensions, N and K must be multiples of 4");
+    TDM_REQUIRE((g.a_rs % 4) == 0 && (g.b_cs % 4) == 0 && (g.c_rs % 4) == 0 && (g.K % 4) == 0,
+                "gemm_nt_bf16: leading dimensions and K must be multiples of 4");
     TDM_REQUIRE((((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.C) & 15) == 0, "gemm_nt_bf16: 16-byte alignment");
     TDM_REQUIRE(g.splitk <= 1, "gemm_nt_bf16: no split-K");
     const int ntx = (g.N + TN_ - 1) / TN_, ntiles = ntx * ((g.M + TM - 1) / TM);

@@ -982,7 +982,7 @@ int tdm_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int
     g.c_split_stride = c_split_stride;
     if (g_gemm_mode != 0) {   // route the K-contiguous (NT) and token-major (TN) forms through the bf16 kernels
         const int nprod = g_gemm_mode == 1 ? 3 : 1;
-        if (a_cs == 1 && b_rs == 1 && splitk <= 1 && (N % 4) == 0 && (c_rs % 4) == 0 && (K % 4) == 0)
+        if (a_cs == 1 && b_rs == 1 && splitk <= 1 && (c_rs % 4) == 0 && (K % 4) == 0)
             return tdm_launch_gemm_nt_bf16(g, nprod, (hipStream_t)stream);
         if (a_rs == 1 && b_cs == 1 && bias == nullptr && res == nullptr && !relu && (M % 4) == 0 && (N % 4) == 0)
             return tdm_launch_gemm_tn_bf16(g, nprod, (hipStream_t)stream);

@@ -4,10 +4,10 @@ TinyTransformer forward/backward, p_sample, reverse loop) on hand-written HIP
 kernels.  Reference lines are cited per function.
 
 Scope: the transformer DENOISER path is native.  The learned
-embedding table and rounding head (src/shakespeare.py:46-102) are row N1
-("next") and are still plain torch modules here, used through autograd around
-the native denoiser; tokenizer / Gemma / dataset loading needs network and is
-out of scope (synthetic vocabularies are used for tests and benchmarks).
+embedding table and rounding head (src/shakespeare.py:46-102, row N1) keep their
+torch parameters; lookup, rounding loss (logits + cross-entropy, fused) and argmax
+decode run on native kernels (rounding.hip).  Tokenizer / Gemma / dataset loading
+needs network and is out of scope (synthetic vocabularies in tests and benchmarks).
 Dropout: train mode applies the reference's 1 + 4*depth dropout sites natively;
 the masks come from a counter-based hash of (seed, site, element index) — torch's
 Philox stream cannot be replayed by anyone else — with one 64-bit seed per forward
@@ -47,9 +47,37 @@ def q_sample(x0: torch.Tensor, t: torch.Tensor, noise=None):
     return E.q_sample_into(x0.contiguous(), t.contiguous(), noise.contiguous(), out)
 
 
+class _EmbedFunction(torch.autograd.Function):
+    """x0 = table[ids] on the native gather; backward = native scatter-add (tdm_embed_*_f32)."""
+
+    @staticmethod
+    def forward(ctx, table, ids):
+        E._need_cuda(table, ids)
+        V, D = table.shape
+        idc = ids.contiguous()       # out-of-range ids are clamped by the kernel (no host sync here to check them)
+        out = torch.empty(*ids.shape, D, dtype=torch.float32, device=table.device)
+        tab = table.detach().contiguous()
+        _lib.check(_lib.lib().tdm_embed_gather_f32(_lib.ptr(tab), _lib.ptr(idc), _lib.ptr(out), idc.numel(), V, D,
+                                                   _lib.stream()), "embed_gather")
+        ctx.save_for_backward(idc)
+        ctx.shape = (V, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idc,) = ctx.saved_tensors
+        V, D = ctx.shape
+        gc = g.contiguous()
+        dtab = torch.zeros(V, D, dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().tdm_embed_scatter_add_f32(_lib.ptr(gc), _lib.ptr(idc), _lib.ptr(dtab), idc.numel(), V, D, 1.0,
+                                                        _lib.stream()), "embed_scatter_add")
+        return dtab, None
+
+
 class LearnedEmbedding(nn.Module):
-    """Custom learnable embedding space for diffusion (src/shakespeare.py:46-85).
-    Row N1: still a torch module (gather on the device); not part of the native path."""
+    """Custom learnable embedding space for diffusion (src/shakespeare.py:46-85).  Same parameter
+    (`embeddings.weight`, an nn.Embedding for checkpoint compatibility); on a HIP device the
+    lookup and its gradient run on the native gather / scatter-add kernels (row N1)."""
 
     def __init__(self, vocab_size, embed_dim, pretrained_embeddings=None):
         super().__init__()
@@ -65,21 +93,106 @@ class LearnedEmbedding(nn.Module):
                 self.embeddings.weight.copy_(proj(pretrained_embeddings))
 
     def forward(self, token_ids):
+        w = self.embeddings.weight
+        if w.is_cuda and self.embed_dim % 4 == 0:
+            return _EmbedFunction.apply(w, token_ids)
         return self.embeddings(token_ids)
 
     def get_embedding_matrix(self):
         return self.embeddings.weight
 
 
+_round_ws = {}
+
+
+def _round_workspace(M, V, D, device):
+    key = (str(device), M, V, D)
+    if key not in _round_ws:
+        _round_ws.clear()          # one live workspace: the logits buffer is the big one (M x V floats)
+        n = _lib.lib().tdm_round_workspace_floats(M, V, D)
+        _round_ws[key] = torch.empty(n, dtype=torch.float32, device=device)
+    return _round_ws[key]
+
+
+class _RoundCEFunction(torch.autograd.Function):
+    """cross_entropy(Linear(D,V)(x), ids) (src/shakespeare.py:239-240) with loss and all three
+    gradients from one native call (tdm_round_ce_loss_grad_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, ids):
+        E._need_cuda(x, W, b, ids)
+        V, D = W.shape
+        xc, Wc, bc, idc = x.detach().reshape(-1, D).contiguous(), W.detach().contiguous(), b.detach().contiguous(), \
+            ids.reshape(-1).contiguous()
+        M = xc.shape[0]
+        if idc.numel() != M:
+            raise RuntimeError("rounding_cross_entropy: one target id per embedding row expected")
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(xc) if ctx.needs_input_grad[0] else None
+        dW, db = torch.empty_like(Wc), torch.empty_like(bc)
+        ws = _round_workspace(M, V, D, x.device)
+        _lib.check(_lib.lib().tdm_round_ce_loss_grad_f32(_lib.ptr(xc), _lib.ptr(Wc), _lib.ptr(bc), _lib.ptr(idc), 1.0,
+                                                         _lib.ptr(loss), _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db), _lib.ptr(ws),
+                                                         M, V, D, _lib.stream()), "round_ce_loss_grad")
+        ctx.grads = (dx, dW, db)
+        ctx.xshape = x.shape
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gl):
+        dx, dW, db = ctx.grads
+        ctx.grads = None
+        return (dx * gl).view(ctx.xshape) if dx is not None else None, dW * gl, db * gl, None
+
+
 class LearnedRounding(nn.Module):
-    """Embeddings -> token logits (src/shakespeare.py:88-102).  Row N1 (torch module)."""
+    """Embeddings -> token logits (src/shakespeare.py:88-102); same parameters (`decoder`, an
+    nn.Linear).  Row N1: `cross_entropy(x, ids)` is the fused native rounding loss of the train
+    step, `argmax(x)` the native decode; `forward` under no_grad computes the logits on the native
+    GEMM (with autograd enabled the unfused logits stay a torch op)."""
 
     def __init__(self, embed_dim, vocab_size):
         super().__init__()
         self.decoder = nn.Linear(embed_dim, vocab_size)
 
+    def _native(self, x):
+        return x.is_cuda and self.decoder.weight.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 4 == 0
+
     def forward(self, embeddings):
+        W, b = self.decoder.weight, self.decoder.bias
+        if self._native(embeddings) and not (torch.is_grad_enabled() and (embeddings.requires_grad or W.requires_grad)):
+            V, D = W.shape
+            xc = embeddings.reshape(-1, D).contiguous()
+            M, ld = xc.shape[0], (V + 3) // 4 * 4
+            out = torch.empty(M, ld, dtype=torch.float32, device=xc.device)
+            Wc, bc = W.detach().contiguous(), b.detach().contiguous()
+            _lib.check(_lib.lib().tdm_round_logits_f32(_lib.ptr(xc), _lib.ptr(Wc), _lib.ptr(bc), _lib.ptr(out), ld, M, V, D,
+                                                       _lib.stream()), "round_logits")
+            return out[:, :V].reshape(*embeddings.shape[:-1], V)
         return self.decoder(embeddings)
+
+    def cross_entropy(self, embeddings, token_ids):
+        """F.cross_entropy(self(embeddings).reshape(-1, V), token_ids.reshape(-1)) (src/shakespeare.py:239-240)."""
+        if self._native(embeddings):
+            return _RoundCEFunction.apply(embeddings, self.decoder.weight, self.decoder.bias, token_ids)
+        logits = self.decoder(embeddings)
+        return F.cross_entropy(logits.reshape(-1, logits.size(-1)), token_ids.reshape(-1))
+
+    @torch.no_grad()
+    def argmax(self, embeddings):
+        """self(embeddings).argmax(dim=-1) (src/shakespeare.py:389-390)."""
+        if not self._native(embeddings):
+            return self.decoder(embeddings).argmax(dim=-1)
+        W, b = self.decoder.weight, self.decoder.bias
+        V, D = W.shape
+        xc = embeddings.reshape(-1, D).contiguous()
+        M = xc.shape[0]
+        out = torch.empty(M, dtype=torch.int64, device=xc.device)
+        Wc, bc = W.detach().contiguous(), b.detach().contiguous()
+        ws = _round_workspace(M, V, D, xc.device)
+        _lib.check(_lib.lib().tdm_round_argmax_f32(_lib.ptr(xc), _lib.ptr(Wc), _lib.ptr(bc), _lib.ptr(out), _lib.ptr(ws), M, V, D,
+                                                   _lib.stream()), "round_argmax")
+        return out.view(embeddings.shape[:-1])
 
 
 class _TTFunction(torch.autograd.Function):
@@ -259,7 +372,7 @@ def decode_tokens(x, rounding_fn, embedding_fn, use_learned_rounding=True, use_l
     """Token ids from final embeddings: rounding-head argmax, or the cosine-similarity
     fallback (src/shakespeare.py:387-401).  Row N1: torch ops."""
     if use_learned_rounding:
-        return rounding_fn(x).argmax(dim=-1)
+        return rounding_fn.argmax(x) if hasattr(rounding_fn, "argmax") else rounding_fn(x).argmax(dim=-1)
     embed_matrix = embedding_fn.get_embedding_matrix() if use_learned_embeddings else embedding_fn
     sims = torch.matmul(F.normalize(x, dim=2), F.normalize(embed_matrix, dim=1).T)
     return sims.argmax(dim=-1)
@@ -296,8 +409,8 @@ def train(model, rounding_fn, embedding_fn, data_loader, val_loader, device, ckp
           use_lr_scheduling=True, warmup_steps=100):
     """src/shakespeare.py:174-341 with the same control flow (cosine-warm-up LR,
     decaying rounding weight, validation pass, early stopping, `_best.pth`, final
-    checkpoint dict).  The denoiser runs natively through the autograd bridge;
-    embedding / rounding / cross-entropy are torch ops (row N1)."""
+    checkpoint dict).  Denoiser, embedding lookup and rounding loss run on the native
+    kernels through autograd bridges; the optimiser is torch's AdamW over all parameters."""
     params = list(model.parameters()) + list(rounding_fn.parameters())
     if use_learned_embeddings:
         params += list(embedding_fn.parameters())
@@ -318,8 +431,7 @@ def train(model, rounding_fn, embedding_fn, data_loader, val_loader, device, ckp
         else:
             x_noisy = q_sample(x0, t, noise)
         diff = F.mse_loss(model(x_noisy, t), noise)
-        logits = rounding_fn(x0)
-        rnd = F.cross_entropy(logits.reshape(-1, logits.size(-1)), token_ids.reshape(-1))
+        rnd = rounding_fn.cross_entropy(x0, token_ids)     # logits + cross-entropy, fused native call (row N1)
         return diff, rnd, diff + rw * rnd
 
     for epoch in range(epochs):
