@@ -8,15 +8,13 @@
 // (tokens x V) logits are materialised once in the caller's workspace (6.6 GB at 32,768
 // tokens x 50,257 entries) and overwritten in place by their gradient, so the head is three
 // MFMA GEMMs on the transformer's kernels (logits = x W^T + b; dx = g W; dW = g^T x with the
-// bias gradient from the same pass) plus two row-wise passes (log-sum-exp, softmax - onehot).
-// Fusing the row passes into the GEMM epilogue / loaders is the follow-up.
+// bias gradient from the same pass) plus one row-wise kernel (online log-sum-exp, then
+// softmax - onehot in place).  Fusing the row work into the GEMM epilogue / loaders is the follow-up.
 #include <math.h>
 #include "tdm_common.h"
 #include "tdm_transformer.h"
 
 namespace {
-
-constexpr int RC_PART = 1024;   // partial sums of the mean loss (fixed-order reduction)
 
 // out[m][:] = table[ids[m]][:]                                     (src/shakespeare.py:67)
 __global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restrict__ table, const int64_t* __restrict__ ids,
@@ -45,45 +43,60 @@ __global__ __launch_bounds__(256) void embed_scatter_add_kernel(const float* __r
     }
 }
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ float wave_add(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-// one workgroup per token row: lse[m] = logsumexp(logits[m][0..V)), part[block % RC_PART] += lse - logits[m][ids[m]]
-// (two sweeps over the row: max, then sum of exp — the row was just written and is L2 / MALL resident)
-__global__ __launch_bounds__(256) void ce_row_stats_kernel(const float* __restrict__ logits, const int64_t* __restrict__ ids,
-                                                           float* __restrict__ lse, float* __restrict__ rowloss, long M,
-                                                           int V, long ld) {
-    __shared__ float red[4];
+// One workgroup per token row, two sweeps over the row in the same kernel:
+//   1. online (max, sum of exp) -> lse[m]; rowloss[m] = lse - logits[m][ids[m]]
+//   2. in place  logits[m][v] <- scale * (softmax(logits[m])[v] - [v == ids[m]]),  padding columns [V, ld) <- 0
+// The second sweep re-reads a 200 KB row the workgroup has just streamed (L2 hit), so HBM sees one read and one write
+// of the logits instead of the three reads + one write of separate statistics / gradient passes.
+__global__ __launch_bounds__(256) void ce_softmax_grad_kernel(float* __restrict__ logits, const int64_t* __restrict__ ids,
+                                                              float* __restrict__ lse, float* __restrict__ rowloss, long M,
+                                                              int V, long ld, float scale) {
+    __shared__ float redm[4], reds[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ld4 = (int)(ld >> 2);
     for (long m = blockIdx.x; m < M; m += gridDim.x) {
-        const float* row = logits + m * ld;
-        float mx = -INFINITY;
-        for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, row[v]);
-        mx = wave_max(mx);
+        float* row = logits + m * ld;
+        long tgtl = ids[m];
+        tgtl = tgtl < 0 ? 0 : (tgtl >= V ? V - 1 : tgtl);   // never index out of bounds on a bad id
+        const int tgt = (int)tgtl;
+        float mx = -INFINITY, sm = 0.f;
+        for (int q = threadIdx.x; q < ld4; q += 256) {
+            const float4 x = reinterpret_cast<const float4*>(row)[q];
+            const float r[4] = {x.x, x.y, x.z, x.w};
+            float lm = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (q * 4 + e < V) lm = fmaxf(lm, r[e]);
+            if (lm > mx) { sm *= expf(mx - lm); mx = lm; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (q * 4 + e < V) sm += expf(r[e] - mx);
+        }
+        // combine the 256 (max, sum) pairs: wave shuffles, then the 4 waves through LDS
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float om = __shfl_xor(mx, o), os = __shfl_xor(sm, o);
+            const float nm = fmaxf(mx, om);
+            sm = (mx == -INFINITY ? 0.f : sm * expf(mx - nm)) + (om == -INFINITY ? 0.f : os * expf(om - nm));
+            mx = nm;
+        }
         __syncthreads();
-        if (lane == 0) red[wave] = mx;
+        if (lane == 0) { redm[wave] = mx; reds[wave] = sm; }
         __syncthreads();
-        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        float sm = 0.f;
-        for (int v = threadIdx.x; v < V; v += 256) sm += expf(row[v] - mx);
-        sm = wave_add(sm);
-        __syncthreads();
-        if (lane == 0) red[wave] = sm;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const float l = mx + logf((red[0] + red[1]) + (red[2] + red[3]));
-            lse[m] = l;
-            long tgt = ids[m];
-            tgt = tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt);   // never read out of bounds on a bad id
-            rowloss[m] = l - row[tgt];
+        const float gm = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+        float gs = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) gs += redm[w] == -INFINITY ? 0.f : reds[w] * expf(redm[w] - gm);
+        const float l = gm + logf(gs);
+        if (threadIdx.x == 0) { lse[m] = l; rowloss[m] = l - row[tgt]; }
+        __syncthreads();   // row[tgt] is read before the row is overwritten
+        for (int q = threadIdx.x; q < ld4; q += 256) {
+            const float4 x = reinterpret_cast<const float4*>(row)[q];
+            float r[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int v = q * 4 + e;
+                r[e] = v < V ? scale * (expf(r[e] - l) - (v == tgt ? 1.f : 0.f)) : 0.f;
+            }
+            reinterpret_cast<float4*>(row)[q] = make_float4(r[0], r[1], r[2], r[3]);
         }
     }
 }
@@ -100,27 +113,6 @@ __global__ __launch_bounds__(256) void ce_mean_kernel(const float* __restrict__ 
         __syncthreads();
     }
     if (threadIdx.x == 0) loss_out[0] = sh[0] / (float)M;
-}
-
-// in place: logits[m][v] <- scale * (softmax(logits[m])[v] - [v == ids[m]]);  padding columns v in [V, ld) <- 0
-__global__ __launch_bounds__(256) void ce_grad_kernel(float* __restrict__ logits, const int64_t* __restrict__ ids,
-                                                      const float* __restrict__ lse, long M, int V, long ld, float scale) {
-    const long ld4 = ld >> 2;
-    const long total = M * ld4;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long m = i / ld4;
-        const int v0 = (int)(i - m * ld4) * 4;
-        float4 x = reinterpret_cast<float4*>(logits)[i];
-        const float l = lse[m];
-        const int tgt = (int)ids[m];
-        float r[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int v = v0 + e;
-            r[e] = v < V ? scale * (expf(r[e] - l) - (v == tgt ? 1.f : 0.f)) : 0.f;
-        }
-        reinterpret_cast<float4*>(logits)[i] = make_float4(r[0], r[1], r[2], r[3]);
-    }
 }
 
 // wT[d][v] = W[v][d] for v < V, 0 for the padding columns v in [V, ldv)
@@ -245,15 +237,12 @@ int tdm_round_ce_loss_grad_f32(const float* x, const float* W, const float* b, c
     // logits = x W^T + b                                            (src/shakespeare.py:239)
     TDM_TRY(logits_gemm(x, W, b, w.logits, M, V, Vp, D, st));
     // cross-entropy, mean over tokens                               (src/shakespeare.py:240)
-    hipLaunchKernelGGL(ce_row_stats_kernel, dim3((unsigned)(M < 8192 ? M : 8192)), dim3(256), 0, st, w.logits, ids, w.lse,
-                       w.rowloss, (long)M, V, (long)Vp);
-    TDM_CHECK_LAUNCH("ce_row_stats");
+    // g = grad_scale * (softmax - onehot) / M, in place over the logits; lse and the per-row loss on the way
+    hipLaunchKernelGGL(ce_softmax_grad_kernel, dim3((unsigned)(M < 16384 ? M : 16384)), dim3(256), 0, st, w.logits, ids, w.lse,
+                       w.rowloss, (long)M, V, (long)Vp, grad_scale / (float)M);
+    TDM_CHECK_LAUNCH("ce_softmax_grad");
     hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, st, w.rowloss, loss_out, (long)M);
     TDM_CHECK_LAUNCH("ce_mean");
-    // g = grad_scale * (softmax - onehot) / M, in place over the logits
-    hipLaunchKernelGGL(ce_grad_kernel, dim3(grid_for(M * (Vp / 4))), dim3(256), 0, st, w.logits, ids, w.lse, (long)M, V,
-                       (long)Vp, grad_scale / (float)M);
-    TDM_CHECK_LAUNCH("ce_grad");
     // dx = g W  (K-contiguous product on the transposed, zero-padded weight)
     if (dx != nullptr) {
         dim3 tg((D + 31) / 32, (Vp + 31) / 32);
