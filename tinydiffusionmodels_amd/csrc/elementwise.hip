@@ -686,6 +686,73 @@ __global__ __launch_bounds__(EW_BLOCK) void relu_mask_s16_kernel(const float* __
     quad_reduce_store(gu, sh, C4, b_unmasked_off >= 0 ? dst + b_unmasked_off : nullptr);
 }
 
+// split_dcat_kernel + relu_mask_s16_kernel in one pass (rb3): dout3 = 2x2 sum of dcat[.., 0:64] (upsample backward),
+// dc2_s16 = split(dout3 * (a2 > 0)), slab partials of the masked gradient (rb3.conv2 bias gradient).
+// One workgroup per slab; c4 = tid & 15 is fixed per thread (the grid stride is a multiple of 16).
+__global__ __launch_bounds__(EW_BLOCK) void split_dcat_mask_s16_kernel(const float* __restrict__ dcat,
+                                                                       const float* __restrict__ a2,
+                                                                       float* __restrict__ dout3, float* __restrict__ dc_s16,
+                                                                       float* __restrict__ slab, long slab_stride,
+                                                                       int b_masked_off, int B) {
+    __shared__ float4 sh[EW_BLOCK];
+    float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t total = (int64_t)B * 196 * 16;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c4 = (int)(i & 15);
+        const int64_t p = i >> 4;
+        const int xo = (int)(p % 14);
+        const int64_t q = p / 14;
+        const int yo = (int)(q % 14);
+        const int64_t b = q / 14;
+        const float4* src = reinterpret_cast<const float4*>(dcat) + ((b * 28 + 2 * yo) * 28 + 2 * xo) * 24 + c4;
+        const float4 v00 = src[0], v01 = src[24], v10 = src[28 * 24], v11 = src[28 * 24 + 24];
+        const float4 av = reinterpret_cast<const float4*>(a2)[i];
+        float4 d;
+        d.x = ((v00.x + v01.x) + v10.x) + v11.x; d.y = ((v00.y + v01.y) + v10.y) + v11.y;
+        d.z = ((v00.z + v01.z) + v10.z) + v11.z; d.w = ((v00.w + v01.w) + v10.w) + v11.w;
+        reinterpret_cast<float4*>(dout3)[i] = d;
+        float4 o;
+        o.x = av.x > 0.f ? d.x : 0.f; o.y = av.y > 0.f ? d.y : 0.f;
+        o.z = av.z > 0.f ? d.z : 0.f; o.w = av.w > 0.f ? d.w : 0.f;
+        tdm_store_s16_4(dc_s16, p, 64, c4 * 4, o);
+        gm.x += o.x; gm.y += o.y; gm.z += o.z; gm.w += o.w;
+    }
+    quad_reduce_store(gm, sh, 16, slab + (long)blockIdx.x * slab_stride + b_masked_off);
+}
+
+// combine_dh1_kernel + relu_mask_s16_kernel in one pass (rb1): dout1 = dcat[.., 64:96] + 0.25 * dp1 (concat skip +
+// avg-pool backward), dc2_s16 = split(dout1 * (a2 > 0)), slab partials of the masked gradient (rb1.conv2 bias).
+__global__ __launch_bounds__(EW_BLOCK) void combine_dh1_mask_s16_kernel(const float* __restrict__ dcat,
+                                                                        const float* __restrict__ dp1,
+                                                                        const float* __restrict__ a2,
+                                                                        float* __restrict__ dout1, float* __restrict__ dc_s16,
+                                                                        float* __restrict__ slab, long slab_stride,
+                                                                        int b_masked_off, int B) {
+    __shared__ float4 sh[EW_BLOCK];
+    float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t total = (int64_t)B * 784 * 8;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c4 = (int)(i & 7);
+        const int64_t p = i >> 3;
+        const int x = (int)(p % 28);
+        const int64_t q = p / 28;
+        const int y = (int)(q % 28);
+        const int64_t b = q / 28;
+        const float4 dc = reinterpret_cast<const float4*>(dcat)[p * 24 + 16 + c4];
+        const float4 dp = reinterpret_cast<const float4*>(dp1)[((b * 14 + (y >> 1)) * 14 + (x >> 1)) * 8 + c4];
+        const float4 av = reinterpret_cast<const float4*>(a2)[i];
+        float4 d;
+        d.x = dc.x + 0.25f * dp.x; d.y = dc.y + 0.25f * dp.y; d.z = dc.z + 0.25f * dp.z; d.w = dc.w + 0.25f * dp.w;
+        reinterpret_cast<float4*>(dout1)[i] = d;
+        float4 o;
+        o.x = av.x > 0.f ? d.x : 0.f; o.y = av.y > 0.f ? d.y : 0.f;
+        o.z = av.z > 0.f ? d.z : 0.f; o.w = av.w > 0.f ? d.w : 0.f;
+        tdm_store_s16_4(dc_s16, p, 32, c4 * 4, o);
+        gm.x += o.x; gm.y += o.y; gm.z += o.z; gm.w += o.w;
+    }
+    quad_reduce_store(gm, sh, 8, slab + (long)blockIdx.x * slab_stride + b_masked_off);
+}
+
 // relu_bwd_tb_kernel + S16 copy of the masked gradient + per-sample masked sums S2
 __global__ __launch_bounds__(EW_BLOCK) void relu_bwd_tb_s16_kernel(float* __restrict__ dh, const float* __restrict__ a1,
                                                                    float* __restrict__ dc1_s16, float* __restrict__ S,
@@ -832,6 +899,20 @@ int tdm_launch_relu_mask_s16(const float* dout, const float* a, float* dc_s16, f
     hipLaunchKernelGGL(relu_mask_s16_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, dout, a, dc_s16, slab, slab_stride,
                        b_masked_off, b_unmasked_off, M, C);
     TDM_CHECK_LAUNCH("relu_mask_s16");
+    return 0;
+}
+int tdm_launch_split_dcat_mask_s16(const float* dcat, const float* a2, float* dout3, float* dc_s16, float* slab,
+                                   long slab_stride, int b_masked_off, int B, int nslab, hipStream_t st) {
+    hipLaunchKernelGGL(split_dcat_mask_s16_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, dcat, a2, dout3, dc_s16, slab,
+                       slab_stride, b_masked_off, B);
+    TDM_CHECK_LAUNCH("split_dcat_mask_s16");
+    return 0;
+}
+int tdm_launch_combine_dh1_mask_s16(const float* dcat, const float* dp1, const float* a2, float* dout1, float* dc_s16,
+                                    float* slab, long slab_stride, int b_masked_off, int B, int nslab, hipStream_t st) {
+    hipLaunchKernelGGL(combine_dh1_mask_s16_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, dcat, dp1, a2, dout1, dc_s16, slab,
+                       slab_stride, b_masked_off, B);
+    TDM_CHECK_LAUNCH("combine_dh1_mask_s16");
     return 0;
 }
 int tdm_launch_relu_bwd_tb_s16(float* dh, const float* a1, float* dc1_s16, float* S, float* S2, int B, int HWpix, int C,

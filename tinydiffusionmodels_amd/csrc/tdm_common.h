@@ -145,6 +145,10 @@ int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, c
                            float* dout_s16, float* dc2_s16, float* slab, long slab_stride, int w_off, int b_off,
                            int c2b_off, int skb_off, int64_t M, int nslab, hipStream_t st);
 // dc_s16 = split(dout * (a > 0)); slab partial sums of the masked (and optionally unmasked) gradient per channel
+int tdm_launch_split_dcat_mask_s16(const float* dcat, const float* a2, float* dout3, float* dc_s16, float* slab,
+                                   long slab_stride, int b_masked_off, int B, int nslab, hipStream_t st);
+int tdm_launch_combine_dh1_mask_s16(const float* dcat, const float* dp1, const float* a2, float* dout1, float* dc_s16,
+                                    float* slab, long slab_stride, int b_masked_off, int B, int nslab, hipStream_t st);
 int tdm_launch_relu_mask_s16(const float* dout, const float* a, float* dc_s16, float* slab, long slab_stride,
                              int b_masked_off, int b_unmasked_off, int64_t M, int C, int nslab, hipStream_t st);
 // dh <- dh * (a1 > 0) in place (fp32) + S16 copy; S[b][c] = sum dh (unmasked), S2[b][c] = sum of the masked values

@@ -333,9 +333,8 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
         a.out = w.dcat; a.B = B;
         TDM_TRY(tdm_launch_conv_s16(a, 28, 96, st));
     }
-    TDM_TRY(tdm_launch_split_dcat(w.dcat, w.dout3, B, st));
-    // ---- rb3 ----
-    TDM_TRY(tdm_launch_relu_mask_s16(w.dout3, w.a2_3, w.dc2s_3, slabs, NP, r3.c2b, -1, M14, 64, NS, st));
+    // ---- rb3 ---- (upsample backward and the ReLU mask of rb3.conv2's output in one pass)
+    TDM_TRY(tdm_launch_split_dcat_mask_s16(w.dcat, w.a2_3, w.dout3, w.dc2s_3, slabs, NP, r3.c2b, B, NS, st));
     TDM_TRY(wgrad_s16(st, 14, B, w.a1s_3, 64, 64, 0, 9, w.dc2s_3, 64, slabs, r3.c2w, 64, 0, NS4));
     TDM_TRY(conv_s16_1(st, w, 14, B, w.dc2s_3, 64, 9, kPack.dg[W_RB3C2], 64, nullptr, 0,
                        S16Out{w.dh3, nullptr, nullptr, nullptr, nullptr}));
@@ -359,9 +358,8 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
         a.out = w.dp1; a.B = B;
         TDM_TRY(tdm_launch_conv_s16(a, 14, 32, st));
     }
-    TDM_TRY(tdm_launch_combine_dh1(w.dcat, w.dp1, w.dout1, B, st));
-    // ---- rb1 ----
-    TDM_TRY(tdm_launch_relu_mask_s16(w.dout1, w.a2_1, w.dc2s_1, slabs, NP, r1.c2b, -1, M28, 32, NS, st));
+    // ---- rb1 ---- (concat skip + avg-pool backward and the ReLU mask of rb1.conv2's output in one pass)
+    TDM_TRY(tdm_launch_combine_dh1_mask_s16(w.dcat, w.dp1, w.a2_1, w.dout1, w.dc2s_1, slabs, NP, r1.c2b, B, NS, st));
     TDM_TRY(wgrad_s16(st, 28, B, w.a1s_1, 32, 32, 0, 9, w.dc2s_1, 32, slabs, r1.c2w, 32, 0, NS));
     TDM_TRY(conv_s16_1(st, w, 28, B, w.dc2s_1, 32, 9, kPack.dg[W_RB1C2], 32, nullptr, 0,
                        S16Out{w.dh1, nullptr, nullptr, nullptr, nullptr}));
