@@ -753,8 +753,9 @@ __global__ __launch_bounds__(EW_BLOCK) void combine_dh1_mask_s16_kernel(const fl
     quad_reduce_store(gm, sh, 8, slab + (long)blockIdx.x * slab_stride + b_masked_off);
 }
 
-// relu_bwd_tb_kernel + S16 copy of the masked gradient + per-sample masked sums S2
-__global__ __launch_bounds__(EW_BLOCK) void relu_bwd_tb_s16_kernel(float* __restrict__ dh, const float* __restrict__ a1,
+// relu_bwd_tb_kernel for the S16 pipeline: the masked gradient is written ONLY as its S16 twin (its consumers are the
+// weight- and data-gradient MFMA kernels; the fp32 tensor is not read again) + per-sample unmasked / masked sums S / S2
+__global__ __launch_bounds__(EW_BLOCK) void relu_bwd_tb_s16_kernel(const float* __restrict__ dh, const float* __restrict__ a1,
                                                                    float* __restrict__ dc1_s16, float* __restrict__ S,
                                                                    float* __restrict__ S2, int HWpix, int C) {
     __shared__ float4 sh[EW_BLOCK];
@@ -771,7 +772,6 @@ __global__ __launch_bounds__(EW_BLOCK) void relu_bwd_tb_s16_kernel(float* __rest
         o.x = av.x > 0.f ? d.x : 0.f; o.y = av.y > 0.f ? d.y : 0.f;
         o.z = av.z > 0.f ? d.z : 0.f; o.w = av.w > 0.f ? d.w : 0.f;
         accm.x += o.x; accm.y += o.y; accm.z += o.z; accm.w += o.w;
-        reinterpret_cast<float4*>(dh)[i] = o;
         tdm_store_s16_4(dc1_s16, pix0 + p, C, c4 * 4, o);
     }
     quad_reduce_store(acc, sh, C4, S + (int64_t)blockIdx.x * C);
@@ -915,8 +915,8 @@ int tdm_launch_combine_dh1_mask_s16(const float* dcat, const float* dp1, const f
     TDM_CHECK_LAUNCH("combine_dh1_mask_s16");
     return 0;
 }
-int tdm_launch_relu_bwd_tb_s16(float* dh, const float* a1, float* dc1_s16, float* S, float* S2, int B, int HWpix, int C,
-                               hipStream_t st) {
+int tdm_launch_relu_bwd_tb_s16(const float* dh, const float* a1, float* dc1_s16, float* S, float* S2, int B, int HWpix,
+                               int C, hipStream_t st) {
     hipLaunchKernelGGL(relu_bwd_tb_s16_kernel, dim3(B), dim3(EW_BLOCK), 0, st, dh, a1, dc1_s16, S, S2, HWpix, C);
     TDM_CHECK_LAUNCH("relu_bwd_tb_s16");
     return 0;

@@ -152,7 +152,7 @@ int tdm_launch_combine_dh1_mask_s16(const float* dcat, const float* dp1, const f
 int tdm_launch_relu_mask_s16(const float* dout, const float* a, float* dc_s16, float* slab, long slab_stride,
                              int b_masked_off, int b_unmasked_off, int64_t M, int C, int nslab, hipStream_t st);
 // dh <- dh * (a1 > 0) in place (fp32) + S16 copy; S[b][c] = sum dh (unmasked), S2[b][c] = sum of the masked values
-int tdm_launch_relu_bwd_tb_s16(float* dh, const float* a1, float* dc1_s16, float* S, float* S2, int B, int HWpix, int C,
+int tdm_launch_relu_bwd_tb_s16(const float* dh, const float* a1, float* dc1_s16, float* S, float* S2, int B, int HWpix, int C,
                                hipStream_t st);
 int tdm_launch_time_grad_multi2(const float* const* S, const float* const* S2, float* const* d_tw, float* const* d_tb,
                                 float* const* d_b, const int* C, int n, const float* that, int B, hipStream_t st);
