@@ -236,6 +236,9 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
                     v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
                 }
                 if (a.aux != nullptr) *reinterpret_cast<float4*>(a.aux + o) = v;
+                if (a.mask_out != nullptr)
+                    a.mask_out[o >> 2] = (unsigned char)((v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) | (v.z > 0.f ? 4 : 0) |
+                                                         (v.w > 0.f ? 8 : 0));
                 if (a.res != nullptr) {
                     const float4 rz = *reinterpret_cast<const float4*>(a.res + o);
                     v.x += rz.x; v.y += rz.y; v.z += rz.z; v.w += rz.w;

@@ -621,10 +621,15 @@ __device__ __forceinline__ void quad_reduce_store(float4 v, float4* sh, int C4, 
     }
 }
 
+// ReLU backward with a byte mask (ConvArgs::mask_out): bit e of mk = (post-ReLU channel e of the quad > 0)
+__device__ __forceinline__ float4 mask4(const float4 d, unsigned mk) {
+    return make_float4((mk & 1u) ? d.x : 0.f, (mk & 2u) ? d.y : 0.f, (mk & 4u) ? d.z : 0.f, (mk & 8u) ? d.w : 0.f);
+}
+
 // out_bwd_kernel + S16 copies of dout / dc2 + bias gradients of rb4.conv2 (sum dc2) and rb4.skip (sum dout)
 __global__ __launch_bounds__(EW_BLOCK) void out_bwd_s16_kernel(const float* __restrict__ deps,
                                                                const float* __restrict__ h4, const float* __restrict__ w,
-                                                               const float* __restrict__ a2, float* __restrict__ dout,
+                                                               const unsigned char* __restrict__ a2m, float* __restrict__ dout,
                                                                float* __restrict__ dout_s16, float* __restrict__ dc2_s16,
                                                                float* __restrict__ slab, long slab_stride, int w_off,
                                                                int b_off, int c2b_off, int skb_off, int64_t M) {
@@ -639,14 +644,12 @@ __global__ __launch_bounds__(EW_BLOCK) void out_bwd_s16_kernel(const float* __re
         const int64_t m = i >> 3;
         const float d = deps[m];
         const float4 hv = reinterpret_cast<const float4*>(h4)[i];
-        const float4 av = reinterpret_cast<const float4*>(a2)[i];
+        const unsigned am = a2m[i];
         float4 o;
         o.x = d * wv.x; o.y = d * wv.y; o.z = d * wv.z; o.w = d * wv.w;
         reinterpret_cast<float4*>(dout)[i] = o;
         tdm_store_s16_4(dout_s16, m, 32, c4 * 4, o);
-        float4 mk;
-        mk.x = av.x > 0.f ? o.x : 0.f; mk.y = av.y > 0.f ? o.y : 0.f;
-        mk.z = av.z > 0.f ? o.z : 0.f; mk.w = av.w > 0.f ? o.w : 0.f;
+        const float4 mk = mask4(o, am);
         tdm_store_s16_4(dc2_s16, m, 32, c4 * 4, mk);
         gw.x += d * hv.x; gw.y += d * hv.y; gw.z += d * hv.z; gw.w += d * hv.w;
         g_c2.x += mk.x; g_c2.y += mk.y; g_c2.z += mk.z; g_c2.w += mk.w;
@@ -663,7 +666,7 @@ __global__ __launch_bounds__(EW_BLOCK) void out_bwd_s16_kernel(const float* __re
 
 // dc_s16 = split(dout * (a > 0)); per-channel slab partials of the masked (and unmasked) gradient
 __global__ __launch_bounds__(EW_BLOCK) void relu_mask_s16_kernel(const float* __restrict__ dout,
-                                                                 const float* __restrict__ a, float* __restrict__ dc_s16,
+                                                                 const unsigned char* __restrict__ am, float* __restrict__ dc_s16,
                                                                  float* __restrict__ slab, long slab_stride,
                                                                  int b_masked_off, int b_unmasked_off, int64_t M, int C) {
     __shared__ float4 sh[EW_BLOCK];
@@ -673,10 +676,7 @@ __global__ __launch_bounds__(EW_BLOCK) void relu_mask_s16_kernel(const float* __
     const int64_t total = M * C4;
     for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
         const float4 d = reinterpret_cast<const float4*>(dout)[i];
-        const float4 av = reinterpret_cast<const float4*>(a)[i];
-        float4 o;
-        o.x = av.x > 0.f ? d.x : 0.f; o.y = av.y > 0.f ? d.y : 0.f;
-        o.z = av.z > 0.f ? d.z : 0.f; o.w = av.w > 0.f ? d.w : 0.f;
+        const float4 o = mask4(d, am[i]);
         tdm_store_s16_4(dc_s16, i / C4, C, c4 * 4, o);
         gm.x += o.x; gm.y += o.y; gm.z += o.z; gm.w += o.w;
         gu.x += d.x; gu.y += d.y; gu.z += d.z; gu.w += d.w;
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(EW_BLOCK) void relu_mask_s16_kernel(const float* __
 // dc2_s16 = split(dout3 * (a2 > 0)), slab partials of the masked gradient (rb3.conv2 bias gradient).
 // One workgroup per slab; c4 = tid & 15 is fixed per thread (the grid stride is a multiple of 16).
 __global__ __launch_bounds__(EW_BLOCK) void split_dcat_mask_s16_kernel(const float* __restrict__ dcat,
-                                                                       const float* __restrict__ a2,
+                                                                       const unsigned char* __restrict__ a2m,
                                                                        float* __restrict__ dout3, float* __restrict__ dc_s16,
                                                                        float* __restrict__ slab, long slab_stride,
                                                                        int b_masked_off, int B) {
@@ -706,14 +706,12 @@ __global__ __launch_bounds__(EW_BLOCK) void split_dcat_mask_s16_kernel(const flo
         const int64_t b = q / 14;
         const float4* src = reinterpret_cast<const float4*>(dcat) + ((b * 28 + 2 * yo) * 28 + 2 * xo) * 24 + c4;
         const float4 v00 = src[0], v01 = src[24], v10 = src[28 * 24], v11 = src[28 * 24 + 24];
-        const float4 av = reinterpret_cast<const float4*>(a2)[i];
+        const unsigned am = a2m[i];
         float4 d;
         d.x = ((v00.x + v01.x) + v10.x) + v11.x; d.y = ((v00.y + v01.y) + v10.y) + v11.y;
         d.z = ((v00.z + v01.z) + v10.z) + v11.z; d.w = ((v00.w + v01.w) + v10.w) + v11.w;
         reinterpret_cast<float4*>(dout3)[i] = d;
-        float4 o;
-        o.x = av.x > 0.f ? d.x : 0.f; o.y = av.y > 0.f ? d.y : 0.f;
-        o.z = av.z > 0.f ? d.z : 0.f; o.w = av.w > 0.f ? d.w : 0.f;
+        const float4 o = mask4(d, am);
         tdm_store_s16_4(dc_s16, p, 64, c4 * 4, o);
         gm.x += o.x; gm.y += o.y; gm.z += o.z; gm.w += o.w;
     }
@@ -724,7 +722,7 @@ __global__ __launch_bounds__(EW_BLOCK) void split_dcat_mask_s16_kernel(const flo
 // avg-pool backward), dc2_s16 = split(dout1 * (a2 > 0)), slab partials of the masked gradient (rb1.conv2 bias).
 __global__ __launch_bounds__(EW_BLOCK) void combine_dh1_mask_s16_kernel(const float* __restrict__ dcat,
                                                                         const float* __restrict__ dp1,
-                                                                        const float* __restrict__ a2,
+                                                                        const unsigned char* __restrict__ a2m,
                                                                         float* __restrict__ dout1, float* __restrict__ dc_s16,
                                                                         float* __restrict__ slab, long slab_stride,
                                                                         int b_masked_off, int B) {
@@ -740,13 +738,11 @@ __global__ __launch_bounds__(EW_BLOCK) void combine_dh1_mask_s16_kernel(const fl
         const int64_t b = q / 28;
         const float4 dc = reinterpret_cast<const float4*>(dcat)[p * 24 + 16 + c4];
         const float4 dp = reinterpret_cast<const float4*>(dp1)[((b * 14 + (y >> 1)) * 14 + (x >> 1)) * 8 + c4];
-        const float4 av = reinterpret_cast<const float4*>(a2)[i];
+        const unsigned am = a2m[i];
         float4 d;
         d.x = dc.x + 0.25f * dp.x; d.y = dc.y + 0.25f * dp.y; d.z = dc.z + 0.25f * dp.z; d.w = dc.w + 0.25f * dp.w;
         reinterpret_cast<float4*>(dout1)[i] = d;
-        float4 o;
-        o.x = av.x > 0.f ? d.x : 0.f; o.y = av.y > 0.f ? d.y : 0.f;
-        o.z = av.z > 0.f ? d.z : 0.f; o.w = av.w > 0.f ? d.w : 0.f;
+        const float4 o = mask4(d, am);
         tdm_store_s16_4(dc_s16, p, 32, c4 * 4, o);
         gm.x += o.x; gm.y += o.y; gm.z += o.z; gm.w += o.w;
     }
@@ -755,7 +751,7 @@ __global__ __launch_bounds__(EW_BLOCK) void combine_dh1_mask_s16_kernel(const fl
 
 // relu_bwd_tb_kernel for the S16 pipeline: the masked gradient is written ONLY as its S16 twin (its consumers are the
 // weight- and data-gradient MFMA kernels; the fp32 tensor is not read again) + per-sample unmasked / masked sums S / S2
-__global__ __launch_bounds__(EW_BLOCK) void relu_bwd_tb_s16_kernel(const float* __restrict__ dh, const float* __restrict__ a1,
+__global__ __launch_bounds__(EW_BLOCK) void relu_bwd_tb_s16_kernel(const float* __restrict__ dh, const unsigned char* __restrict__ a1m,
                                                                    float* __restrict__ dc1_s16, float* __restrict__ S,
                                                                    float* __restrict__ S2, int HWpix, int C) {
     __shared__ float4 sh[EW_BLOCK];
@@ -766,11 +762,8 @@ __global__ __launch_bounds__(EW_BLOCK) void relu_bwd_tb_s16_kernel(const float* 
     for (int p = pg; p < HWpix; p += npg) {
         const int64_t i = (pix0 + p) * C4 + c4;
         const float4 d = reinterpret_cast<const float4*>(dh)[i];
-        const float4 av = reinterpret_cast<const float4*>(a1)[i];
         acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
-        float4 o;
-        o.x = av.x > 0.f ? d.x : 0.f; o.y = av.y > 0.f ? d.y : 0.f;
-        o.z = av.z > 0.f ? d.z : 0.f; o.w = av.w > 0.f ? d.w : 0.f;
+        const float4 o = mask4(d, a1m[i]);
         accm.x += o.x; accm.y += o.y; accm.z += o.z; accm.w += o.w;
         tdm_store_s16_4(dc1_s16, pix0 + p, C, c4 * 4, o);
     }
@@ -885,7 +878,7 @@ int tdm_launch_avgpool_s16(const float* in, float* out, float* out_s16, int B, i
     TDM_CHECK_LAUNCH("avgpool_s16");
     return 0;
 }
-int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, const float* a2, float* dout,
+int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, const unsigned char* a2, float* dout,
                            float* dout_s16, float* dc2_s16, float* slab, long slab_stride, int w_off, int b_off,
                            int c2b_off, int skb_off, int64_t M, int nslab, hipStream_t st) {
     hipLaunchKernelGGL(out_bwd_s16_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, deps, h4, w, a2, dout, dout_s16, dc2_s16,
@@ -893,7 +886,7 @@ int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, c
     TDM_CHECK_LAUNCH("out_bwd_s16");
     return 0;
 }
-int tdm_launch_relu_mask_s16(const float* dout, const float* a, float* dc_s16, float* slab, long slab_stride,
+int tdm_launch_relu_mask_s16(const float* dout, const unsigned char* a, float* dc_s16, float* slab, long slab_stride,
                              int b_masked_off, int b_unmasked_off, int64_t M, int C, int nslab, hipStream_t st) {
     TDM_REQUIRE(C % 16 == 0 && EW_BLOCK % (C / 4) == 0, "relu_mask_s16: C=%d", C);
     hipLaunchKernelGGL(relu_mask_s16_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, dout, a, dc_s16, slab, slab_stride,
@@ -901,21 +894,21 @@ int tdm_launch_relu_mask_s16(const float* dout, const float* a, float* dc_s16, f
     TDM_CHECK_LAUNCH("relu_mask_s16");
     return 0;
 }
-int tdm_launch_split_dcat_mask_s16(const float* dcat, const float* a2, float* dout3, float* dc_s16, float* slab,
+int tdm_launch_split_dcat_mask_s16(const float* dcat, const unsigned char* a2, float* dout3, float* dc_s16, float* slab,
                                    long slab_stride, int b_masked_off, int B, int nslab, hipStream_t st) {
     hipLaunchKernelGGL(split_dcat_mask_s16_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, dcat, a2, dout3, dc_s16, slab,
                        slab_stride, b_masked_off, B);
     TDM_CHECK_LAUNCH("split_dcat_mask_s16");
     return 0;
 }
-int tdm_launch_combine_dh1_mask_s16(const float* dcat, const float* dp1, const float* a2, float* dout1, float* dc_s16,
+int tdm_launch_combine_dh1_mask_s16(const float* dcat, const float* dp1, const unsigned char* a2, float* dout1, float* dc_s16,
                                     float* slab, long slab_stride, int b_masked_off, int B, int nslab, hipStream_t st) {
     hipLaunchKernelGGL(combine_dh1_mask_s16_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, dcat, dp1, a2, dout1, dc_s16, slab,
                        slab_stride, b_masked_off, B);
     TDM_CHECK_LAUNCH("combine_dh1_mask_s16");
     return 0;
 }
-int tdm_launch_relu_bwd_tb_s16(const float* dh, const float* a1, float* dc1_s16, float* S, float* S2, int B, int HWpix,
+int tdm_launch_relu_bwd_tb_s16(const float* dh, const unsigned char* a1, float* dc1_s16, float* S, float* S2, int B, int HWpix,
                                int C, hipStream_t st) {
     hipLaunchKernelGGL(relu_bwd_tb_s16_kernel, dim3(B), dim3(EW_BLOCK), 0, st, dh, a1, dc1_s16, S, S2, HWpix, C);
     TDM_CHECK_LAUNCH("relu_bwd_tb_s16");

@@ -70,6 +70,9 @@ struct ConvArgs {
     float* out_s16;           // [M][N] S16 copy of the result (+ tb_out), or nullptr
     const float* tb_out;      // [B][tb_out_stride]: per-(sample, channel) bias folded into out_s16 only
     int tb_out_stride;
+    // [M][N/4] bytes or nullptr: bit e of byte (m, c/4) = (value after ReLU of channel c + e > 0).  What backward needs of
+    // a post-ReLU tensor is its sign; a byte per 4 channels replaces a 16-byte fp32 quad in both directions.
+    unsigned char* mask_out;
 };
 
 // hw in {28,14}; N in {32,64,96}; dgrad: transposed convolution with the forward weights
@@ -141,18 +144,18 @@ int tdm_launch_first_wgrad(const float* x, const float* dc1, const float* dout1,
 int tdm_launch_conv_first_s16(const float* x, const float* w1, const float* b1, const float* ws, const float* bs,
                               const float* tb, int tb_stride, float* a1, float* a1_s16, float* s, int B, hipStream_t st);
 int tdm_launch_avgpool_s16(const float* in, float* out, float* out_s16, int B, int Hout, int C, hipStream_t st);
-int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, const float* a2, float* dout,
+int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, const unsigned char* a2m, float* dout,
                            float* dout_s16, float* dc2_s16, float* slab, long slab_stride, int w_off, int b_off,
                            int c2b_off, int skb_off, int64_t M, int nslab, hipStream_t st);
 // dc_s16 = split(dout * (a > 0)); slab partial sums of the masked (and optionally unmasked) gradient per channel
-int tdm_launch_split_dcat_mask_s16(const float* dcat, const float* a2, float* dout3, float* dc_s16, float* slab,
+int tdm_launch_split_dcat_mask_s16(const float* dcat, const unsigned char* a2m, float* dout3, float* dc_s16, float* slab,
                                    long slab_stride, int b_masked_off, int B, int nslab, hipStream_t st);
-int tdm_launch_combine_dh1_mask_s16(const float* dcat, const float* dp1, const float* a2, float* dout1, float* dc_s16,
+int tdm_launch_combine_dh1_mask_s16(const float* dcat, const float* dp1, const unsigned char* a2m, float* dout1, float* dc_s16,
                                     float* slab, long slab_stride, int b_masked_off, int B, int nslab, hipStream_t st);
-int tdm_launch_relu_mask_s16(const float* dout, const float* a, float* dc_s16, float* slab, long slab_stride,
+int tdm_launch_relu_mask_s16(const float* dout, const unsigned char* am, float* dc_s16, float* slab, long slab_stride,
                              int b_masked_off, int b_unmasked_off, int64_t M, int C, int nslab, hipStream_t st);
 // dh <- dh * (a1 > 0) in place (fp32) + S16 copy; S[b][c] = sum dh (unmasked), S2[b][c] = sum of the masked values
-int tdm_launch_relu_bwd_tb_s16(const float* dh, const float* a1, float* dc1_s16, float* S, float* S2, int B, int HWpix, int C,
+int tdm_launch_relu_bwd_tb_s16(const float* dh, const unsigned char* a1m, float* dc1_s16, float* S, float* S2, int B, int HWpix, int C,
                                hipStream_t st);
 int tdm_launch_time_grad_multi2(const float* const* S, const float* const* S2, float* const* d_tw, float* const* d_tb,
                                 float* const* d_b, const int* C, int n, const float* that, int B, hipStream_t st);

@@ -104,6 +104,7 @@ struct Ws {
     // S16 pipeline (mode 2): pre-split copies read by the conv / wgrad loaders
     float *a1s_1, *h1s, *p1s, *a1s_2, *h2s, *a1s_3, *h3s, *a1s_4;
     float *dout4s, *dc2s_4, *dh4s, *dc2s_3, *dh3s, *dc2s_2, *dh2s, *dout2s, *dc2s_1, *S2[4];
+    unsigned char *m1[4], *m2[4];   // ReLU byte masks of conv1 / conv2 outputs of the 4 blocks (S16 pipeline, training)
     int64_t total;
 };
 
@@ -136,6 +137,12 @@ Ws carve(float* base, int64_t B, int training) {
         w.dc2s_3 = take(M14 * 64); w.dh3s = take(M14 * 64); w.dc2s_2 = take(M14 * 64); w.dh2s = take(M14 * 64);
         w.dout2s = take(M14 * 64); w.dc2s_1 = take(M28 * 32);
         for (int i = 0; i < 4; ++i) w.S2[i] = take(B * 64);
+        // byte masks: one byte per 4 channels = (pixels * C / 4) bytes = pixels * C / 16 floats
+        const int64_t mfl[4] = {M28 * 32 / 16, M14 * 64 / 16, M14 * 64 / 16, M28 * 32 / 16};
+        for (int i = 0; i < 4; ++i) {
+            w.m1[i] = reinterpret_cast<unsigned char*>(take(mfl[i]));
+            w.m2[i] = reinterpret_cast<unsigned char*>(take(mfl[i]));
+        }
     }
     w.total = off;
     return w;
@@ -237,14 +244,14 @@ ConvSrc s16_src(const float* ptr, int C, int nch, int up, int taps, const unsign
     s.ptr = ptr; s.C = C; s.c0 = 0; s.nch = nch; s.up = up; s.taps = taps; s.wp = wp; s.wchunk0 = wchunk0;
     return s;
 }
-struct S16Out { float* out; float* aux; const float* res; float* out_s16; const float* tb_out; };
+struct S16Out { float* out; unsigned char* mask; const float* res; float* out_s16; const float* tb_out; };
 int conv_s16_1(hipStream_t st, const Ws& ws, int hw, int B, const float* in_s16, int Cin, int taps, long wpoff, int N,
                const float* bias, int relu, const S16Out& o) {
     ConvArgs a{};
     a.nsrc = 1;
     a.src[0] = s16_src(in_s16, Cin, Cin, 0, taps, ws.wpack + wpoff, 0);
     a.bias = bias; a.relu = relu; a.B = B;
-    a.out = o.out; a.aux = o.aux; a.res = o.res; a.out_s16 = o.out_s16; a.tb_out = o.tb_out; a.tb_out_stride = 192;
+    a.out = o.out; a.mask_out = o.mask; a.res = o.res; a.out_s16 = o.out_s16; a.tb_out = o.tb_out; a.tb_out_stride = 192;
     return tdm_launch_conv_s16(a, hw, N, st);
 }
 int wgrad_s16(hipStream_t st, int hw, int B, const float* act_s16, int C, int c_used, int up, int taps,
@@ -269,20 +276,20 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
     TDM_TRY(tdm_launch_conv_first_s16(x, P + r1.c1w, P + r1.c1b, P + r1.skw, P + r1.skb, w.tb + 0, 192, w.a1_1, w.a1s_1,
                                       w.s1, B, st));
     TDM_TRY(conv_s16_1(st, w, 28, B, w.a1s_1, 32, 9, kPack.fwd[W_RB1C2], 32, P + r1.c2b, 1,
-                       S16Out{w.h1, save ? w.a2_1 : nullptr, w.s1, w.h1s, nullptr}));
+                       S16Out{w.h1, save ? w.m2[0] : nullptr, w.s1, w.h1s, nullptr}));
     // rb2 on avg_pool2d(h1)
     TDM_TRY(tdm_launch_avgpool_s16(w.h1, nullptr, w.p1s, B, 14, 32, st));
     TDM_TRY(conv_s16_1(st, w, 14, B, w.p1s, 32, 9, kPack.fwd[W_RB2C1], 64, P + r2.c1b, 1,
-                       S16Out{save ? w.a1_2 : nullptr, nullptr, nullptr, w.a1s_2, w.tb + 32}));
+                       S16Out{nullptr, save ? w.m1[1] : nullptr, nullptr, w.a1s_2, w.tb + 32}));
     TDM_TRY(conv_s16_1(st, w, 14, B, w.p1s, 32, 1, kPack.fwd[W_RB2SK], 64, P + r2.skb, 0,
                        S16Out{w.s2, nullptr, nullptr, nullptr, nullptr}));
     TDM_TRY(conv_s16_1(st, w, 14, B, w.a1s_2, 64, 9, kPack.fwd[W_RB2C2], 64, P + r2.c2b, 1,
-                       S16Out{w.h2, save ? w.a2_2 : nullptr, w.s2, w.h2s, nullptr}));
+                       S16Out{w.h2, save ? w.m2[1] : nullptr, w.s2, w.h2s, nullptr}));
     // rb3 (identity skip)
     TDM_TRY(conv_s16_1(st, w, 14, B, w.h2s, 64, 9, kPack.fwd[W_RB3C1], 64, P + r3.c1b, 1,
-                       S16Out{save ? w.a1_3 : nullptr, nullptr, nullptr, w.a1s_3, w.tb + 96}));
+                       S16Out{nullptr, save ? w.m1[2] : nullptr, nullptr, w.a1s_3, w.tb + 96}));
     TDM_TRY(conv_s16_1(st, w, 14, B, w.a1s_3, 64, 9, kPack.fwd[W_RB3C2], 64, P + r3.c2b, 1,
-                       S16Out{w.h3, save ? w.a2_3 : nullptr, w.h2, w.h3s, nullptr}));
+                       S16Out{w.h3, save ? w.m2[2] : nullptr, w.h2, w.h3s, nullptr}));
     // rb4 on cat([up2(h3), h1])
     {
         ConvArgs a{};
@@ -290,7 +297,7 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
         a.src[0] = s16_src(w.h3s, 64, 64, 1, 9, w.wpack + kPack.fwd[W_RB4C1], 0);
         a.src[1] = s16_src(w.h1s, 32, 32, 0, 9, w.wpack + kPack.fwd[W_RB4C1], 4);
         a.bias = P + r4.c1b; a.relu = 1; a.B = B;
-        a.out = save ? w.a1_4 : nullptr; a.out_s16 = w.a1s_4; a.tb_out = w.tb + 160; a.tb_out_stride = 192;
+        a.mask_out = save ? w.m1[3] : nullptr; a.out_s16 = w.a1s_4; a.tb_out = w.tb + 160; a.tb_out_stride = 192;
         TDM_TRY(tdm_launch_conv_s16(a, 28, 32, st));
         ConvArgs k{};
         k.nsrc = 2;
@@ -300,7 +307,7 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
         TDM_TRY(tdm_launch_conv_s16(k, 28, 32, st));
     }
     TDM_TRY(conv_s16_1(st, w, 28, B, w.a1s_4, 32, 9, kPack.fwd[W_RB4C2], 32, P + r4.c2b, 1,
-                       S16Out{w.h4, save ? w.a2_4 : nullptr, w.s4, nullptr, nullptr}));
+                       S16Out{w.h4, save ? w.m2[3] : nullptr, w.s4, nullptr, nullptr}));
     TDM_TRY(tdm_launch_conv_out(w.h4, P + kL.outw, P + kL.outb, eps, (int64_t)B * 784, st));
     return 0;
 }
@@ -315,12 +322,12 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     const int64_t M28 = (int64_t)B * 784, M14 = (int64_t)B * 196;
     const long NP = TDM_UNET_NPARAM;
     // ---- out conv + rb4 ----
-    TDM_TRY(tdm_launch_out_bwd_s16(deps, w.h4, P + kL.outw, w.a2_4, w.dout4, w.dout4s, w.dc2s_4, slabs, NP, kL.outw,
+    TDM_TRY(tdm_launch_out_bwd_s16(deps, w.h4, P + kL.outw, w.m2[3], w.dout4, w.dout4s, w.dc2s_4, slabs, NP, kL.outw,
                                    kL.outb, r4.c2b, r4.skb, M28, NS, st));
     TDM_TRY(wgrad_s16(st, 28, B, w.a1s_4, 32, 32, 0, 9, w.dc2s_4, 32, slabs, r4.c2w, 32, 0, NS));
     TDM_TRY(conv_s16_1(st, w, 28, B, w.dc2s_4, 32, 9, kPack.dg[W_RB4C2], 32, nullptr, 0,
                        S16Out{w.dh4, nullptr, nullptr, nullptr, nullptr}));
-    TDM_TRY(tdm_launch_relu_bwd_tb_s16(w.dh4, w.a1_4, w.dh4s, w.S[3], w.S2[3], B, 784, 32, st));
+    TDM_TRY(tdm_launch_relu_bwd_tb_s16(w.dh4, w.m1[3], w.dh4s, w.S[3], w.S2[3], B, 784, 32, st));
     TDM_TRY(wgrad_s16(st, 28, B, w.h3s, 64, 64, 1, 9, w.dh4s, 32, slabs, r4.c1w, 96, 0, NS));
     TDM_TRY(wgrad_s16(st, 28, B, w.h1s, 32, 32, 0, 9, w.dh4s, 32, slabs, r4.c1w, 96, 64, NS));
     TDM_TRY(wgrad_s16(st, 28, B, w.h3s, 64, 64, 1, 1, w.dout4s, 32, slabs, r4.skw, 96, 0, NS));
@@ -334,20 +341,20 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
         TDM_TRY(tdm_launch_conv_s16(a, 28, 96, st));
     }
     // ---- rb3 ---- (upsample backward and the ReLU mask of rb3.conv2's output in one pass)
-    TDM_TRY(tdm_launch_split_dcat_mask_s16(w.dcat, w.a2_3, w.dout3, w.dc2s_3, slabs, NP, r3.c2b, B, NS, st));
+    TDM_TRY(tdm_launch_split_dcat_mask_s16(w.dcat, w.m2[2], w.dout3, w.dc2s_3, slabs, NP, r3.c2b, B, NS, st));
     TDM_TRY(wgrad_s16(st, 14, B, w.a1s_3, 64, 64, 0, 9, w.dc2s_3, 64, slabs, r3.c2w, 64, 0, NS4));
     TDM_TRY(conv_s16_1(st, w, 14, B, w.dc2s_3, 64, 9, kPack.dg[W_RB3C2], 64, nullptr, 0,
                        S16Out{w.dh3, nullptr, nullptr, nullptr, nullptr}));
-    TDM_TRY(tdm_launch_relu_bwd_tb_s16(w.dh3, w.a1_3, w.dh3s, w.S[2], w.S2[2], B, 196, 64, st));
+    TDM_TRY(tdm_launch_relu_bwd_tb_s16(w.dh3, w.m1[2], w.dh3s, w.S[2], w.S2[2], B, 196, 64, st));
     TDM_TRY(wgrad_s16(st, 14, B, w.h2s, 64, 64, 0, 9, w.dh3s, 64, slabs, r3.c1w, 64, 0, NS4));
     TDM_TRY(conv_s16_1(st, w, 14, B, w.dh3s, 64, 9, kPack.dg[W_RB3C1], 64, nullptr, 0,
                        S16Out{w.dout2, nullptr, w.dout3, w.dout2s, nullptr}));   // + identity skip
     // ---- rb2 ----
-    TDM_TRY(tdm_launch_relu_mask_s16(w.dout2, w.a2_2, w.dc2s_2, slabs, NP, r2.c2b, r2.skb, M14, 64, NS, st));
+    TDM_TRY(tdm_launch_relu_mask_s16(w.dout2, w.m2[1], w.dc2s_2, slabs, NP, r2.c2b, r2.skb, M14, 64, NS, st));
     TDM_TRY(wgrad_s16(st, 14, B, w.a1s_2, 64, 64, 0, 9, w.dc2s_2, 64, slabs, r2.c2w, 64, 0, NS4));
     TDM_TRY(conv_s16_1(st, w, 14, B, w.dc2s_2, 64, 9, kPack.dg[W_RB2C2], 64, nullptr, 0,
                        S16Out{w.dh2, nullptr, nullptr, nullptr, nullptr}));
-    TDM_TRY(tdm_launch_relu_bwd_tb_s16(w.dh2, w.a1_2, w.dh2s, w.S[1], w.S2[1], B, 196, 64, st));
+    TDM_TRY(tdm_launch_relu_bwd_tb_s16(w.dh2, w.m1[1], w.dh2s, w.S[1], w.S2[1], B, 196, 64, st));
     TDM_TRY(wgrad_s16(st, 14, B, w.p1s, 32, 32, 0, 9, w.dh2s, 64, slabs, r2.c1w, 32, 0, NS2));
     TDM_TRY(wgrad_s16(st, 14, B, w.p1s, 32, 32, 0, 1, w.dout2s, 64, slabs, r2.skw, 32, 0, NS2));
     {
@@ -359,7 +366,7 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
         TDM_TRY(tdm_launch_conv_s16(a, 14, 32, st));
     }
     // ---- rb1 ---- (concat skip + avg-pool backward and the ReLU mask of rb1.conv2's output in one pass)
-    TDM_TRY(tdm_launch_combine_dh1_mask_s16(w.dcat, w.dp1, w.a2_1, w.dout1, w.dc2s_1, slabs, NP, r1.c2b, B, NS, st));
+    TDM_TRY(tdm_launch_combine_dh1_mask_s16(w.dcat, w.dp1, w.m2[0], w.dout1, w.dc2s_1, slabs, NP, r1.c2b, B, NS, st));
     TDM_TRY(wgrad_s16(st, 28, B, w.a1s_1, 32, 32, 0, 9, w.dc2s_1, 32, slabs, r1.c2w, 32, 0, NS));
     TDM_TRY(conv_s16_1(st, w, 28, B, w.dc2s_1, 32, 9, kPack.dg[W_RB1C2], 32, nullptr, 0,
                        S16Out{w.dh1, nullptr, nullptr, nullptr, nullptr}));
