@@ -339,6 +339,34 @@ __global__ __launch_bounds__(EW_BLOCK) void relu_bwd_tb_kernel(float* __restrict
     }
 }
 
+// same, with the byte mask the S16 forward saved instead of the fp32 post-ReLU tensor (rb1 in the S16 pipeline)
+__global__ __launch_bounds__(EW_BLOCK) void relu_bwd_tb_bm_kernel(float* __restrict__ dh, const unsigned char* __restrict__ a1m,
+                                                                  float* __restrict__ S, int HWpix, int C) {
+    __shared__ float4 sh[EW_BLOCK];
+    const int C4 = C >> 2;
+    const int c4 = threadIdx.x % C4, pg = threadIdx.x / C4, npg = EW_BLOCK / C4;
+    const int64_t base = (int64_t)blockIdx.x * HWpix * C4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = pg; p < HWpix; p += npg) {
+        const int64_t i = base + (int64_t)p * C4 + c4;
+        const float4 d = reinterpret_cast<const float4*>(dh)[i];
+        const unsigned mk = a1m[i];
+        acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+        reinterpret_cast<float4*>(dh)[i] = make_float4((mk & 1u) ? d.x : 0.f, (mk & 2u) ? d.y : 0.f, (mk & 4u) ? d.z : 0.f,
+                                                       (mk & 8u) ? d.w : 0.f);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < npg; ++g) {
+            const float4 v = sh[g * C4 + threadIdx.x];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(S)[(int64_t)blockIdx.x * C4 + threadIdx.x] = s;
+    }
+}
+
 // d_tw[c] = sum_b that[b]*S[b][c]; d_tb[c] = sum_b S[b][c].  One block per job (layer):
 // 256 threads = (256/C) batch slices x C channels, 8 independent loads in flight per thread.
 struct TimeGradJobs { const float* S[4]; const float* S2[4]; float* d_tw[4]; float* d_tb[4]; float* d_b[4]; int C[4]; int n; };
@@ -548,8 +576,8 @@ __global__ __launch_bounds__(EW_BLOCK) void conv_first_s16_kernel(const float* _
                                                                   const float* __restrict__ ws,
                                                                   const float* __restrict__ bs,
                                                                   const float* __restrict__ tb, int tb_stride,
-                                                                  float* __restrict__ a1, float* __restrict__ a1_s16,
-                                                                  float* __restrict__ s, int B) {
+                                                                  float* __restrict__ a1, unsigned char* __restrict__ a1m,
+                                                                  float* __restrict__ a1_s16, float* __restrict__ s, int B) {
     const int64_t total = (int64_t)B * 784 * 8;
     for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
         const int c4 = (int)(i & 7);
@@ -571,7 +599,9 @@ __global__ __launch_bounds__(EW_BLOCK) void conv_first_s16_kernel(const float* _
         }
         acc.x = acc.x < 0.f ? 0.f : acc.x; acc.y = acc.y < 0.f ? 0.f : acc.y;
         acc.z = acc.z < 0.f ? 0.f : acc.z; acc.w = acc.w < 0.f ? 0.f : acc.w;
-        *reinterpret_cast<float4*>(a1 + m * 32 + c4 * 4) = acc;
+        if (a1 != nullptr) *reinterpret_cast<float4*>(a1 + m * 32 + c4 * 4) = acc;
+        if (a1m != nullptr)
+            a1m[i] = (unsigned char)((acc.x > 0.f ? 1 : 0) | (acc.y > 0.f ? 2 : 0) | (acc.z > 0.f ? 4 : 0) | (acc.w > 0.f ? 8 : 0));
         const float4 t4 = *reinterpret_cast<const float4*>(tb + (int64_t)b * tb_stride + c4 * 4);
         tdm_store_s16_4(a1_s16, m, 32, c4 * 4, make_float4(acc.x + t4.x, acc.y + t4.y, acc.z + t4.z, acc.w + t4.w));
         const float4 wsv = *reinterpret_cast<const float4*>(ws + c4 * 4);
@@ -647,7 +677,7 @@ __global__ __launch_bounds__(EW_BLOCK) void out_bwd_s16_kernel(const float* __re
         const unsigned am = a2m[i];
         float4 o;
         o.x = d * wv.x; o.y = d * wv.y; o.z = d * wv.z; o.w = d * wv.w;
-        reinterpret_cast<float4*>(dout)[i] = o;
+        if (dout != nullptr) reinterpret_cast<float4*>(dout)[i] = o;
         tdm_store_s16_4(dout_s16, m, 32, c4 * 4, o);
         const float4 mk = mask4(o, am);
         tdm_store_s16_4(dc2_s16, m, 32, c4 * 4, mk);
@@ -810,6 +840,11 @@ int tdm_launch_relu_mask(const float* dout, const float* a, float* dc, int64_t n
     TDM_CHECK_LAUNCH("relu_mask");
     return 0;
 }
+int tdm_launch_relu_bwd_tb_bm(float* dh, const unsigned char* a1m, float* S, int B, int HWpix, int C, hipStream_t st) {
+    hipLaunchKernelGGL(relu_bwd_tb_bm_kernel, dim3(B), dim3(EW_BLOCK), 0, st, dh, a1m, S, HWpix, C);
+    TDM_CHECK_LAUNCH("relu_bwd_tb_bm");
+    return 0;
+}
 int tdm_launch_relu_bwd_tb(float* dh, const float* a1, float* S, int B, int HWpix, int C, hipStream_t st) {
     hipLaunchKernelGGL(relu_bwd_tb_kernel, dim3(B), dim3(EW_BLOCK), 0, st, dh, a1, S, HWpix, C);
     TDM_CHECK_LAUNCH("relu_bwd_tb");
@@ -866,9 +901,10 @@ int tdm_launch_nhwc_to_nchw(const float* in, float* out, int B, int HWpix, int C
 }
 
 int tdm_launch_conv_first_s16(const float* x, const float* w1, const float* b1, const float* ws, const float* bs,
-                              const float* tb, int tb_stride, float* a1, float* a1_s16, float* s, int B, hipStream_t st) {
+                              const float* tb, int tb_stride, float* a1, unsigned char* a1m, float* a1_s16, float* s, int B,
+                              hipStream_t st) {
     hipLaunchKernelGGL(conv_first_s16_kernel, dim3(ew_grid((int64_t)B * 784 * 8)), dim3(EW_BLOCK), 0, st, x, w1, b1, ws, bs,
-                       tb, tb_stride, a1, a1_s16, s, B);
+                       tb, tb_stride, a1, a1m, a1_s16, s, B);
     TDM_CHECK_LAUNCH("conv_first_s16");
     return 0;
 }

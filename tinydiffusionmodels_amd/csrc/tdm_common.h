@@ -133,6 +133,7 @@ int tdm_launch_out_bwd(const float* deps, const float* h4, const float* w, const
                        int64_t M, int nslab, hipStream_t st);
 int tdm_launch_relu_mask(const float* dout, const float* a, float* dc, int64_t n, hipStream_t st);
 int tdm_launch_relu_bwd_tb(float* dh, const float* a1, float* S, int B, int HWpix, int C, hipStream_t st);
+int tdm_launch_relu_bwd_tb_bm(float* dh, const unsigned char* a1m, float* S, int B, int HWpix, int C, hipStream_t st);
 int tdm_launch_time_grad(const float* S, const float* that, float* d_tw, float* d_tb, int B, int C, hipStream_t st);
 int tdm_launch_time_grad_multi(const float* const* S, float* const* d_tw, float* const* d_tb, const int* C, int n,
                                const float* that, int B, hipStream_t st);
@@ -142,7 +143,8 @@ int tdm_launch_first_wgrad(const float* x, const float* dc1, const float* dout1,
                            int w1_off, int b1_off, int ws_off, int bs_off, int B, int nslab, hipStream_t st);
 // S16-pipeline producers (optional extra outputs; nullptr = not written)
 int tdm_launch_conv_first_s16(const float* x, const float* w1, const float* b1, const float* ws, const float* bs,
-                              const float* tb, int tb_stride, float* a1, float* a1_s16, float* s, int B, hipStream_t st);
+                              const float* tb, int tb_stride, float* a1, unsigned char* a1m, float* a1_s16, float* s, int B,
+                              hipStream_t st);
 int tdm_launch_avgpool_s16(const float* in, float* out, float* out_s16, int B, int Hout, int C, hipStream_t st);
 int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, const unsigned char* a2m, float* dout,
                            float* dout_s16, float* dc2_s16, float* slab, long slab_stride, int w_off, int b_off,

@@ -273,8 +273,8 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
     TDM_TRY(tdm_launch_pack(P, kPack.pa, w.wpack, st));
     const BlockOff &r1 = kL.rb[0], &r2 = kL.rb[1], &r3 = kL.rb[2], &r4 = kL.rb[3];
     // rb1: conv1 (Cin = 1) writes a1 (mask) and split(a1 + tb) for conv2
-    TDM_TRY(tdm_launch_conv_first_s16(x, P + r1.c1w, P + r1.c1b, P + r1.skw, P + r1.skb, w.tb + 0, 192, w.a1_1, w.a1s_1,
-                                      w.s1, B, st));
+    TDM_TRY(tdm_launch_conv_first_s16(x, P + r1.c1w, P + r1.c1b, P + r1.skw, P + r1.skb, w.tb + 0, 192, nullptr,
+                                      save ? w.m1[0] : nullptr, w.a1s_1, w.s1, B, st));
     TDM_TRY(conv_s16_1(st, w, 28, B, w.a1s_1, 32, 9, kPack.fwd[W_RB1C2], 32, P + r1.c2b, 1,
                        S16Out{w.h1, save ? w.m2[0] : nullptr, w.s1, w.h1s, nullptr}));
     // rb2 on avg_pool2d(h1)
@@ -322,7 +322,7 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     const int64_t M28 = (int64_t)B * 784, M14 = (int64_t)B * 196;
     const long NP = TDM_UNET_NPARAM;
     // ---- out conv + rb4 ----
-    TDM_TRY(tdm_launch_out_bwd_s16(deps, w.h4, P + kL.outw, w.m2[3], w.dout4, w.dout4s, w.dc2s_4, slabs, NP, kL.outw,
+    TDM_TRY(tdm_launch_out_bwd_s16(deps, w.h4, P + kL.outw, w.m2[3], nullptr, w.dout4s, w.dc2s_4, slabs, NP, kL.outw,
                                    kL.outb, r4.c2b, r4.skb, M28, NS, st));
     TDM_TRY(wgrad_s16(st, 28, B, w.a1s_4, 32, 32, 0, 9, w.dc2s_4, 32, slabs, r4.c2w, 32, 0, NS));
     TDM_TRY(conv_s16_1(st, w, 28, B, w.dc2s_4, 32, 9, kPack.dg[W_RB4C2], 32, nullptr, 0,
@@ -370,7 +370,7 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     TDM_TRY(wgrad_s16(st, 28, B, w.a1s_1, 32, 32, 0, 9, w.dc2s_1, 32, slabs, r1.c2w, 32, 0, NS));
     TDM_TRY(conv_s16_1(st, w, 28, B, w.dc2s_1, 32, 9, kPack.dg[W_RB1C2], 32, nullptr, 0,
                        S16Out{w.dh1, nullptr, nullptr, nullptr, nullptr}));
-    TDM_TRY(tdm_launch_relu_bwd_tb(w.dh1, w.a1_1, w.S[0], B, 784, 32, st));
+    TDM_TRY(tdm_launch_relu_bwd_tb_bm(w.dh1, w.m1[0], w.S[0], B, 784, 32, st));
     {   // time_emb gradients of all four blocks + conv1 bias gradients of rb2..rb4, one launch
         const float* Sv[4] = {w.S[0], w.S[1], w.S[2], w.S[3]};
         const float* S2v[4] = {nullptr, w.S2[1], w.S2[2], w.S2[3]};
