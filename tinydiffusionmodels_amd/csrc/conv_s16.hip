@@ -219,6 +219,13 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
                 *reinterpret_cast<float4*>(T + j * EPI + nt * 32 + 8 * g + 4 * h) =
                     make_float4(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
         const int mbase = m0 + (wave * 2 + mt) * 32;
+        const bool bwd = NT != 3 && a.relu_mask_in != nullptr;   // (N = 32 / 64 outputs only)
+        const int img0 = mbase / (G::H * G::W);   // image of the group's first pixel
+        float4 sacc[2][2];                        // [slot][kind] partial sums of this lane's channel quad (bwd only)
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int kd = 0; kd < 2; ++kd) sacc[sl][kd] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int it = 0; it < N / 8; ++it) {   // 32 * N/4 float4 per pass, 64 per instruction
             const int e = it * 64 + lane;
@@ -243,6 +250,20 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
                     const float4 rz = *reinterpret_cast<const float4*>(a.res + o);
                     v.x += rz.x; v.y += rz.y; v.z += rz.z; v.w += rz.w;
                 }
+                if (bwd) {   // ReLU backward of the tensor this gradient belongs to + the sums its bias gradients need
+                    const unsigned mk = a.relu_mask_in[o >> 2];
+                    const float4 mv = make_float4((mk & 1u) ? v.x : 0.f, (mk & 2u) ? v.y : 0.f, (mk & 4u) ? v.z : 0.f,
+                                                  (mk & 8u) ? v.w : 0.f);
+                    const int sl = (m / (G::H * G::W) != img0) ? 1 : 0;
+                    if (sl == 0) {
+                        sacc[0][0].x += v.x; sacc[0][0].y += v.y; sacc[0][0].z += v.z; sacc[0][0].w += v.w;
+                        sacc[0][1].x += mv.x; sacc[0][1].y += mv.y; sacc[0][1].z += mv.z; sacc[0][1].w += mv.w;
+                    } else {
+                        sacc[1][0].x += v.x; sacc[1][0].y += v.y; sacc[1][0].z += v.z; sacc[1][0].w += v.w;
+                        sacc[1][1].x += mv.x; sacc[1][1].y += mv.y; sacc[1][1].z += mv.z; sacc[1][1].w += mv.w;
+                    }
+                    v = mv;
+                }
                 if (a.out != nullptr) *reinterpret_cast<float4*>(a.out + o) = v;
                 if (a.out_s16 != nullptr) {
                     if (a.tb_out != nullptr) {
@@ -252,6 +273,24 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
                     tdm_store_s16_4(a.out_s16, m, N, c, v);
                 }
             }
+        }
+        if (bwd && a.sums != nullptr) {
+            // lanes with equal lane % (N/4) hold the same channel quad of different pixels: butterfly over the rest
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                for (int kd = 0; kd < 2; ++kd) {
+                    float4 r = sacc[sl][kd];
+#pragma unroll
+                    for (int off = N / 4; off < 64; off <<= 1) {
+                        r.x += __shfl_xor(r.x, off); r.y += __shfl_xor(r.y, off);
+                        r.z += __shfl_xor(r.z, off); r.w += __shfl_xor(r.w, off);
+                    }
+                    if (lane < N / 4 && mbase < Mtot) {
+                        const long grp = mbase >> 5;
+                        *reinterpret_cast<float4*>(a.sums + ((grp * 2 + sl) * 2 + kd) * N + lane * 4) = r;
+                    }
+                }
         }
     }
 }

@@ -370,12 +370,13 @@ __global__ __launch_bounds__(EW_BLOCK) void relu_bwd_tb_bm_kernel(float* __restr
 // d_tw[c] = sum_b that[b]*S[b][c]; d_tb[c] = sum_b S[b][c].  One block per job (layer):
 // 256 threads = (256/C) batch slices x C channels, 8 independent loads in flight per thread.
 struct TimeGradJobs { const float* S[4]; const float* S2[4]; float* d_tw[4]; float* d_tb[4]; float* d_b[4]; int C[4]; int n; };
-__global__ __launch_bounds__(EW_BLOCK) void time_grad_kernel(TimeGradJobs jb, const float* __restrict__ that, int B) {
-    __shared__ float shw[EW_BLOCK], shb[EW_BLOCK];
+constexpr int TG_BLOCK = 1024;   // one workgroup per job: the loop over samples is latency-bound, use all 16 waves
+__global__ __launch_bounds__(TG_BLOCK) void time_grad_kernel(TimeGradJobs jb, const float* __restrict__ that, int B) {
+    __shared__ float shw[TG_BLOCK], shb[TG_BLOCK];
     const int job = blockIdx.x;
     const float* __restrict__ S = jb.S[job];
     const int C = jb.C[job];
-    const int c = threadIdx.x % C, g = threadIdx.x / C, ng = EW_BLOCK / C;
+    const int c = threadIdx.x % C, g = threadIdx.x / C, ng = TG_BLOCK / C;
     float aw = 0.f, ab = 0.f;
     int b = g;
     for (; b + 7 * ng < B; b += 8 * ng) {
@@ -840,6 +841,34 @@ int tdm_launch_relu_mask(const float* dout, const float* a, float* dc, int64_t n
     TDM_CHECK_LAUNCH("relu_mask");
     return 0;
 }
+// S[b][c] (kind 0) and S2[b][c] (kind 1) from the per-32-pixel-group partials a data-gradient conv launch wrote
+// (ConvArgs::sums): one workgroup per image, thread (kind, c); fixed summation order.
+__global__ __launch_bounds__(128) void image_sums_kernel(const float* __restrict__ sums, float* __restrict__ S,
+                                                         float* __restrict__ S2, int HWpix, int C) {
+    const int b = blockIdx.x;
+    const int kd = threadIdx.x / C, c = threadIdx.x - kd * C;
+    if (kd >= 2) return;
+    const long p0 = (long)b * HWpix, p1 = p0 + HWpix;      // pixel range of the image
+    const long g0 = p0 >> 5, g1 = (p1 - 1) >> 5;
+    // only the first group can start in the previous image (it then reaches this image through slot 1)
+    const int sl0 = ((g0 << 5) < p0) ? 1 : 0;
+    const long gstride = 4L * C;                            // floats per group: [slot][kind][C]
+    const float* base = sums + kd * C + c;
+    float a0 = base[g0 * gstride + sl0 * 2 * C], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    long g = g0 + 1;
+    for (; g + 3 <= g1; g += 4) {                           // 4 independent loads in flight
+        a0 += base[g * gstride]; a1 += base[(g + 1) * gstride];
+        a2 += base[(g + 2) * gstride]; a3 += base[(g + 3) * gstride];
+    }
+    for (; g <= g1; ++g) a0 += base[g * gstride];
+    (kd == 0 ? S : S2)[(long)b * C + c] = (a0 + a1) + (a2 + a3);
+}
+int tdm_launch_image_sums(const float* sums, float* S, float* S2, int B, int HWpix, int C, hipStream_t st) {
+    TDM_REQUIRE(2 * C <= 128, "image_sums: C=%d", C);
+    hipLaunchKernelGGL(image_sums_kernel, dim3(B), dim3(128), 0, st, sums, S, S2, HWpix, C);
+    TDM_CHECK_LAUNCH("image_sums");
+    return 0;
+}
 int tdm_launch_relu_bwd_tb_bm(float* dh, const unsigned char* a1m, float* S, int B, int HWpix, int C, hipStream_t st) {
     hipLaunchKernelGGL(relu_bwd_tb_bm_kernel, dim3(B), dim3(EW_BLOCK), 0, st, dh, a1m, S, HWpix, C);
     TDM_CHECK_LAUNCH("relu_bwd_tb_bm");
@@ -872,7 +901,7 @@ int tdm_launch_time_grad_multi2(const float* const* S, const float* const* S2, f
         jb.d_b[i] = (d_b != nullptr) ? d_b[i] : nullptr;
     }
     jb.n = n;
-    hipLaunchKernelGGL(time_grad_kernel, dim3(n), dim3(EW_BLOCK), 0, st, jb, that, B);
+    hipLaunchKernelGGL(time_grad_kernel, dim3(n), dim3(TG_BLOCK), 0, st, jb, that, B);
     TDM_CHECK_LAUNCH("time_grad");
     return 0;
 }

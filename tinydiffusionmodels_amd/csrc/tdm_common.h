@@ -73,6 +73,13 @@ struct ConvArgs {
     // [M][N/4] bytes or nullptr: bit e of byte (m, c/4) = (value after ReLU of channel c + e > 0).  What backward needs of
     // a post-ReLU tensor is its sign; a byte per 4 channels replaces a 16-byte fp32 quad in both directions.
     unsigned char* mask_out;
+    // ReLU backward fused into a data-gradient launch (S16 kernel): when relu_mask_in != nullptr the result v of the
+    // transposed conv is the gradient w.r.t. a post-ReLU tensor (+ time bias); `out` / `out_s16` then receive
+    // v * (mask bit) and `sums` the per-32-pixel-group partial sums the time-bias / bias gradients need:
+    // sums[((group*2 + slot)*2 + kind)*N + c], kind 0 = sum v (unmasked), 1 = sum of the masked value; slot 0 = pixels
+    // of the image the group's first pixel belongs to, slot 1 = pixels of the next image (a group may straddle two).
+    const unsigned char* relu_mask_in;
+    float* sums;
 };
 
 // hw in {28,14}; N in {32,64,96}; dgrad: transposed convolution with the forward weights
@@ -133,6 +140,8 @@ int tdm_launch_out_bwd(const float* deps, const float* h4, const float* w, const
                        int64_t M, int nslab, hipStream_t st);
 int tdm_launch_relu_mask(const float* dout, const float* a, float* dc, int64_t n, hipStream_t st);
 int tdm_launch_relu_bwd_tb(float* dh, const float* a1, float* S, int B, int HWpix, int C, hipStream_t st);
+// S[b][c] / S2[b][c] = per-image sums of the group partials written by a conv launch with relu_mask_in (ConvArgs::sums)
+int tdm_launch_image_sums(const float* sums, float* S, float* S2, int B, int HWpix, int C, hipStream_t st);
 int tdm_launch_relu_bwd_tb_bm(float* dh, const unsigned char* a1m, float* S, int B, int HWpix, int C, hipStream_t st);
 int tdm_launch_time_grad(const float* S, const float* that, float* d_tw, float* d_tb, int B, int C, hipStream_t st);
 int tdm_launch_time_grad_multi(const float* const* S, float* const* d_tw, float* const* d_tb, const int* C, int n,

@@ -104,6 +104,7 @@ struct Ws {
     // S16 pipeline (mode 2): pre-split copies read by the conv / wgrad loaders
     float *a1s_1, *h1s, *p1s, *a1s_2, *h2s, *a1s_3, *h3s, *a1s_4;
     float *dout4s, *dc2s_4, *dh4s, *dc2s_3, *dh3s, *dc2s_2, *dh2s, *dout2s, *dc2s_1, *S2[4];
+    float* gsum;                    // per-32-pixel-group partial sums of a data-gradient launch (ConvArgs::sums)
     unsigned char *m1[4], *m2[4];   // ReLU byte masks of conv1 / conv2 outputs of the 4 blocks (S16 pipeline, training)
     int64_t total;
 };
@@ -137,6 +138,7 @@ Ws carve(float* base, int64_t B, int training) {
         w.dc2s_3 = take(M14 * 64); w.dh3s = take(M14 * 64); w.dc2s_2 = take(M14 * 64); w.dh2s = take(M14 * 64);
         w.dout2s = take(M14 * 64); w.dc2s_1 = take(M28 * 32);
         for (int i = 0; i < 4; ++i) w.S2[i] = take(B * 64);
+        w.gsum = take((M28 / 32 + 2) * 4 * 32 > (M14 / 32 + 2) * 4 * 64 ? (M28 / 32 + 2) * 4 * 32 : (M14 / 32 + 2) * 4 * 64);
         // byte masks: one byte per 4 channels = (pixels * C / 4) bytes = pixels * C / 16 floats
         const int64_t mfl[4] = {M28 * 32 / 16, M14 * 64 / 16, M14 * 64 / 16, M28 * 32 / 16};
         for (int i = 0; i < 4; ++i) {
@@ -244,7 +246,8 @@ ConvSrc s16_src(const float* ptr, int C, int nch, int up, int taps, const unsign
     s.ptr = ptr; s.C = C; s.c0 = 0; s.nch = nch; s.up = up; s.taps = taps; s.wp = wp; s.wchunk0 = wchunk0;
     return s;
 }
-struct S16Out { float* out; unsigned char* mask; const float* res; float* out_s16; const float* tb_out; };
+struct S16Out { float* out; unsigned char* mask; const float* res; float* out_s16; const float* tb_out;
+                const unsigned char* relu_mask_in = nullptr; float* sums = nullptr; };
 int conv_s16_1(hipStream_t st, const Ws& ws, int hw, int B, const float* in_s16, int Cin, int taps, long wpoff, int N,
                const float* bias, int relu, const S16Out& o) {
     ConvArgs a{};
@@ -252,6 +255,7 @@ int conv_s16_1(hipStream_t st, const Ws& ws, int hw, int B, const float* in_s16,
     a.src[0] = s16_src(in_s16, Cin, Cin, 0, taps, ws.wpack + wpoff, 0);
     a.bias = bias; a.relu = relu; a.B = B;
     a.out = o.out; a.mask_out = o.mask; a.res = o.res; a.out_s16 = o.out_s16; a.tb_out = o.tb_out; a.tb_out_stride = 192;
+    a.relu_mask_in = o.relu_mask_in; a.sums = o.sums;
     return tdm_launch_conv_s16(a, hw, N, st);
 }
 int wgrad_s16(hipStream_t st, int hw, int B, const float* act_s16, int C, int c_used, int up, int taps,
@@ -326,8 +330,8 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
                                    kL.outb, r4.c2b, r4.skb, M28, NS, st));
     TDM_TRY(wgrad_s16(st, 28, B, w.a1s_4, 32, 32, 0, 9, w.dc2s_4, 32, slabs, r4.c2w, 32, 0, NS));
     TDM_TRY(conv_s16_1(st, w, 28, B, w.dc2s_4, 32, 9, kPack.dg[W_RB4C2], 32, nullptr, 0,
-                       S16Out{w.dh4, nullptr, nullptr, nullptr, nullptr}));
-    TDM_TRY(tdm_launch_relu_bwd_tb_s16(w.dh4, w.m1[3], w.dh4s, w.S[3], w.S2[3], B, 784, 32, st));
+                       S16Out{nullptr, nullptr, nullptr, w.dh4s, nullptr, w.m1[3], w.gsum}));   // + ReLU backward of a1
+    TDM_TRY(tdm_launch_image_sums(w.gsum, w.S[3], w.S2[3], B, 784, 32, st));
     TDM_TRY(wgrad_s16(st, 28, B, w.h3s, 64, 64, 1, 9, w.dh4s, 32, slabs, r4.c1w, 96, 0, NS));
     TDM_TRY(wgrad_s16(st, 28, B, w.h1s, 32, 32, 0, 9, w.dh4s, 32, slabs, r4.c1w, 96, 64, NS));
     TDM_TRY(wgrad_s16(st, 28, B, w.h3s, 64, 64, 1, 1, w.dout4s, 32, slabs, r4.skw, 96, 0, NS));
@@ -344,8 +348,8 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     TDM_TRY(tdm_launch_split_dcat_mask_s16(w.dcat, w.m2[2], w.dout3, w.dc2s_3, slabs, NP, r3.c2b, B, NS, st));
     TDM_TRY(wgrad_s16(st, 14, B, w.a1s_3, 64, 64, 0, 9, w.dc2s_3, 64, slabs, r3.c2w, 64, 0, NS4));
     TDM_TRY(conv_s16_1(st, w, 14, B, w.dc2s_3, 64, 9, kPack.dg[W_RB3C2], 64, nullptr, 0,
-                       S16Out{w.dh3, nullptr, nullptr, nullptr, nullptr}));
-    TDM_TRY(tdm_launch_relu_bwd_tb_s16(w.dh3, w.m1[2], w.dh3s, w.S[2], w.S2[2], B, 196, 64, st));
+                       S16Out{nullptr, nullptr, nullptr, w.dh3s, nullptr, w.m1[2], w.gsum}));
+    TDM_TRY(tdm_launch_image_sums(w.gsum, w.S[2], w.S2[2], B, 196, 64, st));
     TDM_TRY(wgrad_s16(st, 14, B, w.h2s, 64, 64, 0, 9, w.dh3s, 64, slabs, r3.c1w, 64, 0, NS4));
     TDM_TRY(conv_s16_1(st, w, 14, B, w.dh3s, 64, 9, kPack.dg[W_RB3C1], 64, nullptr, 0,
                        S16Out{w.dout2, nullptr, w.dout3, w.dout2s, nullptr}));   // + identity skip
@@ -353,8 +357,8 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     TDM_TRY(tdm_launch_relu_mask_s16(w.dout2, w.m2[1], w.dc2s_2, slabs, NP, r2.c2b, r2.skb, M14, 64, NS, st));
     TDM_TRY(wgrad_s16(st, 14, B, w.a1s_2, 64, 64, 0, 9, w.dc2s_2, 64, slabs, r2.c2w, 64, 0, NS4));
     TDM_TRY(conv_s16_1(st, w, 14, B, w.dc2s_2, 64, 9, kPack.dg[W_RB2C2], 64, nullptr, 0,
-                       S16Out{w.dh2, nullptr, nullptr, nullptr, nullptr}));
-    TDM_TRY(tdm_launch_relu_bwd_tb_s16(w.dh2, w.m1[1], w.dh2s, w.S[1], w.S2[1], B, 196, 64, st));
+                       S16Out{nullptr, nullptr, nullptr, w.dh2s, nullptr, w.m1[1], w.gsum}));
+    TDM_TRY(tdm_launch_image_sums(w.gsum, w.S[1], w.S2[1], B, 196, 64, st));
     TDM_TRY(wgrad_s16(st, 14, B, w.p1s, 32, 32, 0, 9, w.dh2s, 64, slabs, r2.c1w, 32, 0, NS2));
     TDM_TRY(wgrad_s16(st, 14, B, w.p1s, 32, 32, 0, 1, w.dout2s, 64, slabs, r2.skw, 32, 0, NS2));
     {
@@ -369,8 +373,8 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     TDM_TRY(tdm_launch_combine_dh1_mask_s16(w.dcat, w.dp1, w.m2[0], w.dout1, w.dc2s_1, slabs, NP, r1.c2b, B, NS, st));
     TDM_TRY(wgrad_s16(st, 28, B, w.a1s_1, 32, 32, 0, 9, w.dc2s_1, 32, slabs, r1.c2w, 32, 0, NS));
     TDM_TRY(conv_s16_1(st, w, 28, B, w.dc2s_1, 32, 9, kPack.dg[W_RB1C2], 32, nullptr, 0,
-                       S16Out{w.dh1, nullptr, nullptr, nullptr, nullptr}));
-    TDM_TRY(tdm_launch_relu_bwd_tb_bm(w.dh1, w.m1[0], w.S[0], B, 784, 32, st));
+                       S16Out{w.dh1, nullptr, nullptr, nullptr, nullptr, w.m1[0], w.gsum}));   // dh1 <- masked, fp32 (rb1.conv1 wgrad)
+    TDM_TRY(tdm_launch_image_sums(w.gsum, w.S[0], w.S2[0], B, 784, 32, st));
     {   // time_emb gradients of all four blocks + conv1 bias gradients of rb2..rb4, one launch
         const float* Sv[4] = {w.S[0], w.S[1], w.S[2], w.S[3]};
         const float* S2v[4] = {nullptr, w.S2[1], w.S2[2], w.S2[3]};
