@@ -187,17 +187,27 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
     const bool pf = !(a.ablate & 1);
     prefetch_in(pinA, goffA, planA, 0);
     prefetch_w(0);
-    if (nchunks > 1) prefetch_in(pinB, goffB, planB, 1);
-    for (int c = 0; c < nchunks; c += 2) {
-        stage(pinA);                                                  // chunk c
-        if (c + 2 < nchunks && pf) prefetch_in(pinA, goffA, planA, c + 2);
-        if (c + 1 < nchunks && pf) prefetch_w(c + 1);
-        compute(c);
-        if (c + 1 >= nchunks) break;
-        stage(pinB);                                                  // chunk c + 1
-        if (c + 3 < nchunks && pf) prefetch_in(pinB, goffB, planB, c + 3);
-        if (c + 2 < nchunks && pf) prefetch_w(c + 2);
-        compute(c + 1);
+    if constexpr (NT == 1) {
+        if (nchunks > 1) prefetch_in(pinB, goffB, planB, 1);
+        for (int c = 0; c < nchunks; c += 2) {
+            stage(pinA);                                                  // chunk c
+            if (c + 2 < nchunks && pf) prefetch_in(pinA, goffA, planA, c + 2);
+            if (c + 1 < nchunks && pf) prefetch_w(c + 1);
+            compute(c);
+            if (c + 1 >= nchunks) break;
+            stage(pinB);                                                  // chunk c + 1
+            if (c + 3 < nchunks && pf) prefetch_in(pinB, goffB, planB, c + 3);
+            if (c + 2 < nchunks && pf) prefetch_w(c + 2);
+            compute(c + 1);
+        }
+    } else {
+        // N = 64 / 96: 64-96 accumulator registers; a second input register set spills inside the K loop
+        // (21 scratch reloads per chunk were measured), so these widths prefetch one chunk ahead
+        for (int c = 0; c < nchunks; ++c) {
+            stage(pinA);
+            if (c + 1 < nchunks && pf) { prefetch_in(pinA, goffA, planA, c + 1); prefetch_w(c + 1); }
+            compute(c);
+        }
     }
 
     // Epilogue through LDS.  In the accumulator layout lane = pixel j of its M tile and register quad g of N tile
