@@ -69,7 +69,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 template <int NPROD>
-__global__ __launch_bounds__(256, 3) void gemm_nt_bf16_kernel(GemmArgs g, int ntx, int ntiles) {
+__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g, int ntx, int ntiles) {
     // planes: A hi, A lo, B hi, B lo  (lo planes unused when NPROD == 1)
     __shared__ __attribute__((aligned(16))) char lds[4 * PLANE];
     char* Ahi = lds; char* Alo = lds + PLANE; char* Bhi = lds + 2 * PLANE; char* Blo = lds + 3 * PLANE;
