@@ -339,34 +339,6 @@ __global__ __launch_bounds__(EW_BLOCK) void relu_bwd_tb_kernel(float* __restrict
     }
 }
 
-// same, with the byte mask the S16 forward saved instead of the fp32 post-ReLU tensor (rb1 in the S16 pipeline)
-__global__ __launch_bounds__(EW_BLOCK) void relu_bwd_tb_bm_kernel(float* __restrict__ dh, const unsigned char* __restrict__ a1m,
-                                                                  float* __restrict__ S, int HWpix, int C) {
-    __shared__ float4 sh[EW_BLOCK];
-    const int C4 = C >> 2;
-    const int c4 = threadIdx.x % C4, pg = threadIdx.x / C4, npg = EW_BLOCK / C4;
-    const int64_t base = (int64_t)blockIdx.x * HWpix * C4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p = pg; p < HWpix; p += npg) {
-        const int64_t i = base + (int64_t)p * C4 + c4;
-        const float4 d = reinterpret_cast<const float4*>(dh)[i];
-        const unsigned mk = a1m[i];
-        acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
-        reinterpret_cast<float4*>(dh)[i] = make_float4((mk & 1u) ? d.x : 0.f, (mk & 2u) ? d.y : 0.f, (mk & 4u) ? d.z : 0.f,
-                                                       (mk & 8u) ? d.w : 0.f);
-    }
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    if (threadIdx.x < C4) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int g = 0; g < npg; ++g) {
-            const float4 v = sh[g * C4 + threadIdx.x];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        reinterpret_cast<float4*>(S)[(int64_t)blockIdx.x * C4 + threadIdx.x] = s;
-    }
-}
-
 // d_tw[c] = sum_b that[b]*S[b][c]; d_tb[c] = sum_b S[b][c].  One block per job (layer):
 // 256 threads = (256/C) batch slices x C channels, 8 independent loads in flight per thread.
 struct TimeGradJobs { const float* S[4]; const float* S2[4]; float* d_tw[4]; float* d_tb[4]; float* d_b[4]; int C[4]; int n; };
@@ -780,28 +752,6 @@ __global__ __launch_bounds__(EW_BLOCK) void combine_dh1_mask_s16_kernel(const fl
     quad_reduce_store(gm, sh, 8, slab + (long)blockIdx.x * slab_stride + b_masked_off);
 }
 
-// relu_bwd_tb_kernel for the S16 pipeline: the masked gradient is written ONLY as its S16 twin (its consumers are the
-// weight- and data-gradient MFMA kernels; the fp32 tensor is not read again) + per-sample unmasked / masked sums S / S2
-__global__ __launch_bounds__(EW_BLOCK) void relu_bwd_tb_s16_kernel(const float* __restrict__ dh, const unsigned char* __restrict__ a1m,
-                                                                   float* __restrict__ dc1_s16, float* __restrict__ S,
-                                                                   float* __restrict__ S2, int HWpix, int C) {
-    __shared__ float4 sh[EW_BLOCK];
-    const int C4 = C >> 2;
-    const int c4 = threadIdx.x % C4, pg = threadIdx.x / C4, npg = EW_BLOCK / C4;
-    const int64_t pix0 = (int64_t)blockIdx.x * HWpix;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accm = acc;
-    for (int p = pg; p < HWpix; p += npg) {
-        const int64_t i = (pix0 + p) * C4 + c4;
-        const float4 d = reinterpret_cast<const float4*>(dh)[i];
-        acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
-        const float4 o = mask4(d, a1m[i]);
-        accm.x += o.x; accm.y += o.y; accm.z += o.z; accm.w += o.w;
-        tdm_store_s16_4(dc1_s16, pix0 + p, C, c4 * 4, o);
-    }
-    quad_reduce_store(acc, sh, C4, S + (int64_t)blockIdx.x * C);
-    quad_reduce_store(accm, sh, C4, S2 + (int64_t)blockIdx.x * C);
-}
-
 // ------------------------------- launchers -----------------------------------
 int tdm_launch_timebias(const int64_t* t, const float* params, const int* te_w_off, const int* te_b_off, float* that,
                         float* tb, int B, hipStream_t st) {
@@ -867,11 +817,6 @@ int tdm_launch_image_sums(const float* sums, float* S, float* S2, int B, int HWp
     TDM_REQUIRE(2 * C <= 128, "image_sums: C=%d", C);
     hipLaunchKernelGGL(image_sums_kernel, dim3(B), dim3(128), 0, st, sums, S, S2, HWpix, C);
     TDM_CHECK_LAUNCH("image_sums");
-    return 0;
-}
-int tdm_launch_relu_bwd_tb_bm(float* dh, const unsigned char* a1m, float* S, int B, int HWpix, int C, hipStream_t st) {
-    hipLaunchKernelGGL(relu_bwd_tb_bm_kernel, dim3(B), dim3(EW_BLOCK), 0, st, dh, a1m, S, HWpix, C);
-    TDM_CHECK_LAUNCH("relu_bwd_tb_bm");
     return 0;
 }
 int tdm_launch_relu_bwd_tb(float* dh, const float* a1, float* S, int B, int HWpix, int C, hipStream_t st) {
@@ -971,12 +916,6 @@ int tdm_launch_combine_dh1_mask_s16(const float* dcat, const float* dp1, const u
     hipLaunchKernelGGL(combine_dh1_mask_s16_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, dcat, dp1, a2, dout1, dc_s16, slab,
                        slab_stride, b_masked_off, B);
     TDM_CHECK_LAUNCH("combine_dh1_mask_s16");
-    return 0;
-}
-int tdm_launch_relu_bwd_tb_s16(const float* dh, const unsigned char* a1, float* dc1_s16, float* S, float* S2, int B, int HWpix,
-                               int C, hipStream_t st) {
-    hipLaunchKernelGGL(relu_bwd_tb_s16_kernel, dim3(B), dim3(EW_BLOCK), 0, st, dh, a1, dc1_s16, S, S2, HWpix, C);
-    TDM_CHECK_LAUNCH("relu_bwd_tb_s16");
     return 0;
 }
 

@@ -142,7 +142,6 @@ int tdm_launch_relu_mask(const float* dout, const float* a, float* dc, int64_t n
 int tdm_launch_relu_bwd_tb(float* dh, const float* a1, float* S, int B, int HWpix, int C, hipStream_t st);
 // S[b][c] / S2[b][c] = per-image sums of the group partials written by a conv launch with relu_mask_in (ConvArgs::sums)
 int tdm_launch_image_sums(const float* sums, float* S, float* S2, int B, int HWpix, int C, hipStream_t st);
-int tdm_launch_relu_bwd_tb_bm(float* dh, const unsigned char* a1m, float* S, int B, int HWpix, int C, hipStream_t st);
 int tdm_launch_time_grad(const float* S, const float* that, float* d_tw, float* d_tb, int B, int C, hipStream_t st);
 int tdm_launch_time_grad_multi(const float* const* S, float* const* d_tw, float* const* d_tb, const int* C, int n,
                                const float* that, int B, hipStream_t st);
@@ -166,8 +165,6 @@ int tdm_launch_combine_dh1_mask_s16(const float* dcat, const float* dp1, const u
 int tdm_launch_relu_mask_s16(const float* dout, const unsigned char* am, float* dc_s16, float* slab, long slab_stride,
                              int b_masked_off, int b_unmasked_off, int64_t M, int C, int nslab, hipStream_t st);
 // dh <- dh * (a1 > 0) in place (fp32) + S16 copy; S[b][c] = sum dh (unmasked), S2[b][c] = sum of the masked values
-int tdm_launch_relu_bwd_tb_s16(const float* dh, const unsigned char* a1m, float* dc1_s16, float* S, float* S2, int B, int HWpix, int C,
-                               hipStream_t st);
 int tdm_launch_time_grad_multi2(const float* const* S, const float* const* S2, float* const* d_tw, float* const* d_tb,
                                 float* const* d_b, const int* C, int n, const float* that, int B, hipStream_t st);
 int tdm_launch_nhwc_to_nchw(const float* in, float* out, int B, int HWpix, int C, hipStream_t st);
