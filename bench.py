@@ -73,10 +73,10 @@ def time_kernel(fn, iters=20, warm=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--sample-steps", type=int, default=40, help="reverse steps timed at B=4096 (0 = skip)")
-    ap.add_argument("--text-steps", type=int, default=10, help="text-denoiser train steps timed (0 = skip)")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--sample-steps", type=int, default=100, help="reverse steps timed at B=4096 (0 = skip)")
+    ap.add_argument("--text-steps", type=int, default=20, help="text-denoiser train steps timed (0 = skip)")
     ap.add_argument("--gemm-mode", type=int, default=1, choices=[0, 1, 2],
                     help="transformer linear layers: 1 = bf16x3 split MFMA (default), 2 = plain bf16 MFMA, 0 = fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
