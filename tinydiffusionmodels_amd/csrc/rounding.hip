@@ -48,10 +48,11 @@ __global__ __launch_bounds__(256) void embed_scatter_add_kernel(const float* __r
 //   2. in place  logits[m][v] <- scale * (softmax(logits[m])[v] - [v == ids[m]]),  padding columns [V, ld) <- 0
 // The second sweep re-reads a 200 KB row the workgroup has just streamed (L2 hit), so HBM sees one read and one write
 // of the logits instead of the three reads + one write of separate statistics / gradient passes.
-__global__ __launch_bounds__(256) void ce_softmax_grad_kernel(float* __restrict__ logits, const int64_t* __restrict__ ids,
+constexpr int CE_BLOCK = 1024;   // 16 waves stream one 200 KB row: the kernel is latency-bound with fewer
+__global__ __launch_bounds__(CE_BLOCK) void ce_softmax_grad_kernel(float* __restrict__ logits, const int64_t* __restrict__ ids,
                                                               float* __restrict__ lse, float* __restrict__ rowloss, long M,
                                                               int V, long ld, float scale) {
-    __shared__ float redm[4], reds[4];
+    __shared__ float redm[CE_BLOCK / 64], reds[CE_BLOCK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ld4 = (int)(ld >> 2);
     for (long m = blockIdx.x; m < M; m += gridDim.x) {
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void ce_softmax_grad_kernel(float* __restrict_
         tgtl = tgtl < 0 ? 0 : (tgtl >= V ? V - 1 : tgtl);   // never index out of bounds on a bad id
         const int tgt = (int)tgtl;
         float mx = -INFINITY, sm = 0.f;
-        for (int q = threadIdx.x; q < ld4; q += 256) {
+        for (int q = threadIdx.x; q < ld4; q += CE_BLOCK) {
             const float4 x = reinterpret_cast<const float4*>(row)[q];
             const float r[4] = {x.x, x.y, x.z, x.w};
             float lm = -INFINITY;
@@ -81,14 +82,16 @@ __global__ __launch_bounds__(256) void ce_softmax_grad_kernel(float* __restrict_
         __syncthreads();
         if (lane == 0) { redm[wave] = mx; reds[wave] = sm; }
         __syncthreads();
-        const float gm = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+        float gm = redm[0];
+#pragma unroll
+        for (int w = 1; w < CE_BLOCK / 64; ++w) gm = fmaxf(gm, redm[w]);
         float gs = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) gs += redm[w] == -INFINITY ? 0.f : reds[w] * expf(redm[w] - gm);
+        for (int w = 0; w < CE_BLOCK / 64; ++w) gs += redm[w] == -INFINITY ? 0.f : reds[w] * expf(redm[w] - gm);
         const float l = gm + logf(gs);
         if (threadIdx.x == 0) { lse[m] = l; rowloss[m] = l - row[tgt]; }
         __syncthreads();   // row[tgt] is read before the row is overwritten
-        for (int q = threadIdx.x; q < ld4; q += 256) {
+        for (int q = threadIdx.x; q < ld4; q += CE_BLOCK) {
             const float4 x = reinterpret_cast<const float4*>(row)[q];
             float r[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
@@ -238,7 +241,7 @@ int tdm_round_ce_loss_grad_f32(const float* x, const float* W, const float* b, c
     TDM_TRY(logits_gemm(x, W, b, w.logits, M, V, Vp, D, st));
     // cross-entropy, mean over tokens                               (src/shakespeare.py:240)
     // g = grad_scale * (softmax - onehot) / M, in place over the logits; lse and the per-row loss on the way
-    hipLaunchKernelGGL(ce_softmax_grad_kernel, dim3((unsigned)(M < 16384 ? M : 16384)), dim3(256), 0, st, w.logits, ids, w.lse,
+    hipLaunchKernelGGL(ce_softmax_grad_kernel, dim3((unsigned)(M < 16384 ? M : 16384)), dim3(CE_BLOCK), 0, st, w.logits, ids, w.lse,
                        w.rowloss, (long)M, V, (long)Vp, grad_scale / (float)M);
     TDM_CHECK_LAUNCH("ce_softmax_grad");
     hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, st, w.rowloss, loss_out, (long)M);
