@@ -127,3 +127,23 @@ def test_mnist_idx_reader(tmp_path):
     assert torch.allclose(x[:, 0], (torch.from_numpy(imgs).float() / 255 - 0.5) / 0.5)
     with pytest.raises(RuntimeError, match="MNIST not found"):
         load_mnist_idx(str(tmp_path / "absent"))
+
+
+def test_text_corpus_pipeline(tmp_path):
+    """Local-file corpus -> byte tokens -> fixed-length chunks with a train/val split (src/shakespeare.py:122-156)."""
+    from tinydiffusionmodels_amd import shakespeare as S
+    text = "To be, or not to be, that is the question.\n" * 40
+    f = tmp_path / "corpus.txt"
+    f.write_text(text, encoding="utf-8")
+    assert S.load_text_dataset(str(f)) == text
+    with pytest.raises(FileNotFoundError):
+        S.load_text_dataset(str(tmp_path / "missing.txt"))
+    tok = S.ByteTokenizer()
+    torch.manual_seed(0)
+    train, val = S.tokenize_corpus(text, tok, seq_len=16, val_split=0.1)
+    n_chunks = len(text.encode()) // 16
+    assert len(val) == int(n_chunks * 0.1) and len(train) == n_chunks - len(val)
+    assert train[0].shape == (16,) and train[0].dtype == torch.long
+    allrows = torch.stack([train[i] for i in range(len(train))] + [val[i] for i in range(len(val))])
+    assert sorted(map(tuple, allrows.tolist())) == sorted(map(tuple, torch.tensor(list(text.encode()))[: n_chunks * 16].view(-1, 16).tolist()))
+    assert tok.batch_decode(torch.tensor([list(b"hello")])) == ["hello"]

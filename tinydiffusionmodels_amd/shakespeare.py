@@ -274,6 +274,46 @@ class TinyTransformer(nn.Module):
                              p_drop=p_drop, seed=seed)
 
 
+class ByteTokenizer:
+    """Offline stand-in for the HF tokenizer the reference loads (src/shakespeare.py:508): UTF-8 bytes as token ids
+    (vocab 256).  Implements the two calls the reference makes: `tokenizer(text, ...).input_ids` and `batch_decode`."""
+    vocab_size = 256
+    bos_token_id = None
+    eos_token_id = 0
+
+    class _Enc:
+        def __init__(self, ids):
+            self.input_ids = ids
+
+    def __call__(self, text, add_special_tokens=False, return_attention_mask=False, return_tensors="pt"):
+        ids = torch.tensor(list(text.encode("utf-8")), dtype=torch.long).unsqueeze(0)
+        return ByteTokenizer._Enc(ids)
+
+    def batch_decode(self, tokens, skip_special_tokens=True):
+        return [bytes(int(t) & 0xFF for t in row).decode("utf-8", errors="replace") for row in tokens.tolist()]
+
+
+def load_text_dataset(path: Optional[str] = None) -> str:
+    """The raw corpus as a single string (src/shakespeare.py:122-125).  The reference downloads
+    `tiny_shakespeare` through `datasets`; there is no network here, so the corpus comes from a local text file
+    (`path` or $TDM_TEXT_CORPUS)."""
+    path = path or os.environ.get("TDM_TEXT_CORPUS")
+    if not path or not os.path.exists(path):
+        raise FileNotFoundError("load_text_dataset: pass the path of a local text corpus (or set TDM_TEXT_CORPUS); "
+                                "the reference's `datasets` download needs network access")
+    return Path(path).read_text(encoding="utf-8")
+
+
+def tokenize_corpus(text: str, tokenizer, seq_len: int, val_split=0.1):
+    """Tokenize the full corpus once and slice it into fixed-length chunks with a random train / val split
+    (src/shakespeare.py:128-156): returns two `torch.utils.data.Subset`s of a (N_chunks, seq_len) long tensor."""
+    ids = tokenizer(text, add_special_tokens=False, return_attention_mask=False, return_tensors="pt").input_ids.squeeze(0)
+    n_chunks = ids.size(0) // seq_len
+    chunks = ids[: n_chunks * seq_len].view(n_chunks, seq_len)      # drop the remainder
+    n_val = int(n_chunks * val_split)
+    return torch.utils.data.random_split(chunks, [n_chunks - n_val, n_val])
+
+
 def get_cosine_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps, eta_min=0):
     """Cosine annealing with linear warm-up; lr_lambda(0) = 0 (src/shakespeare.py:159-167)."""
     def lr_lambda(step):
