@@ -416,3 +416,29 @@ def test_rounding_ce_c_abi_vs_oracle(dev, gemm_mode, M, V, D):
                                             None, _lib.ptr(dW2), _lib.ptr(db2), _lib.ptr(ws), M, V, D, _lib.stream()))
     torch.cuda.synchronize()
     assert torch.equal(dW2, dW) and torch.equal(db2, db)      # deterministic (fixed-order slab sums)
+
+
+def test_text_cli_train_then_sample_end_to_end(dev, gemm_mode, tmp_path, monkeypatch, capsys):
+    """`python -m src.shakespeare --train` then `--sample` on a local corpus with the offline byte vocabulary:
+    the reference's whole text loop (embedding lookup, q_sample, denoiser in train mode with dropout, rounding loss,
+    AdamW + cosine warm-up, validation, checkpoint dict; then 1000 reverse steps, argmax decode, sample files)."""
+    if gemm_mode != 1:
+        pytest.skip("one arithmetic is enough for the end-to-end smoke")
+    from tinydiffusionmodels_amd import shakespeare as S
+    corpus = tmp_path / "corpus.txt"
+    corpus.write_text("All the world's a stage, and all the men and women merely players.\n" * 30, encoding="utf-8")
+    ckpt = str(tmp_path / "text_ckpt.pth")
+    monkeypatch.chdir(tmp_path)
+    S.main(["--train", "--byte_tokenizer", "--embed_dim", "32", "--epochs", "2", "--batch_size", "16", "--seq_len", "16",
+            "--corpus", str(corpus), "--ckpt", ckpt, "--seed", "0", "--warmup_steps", "2", "--lr", "1e-3"])
+    out = capsys.readouterr().out
+    assert "Epoch 2/2" in out and os.path.exists(ckpt) and os.path.exists(ckpt.replace(".pth", "_best.pth"))
+    ck = torch.load(ckpt, map_location="cpu", weights_only=True)
+    assert set(ck) >= {"diffusion_model", "rounding_fn", "embedding_fn", "epoch", "final_training"}
+    assert "encoder.layers.0.self_attn.in_proj_weight" in ck["diffusion_model"] and ck["rounding_fn"]["decoder.weight"].shape == (256, 32)
+    import re
+    losses = [float(x) for x in re.findall(r"Train: diff=([0-9.]+)", out)]
+    assert len(losses) == 2 and all(np.isfinite(losses)) and losses[1] < losses[0]
+    texts = S.main(["--sample", "--byte_tokenizer", "--embed_dim", "32", "--n", "2", "--seq_len", "16", "--ckpt", ckpt, "--seed", "1"])
+    assert len(texts) == 2 and all(isinstance(t, str) for t in texts)
+    assert (tmp_path / "samples" / "sample_0.txt").exists() and (tmp_path / "samples" / "sample_1.txt").exists()

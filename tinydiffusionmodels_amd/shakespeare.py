@@ -534,3 +534,107 @@ def load_text_checkpoint(ckpt, model, rounding_fn, embedding_fn=None):
             embedding_fn.load_state_dict(ckpt["embedding_fn"])
     else:
         model.load_state_dict(ckpt)
+
+
+def main(argv=None):
+    """CLI of src/shakespeare.py:473-600 (`python -m src.shakespeare --train | --sample`), same flags.
+    The reference always loads an HF tokenizer + causal LM (`--model_id`) for the vocabulary and the pre-trained
+    embedding matrix; with no network those are unavailable here, so `--byte_tokenizer` selects the offline
+    stand-in (UTF-8 bytes, vocab 256, learned embeddings) and `--corpus PATH` (or $TDM_TEXT_CORPUS) the local
+    text file `--train` reads.  `--guided_sample` needs the causal LM and is out of scope."""
+    import argparse
+    from torch.utils.data import DataLoader
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--train", action="store_true")
+    parser.add_argument("--sample", action="store_true", help="plain diffusion sample")
+    parser.add_argument("--guided_sample", action="store_true", help="AR + diffusion guidance (not available offline)")
+    parser.add_argument("--epochs", type=int, default=1)
+    parser.add_argument("--batch_size", type=int, default=32)
+    parser.add_argument("--seq_len", type=int, default=64)
+    parser.add_argument("--ckpt", type=str, default="gs://text-diffusion/diffusion/outputs/model/text-model.pth"
+                        if "AIP_MODEL_DIR" in os.environ else "text_ckpt.pth")
+    parser.add_argument("--model_id", type=str, default="google/gemma-2b-it")
+    parser.add_argument("--n", type=int, default=10)
+    parser.add_argument("--alpha", type=float, default=0.3)
+    parser.add_argument("--rounding_weight", type=float, default=1.0, help="Weight for learned rounding loss")
+    parser.add_argument("--use_cosine_fallback", action="store_true", help="Use cosine similarity instead of learned rounding")
+    parser.add_argument("--use_learned_embeddings", action="store_true", help="Use custom learned embedding space")
+    parser.add_argument("--embed_dim", type=int, default=None, help="Custom embedding dimension")
+    parser.add_argument("--init_from_pretrained", action="store_true", help="Initialize learned embeddings from pre-trained weights")
+    parser.add_argument("--dropout", type=float, default=0.1, help="Dropout rate for regularization")
+    parser.add_argument("--weight_decay", type=float, default=1e-4, help="Weight decay for regularization")
+    parser.add_argument("--patience", type=int, default=5, help="Early stopping patience")
+    parser.add_argument("--use_lr_scheduling", action="store_true", default=True, help="Use cosine learning rate scheduling")
+    parser.add_argument("--warmup_steps", type=int, default=100, help="Number of warmup steps for learning rate scheduling")
+    parser.add_argument("--val_split", type=float, default=0.1, help="Fraction of data for validation")
+    parser.add_argument("--lr", type=float, default=1e-4, help="Learning rate")
+    parser.add_argument("--byte_tokenizer", action="store_true", help="[build] offline UTF-8 byte vocabulary instead of --model_id")
+    parser.add_argument("--corpus", type=str, default=None, help="[build] local text corpus for --train")
+    parser.add_argument("--seed", type=int, default=None, help="[build] torch.manual_seed")
+    args = parser.parse_args(argv)
+    if args.guided_sample:
+        raise SystemExit("--guided_sample needs the causal LM of --model_id (network / gated weights): out of scope here")
+    if not torch.cuda.is_available():
+        raise RuntimeError("src.shakespeare (HIP build) needs a GPU: there is no CPU fallback")
+    if args.seed is not None:
+        torch.manual_seed(args.seed)
+    device = torch.device("cuda")
+    print(f"Device: {device}")
+
+    pretrained = None
+    if args.byte_tokenizer:
+        tokenizer = ByteTokenizer()
+        vocab_size, pretrained_dim = tokenizer.vocab_size, 256
+        args.use_learned_embeddings = True
+    else:   # the reference's path; needs the model files in the local HF cache
+        from transformers import AutoModelForCausalLM, AutoTokenizer
+        tokenizer = AutoTokenizer.from_pretrained(args.model_id)
+        lm_model = AutoModelForCausalLM.from_pretrained(args.model_id).to(device)
+        pretrained = lm_model.get_input_embeddings().weight.detach().float().to(device)
+        vocab_size, pretrained_dim = pretrained.size(0), pretrained.size(1)
+
+    if args.use_learned_embeddings:
+        embed_dim = args.embed_dim if args.embed_dim is not None else pretrained_dim
+        embedding_fn = LearnedEmbedding(vocab_size, embed_dim, pretrained if args.init_from_pretrained else None).to(device)
+        print(f"Using learned embeddings (dim={embed_dim}, init_from_pretrained={args.init_from_pretrained})")
+    else:
+        embed_dim = pretrained_dim
+        embedding_fn = pretrained
+        print(f"Using pre-trained embeddings (dim={embed_dim})")
+    diff_model = TinyTransformer(embed_dim, dropout=args.dropout).to(device)
+    rounding_fn = LearnedRounding(embed_dim, vocab_size).to(device)
+
+    if args.train:
+        raw = load_text_dataset(args.corpus)
+        train_chunks, val_chunks = tokenize_corpus(raw, tokenizer, args.seq_len, args.val_split)
+        train_dl = DataLoader(train_chunks, batch_size=args.batch_size, shuffle=True)
+        val_dl = DataLoader(val_chunks, batch_size=args.batch_size, shuffle=False)
+        print(f"Training on {len(train_chunks)} chunks, validating on {len(val_chunks)} chunks")
+        train(diff_model, rounding_fn, embedding_fn, train_dl, val_dl, device, args.ckpt, epochs=args.epochs, lr=args.lr,
+              weight_decay=args.weight_decay, rounding_weight=args.rounding_weight,
+              use_learned_embeddings=args.use_learned_embeddings, patience=args.patience,
+              use_lr_scheduling=args.use_lr_scheduling, warmup_steps=args.warmup_steps)
+    texts = None
+    if args.sample:
+        checkpoint = load_checkpoint(args.ckpt, device)
+        if isinstance(checkpoint, dict) and "diffusion_model" in checkpoint:
+            load_text_checkpoint(checkpoint, diff_model, rounding_fn, embedding_fn if args.use_learned_embeddings else None)
+            if args.use_learned_embeddings and "embedding_fn" not in checkpoint:
+                print("Warning: Learned embeddings requested but not found in checkpoint. Using pre-trained fallback.")
+                if pretrained is None:
+                    raise RuntimeError("no pre-trained embedding matrix to fall back to (--byte_tokenizer)")
+                args.use_learned_embeddings, embedding_fn = False, pretrained
+        else:
+            diff_model.load_state_dict(checkpoint)
+            print("Warning: Using old checkpoint format. Falling back to pre-trained embeddings and cosine similarity.")
+            if pretrained is None:
+                raise RuntimeError("an old-format checkpoint needs the pre-trained embedding matrix (--model_id)")
+            args.use_cosine_fallback, args.use_learned_embeddings, embedding_fn = True, False, pretrained
+        texts = sample(diff_model, rounding_fn, embedding_fn, tokenizer, device, args.n, args.seq_len,
+                       use_learned_rounding=not args.use_cosine_fallback,
+                       use_learned_embeddings=args.use_learned_embeddings, embed_dim=embed_dim)
+    return texts
+
+
+if __name__ == "__main__":
+    main()
