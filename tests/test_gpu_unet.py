@@ -410,3 +410,23 @@ def test_reverse_diffusion_hipgraph_matches_eager(dev, model):
         assert torch.equal(a, b), t_start          # same kernels, same inputs: bitwise
     c = reverse_diffusion(model, x, t_start=31, use_graph=True)
     assert torch.isfinite(c).all() and c.shape == x.shape
+
+
+def test_mnist_cli_train_then_sample_end_to_end(dev, conv_mode, tmp_path, monkeypatch):
+    """`python -m src.mnist --train` then `--sample` (src/mnist.py:214-241) on synthetic images: the whole loop
+    (epoch shuffling, DDPMTrainer steps, per-epoch sample grid, raw-state_dict checkpoint with the reference's 32 keys,
+    then 1000 reverse steps and the 4x4 PNG grid)."""
+    if conv_mode != 2:
+        pytest.skip("one arithmetic is enough for the end-to-end smoke")
+    from tinydiffusionmodels_amd import mnist as M
+    monkeypatch.chdir(tmp_path)
+    ckpt = str(tmp_path / "ckpt.pth")
+    M.main(["--train", "--synthetic", "256", "--epochs", "1", "--batch_size", "64", "--ckpt", ckpt, "--seed", "0"])
+    sd = torch.load(ckpt, map_location="cpu", weights_only=True)
+    assert len(sd) == 32 and sd["rb4.conv1.weight"].shape == (32, 96, 3, 3) and sd["out.weight"].shape == (1, 32, 1, 1)
+    assert all(torch.isfinite(v).all() for v in sd.values())
+    M.main(["--sample", "--ckpt", ckpt, "--seed", "1"])
+    pngs = sorted(p.name for p in (tmp_path / "samples").glob("*.png"))
+    assert "samples.png" in pngs and "epoch_001.png" in pngs
+    png = (tmp_path / "samples" / "samples.png").read_bytes()
+    assert png[:8] == b"\x89PNG\r\n\x1a\n"
