@@ -9,7 +9,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libtdm_hip.so")
+LIB_PATH = os.environ.get("TDM_HIP_LIB") or os.path.join(_HERE, "csrc", "libtdm_hip.so")   # TDM_HIP_LIB: A/B a second build
 
 _lib = None
 _lock = threading.Lock()

@@ -64,7 +64,11 @@ __device__ __forceinline__ int src_offset(const ConvSrc& s, int PR0, int pos, in
 // ---------------------------------------------------------------------------
 // convolution / transposed convolution
 // ---------------------------------------------------------------------------
-template <int HW, int NT>
+// registers of the fused 1x1 skip conv (ConvArgs::skip_out): exist only in the SKIP instantiation
+template <int NT, bool SKIP> struct SkipState {};
+template <int NT> struct SkipState<NT, true> { f32x16 acc2[2][NT]; uint4 psk; };
+
+template <int HW, int NT, bool SKIP>
 __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvArgs a) {
     using G = Geo<HW>;
     constexpr int N = NT * 32;
@@ -100,6 +104,16 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    SkipState<NT, SKIP> sk;
+    if constexpr (SKIP) {
+        sk.psk = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sk.acc2[mt][nt][r] = 0.f;
+    }
 
     // Software pipeline over K chunks, register-staged.  Input pieces are prefetched TWO chunks ahead (two register
     // sets, 8 x 16 B per thread each), the L2-resident packed weights one chunk ahead: with a single chunk of
@@ -143,6 +157,10 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
             const int e = tid + 256 * i;
             pwt[i] = (e < n16) ? wsrc[e] : make_uint4(0u, 0u, 0u, 0u);
         }
+        if constexpr (SKIP) {   // NT * 128 pieces of the 1x1 weights of the same chunk
+            const uint4* ssrc = reinterpret_cast<const uint4*>(a.skip_wp + (long)(s.wchunk0 + ch) * (NT * 1024));
+            sk.psk = (tid < NT * 128) ? ssrc[tid] : make_uint4(0u, 0u, 0u, 0u);
+        }
     };
     auto stage = [&](const uint4 (&pin)[8]) {
         __syncthreads();      // everyone finished reading the previous chunk's LDS image
@@ -152,6 +170,9 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
 #pragma unroll
         for (int i = 0; i < WN; ++i)
             if (tid + 256 * i < 9 * NT * 128) reinterpret_cast<uint4*>(wl)[tid + 256 * i] = pwt[i];
+        if constexpr (SKIP) {   // packed 1x1 weights of the chunk: NT x (hi 1 KB | lo 1 KB) behind the 3x3 weights
+            if (tid < NT * 128) reinterpret_cast<uint4*>(wl + 9 * NT * 2048)[tid] = sk.psk;
+        }
         __syncthreads();
     };
     auto compute = [&](int c) {
@@ -179,6 +200,17 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[mt], acc[mt][nt], 0, 0, 0);
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[mt], acc[mt][nt], 0, 0, 0);
                     }
+                    if constexpr (SKIP) if (tp == 4) {   // the block's 1x1 skip conv reads exactly the centre-tap pixels
+                        const char* sb = wl + 9 * NT * 2048 + (nt * 2) * 1024 + lane * 16;
+                        const bf16x8 sh = *reinterpret_cast<const bf16x8*>(sb);
+                        const bf16x8 sl = *reinterpret_cast<const bf16x8*>(sb + 1024);
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            sk.acc2[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh, al[mt], sk.acc2[mt][nt], 0, 0, 0);
+                            sk.acc2[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sl, ah[mt], sk.acc2[mt][nt], 0, 0, 0);
+                            sk.acc2[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh, ah[mt], sk.acc2[mt][nt], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
@@ -187,7 +219,7 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
     const bool pf = !(a.ablate & 1);
     prefetch_in(pinA, goffA, planA, 0);
     prefetch_w(0);
-    if constexpr (NT == 1) {
+    if constexpr (NT == 1 && !SKIP) {
         if (nchunks > 1) prefetch_in(pinB, goffB, planB, 1);
         for (int c = 0; c < nchunks; c += 2) {
             stage(pinA);                                                  // chunk c
@@ -201,7 +233,7 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
             compute(c + 1);
         }
     } else {
-        // N = 64 / 96: 64-96 accumulator registers; a second input register set spills inside the K loop
+        // N = 64 / 96 (and N = 32 with the fused skip conv): 64-96 accumulator registers; a second input register set spills inside the K loop
         // (21 scratch reloads per chunk were measured), so these widths prefetch one chunk ahead
         for (int c = 0; c < nchunks; ++c) {
             stage(pinA);
@@ -302,16 +334,36 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
                     }
                 }
         }
+        if constexpr (SKIP) {   // second accumulator: skip_out = 1x1 conv + its bias, same transposed walk (wave-private LDS block)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(T + j * EPI + nt * 32 + 8 * g + 4 * h) =
+                        make_float4(sk.acc2[mt][nt][4 * g], sk.acc2[mt][nt][4 * g + 1], sk.acc2[mt][nt][4 * g + 2], sk.acc2[mt][nt][4 * g + 3]);
+#pragma unroll
+            for (int it = 0; it < N / 8; ++it) {
+                const int e = it * 64 + lane;
+                const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
+                const int m = mbase + px;
+                float4 v = *reinterpret_cast<const float4*>(T + px * EPI + c);
+                if (m < Mtot) {
+                    const float4 bz = *reinterpret_cast<const float4*>(a.skip_bias + c);
+                    v.x += bz.x; v.y += bz.y; v.z += bz.z; v.w += bz.w;
+                    *reinterpret_cast<float4*>(a.skip_out + (long)m * N + c) = v;
+                }
+            }
+        }
     }
 }
 
-template <int HW, int NT>
+template <int HW, int NT, bool SKIP>
 int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     using G = Geo<HW>;
-    constexpr size_t lds = (size_t)G::NR * G::WP * PIXB + (size_t)9 * NT * 2048;
+    constexpr size_t lds = (size_t)G::NR * G::WP * PIXB + (size_t)9 * NT * 2048 + (SKIP ? (size_t)NT * 2048 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<HW, NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<HW, NT, SKIP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             tdm_set_error("conv_s16: hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
@@ -321,7 +373,7 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     }
     const long Mtot = (long)a.B * G::H * G::W;
     const int ntiles = (int)((Mtot + TILE_PX - 1) / TILE_PX);
-    hipLaunchKernelGGL((conv_s16_kernel<HW, NT>), dim3(ntiles), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_s16_kernel<HW, NT, SKIP>), dim3(ntiles), dim3(256), lds, st, a);
     TDM_CHECK_LAUNCH("conv_s16");
     return 0;
 }
@@ -574,11 +626,16 @@ int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st) {
     }
     TDM_REQUIRE(a.out != nullptr || a.out_s16 != nullptr, "conv_s16: no output");
     TDM_REQUIRE(a.B > 0 && (long)a.B * hw * hw * 96 < 2147483647L, "conv_s16: batch %d out of range", a.B);
-    if (hw == 28 && N == 32) return launch_conv_t<28, 1>(a, st);
-    if (hw == 28 && N == 64) return launch_conv_t<28, 2>(a, st);
-    if (hw == 28 && N == 96) return launch_conv_t<28, 3>(a, st);
-    if (hw == 14 && N == 32) return launch_conv_t<14, 1>(a, st);
-    if (hw == 14 && N == 64) return launch_conv_t<14, 2>(a, st);
+    if (a.skip_out != nullptr) {   // fused 1x1 skip conv: built for the one geometry that uses it (rb4: 96 -> 32 @ 28x28)
+        TDM_REQUIRE(hw == 28 && N == 32 && a.skip_wp != nullptr && a.skip_bias != nullptr, "conv_s16: fused skip needs hw=28, N=32");
+        for (int i = 0; i < a.nsrc; ++i) TDM_REQUIRE(a.src[i].taps == 9, "conv_s16: fused skip rides on 3x3 sources");
+        return launch_conv_t<28, 1, true>(a, st);
+    }
+    if (hw == 28 && N == 32) return launch_conv_t<28, 1, false>(a, st);
+    if (hw == 28 && N == 64) return launch_conv_t<28, 2, false>(a, st);
+    if (hw == 28 && N == 96) return launch_conv_t<28, 3, false>(a, st);
+    if (hw == 14 && N == 32) return launch_conv_t<14, 1, false>(a, st);
+    if (hw == 14 && N == 64) return launch_conv_t<14, 2, false>(a, st);
     tdm_set_error("conv_s16: unsupported geometry hw=%d N=%d", hw, N);
     return 1;
 }

@@ -80,6 +80,12 @@ struct ConvArgs {
     // of the image the group's first pixel belongs to, slot 1 = pixels of the next image (a group may straddle two).
     const unsigned char* relu_mask_in;
     float* sums;
+    // Fused 1x1 "skip" conv of a residual block (src/mnist.py:52,61) over the SAME sources (N = 32 kernels, 3x3 sources):
+    // a second accumulator fed by the centre-tap pixel fragments the 3x3 conv has already read.  skip_wp: packed 1x1
+    // weights with the same chunk numbering as the sources' 3x3 weights; skip_out[M][N] = skip conv + skip_bias (fp32).
+    const unsigned short* skip_wp;
+    const float* skip_bias;
+    float* skip_out;
 };
 
 // hw in {28,14}; N in {32,64,96}; dgrad: transposed convolution with the forward weights

@@ -302,13 +302,9 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
         a.src[1] = s16_src(w.h1s, 32, 32, 0, 9, w.wpack + kPack.fwd[W_RB4C1], 4);
         a.bias = P + r4.c1b; a.relu = 1; a.B = B;
         a.mask_out = save ? w.m1[3] : nullptr; a.out_s16 = w.a1s_4; a.tb_out = w.tb + 160; a.tb_out_stride = 192;
+        // rb4.skip (1x1 over the same concat) rides on this launch as a second accumulator: s4 = skip(cat) + bias
+        a.skip_wp = w.wpack + kPack.fwd[W_RB4SK]; a.skip_bias = P + r4.skb; a.skip_out = w.s4;
         TDM_TRY(tdm_launch_conv_s16(a, 28, 32, st));
-        ConvArgs k{};
-        k.nsrc = 2;
-        k.src[0] = s16_src(w.h3s, 64, 64, 1, 1, w.wpack + kPack.fwd[W_RB4SK], 0);
-        k.src[1] = s16_src(w.h1s, 32, 32, 0, 1, w.wpack + kPack.fwd[W_RB4SK], 4);
-        k.bias = P + r4.skb; k.relu = 0; k.B = B; k.out = w.s4;
-        TDM_TRY(tdm_launch_conv_s16(k, 28, 32, st));
     }
     TDM_TRY(conv_s16_1(st, w, 28, B, w.a1s_4, 32, 9, kPack.fwd[W_RB4C2], 32, P + r4.c2b, 1,
                        S16Out{w.h4, save ? w.m2[3] : nullptr, w.s4, nullptr, nullptr}));
