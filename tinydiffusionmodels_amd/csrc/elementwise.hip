@@ -609,6 +609,57 @@ __global__ __launch_bounds__(EW_BLOCK) void avgpool_s16_kernel(const float* __re
     }
 }
 
+// rb2's entry in one pass (src/mnist.py:80 + the block's 1x1 skip, :52,61): p1 = avg_pool2d(h1, 2) -> S16 twin (the
+// only form rb2.conv1 reads) and s2 = skip(p1) + bias in exact fp32 on the vector units (32 x 64 MACs per pixel: 0.4 GFLOP
+// at B = 512 — a matrix-core launch for it cost 15 us of a train step and 4 % of a B = 4096 reverse step).
+// 256 threads = 16 output pixels per trip: threads 0..127 pool one channel quad each into LDS, then thread
+// (pixel, co quad) runs the 32-term dot products against the LDS-resident weights.
+__global__ __launch_bounds__(EW_BLOCK) void pool_skip_s16_kernel(const float* __restrict__ h1, const float* __restrict__ wsk,
+                                                                 const float* __restrict__ bsk, float* __restrict__ p1_s16,
+                                                                 float* __restrict__ s2, int B) {
+    __shared__ float4 Wl[32 * 16];     // [ci][co quad]
+    __shared__ float pooled[16][32];
+    for (int i = threadIdx.x; i < 32 * 16; i += EW_BLOCK) Wl[i] = reinterpret_cast<const float4*>(wsk)[i];
+    const int64_t npix = (int64_t)B * 196;
+    const int px = threadIdx.x >> 4, cq = threadIdx.x & 15;
+    const float4 bias = reinterpret_cast<const float4*>(bsk)[cq];
+    for (int64_t p0 = (int64_t)blockIdx.x * 16; p0 < npix; p0 += (int64_t)gridDim.x * 16) {
+        __syncthreads();   // previous trip's pooled values consumed (and, first trip, Wl complete)
+        if (threadIdx.x < 128) {
+            const int lp = threadIdx.x >> 3, c4 = threadIdx.x & 7;
+            const int64_t p = p0 + lp;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < npix) {
+                const int xo = (int)(p % 14);
+                const int64_t q = p / 14;
+                const int yo = (int)(q % 14);
+                const int64_t b = q / 14;
+                const float4* src = reinterpret_cast<const float4*>(h1) + ((b * 28 + 2 * yo) * 28 + 2 * xo) * 8 + c4;
+                const float4 v00 = src[0], v01 = src[8], v10 = src[28 * 8], v11 = src[28 * 8 + 8];
+                o.x = (((v00.x + v01.x) + v10.x) + v11.x) * 0.25f;
+                o.y = (((v00.y + v01.y) + v10.y) + v11.y) * 0.25f;
+                o.z = (((v00.z + v01.z) + v10.z) + v11.z) * 0.25f;
+                o.w = (((v00.w + v01.w) + v10.w) + v11.w) * 0.25f;
+                tdm_store_s16_4(p1_s16, p, 32, c4 * 4, o);
+            }
+            *reinterpret_cast<float4*>(&pooled[lp][c4 * 4]) = o;
+        }
+        __syncthreads();
+        const int64_t p = p0 + px;
+        if (p < npix) {
+            float4 acc = bias;
+#pragma unroll
+            for (int ci = 0; ci < 32; ++ci) {
+                const float a = pooled[px][ci];
+                const float4 w4 = Wl[ci * 16 + cq];
+                acc.x = fmaf(a, w4.x, acc.x); acc.y = fmaf(a, w4.y, acc.y);
+                acc.z = fmaf(a, w4.z, acc.z); acc.w = fmaf(a, w4.w, acc.w);
+            }
+            reinterpret_cast<float4*>(s2)[p * 16 + cq] = acc;
+        }
+    }
+}
+
 // block-level per-channel-quad reduction: threads with equal (tid % C4) hold partial sums of the same 4 channels
 __device__ __forceinline__ void quad_reduce_store(float4 v, float4* sh, int C4, float* dst /* slab + off, or nullptr */) {
     __syncthreads();
@@ -880,6 +931,14 @@ int tdm_launch_conv_first_s16(const float* x, const float* w1, const float* b1, 
     hipLaunchKernelGGL(conv_first_s16_kernel, dim3(ew_grid((int64_t)B * 784 * 8)), dim3(EW_BLOCK), 0, st, x, w1, b1, ws, bs,
                        tb, tb_stride, a1, a1m, a1_s16, s, B);
     TDM_CHECK_LAUNCH("conv_first_s16");
+    return 0;
+}
+int tdm_launch_pool_skip_s16(const float* h1, const float* wsk, const float* bsk, float* p1_s16, float* s2, int B,
+                             hipStream_t st) {
+    const int64_t groups = ((int64_t)B * 196 + 15) / 16;
+    hipLaunchKernelGGL(pool_skip_s16_kernel, dim3((unsigned)(groups < 4096 ? groups : 4096)), dim3(EW_BLOCK), 0, st, h1, wsk, bsk,
+                       p1_s16, s2, B);
+    TDM_CHECK_LAUNCH("pool_skip_s16");
     return 0;
 }
 int tdm_launch_avgpool_s16(const float* in, float* out, float* out_s16, int B, int Hout, int C, hipStream_t st) {

@@ -282,11 +282,9 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
     TDM_TRY(conv_s16_1(st, w, 28, B, w.a1s_1, 32, 9, kPack.fwd[W_RB1C2], 32, P + r1.c2b, 1,
                        S16Out{w.h1, save ? w.m2[0] : nullptr, w.s1, w.h1s, nullptr}));
     // rb2 on avg_pool2d(h1)
-    TDM_TRY(tdm_launch_avgpool_s16(w.h1, nullptr, w.p1s, B, 14, 32, st));
+    TDM_TRY(tdm_launch_pool_skip_s16(w.h1, P + r2.skw, P + r2.skb, w.p1s, w.s2, B, st));   // pooling + rb2.skip (1x1)
     TDM_TRY(conv_s16_1(st, w, 14, B, w.p1s, 32, 9, kPack.fwd[W_RB2C1], 64, P + r2.c1b, 1,
                        S16Out{nullptr, save ? w.m1[1] : nullptr, nullptr, w.a1s_2, w.tb + 32}));
-    TDM_TRY(conv_s16_1(st, w, 14, B, w.p1s, 32, 1, kPack.fwd[W_RB2SK], 64, P + r2.skb, 0,
-                       S16Out{w.s2, nullptr, nullptr, nullptr, nullptr}));
     TDM_TRY(conv_s16_1(st, w, 14, B, w.a1s_2, 64, 9, kPack.fwd[W_RB2C2], 64, P + r2.c2b, 1,
                        S16Out{w.h2, save ? w.m2[1] : nullptr, w.s2, w.h2s, nullptr}));
     // rb3 (identity skip)
