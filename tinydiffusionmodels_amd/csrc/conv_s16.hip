@@ -64,26 +64,81 @@ __device__ __forceinline__ int src_offset(const ConvSrc& s, int PR0, int pos, in
 // ---------------------------------------------------------------------------
 // convolution / transposed convolution
 // ---------------------------------------------------------------------------
+#define TDM_PIN(x) asm volatile("" : "+s"(x))
+struct PinnedSrc {
+    const float* ptr; const unsigned short* wp; int C, c0, nch, up, taps, wchunk0;
+    __device__ __forceinline__ void load(const ConvSrc& s) {
+        ptr = s.ptr; wp = s.wp; C = s.C; c0 = s.c0; nch = s.nch; up = s.up; taps = s.taps; wchunk0 = s.wchunk0;
+        TDM_PIN(ptr); TDM_PIN(wp); TDM_PIN(C); TDM_PIN(c0); TDM_PIN(nch); TDM_PIN(up); TDM_PIN(taps); TDM_PIN(wchunk0);
+    }
+};
+struct PinnedArgs {
+    PinnedSrc s0, s1;
+    int nsrc, relu, B, ablate, tb_out_stride;
+    const float *bias, *res, *tb_out, *skip_bias;
+    float *out, *aux, *out_s16, *sums, *skip_out;
+    unsigned char* mask_out;
+    const unsigned char* relu_mask_in;
+    const unsigned short* skip_wp;
+    __device__ __forceinline__ explicit PinnedArgs(const ConvArgs& k) {
+        s0.load(k.src[0]); s1.load(k.src[1]);
+        nsrc = k.nsrc; relu = k.relu; B = k.B; ablate = k.ablate; tb_out_stride = k.tb_out_stride;
+        bias = k.bias; res = k.res; tb_out = k.tb_out; skip_bias = k.skip_bias;
+        out = k.out; aux = k.aux; out_s16 = k.out_s16; sums = k.sums; skip_out = k.skip_out;
+        mask_out = k.mask_out; relu_mask_in = k.relu_mask_in; skip_wp = k.skip_wp;
+        TDM_PIN(nsrc); TDM_PIN(relu); TDM_PIN(B); TDM_PIN(ablate); TDM_PIN(tb_out_stride);
+        TDM_PIN(bias); TDM_PIN(res); TDM_PIN(tb_out); TDM_PIN(skip_bias);
+        TDM_PIN(out); TDM_PIN(aux); TDM_PIN(out_s16); TDM_PIN(sums); TDM_PIN(skip_out);
+        TDM_PIN(mask_out); TDM_PIN(relu_mask_in); TDM_PIN(skip_wp);
+    }
+    // field of source si (uniform): scalar selects, no indexed kernarg read
+    __device__ __forceinline__ PinnedSrc src(int si) const {
+        PinnedSrc r;
+        r.ptr = si ? s1.ptr : s0.ptr; r.wp = si ? s1.wp : s0.wp; r.C = si ? s1.C : s0.C; r.c0 = si ? s1.c0 : s0.c0;
+        r.nch = si ? s1.nch : s0.nch; r.up = si ? s1.up : s0.up; r.taps = si ? s1.taps : s0.taps;
+        r.wchunk0 = si ? s1.wchunk0 : s0.wchunk0;
+        return r;
+    }
+};
+
 // registers of the fused 1x1 skip conv (ConvArgs::skip_out): exist only in the SKIP instantiation
 template <int NT, bool SKIP> struct SkipState {};
 template <int NT> struct SkipState<NT, true> { f32x16 acc2[2][NT]; uint4 psk; };
 
 template <int HW, int NT, bool SKIP>
-__global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvArgs ka) {
     using G = Geo<HW>;
+    // The ~300-byte argument block does not stay in scalar registers by itself: the compiler re-reads a field from the
+    // kernarg segment (s_load + s_waitcnt lgkmcnt(0), a scalar-cache round trip) next to almost every use — before each
+    // prefetch load, around every uniform branch of the epilogue.  Everything the kernel uses is copied ONCE into
+    // scalars the optimiser cannot rematerialise (opaque asm), about 60 SGPRs.
+    PinnedArgs a(ka);
     constexpr int N = NT * 32;
     constexpr int TILE_B = G::NR * G::WP * PIXB;
     extern __shared__ float4 smem4[];
     char* tile = reinterpret_cast<char*>(smem4);
     char* wl = tile + TILE_B;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: everything derived from it stays scalar
     const int h = lane >> 5, j = lane & 31;
     const int t = xcd_remap(blockIdx.x, gridDim.x);
+    // phase probe (ablate & 16, tools/phase_probe.py): thread 0 stamps the shader clock at phase boundaries into the
+    // int64 table [blockIdx.x][8] that the caller appended BEHIND the B*H*W*N floats of aux
+    int nstamp = 0;
+    auto stamp = [&]() {
+        if ((a.ablate & 16) && tid == 0 && nstamp < 8)
+            reinterpret_cast<long long*>(a.aux + (long)a.B * G::H * G::W * N)[(long)blockIdx.x * 8 + nstamp] =
+                (long long)__builtin_readcyclecounter();
+        ++nstamp;
+    };
+    stamp();
     const int Mtot = a.B * G::H * G::W;
     const int m0 = t * TILE_PX;
     const int mlast = min(m0 + TILE_PX - 1, Mtot - 1);
-    const int PR0 = padded_row<HW>(m0) - 1;
+    const int tb0 = m0 / (G::H * G::W);                       // image and row of the tile's first pixel:
+    const int ty0 = (m0 - tb0 * (G::H * G::W)) / G::W;        // the staged image starts at padded row PR0 = tb0 * HP + ty0
+    const int PR0 = tb0 * G::HP + ty0;
     const int nrows = padded_row<HW>(mlast) - PR0 + 2;
     const int nelem = nrows * G::WP * 4;      // 16-byte pieces of one chunk
 
@@ -97,22 +152,27 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
         aoff[mt] = ((b * G::HP + y + 1 - PR0) * G::WP + x + 1) * PIXB + h * 16;
     }
 
+    // accumulators start from the conv bias (register quad g of N tile nt = channels nt*32 + 8g + 4h .. +3 of the lane's
+    // pixel): the loads are issued first thing and the epilogue has nothing left to add
     f32x16 acc[2][NT];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    auto init_acc = [&](f32x16 (&ac)[2][NT], const float* bias) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+            for (int g = 0; g < 4; ++g) {
+                float4 bz = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bias != nullptr) bz = *reinterpret_cast<const float4*>(bias + nt * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    ac[mt][nt][4 * g] = bz.x; ac[mt][nt][4 * g + 1] = bz.y; ac[mt][nt][4 * g + 2] = bz.z; ac[mt][nt][4 * g + 3] = bz.w;
+                }
+            }
+    };
+    init_acc(acc, a.bias);
     SkipState<NT, SKIP> sk;
     if constexpr (SKIP) {
         sk.psk = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sk.acc2[mt][nt][r] = 0.f;
+        init_acc(sk.acc2, a.skip_bias);
     }
 
     // Software pipeline over K chunks, register-staged.  Input pieces are prefetched TWO chunks ahead (two register
@@ -121,8 +181,8 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
     // stalled (ablation: K loop without global loads 73-86 us vs ~30 us of MFMA / LDS time for the 96->32 layer).
     constexpr int WN = (9 * NT * 128 + 255) / 256;
     char* const sdst = tile + (tid >> 2) * PIXB + (tid & 3) * 16;
-    const int nc0 = a.src[0].nch >> 4;
-    const int nchunks = nc0 + (a.nsrc > 1 ? (a.src[1].nch >> 4) : 0);
+    const int nc0 = a.s0.nch >> 4;
+    const int nchunks = nc0 + (a.nsrc > 1 ? (a.s1.nch >> 4) : 0);
     int goffA[8], goffB[8];   // staging plans of the sources the two input sets were loaded from
     int planA = -1, planB = -1;
     uint4 pinA[8], pinB[8], pwt[WN];
@@ -130,12 +190,24 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
     auto prefetch_in = [&](uint4 (&pin)[8], int (&goff)[8], int& plan_src, int c) {
         const int si = (c >= nc0) ? 1 : 0;
         const int ch = si ? c - nc0 : c;
-        const ConvSrc& s = a.src[si];
+        const PinnedSrc s = a.src(si);
         if (plan_src != si) {
+            // staged position of piece e = tid + 256 i is (tid >> 2) + 64 i: walk (row, column) of the padded-tall image
+            // incrementally — no division per element (src_offset's three cost ~1/3 of a 32 -> 32 launch in index math)
+            const int up = s.up, Hs = G::H >> up, Ws = G::W >> up;
+            int lr = (tid >> 2) / G::WP;
+            int pc = (tid >> 2) - lr * G::WP;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int e = tid + 256 * i;
-                goff[i] = (e < nelem) ? src_offset<HW>(s, PR0, e >> 2, a.B) : -2;
+                int py = ty0 + lr, b = tb0;
+                if (py >= G::HP) { py -= G::HP; ++b; }
+                if (HW == 14 && py >= G::HP) { py -= G::HP; ++b; }   // 26 staged rows span up to three images at 14x14
+                const bool ok = tid + 256 * i < nelem && py >= 1 && py <= G::H && pc >= 1 && pc <= G::W && b < a.B;
+                const int off = __mul24(__mul24(__mul24(b, Hs) + ((py - 1) >> up), Ws) + ((pc - 1) >> up), s.C) + s.c0;
+                goff[i] = ok ? off : -1;
+                pc += 64 % G::WP;
+                lr += 64 / G::WP;
+                if (pc >= G::WP) { pc -= G::WP; ++lr; }
             }
             plan_src = si;
         }
@@ -149,7 +221,7 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
     auto prefetch_w = [&](int c) {
         const int si = (c >= nc0) ? 1 : 0;
         const int ch = si ? c - nc0 : c;
-        const ConvSrc& s = a.src[si];
+        const PinnedSrc s = a.src(si);
         const int n16 = s.taps * NT * 128;
         const uint4* wsrc = reinterpret_cast<const uint4*>(s.wp + (long)(s.wchunk0 + ch) * (s.taps * NT * 1024));
 #pragma unroll
@@ -177,7 +249,7 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
     };
     auto compute = [&](int c) {
         if (a.ablate & 4) return;
-        const int taps = a.src[(c >= nc0) ? 1 : 0].taps;
+        const int taps = (c >= nc0) ? a.s1.taps : a.s0.taps;
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
             if (taps == 9 || tp == 4) {   // a 1x1 source uses the centre-tap site with packed tap 0
@@ -221,16 +293,21 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
     prefetch_w(0);
     if constexpr (NT == 1 && !SKIP) {
         if (nchunks > 1) prefetch_in(pinB, goffB, planB, 1);
+        stamp();
         for (int c = 0; c < nchunks; c += 2) {
             stage(pinA);                                                  // chunk c
+            stamp();
             if (c + 2 < nchunks && pf) prefetch_in(pinA, goffA, planA, c + 2);
             if (c + 1 < nchunks && pf) prefetch_w(c + 1);
             compute(c);
+            stamp();
             if (c + 1 >= nchunks) break;
             stage(pinB);                                                  // chunk c + 1
+            stamp();
             if (c + 3 < nchunks && pf) prefetch_in(pinB, goffB, planB, c + 3);
             if (c + 2 < nchunks && pf) prefetch_w(c + 2);
             compute(c + 1);
+            stamp();
         }
     } else {
         // N = 64 / 96 (and N = 32 with the fused skip conv): 64-96 accumulator registers; a second input register set spills inside the K loop
@@ -248,55 +325,76 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
     // row-major — 32 pixels x N floats are ONE contiguous range of every NHWC tensor involved — so each load / store
     // instruction of the epilogue (residual in; out, saved post-ReLU copy, S16 twin out) covers 1 KB of consecutive
     // addresses.
+    // The walk's own inputs (residual, ReLU byte mask, time-bias row) are fetched into registers for a whole M tile
+    // BEFORE its transpose — one exposed memory latency per tile, not one per 64-float4 pass (the passes used to be
+    // separated by uniform branches, so the compiler waited for each pass's loads on the spot: 40 % of a 32 -> 32
+    // workgroup's lifetime was this epilogue, tools/phase_probe.py).  The conv bias is already in the accumulators.
     if (a.ablate & 8) return;
+    nstamp = 6;
     constexpr int EPI = N + 4;   // floats per staged pixel row: (N/4 + 1) x 16 B, an odd slot count
-    __syncthreads();             // every wave is done with the operand images
-    float* T = reinterpret_cast<float*>(smem4) + wave * (32 * EPI);
+    constexpr int NIT = N / 8;   // passes per M tile: 32 * N/4 float4, 64 per instruction
+    constexpr bool TWO_T = NT <= 2;   // room for a private LDS block per M tile (not at N = 96)
+    static_assert(!TWO_T || 4 * 2 * 32 * EPI * 4 <= TILE_B + 9 * NT * 2048, "epilogue blocks exceed the operand images");
+    const bool bwd = NT != 3 && a.relu_mask_in != nullptr;   // (N = 32 / 64 outputs only)
+    struct Pre { float4 rz[NIT], tz[NIT]; unsigned mk[NIT]; };
+    auto preload = [&](int mt, Pre& p) {
+        const int mbase = m0 + (wave * 2 + mt) * 32;
+        const int img0 = mbase / (G::H * G::W);
+        const int mnext = (img0 + 1) * (G::H * G::W);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+        for (int it = 0; it < NIT; ++it) {
+            const int e = it * 64 + lane;
+            const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
+            const int m = min(mbase + px, Mtot - 1);   // clamped: the walk skips pixels past the end
+            const long o = (long)m * N + c;
+            if (a.res != nullptr) p.rz[it] = *reinterpret_cast<const float4*>(a.res + o);
+            if (bwd) p.mk[it] = a.relu_mask_in[o >> 2];
+            if (a.out_s16 != nullptr && a.tb_out != nullptr)
+                p.tz[it] = *reinterpret_cast<const float4*>(a.tb_out + (long)(img0 + (m >= mnext ? 1 : 0)) * a.tb_out_stride + c);
+        }
+    };
+    auto to_lds = [&](float* T, const f32x16 (&ac)[NT]) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<float4*>(T + j * EPI + nt * 32 + 8 * g + 4 * h) =
-                    make_float4(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
+                    make_float4(ac[nt][4 * g], ac[nt][4 * g + 1], ac[nt][4 * g + 2], ac[nt][4 * g + 3]);
+    };
+    auto walk = [&](int mt, const float* T, const Pre& p) {
         const int mbase = m0 + (wave * 2 + mt) * 32;
-        const bool bwd = NT != 3 && a.relu_mask_in != nullptr;   // (N = 32 / 64 outputs only)
-        const int img0 = mbase / (G::H * G::W);   // image of the group's first pixel
+        const int img0 = mbase / (G::H * G::W);   // image of the group's first pixel (scalar: mbase is wave-uniform)
+        const int mnext = (img0 + 1) * (G::H * G::W);   // a 32-pixel group touches at most two images
         float4 sacc[2][2];                        // [slot][kind] partial sums of this lane's channel quad (bwd only)
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
             for (int kd = 0; kd < 2; ++kd) sacc[sl][kd] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int it = 0; it < N / 8; ++it) {   // 32 * N/4 float4 per pass, 64 per instruction
+        for (int it = 0; it < NIT; ++it) {
             const int e = it * 64 + lane;
             const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
             const int m = mbase + px;
             float4 v = *reinterpret_cast<const float4*>(T + px * EPI + c);
             if (m < Mtot) {
                 const long o = (long)m * N + c;
-                if (a.bias != nullptr) {
-                    const float4 bz = *reinterpret_cast<const float4*>(a.bias + c);
-                    v.x += bz.x; v.y += bz.y; v.z += bz.z; v.w += bz.w;
-                }
                 if (a.relu) {
                     v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y;
                     v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
                 }
-                if (a.aux != nullptr) *reinterpret_cast<float4*>(a.aux + o) = v;
+                if (a.aux != nullptr && !(a.ablate & 16)) *reinterpret_cast<float4*>(a.aux + o) = v;
                 if (a.mask_out != nullptr)
                     a.mask_out[o >> 2] = (unsigned char)((v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) | (v.z > 0.f ? 4 : 0) |
                                                          (v.w > 0.f ? 8 : 0));
                 if (a.res != nullptr) {
-                    const float4 rz = *reinterpret_cast<const float4*>(a.res + o);
+                    const float4 rz = p.rz[it];
                     v.x += rz.x; v.y += rz.y; v.z += rz.z; v.w += rz.w;
                 }
                 if (bwd) {   // ReLU backward of the tensor this gradient belongs to + the sums its bias gradients need
-                    const unsigned mk = a.relu_mask_in[o >> 2];
+                    const unsigned mk = p.mk[it];
                     const float4 mv = make_float4((mk & 1u) ? v.x : 0.f, (mk & 2u) ? v.y : 0.f, (mk & 4u) ? v.z : 0.f,
                                                   (mk & 8u) ? v.w : 0.f);
-                    const int sl = (m / (G::H * G::W) != img0) ? 1 : 0;
+                    const int sl = (m >= mnext) ? 1 : 0;
                     if (sl == 0) {
                         sacc[0][0].x += v.x; sacc[0][0].y += v.y; sacc[0][0].z += v.z; sacc[0][0].w += v.w;
                         sacc[0][1].x += mv.x; sacc[0][1].y += mv.y; sacc[0][1].z += mv.z; sacc[0][1].w += mv.w;
@@ -309,7 +407,7 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
                 if (a.out != nullptr) *reinterpret_cast<float4*>(a.out + o) = v;
                 if (a.out_s16 != nullptr) {
                     if (a.tb_out != nullptr) {
-                        const float4 tz = *reinterpret_cast<const float4*>(a.tb_out + (long)(m / (G::H * G::W)) * a.tb_out_stride + c);
+                        const float4 tz = p.tz[it];
                         v.x += tz.x; v.y += tz.y; v.z += tz.z; v.w += tz.w;
                     }
                     tdm_store_s16_4(a.out_s16, m, N, c, v);
@@ -334,27 +432,40 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
                     }
                 }
         }
-        if constexpr (SKIP) {   // second accumulator: skip_out = 1x1 conv + its bias, same transposed walk (wave-private LDS block)
+    };
+
+    Pre p0, p1;
+    preload(0, p0);
+    if constexpr (NT == 1) preload(1, p1);
+    __syncthreads();             // every wave is done with the operand images
+    float* T0 = reinterpret_cast<float*>(smem4) + wave * ((TWO_T ? 2 : 1) * 32 * EPI);
+    float* T1 = TWO_T ? T0 + 32 * EPI : T0;
+    to_lds(T0, acc[0]);
+    if constexpr (TWO_T) to_lds(T1, acc[1]);
+    if constexpr (NT != 1) preload(1, p1);
+    walk(0, T0, p0);
+    if constexpr (!TWO_T) to_lds(T1, acc[1]);
+    walk(1, T1, p1);
+    if constexpr (SKIP) {   // second accumulator: skip_out = 1x1 conv (+ its bias, already accumulated), same transposed walk
+        to_lds(T0, sk.acc2[0]);
+        to_lds(T1, sk.acc2[1]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+        for (int mt = 0; mt < 2; ++mt) {
+            const int mbase = m0 + (wave * 2 + mt) * 32;
+            const float* T = mt ? T1 : T0;
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(T + j * EPI + nt * 32 + 8 * g + 4 * h) =
-                        make_float4(sk.acc2[mt][nt][4 * g], sk.acc2[mt][nt][4 * g + 1], sk.acc2[mt][nt][4 * g + 2], sk.acc2[mt][nt][4 * g + 3]);
-#pragma unroll
-            for (int it = 0; it < N / 8; ++it) {
+            for (int it = 0; it < NIT; ++it) {
                 const int e = it * 64 + lane;
                 const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
                 const int m = mbase + px;
-                float4 v = *reinterpret_cast<const float4*>(T + px * EPI + c);
-                if (m < Mtot) {
-                    const float4 bz = *reinterpret_cast<const float4*>(a.skip_bias + c);
-                    v.x += bz.x; v.y += bz.y; v.z += bz.z; v.w += bz.w;
-                    *reinterpret_cast<float4*>(a.skip_out + (long)m * N + c) = v;
-                }
+                const float4 v = *reinterpret_cast<const float4*>(T + px * EPI + c);
+                if (m < Mtot) *reinterpret_cast<float4*>(a.skip_out + (long)m * N + c) = v;
             }
         }
     }
+    stamp();   // stores issued
+    if (a.ablate & 16) __builtin_amdgcn_s_waitcnt(0);   // (probe only) stores acknowledged
+    stamp();
 }
 
 template <int HW, int NT, bool SKIP>

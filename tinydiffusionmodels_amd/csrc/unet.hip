@@ -568,7 +568,7 @@ int tdm_conv_nhwc_bf16x3_f32(const float* in, const float* w, const float* bias,
     a.src[0] = mk_src(in, Cin, 0, Cin, 0, taps, w, 0, 0, 0, tb, wp, 0);
     a.src[0].tb_stride = Cin;
     a.bias = bias; a.res = res; a.out = out; a.aux = aux_relu_out; a.relu = flags & 1; a.B = (int)B;
-    a.ablate = (flags >> 8) & 15;   // timing diagnostics only (results are wrong when set)
+    a.ablate = (flags >> 8) & 0xffff;   // timing diagnostics only (results are wrong when set)
     return tdm_launch_conv_bf16(a, HW, Cout, (hipStream_t)stream);
 }
 
@@ -598,7 +598,7 @@ int tdm_conv_nhwc_s16_f32(const float* in, const float* w, const float* bias, co
     a.nsrc = 1;
     a.src[0] = s16_src(in_s16, Cin, Cin, 0, taps, wp, 0);
     a.bias = bias; a.res = res; a.out = out; a.aux = aux_relu_out; a.relu = flags & 1; a.B = (int)B;
-    a.ablate = (flags >> 8) & 15;   // timing diagnostics only (results are wrong when set)
+    a.ablate = (flags >> 8) & 0xffff;   // timing diagnostics only (results are wrong when set)
     a.out_s16 = out_s16; a.tb_out = tb_out; a.tb_out_stride = Cout;
     return tdm_launch_conv_s16(a, HW, Cout, st);
 }
