@@ -65,6 +65,22 @@ __device__ __forceinline__ int src_offset(const ConvSrc& s, int PR0, int pos, in
 // convolution / transposed convolution
 // ---------------------------------------------------------------------------
 #define TDM_PIN(x) asm volatile("" : "+s"(x))
+// A pointer that went through TDM_PIN is no longer known to be a kernel argument, i.e. to point to global memory, and
+// would be dereferenced with flat_* instructions (both memory counters, slower issue): every access casts it back.
+#define TDM_GLOBAL __attribute__((address_space(1)))
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ T gload(const void* p) { return *(const TDM_GLOBAL T*)p; }
+template <typename T> __device__ __forceinline__ void gstore(void* p, const T v) { *(TDM_GLOBAL T*)p = v; }
+__device__ __forceinline__ float4 gload4(const float* p) { const f32x4 v = gload<f32x4>(p); return make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void gstore4(float* p, const float4 v) { f32x4 t; t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w; gstore<f32x4>(p, t); }
+__device__ __forceinline__ uint4 gload16(const void* p) { const u32x4 v = gload<u32x4>(p); return make_uint4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void gstore_s16_4(float* s16, long m, int C, int c, const float4 v) {   // tdm_store_s16_4, global
+    tdm_bf16x4 hi, lo;
+    tdm_split4(v, hi, lo);
+    char* base = reinterpret_cast<char*>(s16 + m * C + (c & ~15)) + (c & 15) * 2;
+    gstore<tdm_bf16x4>(base, hi);
+    gstore<tdm_bf16x4>(base + 32, lo);
+}
 struct PinnedSrc {
     const float* ptr; const unsigned short* wp; int C, c0, nch, up, taps, wchunk0;
     __device__ __forceinline__ void load(const ConvSrc& s) {
@@ -124,12 +140,12 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
     const int h = lane >> 5, j = lane & 31;
     const int t = xcd_remap(blockIdx.x, gridDim.x);
     // phase probe (ablate & 16, tools/phase_probe.py): thread 0 stamps the shader clock at phase boundaries into the
-    // int64 table [blockIdx.x][8] that the caller appended BEHIND the B*H*W*N floats of aux
+    // int64 table [blockIdx.x][16] that the caller appended BEHIND the B*H*W*N floats of aux
     int nstamp = 0;
     auto stamp = [&]() {
-        if ((a.ablate & 16) && tid == 0 && nstamp < 8)
-            reinterpret_cast<long long*>(a.aux + (long)a.B * G::H * G::W * N)[(long)blockIdx.x * 8 + nstamp] =
-                (long long)__builtin_readcyclecounter();
+        if ((a.ablate & 16) && tid == 0 && nstamp < 16)
+            gstore<long long>(reinterpret_cast<long long*>(a.aux + (long)a.B * G::H * G::W * N) + (long)blockIdx.x * 16 + nstamp,
+                              (long long)__builtin_readcyclecounter());
         ++nstamp;
     };
     stamp();
@@ -161,7 +177,7 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 bz = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (bias != nullptr) bz = *reinterpret_cast<const float4*>(bias + nt * 32 + 8 * g + 4 * h);
+                if (bias != nullptr) bz = gload4(bias + nt * 32 + 8 * g + 4 * h);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     ac[mt][nt][4 * g] = bz.x; ac[mt][nt][4 * g + 1] = bz.y; ac[mt][nt][4 * g + 2] = bz.z; ac[mt][nt][4 * g + 3] = bz.w;
@@ -215,7 +231,7 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             pin[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (goff[i] >= 0) pin[i] = reinterpret_cast<const uint4*>(s.ptr + goff[i] + kc)[tid & 3];
+            if (goff[i] >= 0) pin[i] = gload16(s.ptr + goff[i] + kc + (tid & 3) * 4);
         }
     };
     auto prefetch_w = [&](int c) {
@@ -227,11 +243,11 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
 #pragma unroll
         for (int i = 0; i < WN; ++i) {
             const int e = tid + 256 * i;
-            pwt[i] = (e < n16) ? wsrc[e] : make_uint4(0u, 0u, 0u, 0u);
+            pwt[i] = (e < n16) ? gload16(wsrc + e) : make_uint4(0u, 0u, 0u, 0u);
         }
         if constexpr (SKIP) {   // NT * 128 pieces of the 1x1 weights of the same chunk
             const uint4* ssrc = reinterpret_cast<const uint4*>(a.skip_wp + (long)(s.wchunk0 + ch) * (NT * 1024));
-            sk.psk = (tid < NT * 128) ? ssrc[tid] : make_uint4(0u, 0u, 0u, 0u);
+            sk.psk = (tid < NT * 128) ? gload16(ssrc + tid) : make_uint4(0u, 0u, 0u, 0u);
         }
     };
     auto stage = [&](const uint4 (&pin)[8]) {
@@ -347,10 +363,10 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
             const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
             const int m = min(mbase + px, Mtot - 1);   // clamped: the walk skips pixels past the end
             const long o = (long)m * N + c;
-            if (a.res != nullptr) p.rz[it] = *reinterpret_cast<const float4*>(a.res + o);
-            if (bwd) p.mk[it] = a.relu_mask_in[o >> 2];
+            if (a.res != nullptr) p.rz[it] = gload4(a.res + o);
+            if (bwd) p.mk[it] = gload<unsigned char>(a.relu_mask_in + (o >> 2));
             if (a.out_s16 != nullptr && a.tb_out != nullptr)
-                p.tz[it] = *reinterpret_cast<const float4*>(a.tb_out + (long)(img0 + (m >= mnext ? 1 : 0)) * a.tb_out_stride + c);
+                p.tz[it] = gload4(a.tb_out + (long)(img0 + (m >= mnext ? 1 : 0)) * a.tb_out_stride + c);
         }
     };
     auto to_lds = [&](float* T, const f32x16 (&ac)[NT]) {
@@ -382,10 +398,10 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
                     v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y;
                     v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
                 }
-                if (a.aux != nullptr && !(a.ablate & 16)) *reinterpret_cast<float4*>(a.aux + o) = v;
+                if (a.aux != nullptr && !(a.ablate & 16)) gstore4(a.aux + o, v);
                 if (a.mask_out != nullptr)
-                    a.mask_out[o >> 2] = (unsigned char)((v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) | (v.z > 0.f ? 4 : 0) |
-                                                         (v.w > 0.f ? 8 : 0));
+                    gstore<unsigned char>(a.mask_out + (o >> 2), (unsigned char)((v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) |
+                                                                                 (v.z > 0.f ? 4 : 0) | (v.w > 0.f ? 8 : 0)));
                 if (a.res != nullptr) {
                     const float4 rz = p.rz[it];
                     v.x += rz.x; v.y += rz.y; v.z += rz.z; v.w += rz.w;
@@ -404,13 +420,13 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
                     }
                     v = mv;
                 }
-                if (a.out != nullptr) *reinterpret_cast<float4*>(a.out + o) = v;
+                if (a.out != nullptr) gstore4(a.out + o, v);
                 if (a.out_s16 != nullptr) {
                     if (a.tb_out != nullptr) {
                         const float4 tz = p.tz[it];
                         v.x += tz.x; v.y += tz.y; v.z += tz.z; v.w += tz.w;
                     }
-                    tdm_store_s16_4(a.out_s16, m, N, c, v);
+                    gstore_s16_4(a.out_s16, m, N, c, v);
                 }
             }
         }
@@ -428,7 +444,7 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
                     }
                     if (lane < N / 4 && mbase < Mtot) {
                         const long grp = mbase >> 5;
-                        *reinterpret_cast<float4*>(a.sums + ((grp * 2 + sl) * 2 + kd) * N + lane * 4) = r;
+                        gstore4(a.sums + ((grp * 2 + sl) * 2 + kd) * N + lane * 4, r);
                     }
                 }
         }
@@ -437,13 +453,21 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
     Pre p0, p1;
     preload(0, p0);
     if constexpr (NT == 1) preload(1, p1);
+    stamp();                     // 6: tile inputs requested
     __syncthreads();             // every wave is done with the operand images
+    stamp();                     // 7
     float* T0 = reinterpret_cast<float*>(smem4) + wave * ((TWO_T ? 2 : 1) * 32 * EPI);
     float* T1 = TWO_T ? T0 + 32 * EPI : T0;
     to_lds(T0, acc[0]);
     if constexpr (TWO_T) to_lds(T1, acc[1]);
     if constexpr (NT != 1) preload(1, p1);
+    stamp();                     // 8: transposes written
+    // All of p0 / p1 has been requested: wait for it HERE, once.  The requests sit under uniform branches, so without
+    // this the compiler guards every pass's first use of p.rz / p.mk / p.tz with s_waitcnt vmcnt(0) — which on gfx9
+    // also waits for the previous pass's STORES (same counter): one L2 round trip per 64-float4 pass, 70 % of the walk.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only
     walk(0, T0, p0);
+    stamp();                     // 9
     if constexpr (!TWO_T) to_lds(T1, acc[1]);
     walk(1, T1, p1);
     if constexpr (SKIP) {   // second accumulator: skip_out = 1x1 conv (+ its bias, already accumulated), same transposed walk
@@ -459,7 +483,7 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
                 const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
                 const int m = mbase + px;
                 const float4 v = *reinterpret_cast<const float4*>(T + px * EPI + c);
-                if (m < Mtot) *reinterpret_cast<float4*>(a.skip_out + (long)m * N + c) = v;
+                if (m < Mtot) gstore4(a.skip_out + (long)m * N + c, v);
             }
         }
     }
@@ -484,6 +508,13 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     }
     const long Mtot = (long)a.B * G::H * G::W;
     const int ntiles = (int)((Mtot + TILE_PX - 1) / TILE_PX);
+    if (a.ablate & 32) {   // probe: one workgroup per CU (LDS request > half of 160 KB) — phase times without a co-resident workgroup
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<HW, NT, SKIP>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100000);
+        hipLaunchKernelGGL((conv_s16_kernel<HW, NT, SKIP>), dim3(ntiles), dim3(256), 100000, st, a);
+        TDM_CHECK_LAUNCH("conv_s16");
+        return 0;
+    }
     hipLaunchKernelGGL((conv_s16_kernel<HW, NT, SKIP>), dim3(ntiles), dim3(256), lds, st, a);
     TDM_CHECK_LAUNCH("conv_s16");
     return 0;
