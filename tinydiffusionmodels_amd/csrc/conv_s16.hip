@@ -119,11 +119,28 @@ struct PinnedArgs {
 
 // registers of the fused 1x1 skip conv (ConvArgs::skip_out): exist only in the SKIP instantiation
 template <int NT, bool SKIP> struct SkipState {};
-template <int NT> struct SkipState<NT, true> { f32x16 acc2[2][NT]; uint4 psk; };
+template <int NT> struct SkipState<NT, true> { f32x16 acc2[NT]; uint4 psk; };
+
+// 8 waves per workgroup, ONE 32-pixel M tile per wave.  tools/phase_probe.py showed every phase of the former 4-wave /
+// 2-M-tile workgroup taking the same time with the CU to itself as with a second workgroup next to it: at two waves per
+// SIMD the kernel is bound by the latency of its own dependent instruction chains (index math, LDS round trips,
+// epilogue), not by any throughput.  Halving the per-wave work and the register budget (<= 128 VGPRs at N <= 64) puts
+// four waves on every SIMD with the same 256-pixel tile and the same LDS images.
+constexpr int CONV_THREADS = 512;
+constexpr int NPIN = 4;   // 16-byte input pieces per thread and K chunk
+
+__device__ __forceinline__ void gstore_s16_o(float* s16, unsigned o, int c, const float4 v) {   // o = pixel * C + c (elements)
+    tdm_bf16x4 hi, lo;
+    tdm_split4(v, hi, lo);
+    char* base = reinterpret_cast<char*>(s16 + (o - (unsigned)(c & 15))) + (c & 15) * 2;
+    gstore<tdm_bf16x4>(base, hi);
+    gstore<tdm_bf16x4>(base + 32, lo);
+}
 
 template <int HW, int NT, bool SKIP>
-__global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvArgs ka) {
+__global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kernel(ConvArgs ka) {
     using G = Geo<HW>;
+    static_assert(G::NR * G::WP * 4 <= NPIN * CONV_THREADS, "staging plan too small");
     // The ~300-byte argument block does not stay in scalar registers by itself: the compiler re-reads a field from the
     // kernarg segment (s_load + s_waitcnt lgkmcnt(0), a scalar-cache round trip) next to almost every use — before each
     // prefetch load, around every uniform branch of the epilogue.  Everything the kernel uses is copied ONCE into
@@ -157,31 +174,28 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
     const int PR0 = tb0 * G::HP + ty0;
     const int nrows = padded_row<HW>(mlast) - PR0 + 2;
     const int nelem = nrows * G::WP * 4;      // 16-byte pieces of one chunk
+    const int mbase = m0 + wave * 32;         // this wave's M tile (scalar)
 
-    int aoff[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int m = min(m0 + (wave * 2 + mt) * 32 + j, Mtot - 1);
+    int aoff;
+    {
+        const int m = min(mbase + j, Mtot - 1);
         const int b = m / (G::H * G::W);
         const int rem = m - b * (G::H * G::W);
         const int y = rem / G::W, x = rem - y * G::W;
-        aoff[mt] = ((b * G::HP + y + 1 - PR0) * G::WP + x + 1) * PIXB + h * 16;
+        aoff = ((b * G::HP + y + 1 - PR0) * G::WP + x + 1) * PIXB + h * 16;
     }
 
     // accumulators start from the conv bias (register quad g of N tile nt = channels nt*32 + 8g + 4h .. +3 of the lane's
     // pixel): the loads are issued first thing and the epilogue has nothing left to add
-    f32x16 acc[2][NT];
-    auto init_acc = [&](f32x16 (&ac)[2][NT], const float* bias) {
+    f32x16 acc[NT];
+    auto init_acc = [&](f32x16 (&ac)[NT], const float* bias) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 bz = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (bias != nullptr) bz = gload4(bias + nt * 32 + 8 * g + 4 * h);
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    ac[mt][nt][4 * g] = bz.x; ac[mt][nt][4 * g + 1] = bz.y; ac[mt][nt][4 * g + 2] = bz.z; ac[mt][nt][4 * g + 3] = bz.w;
-                }
+                ac[nt][4 * g] = bz.x; ac[nt][4 * g + 1] = bz.y; ac[nt][4 * g + 2] = bz.z; ac[nt][4 * g + 3] = bz.w;
             }
     };
     init_acc(acc, a.bias);
@@ -191,47 +205,47 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
         init_acc(sk.acc2, a.skip_bias);
     }
 
-    // Software pipeline over K chunks, register-staged.  Input pieces are prefetched TWO chunks ahead (two register
-    // sets, 8 x 16 B per thread each), the L2-resident packed weights one chunk ahead: with a single chunk of
-    // distance a workgroup's MFMA phase (~0.8 us) is shorter than the HBM latency under load and every chunk
-    // stalled (ablation: K loop without global loads 73-86 us vs ~30 us of MFMA / LDS time for the 96->32 layer).
-    constexpr int WN = (9 * NT * 128 + 255) / 256;
+    // Software pipeline over K chunks, register-staged.  At N = 32 input pieces are prefetched TWO chunks ahead (two
+    // register sets, 4 x 16 B per thread each), the L2-resident packed weights one chunk ahead: with a single chunk of
+    // distance a workgroup's MFMA phase is shorter than the HBM latency under load and every chunk stalled.
+    constexpr int WN = (9 * NT * 128 + CONV_THREADS - 1) / CONV_THREADS;
+    constexpr int STEP = CONV_THREADS / 4;   // staged positions between a thread's consecutive pieces
     char* const sdst = tile + (tid >> 2) * PIXB + (tid & 3) * 16;
     const int nc0 = a.s0.nch >> 4;
     const int nchunks = nc0 + (a.nsrc > 1 ? (a.s1.nch >> 4) : 0);
-    int goffA[8], goffB[8];   // staging plans of the sources the two input sets were loaded from
+    int goffA[NPIN], goffB[NPIN];   // staging plans of the sources the two input sets were loaded from
     int planA = -1, planB = -1;
-    uint4 pinA[8], pinB[8], pwt[WN];
+    uint4 pinA[NPIN], pinB[NPIN], pwt[WN];
 
-    auto prefetch_in = [&](uint4 (&pin)[8], int (&goff)[8], int& plan_src, int c) {
+    auto prefetch_in = [&](uint4 (&pin)[NPIN], int (&goff)[NPIN], int& plan_src, int c) {
         const int si = (c >= nc0) ? 1 : 0;
         const int ch = si ? c - nc0 : c;
         const PinnedSrc s = a.src(si);
         if (plan_src != si) {
-            // staged position of piece e = tid + 256 i is (tid >> 2) + 64 i: walk (row, column) of the padded-tall image
+            // staged position of piece e = tid + 512 i is (tid >> 2) + 128 i: walk (row, column) of the padded-tall image
             // incrementally — no division per element (src_offset's three cost ~1/3 of a 32 -> 32 launch in index math)
             const int up = s.up, Hs = G::H >> up, Ws = G::W >> up;
             int lr = (tid >> 2) / G::WP;
             int pc = (tid >> 2) - lr * G::WP;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NPIN; ++i) {
                 int py = ty0 + lr, b = tb0;
                 if (py >= G::HP) { py -= G::HP; ++b; }
                 if (HW == 14 && py >= G::HP) { py -= G::HP; ++b; }   // 26 staged rows span up to three images at 14x14
-                const bool ok = tid + 256 * i < nelem && py >= 1 && py <= G::H && pc >= 1 && pc <= G::W && b < a.B;
+                const bool ok = tid + CONV_THREADS * i < nelem && py >= 1 && py <= G::H && pc >= 1 && pc <= G::W && b < a.B;
                 const int off = __mul24(__mul24(__mul24(b, Hs) + ((py - 1) >> up), Ws) + ((pc - 1) >> up), s.C) + s.c0;
-                goff[i] = ok ? off : -1;
-                pc += 64 % G::WP;
-                lr += 64 / G::WP;
+                goff[i] = ok ? off + (tid & 3) * 4 : -1;
+                pc += STEP % G::WP;
+                lr += STEP / G::WP;
                 if (pc >= G::WP) { pc -= G::WP; ++lr; }
             }
             plan_src = si;
         }
-        const int kc = ch << 4;
+        const float* base = s.ptr + (ch << 4);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NPIN; ++i) {
             pin[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (goff[i] >= 0) pin[i] = gload16(s.ptr + goff[i] + kc + (tid & 3) * 4);
+            if (goff[i] >= 0) pin[i] = gload16(base + (unsigned)goff[i]);
         }
     };
     auto prefetch_w = [&](int c) {
@@ -242,22 +256,22 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
         const uint4* wsrc = reinterpret_cast<const uint4*>(s.wp + (long)(s.wchunk0 + ch) * (s.taps * NT * 1024));
 #pragma unroll
         for (int i = 0; i < WN; ++i) {
-            const int e = tid + 256 * i;
-            pwt[i] = (e < n16) ? gload16(wsrc + e) : make_uint4(0u, 0u, 0u, 0u);
+            const unsigned e = tid + CONV_THREADS * i;
+            pwt[i] = ((int)e < n16) ? gload16(wsrc + e) : make_uint4(0u, 0u, 0u, 0u);
         }
         if constexpr (SKIP) {   // NT * 128 pieces of the 1x1 weights of the same chunk
             const uint4* ssrc = reinterpret_cast<const uint4*>(a.skip_wp + (long)(s.wchunk0 + ch) * (NT * 1024));
-            sk.psk = (tid < NT * 128) ? gload16(ssrc + tid) : make_uint4(0u, 0u, 0u, 0u);
+            sk.psk = (tid < NT * 128) ? gload16(ssrc + (unsigned)tid) : make_uint4(0u, 0u, 0u, 0u);
         }
     };
-    auto stage = [&](const uint4 (&pin)[8]) {
+    auto stage = [&](const uint4 (&pin)[NPIN]) {
         __syncthreads();      // everyone finished reading the previous chunk's LDS image
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (tid + 256 * i < nelem) *reinterpret_cast<uint4*>(sdst + i * (64 * PIXB)) = pin[i];
+        for (int i = 0; i < NPIN; ++i)
+            if (tid + CONV_THREADS * i < nelem) *reinterpret_cast<uint4*>(sdst + i * (STEP * PIXB)) = pin[i];
 #pragma unroll
         for (int i = 0; i < WN; ++i)
-            if (tid + 256 * i < 9 * NT * 128) reinterpret_cast<uint4*>(wl)[tid + 256 * i] = pwt[i];
+            if (tid + CONV_THREADS * i < 9 * NT * 128) reinterpret_cast<uint4*>(wl)[tid + CONV_THREADS * i] = pwt[i];
         if constexpr (SKIP) {   // packed 1x1 weights of the chunk: NT x (hi 1 KB | lo 1 KB) behind the 3x3 weights
             if (tid < NT * 128) reinterpret_cast<uint4*>(wl + 9 * NT * 2048)[tid] = sk.psk;
         }
@@ -271,33 +285,24 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
             if (taps == 9 || tp == 4) {   // a 1x1 source uses the centre-tap site with packed tap 0
                 const int toff = ((tp / 3 - 1) * G::WP + (tp % 3 - 1)) * PIXB;
                 const int wt = (taps == 9) ? tp : 0;
-                bf16x8 ah[2], al[2];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    ah[mt] = *reinterpret_cast<const bf16x8*>(tile + aoff[mt] + toff);
-                    al[mt] = *reinterpret_cast<const bf16x8*>(tile + aoff[mt] + toff + 32);
-                }
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(tile + aoff + toff);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(tile + aoff + toff + 32);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const char* wb = wl + ((wt * NT + nt) * 2) * 1024 + lane * 16;
                     const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wb);
                     const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wb + 1024);
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {   // D[co][pixel]: weights are the A operand
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al[mt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[mt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[mt], acc[mt][nt], 0, 0, 0);
-                    }
+                    // D[co][pixel]: weights are the A operand
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc[nt], 0, 0, 0);
                     if constexpr (SKIP) if (tp == 4) {   // the block's 1x1 skip conv reads exactly the centre-tap pixels
                         const char* sb = wl + 9 * NT * 2048 + (nt * 2) * 1024 + lane * 16;
                         const bf16x8 sh = *reinterpret_cast<const bf16x8*>(sb);
                         const bf16x8 sl = *reinterpret_cast<const bf16x8*>(sb + 1024);
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) {
-                            sk.acc2[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh, al[mt], sk.acc2[mt][nt], 0, 0, 0);
-                            sk.acc2[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sl, ah[mt], sk.acc2[mt][nt], 0, 0, 0);
-                            sk.acc2[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh, ah[mt], sk.acc2[mt][nt], 0, 0, 0);
-                        }
+                        sk.acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh, al, sk.acc2[nt], 0, 0, 0);
+                        sk.acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sl, ah, sk.acc2[nt], 0, 0, 0);
+                        sk.acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh, ah, sk.acc2[nt], 0, 0, 0);
                     }
                 }
             }
@@ -326,8 +331,8 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
             stamp();
         }
     } else {
-        // N = 64 / 96 (and N = 32 with the fused skip conv): 64-96 accumulator registers; a second input register set spills inside the K loop
-        // (21 scratch reloads per chunk were measured), so these widths prefetch one chunk ahead
+        // N = 64 / 96 (and N = 32 with the fused skip conv): a second input register set does not fit the 128-register
+        // budget of four waves per SIMD, so these widths prefetch one chunk ahead
         for (int c = 0; c < nchunks; ++c) {
             stage(pinA);
             if (c + 1 < nchunks && pf) { prefetch_in(pinA, goffA, planA, c + 1); prefetch_w(c + 1); }
@@ -341,35 +346,34 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
     // row-major — 32 pixels x N floats are ONE contiguous range of every NHWC tensor involved — so each load / store
     // instruction of the epilogue (residual in; out, saved post-ReLU copy, S16 twin out) covers 1 KB of consecutive
     // addresses.
-    // The walk's own inputs (residual, ReLU byte mask, time-bias row) are fetched into registers for a whole M tile
+    // The walk's own inputs (residual, ReLU byte mask, time-bias row) are fetched into registers for the whole M tile
     // BEFORE its transpose — one exposed memory latency per tile, not one per 64-float4 pass (the passes used to be
-    // separated by uniform branches, so the compiler waited for each pass's loads on the spot: 40 % of a 32 -> 32
-    // workgroup's lifetime was this epilogue, tools/phase_probe.py).  The conv bias is already in the accumulators.
+    // separated by uniform branches, so the compiler waited for each pass's loads on the spot).  The conv bias is
+    // already in the accumulators.  All offsets are 32-bit element offsets from scalar bases (tensors < 2^32 bytes).
     if (a.ablate & 8) return;
     nstamp = 6;
     constexpr int EPI = N + 4;   // floats per staged pixel row: (N/4 + 1) x 16 B, an odd slot count
     constexpr int NIT = N / 8;   // passes per M tile: 32 * N/4 float4, 64 per instruction
-    constexpr bool TWO_T = NT <= 2;   // room for a private LDS block per M tile (not at N = 96)
-    static_assert(!TWO_T || 4 * 2 * 32 * EPI * 4 <= TILE_B + 9 * NT * 2048, "epilogue blocks exceed the operand images");
     const bool bwd = NT != 3 && a.relu_mask_in != nullptr;   // (N = 32 / 64 outputs only)
-    struct Pre { float4 rz[NIT], tz[NIT]; unsigned mk[NIT]; };
-    auto preload = [&](int mt, Pre& p) {
-        const int mbase = m0 + (wave * 2 + mt) * 32;
-        const int img0 = mbase / (G::H * G::W);
-        const int mnext = (img0 + 1) * (G::H * G::W);
+    const int img0 = mbase / (G::H * G::W);         // image of the group's first pixel (scalar)
+    const int mnext = (img0 + 1) * (G::H * G::W);   // a 32-pixel group touches at most two images
+    struct Pre { float4 rt[NIT]; unsigned mk[NIT]; } p;   // rt: residual, else the time-bias row
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int e = it * 64 + lane;
-            const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
-            const int m = min(mbase + px, Mtot - 1);   // clamped: the walk skips pixels past the end
-            const long o = (long)m * N + c;
-            if (a.res != nullptr) p.rz[it] = gload4(a.res + o);
-            if (bwd) p.mk[it] = gload<unsigned char>(a.relu_mask_in + (o >> 2));
-            if (a.out_s16 != nullptr && a.tb_out != nullptr)
-                p.tz[it] = gload4(a.tb_out + (long)(img0 + (m >= mnext ? 1 : 0)) * a.tb_out_stride + c);
-        }
-    };
-    auto to_lds = [&](float* T, const f32x16 (&ac)[NT]) {
+    for (int it = 0; it < NIT; ++it) {
+        const int e = it * 64 + lane;
+        const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
+        const int m = min(mbase + px, Mtot - 1);   // clamped: the walk skips pixels past the end
+        const unsigned o = (unsigned)m * N + c;
+        if (a.res != nullptr) p.rt[it] = gload4(a.res + o);
+        if (bwd) p.mk[it] = gload<unsigned char>(a.relu_mask_in + (o >> 2));
+        if (a.out_s16 != nullptr && a.tb_out != nullptr && a.res == nullptr)
+            p.rt[it] = gload4(a.tb_out + (unsigned)((img0 + (m >= mnext ? 1 : 0)) * a.tb_out_stride + c));
+    }
+    stamp();                     // 6: tile inputs requested
+    __syncthreads();             // every wave is done with the operand images
+    stamp();                     // 7
+    float* T = reinterpret_cast<float*>(smem4) + wave * (32 * EPI);
+    auto to_lds = [&](const f32x16 (&ac)[NT]) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -377,10 +381,13 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
                 *reinterpret_cast<float4*>(T + j * EPI + nt * 32 + 8 * g + 4 * h) =
                     make_float4(ac[nt][4 * g], ac[nt][4 * g + 1], ac[nt][4 * g + 2], ac[nt][4 * g + 3]);
     };
-    auto walk = [&](int mt, const float* T, const Pre& p) {
-        const int mbase = m0 + (wave * 2 + mt) * 32;
-        const int img0 = mbase / (G::H * G::W);   // image of the group's first pixel (scalar: mbase is wave-uniform)
-        const int mnext = (img0 + 1) * (G::H * G::W);   // a 32-pixel group touches at most two images
+    to_lds(acc);
+    stamp();                     // 8: transpose written
+    // Everything of p has been requested: wait for it HERE, once.  The requests sit under uniform branches, so without
+    // this the compiler guards every pass's first use of p.rt / p.mk with s_waitcnt vmcnt(0) — which on gfx9
+    // also waits for the previous pass's STORES (same counter).
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only
+    {
         float4 sacc[2][2];                        // [slot][kind] partial sums of this lane's channel quad (bwd only)
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl)
@@ -393,17 +400,14 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
             const int m = mbase + px;
             float4 v = *reinterpret_cast<const float4*>(T + px * EPI + c);
             if (m < Mtot) {
-                const long o = (long)m * N + c;
-                if (a.relu) {
-                    v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y;
-                    v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
-                }
+                const unsigned o = (unsigned)m * N + c;
+                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (a.aux != nullptr && !(a.ablate & 16)) gstore4(a.aux + o, v);
                 if (a.mask_out != nullptr)
                     gstore<unsigned char>(a.mask_out + (o >> 2), (unsigned char)((v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) |
                                                                                  (v.z > 0.f ? 4 : 0) | (v.w > 0.f ? 8 : 0)));
                 if (a.res != nullptr) {
-                    const float4 rz = p.rz[it];
+                    const float4 rz = p.rt[it];
                     v.x += rz.x; v.y += rz.y; v.z += rz.z; v.w += rz.w;
                 }
                 if (bwd) {   // ReLU backward of the tensor this gradient belongs to + the sums its bias gradients need
@@ -423,10 +427,12 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
                 if (a.out != nullptr) gstore4(a.out + o, v);
                 if (a.out_s16 != nullptr) {
                     if (a.tb_out != nullptr) {
-                        const float4 tz = p.tz[it];
+                        float4 tz = p.rt[it];
+                        if (a.res != nullptr)   // both a residual and a time-bias row (no UNet launch; C-ABI layer tests): fetch in place
+                            tz = gload4(a.tb_out + (unsigned)((img0 + (m >= mnext ? 1 : 0)) * a.tb_out_stride + c));
                         v.x += tz.x; v.y += tz.y; v.z += tz.z; v.w += tz.w;
                     }
-                    gstore_s16_4(a.out_s16, m, N, c, v);
+                    gstore_s16_o(a.out_s16, o, c, v);
                 }
             }
         }
@@ -443,48 +449,23 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
                         r.z += __shfl_xor(r.z, off); r.w += __shfl_xor(r.w, off);
                     }
                     if (lane < N / 4 && mbase < Mtot) {
-                        const long grp = mbase >> 5;
-                        gstore4(a.sums + ((grp * 2 + sl) * 2 + kd) * N + lane * 4, r);
+                        const unsigned grp = (unsigned)mbase >> 5;
+                        gstore4(a.sums + (unsigned)(((grp * 2 + sl) * 2 + kd) * N + lane * 4), r);
                     }
                 }
         }
-    };
-
-    Pre p0, p1;
-    preload(0, p0);
-    if constexpr (NT == 1) preload(1, p1);
-    stamp();                     // 6: tile inputs requested
-    __syncthreads();             // every wave is done with the operand images
-    stamp();                     // 7
-    float* T0 = reinterpret_cast<float*>(smem4) + wave * ((TWO_T ? 2 : 1) * 32 * EPI);
-    float* T1 = TWO_T ? T0 + 32 * EPI : T0;
-    to_lds(T0, acc[0]);
-    if constexpr (TWO_T) to_lds(T1, acc[1]);
-    if constexpr (NT != 1) preload(1, p1);
-    stamp();                     // 8: transposes written
-    // All of p0 / p1 has been requested: wait for it HERE, once.  The requests sit under uniform branches, so without
-    // this the compiler guards every pass's first use of p.rz / p.mk / p.tz with s_waitcnt vmcnt(0) — which on gfx9
-    // also waits for the previous pass's STORES (same counter): one L2 round trip per 64-float4 pass, 70 % of the walk.
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only
-    walk(0, T0, p0);
+    }
     stamp();                     // 9
-    if constexpr (!TWO_T) to_lds(T1, acc[1]);
-    walk(1, T1, p1);
+    stamp();                     // 10 (second M tile of the former 4-wave layout: none)
     if constexpr (SKIP) {   // second accumulator: skip_out = 1x1 conv (+ its bias, already accumulated), same transposed walk
-        to_lds(T0, sk.acc2[0]);
-        to_lds(T1, sk.acc2[1]);
+        to_lds(sk.acc2);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int mbase = m0 + (wave * 2 + mt) * 32;
-            const float* T = mt ? T1 : T0;
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int e = it * 64 + lane;
-                const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
-                const int m = mbase + px;
-                const float4 v = *reinterpret_cast<const float4*>(T + px * EPI + c);
-                if (m < Mtot) gstore4(a.skip_out + (long)m * N + c, v);
-            }
+        for (int it = 0; it < NIT; ++it) {
+            const int e = it * 64 + lane;
+            const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
+            const int m = mbase + px;
+            const float4 v = *reinterpret_cast<const float4*>(T + px * EPI + c);
+            if (m < Mtot) gstore4(a.skip_out + ((unsigned)m * N + c), v);
         }
     }
     stamp();   // stores issued
@@ -495,11 +476,13 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void conv_s16_kernel(ConvAr
 template <int HW, int NT, bool SKIP>
 int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     using G = Geo<HW>;
-    constexpr size_t lds = (size_t)G::NR * G::WP * PIXB + (size_t)9 * NT * 2048 + (SKIP ? (size_t)NT * 2048 : 0);
+    constexpr size_t lds_op = (size_t)G::NR * G::WP * PIXB + (size_t)9 * NT * 2048 + (SKIP ? (size_t)NT * 2048 : 0);
+    constexpr size_t lds_epi = (size_t)(CONV_THREADS / 64) * 32 * (NT * 32 + 4) * sizeof(float);   // per-wave transpose blocks
+    constexpr size_t lds = lds_op > lds_epi ? lds_op : lds_epi;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<HW, NT, SKIP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 110000);
         if (e != hipSuccess) {
             tdm_set_error("conv_s16: hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
             return 100 + (int)e;
@@ -508,14 +491,9 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     }
     const long Mtot = (long)a.B * G::H * G::W;
     const int ntiles = (int)((Mtot + TILE_PX - 1) / TILE_PX);
-    if (a.ablate & 32) {   // probe: one workgroup per CU (LDS request > half of 160 KB) — phase times without a co-resident workgroup
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<HW, NT, SKIP>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100000);
-        hipLaunchKernelGGL((conv_s16_kernel<HW, NT, SKIP>), dim3(ntiles), dim3(256), 100000, st, a);
-        TDM_CHECK_LAUNCH("conv_s16");
-        return 0;
-    }
-    hipLaunchKernelGGL((conv_s16_kernel<HW, NT, SKIP>), dim3(ntiles), dim3(256), lds, st, a);
+    // ablate & 32 (probe): one workgroup per CU (LDS request > half of 160 KB) — phase times without a co-resident workgroup
+    const size_t lds_req = (a.ablate & 32) ? (size_t)110000 : lds;
+    hipLaunchKernelGGL((conv_s16_kernel<HW, NT, SKIP>), dim3(ntiles), dim3(CONV_THREADS), lds_req, st, a);
     TDM_CHECK_LAUNCH("conv_s16");
     return 0;
 }
