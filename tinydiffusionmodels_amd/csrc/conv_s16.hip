@@ -14,6 +14,7 @@
 //     producers of the gradient tensors sum them in fp32, elementwise.hip).
 #include "tdm_common.h"
 #include "tdm_s16.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -117,6 +118,15 @@ struct PinnedArgs {
     }
 };
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 // registers of the fused 1x1 skip conv (ConvArgs::skip_out): exist only in the SKIP instantiation
 template <int NT, bool SKIP> struct SkipState {};
 template <int NT> struct SkipState<NT, true> { f32x16 acc2[NT]; uint4 psk; };
@@ -217,14 +227,18 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     int planA = -1, planB = -1;
     uint4 pinA[NPIN], pinB[NPIN], pwt[WN];
 
+    // Inputs and weights come through buffer descriptors: a piece that is padding (or past the end) gets an offset
+    // beyond num_records and the hardware returns zeros — no exec-mask branch per load, no zero-initialised
+    // destination, and (straight-line code) exact vmcnt(n) waits, so the second register set really stays in flight
+    // while the first is staged.
     auto prefetch_in = [&](uint4 (&pin)[NPIN], int (&goff)[NPIN], int& plan_src, int c) {
         const int si = (c >= nc0) ? 1 : 0;
         const int ch = si ? c - nc0 : c;
         const PinnedSrc s = a.src(si);
+        const int up = s.up, Hs = G::H >> up, Ws = G::W >> up;
         if (plan_src != si) {
             // staged position of piece e = tid + 512 i is (tid >> 2) + 128 i: walk (row, column) of the padded-tall image
             // incrementally — no division per element (src_offset's three cost ~1/3 of a 32 -> 32 launch in index math)
-            const int up = s.up, Hs = G::H >> up, Ws = G::W >> up;
             int lr = (tid >> 2) / G::WP;
             int pc = (tid >> 2) - lr * G::WP;
 #pragma unroll
@@ -234,34 +248,38 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
                 if (HW == 14 && py >= G::HP) { py -= G::HP; ++b; }   // 26 staged rows span up to three images at 14x14
                 const bool ok = tid + CONV_THREADS * i < nelem && py >= 1 && py <= G::H && pc >= 1 && pc <= G::W && b < a.B;
                 const int off = __mul24(__mul24(__mul24(b, Hs) + ((py - 1) >> up), Ws) + ((pc - 1) >> up), s.C) + s.c0;
-                goff[i] = ok ? off + (tid & 3) * 4 : -1;
+                goff[i] = ok ? (off + (tid & 3) * 4) * 4 : (int)0x80000000;   // byte offset, or out of range
                 pc += STEP % G::WP;
                 lr += STEP / G::WP;
                 if (pc >= G::WP) { pc -= G::WP; ++lr; }
             }
             plan_src = si;
         }
-        const float* base = s.ptr + (ch << 4);
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.ptr), 0, a.B * Hs * Ws * s.C * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NPIN; ++i) {
-            pin[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (goff[i] >= 0) pin[i] = gload16(base + (unsigned)goff[i]);
+            const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i], ch << 6, 0));
+            pin[i] = make_uint4(v[0], v[1], v[2], v[3]);
         }
     };
     auto prefetch_w = [&](int c) {
         const int si = (c >= nc0) ? 1 : 0;
         const int ch = si ? c - nc0 : c;
         const PinnedSrc s = a.src(si);
-        const int n16 = s.taps * NT * 128;
-        const uint4* wsrc = reinterpret_cast<const uint4*>(s.wp + (long)(s.wchunk0 + ch) * (s.taps * NT * 1024));
+        const int nbytes = s.taps * NT * 2048;   // one chunk of packed weights
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned short*>(s.wp) + (long)(s.wchunk0 + ch) * (s.taps * NT * 1024), 0, nbytes, 0x00020000);
 #pragma unroll
         for (int i = 0; i < WN; ++i) {
-            const unsigned e = tid + CONV_THREADS * i;
-            pwt[i] = ((int)e < n16) ? gload16(wsrc + e) : make_uint4(0u, 0u, 0u, 0u);
+            const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + CONV_THREADS * i) * 16, 0, 0));
+            pwt[i] = make_uint4(v[0], v[1], v[2], v[3]);
         }
         if constexpr (SKIP) {   // NT * 128 pieces of the 1x1 weights of the same chunk
-            const uint4* ssrc = reinterpret_cast<const uint4*>(a.skip_wp + (long)(s.wchunk0 + ch) * (NT * 1024));
-            sk.psk = (tid < NT * 128) ? gload16(ssrc + (unsigned)tid) : make_uint4(0u, 0u, 0u, 0u);
+            const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<unsigned short*>(a.skip_wp) + (long)(s.wchunk0 + ch) * (NT * 1024), 0, NT * 2048, 0x00020000);
+            const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, tid * 16, 0, 0));
+            sk.psk = make_uint4(v[0], v[1], v[2], v[3]);
         }
     };
     auto stage = [&](const uint4 (&pin)[NPIN]) {
@@ -387,73 +405,116 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     // this the compiler guards every pass's first use of p.rt / p.mk with s_waitcnt vmcnt(0) — which on gfx9
     // also waits for the previous pass's STORES (same counter).
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only
-    {
-        float4 sacc[2][2];                        // [slot][kind] partial sums of this lane's channel quad (bwd only)
+    // The walk runs phase by phase over ALL passes of the tile (values in registers), not pass by pass: every uniform
+    // "is this output wanted" branch then wraps NIT independent instruction chains that the scheduler can interleave.
+    // Pass by pass, each chain (LDS read -> ReLU -> split -> store, ~30 dependent instructions) ran alone at one
+    // instruction per ~10 cycles.  `full` (all 32 pixels exist) removes the per-lane bounds check from all but the last tile.
+    constexpr int GI = 4;   // passes per group: 4 independent chains, 16 value registers
+    float4 sacc[2][2];      // [slot][kind] partial sums of this lane's channel quad (bwd only)
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int kd = 0; kd < 2; ++kd) sacc[sl][kd] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto walk = [&](auto full_c, auto group_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+        constexpr int I0 = decltype(group_c)::value * GI;
+        float4 v[GI];
+        unsigned o[GI];
+        bool ok[GI];
+#pragma unroll
+        for (int k = 0; k < GI; ++k) {
+            const int e = (I0 + k) * 64 + lane;
+            const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
+            v[k] = *reinterpret_cast<const float4*>(T + px * EPI + c);
+            o[k] = (unsigned)(mbase + px) * N + c;
+            ok[k] = FULL || mbase + px < Mtot;
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int k = 0; k < GI; ++k) {
+                v[k].x = fmaxf(v[k].x, 0.f); v[k].y = fmaxf(v[k].y, 0.f); v[k].z = fmaxf(v[k].z, 0.f); v[k].w = fmaxf(v[k].w, 0.f);
+            }
+        }
+        if (a.aux != nullptr && !(a.ablate & 16)) {
+#pragma unroll
+            for (int k = 0; k < GI; ++k) if (ok[k]) gstore4(a.aux + o[k], v[k]);
+        }
+        if (a.mask_out != nullptr) {
+#pragma unroll
+            for (int k = 0; k < GI; ++k)
+                if (ok[k])
+                    gstore<unsigned char>(a.mask_out + (o[k] >> 2),
+                                          (unsigned char)((v[k].x > 0.f ? 1 : 0) | (v[k].y > 0.f ? 2 : 0) |
+                                                          (v[k].z > 0.f ? 4 : 0) | (v[k].w > 0.f ? 8 : 0)));
+        }
+        if (a.res != nullptr) {
+#pragma unroll
+            for (int k = 0; k < GI; ++k) {
+                const float4 rz = p.rt[I0 + k];
+                v[k].x += rz.x; v[k].y += rz.y; v[k].z += rz.z; v[k].w += rz.w;
+            }
+        }
+        if (bwd) {   // ReLU backward of the tensor this gradient belongs to + the sums its bias gradients need
+#pragma unroll
+            for (int k = 0; k < GI; ++k) {
+                const int m = mbase + ((I0 + k) * 64 + lane) / (N / 4);
+                const unsigned mk = p.mk[I0 + k];
+                const float4 u = v[k];
+                const float4 mv = make_float4((mk & 1u) ? u.x : 0.f, (mk & 2u) ? u.y : 0.f, (mk & 4u) ? u.z : 0.f,
+                                              (mk & 8u) ? u.w : 0.f);
+                const bool s0 = ok[k] && m < mnext, s1 = ok[k] && m >= mnext;   // slot 0: image of the first pixel; slot 1: the next
+                sacc[0][0].x += s0 ? u.x : 0.f; sacc[0][0].y += s0 ? u.y : 0.f; sacc[0][0].z += s0 ? u.z : 0.f; sacc[0][0].w += s0 ? u.w : 0.f;
+                sacc[0][1].x += s0 ? mv.x : 0.f; sacc[0][1].y += s0 ? mv.y : 0.f; sacc[0][1].z += s0 ? mv.z : 0.f; sacc[0][1].w += s0 ? mv.w : 0.f;
+                sacc[1][0].x += s1 ? u.x : 0.f; sacc[1][0].y += s1 ? u.y : 0.f; sacc[1][0].z += s1 ? u.z : 0.f; sacc[1][0].w += s1 ? u.w : 0.f;
+                sacc[1][1].x += s1 ? mv.x : 0.f; sacc[1][1].y += s1 ? mv.y : 0.f; sacc[1][1].z += s1 ? mv.z : 0.f; sacc[1][1].w += s1 ? mv.w : 0.f;
+                v[k] = mv;
+            }
+        }
+        if (a.out != nullptr) {
+#pragma unroll
+            for (int k = 0; k < GI; ++k) if (ok[k]) gstore4(a.out + o[k], v[k]);
+        }
+        if (a.out_s16 != nullptr) {
+            if (a.tb_out != nullptr) {
+#pragma unroll
+                for (int k = 0; k < GI; ++k) {
+                    float4 tz = p.rt[I0 + k];
+                    if (a.res != nullptr) {   // both a residual and a time-bias row (no UNet launch; C-ABI layer tests): fetch in place
+                        const int e = (I0 + k) * 64 + lane;
+                        const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
+                        const int m = min(mbase + px, Mtot - 1);
+                        tz = gload4(a.tb_out + (unsigned)((img0 + (m >= mnext ? 1 : 0)) * a.tb_out_stride + c));
+                    }
+                    v[k].x += tz.x; v[k].y += tz.y; v[k].z += tz.z; v[k].w += tz.w;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < GI; ++k) {
+                const int c = (((I0 + k) * 64 + lane) % (N / 4)) * 4;
+                if (ok[k]) gstore_s16_o(a.out_s16, o[k], c, v[k]);
+            }
+        }
+    };
+    static_assert(NIT % GI == 0, "pass groups");
+    if (mbase + 32 <= Mtot) static_for<0, NIT / GI>([&](auto g) { walk(std::true_type{}, g); });
+    else static_for<0, NIT / GI>([&](auto g) { walk(std::false_type{}, g); });
+    if (bwd && a.sums != nullptr) {
+        // lanes with equal lane % (N/4) hold the same channel quad of different pixels: butterfly over the rest
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
-            for (int kd = 0; kd < 2; ++kd) sacc[sl][kd] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int kd = 0; kd < 2; ++kd) {
+                float4 r = sacc[sl][kd];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int e = it * 64 + lane;
-            const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
-            const int m = mbase + px;
-            float4 v = *reinterpret_cast<const float4*>(T + px * EPI + c);
-            if (m < Mtot) {
-                const unsigned o = (unsigned)m * N + c;
-                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (a.aux != nullptr && !(a.ablate & 16)) gstore4(a.aux + o, v);
-                if (a.mask_out != nullptr)
-                    gstore<unsigned char>(a.mask_out + (o >> 2), (unsigned char)((v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) |
-                                                                                 (v.z > 0.f ? 4 : 0) | (v.w > 0.f ? 8 : 0)));
-                if (a.res != nullptr) {
-                    const float4 rz = p.rt[it];
-                    v.x += rz.x; v.y += rz.y; v.z += rz.z; v.w += rz.w;
+                for (int off = N / 4; off < 64; off <<= 1) {
+                    r.x += __shfl_xor(r.x, off); r.y += __shfl_xor(r.y, off);
+                    r.z += __shfl_xor(r.z, off); r.w += __shfl_xor(r.w, off);
                 }
-                if (bwd) {   // ReLU backward of the tensor this gradient belongs to + the sums its bias gradients need
-                    const unsigned mk = p.mk[it];
-                    const float4 mv = make_float4((mk & 1u) ? v.x : 0.f, (mk & 2u) ? v.y : 0.f, (mk & 4u) ? v.z : 0.f,
-                                                  (mk & 8u) ? v.w : 0.f);
-                    const int sl = (m >= mnext) ? 1 : 0;
-                    if (sl == 0) {
-                        sacc[0][0].x += v.x; sacc[0][0].y += v.y; sacc[0][0].z += v.z; sacc[0][0].w += v.w;
-                        sacc[0][1].x += mv.x; sacc[0][1].y += mv.y; sacc[0][1].z += mv.z; sacc[0][1].w += mv.w;
-                    } else {
-                        sacc[1][0].x += v.x; sacc[1][0].y += v.y; sacc[1][0].z += v.z; sacc[1][0].w += v.w;
-                        sacc[1][1].x += mv.x; sacc[1][1].y += mv.y; sacc[1][1].z += mv.z; sacc[1][1].w += mv.w;
-                    }
-                    v = mv;
-                }
-                if (a.out != nullptr) gstore4(a.out + o, v);
-                if (a.out_s16 != nullptr) {
-                    if (a.tb_out != nullptr) {
-                        float4 tz = p.rt[it];
-                        if (a.res != nullptr)   // both a residual and a time-bias row (no UNet launch; C-ABI layer tests): fetch in place
-                            tz = gload4(a.tb_out + (unsigned)((img0 + (m >= mnext ? 1 : 0)) * a.tb_out_stride + c));
-                        v.x += tz.x; v.y += tz.y; v.z += tz.z; v.w += tz.w;
-                    }
-                    gstore_s16_o(a.out_s16, o, c, v);
+                if (lane < N / 4 && mbase < Mtot) {
+                    const unsigned grp = (unsigned)mbase >> 5;
+                    gstore4(a.sums + (unsigned)(((grp * 2 + sl) * 2 + kd) * N + lane * 4), r);
                 }
             }
-        }
-        if (bwd && a.sums != nullptr) {
-            // lanes with equal lane % (N/4) hold the same channel quad of different pixels: butterfly over the rest
-#pragma unroll
-            for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-                for (int kd = 0; kd < 2; ++kd) {
-                    float4 r = sacc[sl][kd];
-#pragma unroll
-                    for (int off = N / 4; off < 64; off <<= 1) {
-                        r.x += __shfl_xor(r.x, off); r.y += __shfl_xor(r.y, off);
-                        r.z += __shfl_xor(r.z, off); r.w += __shfl_xor(r.w, off);
-                    }
-                    if (lane < N / 4 && mbase < Mtot) {
-                        const unsigned grp = (unsigned)mbase >> 5;
-                        gstore4(a.sums + (unsigned)(((grp * 2 + sl) * 2 + kd) * N + lane * 4), r);
-                    }
-                }
-        }
     }
     stamp();                     // 9
     stamp();                     // 10 (second M tile of the former 4-wave layout: none)
