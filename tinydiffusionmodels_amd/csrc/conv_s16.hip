@@ -370,15 +370,20 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     // already in the accumulators.  All offsets are 32-bit element offsets from scalar bases (tensors < 2^32 bytes).
     if (a.ablate & 8) return;
     nstamp = 6;
+    // opaque copies: keeps the optimiser from computing the epilogue's per-lane offsets before the K loop and carrying
+    // them through it (at N = 64 that cost spills inside the loop under the 128-register budget)
+    int lane_e = lane, j_e = j, h_e = h;
+    asm volatile("" : "+v"(lane_e), "+v"(j_e), "+v"(h_e));
     constexpr int EPI = N + 4;   // floats per staged pixel row: (N/4 + 1) x 16 B, an odd slot count
     constexpr int NIT = N / 8;   // passes per M tile: 32 * N/4 float4, 64 per instruction
     const bool bwd = NT != 3 && a.relu_mask_in != nullptr;   // (N = 32 / 64 outputs only)
     const int img0 = mbase / (G::H * G::W);         // image of the group's first pixel (scalar)
     const int mnext = (img0 + 1) * (G::H * G::W);   // a 32-pixel group touches at most two images
     struct Pre { float4 rt[NIT]; unsigned mk[NIT]; } p;   // rt: residual, else the time-bias row
+    auto preload = [&]() {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int e = it * 64 + lane;
+        const int e = it * 64 + lane_e;
         const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
         const int m = min(mbase + px, Mtot - 1);   // clamped: the walk skips pixels past the end
         const unsigned o = (unsigned)m * N + c;
@@ -387,6 +392,8 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         if (a.out_s16 != nullptr && a.tb_out != nullptr && a.res == nullptr)
             p.rt[it] = gload4(a.tb_out + (unsigned)((img0 + (m >= mnext ? 1 : 0)) * a.tb_out_stride + c));
     }
+    };
+    if constexpr (NT == 1) preload();   // (wider tiles: after the accumulators have left their registers)
     stamp();                     // 6: tile inputs requested
     __syncthreads();             // every wave is done with the operand images
     stamp();                     // 7
@@ -396,10 +403,11 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(T + j * EPI + nt * 32 + 8 * g + 4 * h) =
+                *reinterpret_cast<float4*>(T + j_e * EPI + nt * 32 + 8 * g + 4 * h_e) =
                     make_float4(ac[nt][4 * g], ac[nt][4 * g + 1], ac[nt][4 * g + 2], ac[nt][4 * g + 3]);
     };
     to_lds(acc);
+    if constexpr (NT != 1) preload();
     stamp();                     // 8: transpose written
     // Everything of p has been requested: wait for it HERE, once.  The requests sit under uniform branches, so without
     // this the compiler guards every pass's first use of p.rt / p.mk with s_waitcnt vmcnt(0) — which on gfx9
@@ -408,9 +416,9 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     // The walk runs phase by phase over ALL passes of the tile (values in registers), not pass by pass: every uniform
     // "is this output wanted" branch then wraps NIT independent instruction chains that the scheduler can interleave.
     // Pass by pass, each chain (LDS read -> ReLU -> split -> store, ~30 dependent instructions) ran alone at one
-    // instruction per ~10 cycles.  `full` (all 32 pixels exist) removes the per-lane bounds check from all but the last tile.
+    // instruction per ~10 cycles.  `full` (all 32 pixels exist) removes the per-lane_e bounds check from all but the last tile.
     constexpr int GI = 4;   // passes per group: 4 independent chains, 16 value registers
-    float4 sacc[2][2];      // [slot][kind] partial sums of this lane's channel quad (bwd only)
+    float4 sacc[2][2];      // [slot][kind] partial sums of this lane_e's channel quad (bwd only)
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
@@ -423,7 +431,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         bool ok[GI];
 #pragma unroll
         for (int k = 0; k < GI; ++k) {
-            const int e = (I0 + k) * 64 + lane;
+            const int e = (I0 + k) * 64 + lane_e;
             const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
             v[k] = *reinterpret_cast<const float4*>(T + px * EPI + c);
             o[k] = (unsigned)(mbase + px) * N + c;
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         if (bwd) {   // ReLU backward of the tensor this gradient belongs to + the sums its bias gradients need
 #pragma unroll
             for (int k = 0; k < GI; ++k) {
-                const int m = mbase + ((I0 + k) * 64 + lane) / (N / 4);
+                const int m = mbase + ((I0 + k) * 64 + lane_e) / (N / 4);
                 const unsigned mk = p.mk[I0 + k];
                 const float4 u = v[k];
                 const float4 mv = make_float4((mk & 1u) ? u.x : 0.f, (mk & 2u) ? u.y : 0.f, (mk & 4u) ? u.z : 0.f,
@@ -480,7 +488,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
                 for (int k = 0; k < GI; ++k) {
                     float4 tz = p.rt[I0 + k];
                     if (a.res != nullptr) {   // both a residual and a time-bias row (no UNet launch; C-ABI layer tests): fetch in place
-                        const int e = (I0 + k) * 64 + lane;
+                        const int e = (I0 + k) * 64 + lane_e;
                         const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
                         const int m = min(mbase + px, Mtot - 1);
                         tz = gload4(a.tb_out + (unsigned)((img0 + (m >= mnext ? 1 : 0)) * a.tb_out_stride + c));
@@ -490,7 +498,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
             }
 #pragma unroll
             for (int k = 0; k < GI; ++k) {
-                const int c = (((I0 + k) * 64 + lane) % (N / 4)) * 4;
+                const int c = (((I0 + k) * 64 + lane_e) % (N / 4)) * 4;
                 if (ok[k]) gstore_s16_o(a.out_s16, o[k], c, v[k]);
             }
         }
@@ -499,7 +507,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     if (mbase + 32 <= Mtot) static_for<0, NIT / GI>([&](auto g) { walk(std::true_type{}, g); });
     else static_for<0, NIT / GI>([&](auto g) { walk(std::false_type{}, g); });
     if (bwd && a.sums != nullptr) {
-        // lanes with equal lane % (N/4) hold the same channel quad of different pixels: butterfly over the rest
+        // lanes with equal lane_e % (N/4) hold the same channel quad of different pixels: butterfly over the rest
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
@@ -510,9 +518,9 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
                     r.x += __shfl_xor(r.x, off); r.y += __shfl_xor(r.y, off);
                     r.z += __shfl_xor(r.z, off); r.w += __shfl_xor(r.w, off);
                 }
-                if (lane < N / 4 && mbase < Mtot) {
+                if (lane_e < N / 4 && mbase < Mtot) {
                     const unsigned grp = (unsigned)mbase >> 5;
-                    gstore4(a.sums + (unsigned)(((grp * 2 + sl) * 2 + kd) * N + lane * 4), r);
+                    gstore4(a.sums + (unsigned)(((grp * 2 + sl) * 2 + kd) * N + lane_e * 4), r);
                 }
             }
     }
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         to_lds(sk.acc2);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int e = it * 64 + lane;
+            const int e = it * 64 + lane_e;
             const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
             const int m = mbase + px;
             const float4 v = *reinterpret_cast<const float4*>(T + px * EPI + c);
