@@ -622,19 +622,30 @@ __global__ __launch_bounds__(512) void wgrad_s16_kernel(WgradArgs a) {
 
     constexpr int NA = (NPX * 8 + 511) / 512;
     constexpr int NG = TILE_PX * 8 / 512;
-    // Every prefetch issues exactly NA + NG loads, unconditionally (invalid pieces read offset 0 and are zeroed from
-    // `ok` when they are written to LDS): with a static load count the compiler can wait for the OLDER register set
-    // only (s_waitcnt vmcnt(NA + NG)) instead of draining both sets with vmcnt(0).
-    struct Stage { u32x4 pa[NA]; u32x4 pg[NG]; int pix; int nelem; unsigned ok; };
+    // Both operands come through buffer descriptors: a padding piece (or one past the end) gets an offset beyond
+    // num_records and reads as zeros — every prefetch is exactly NA + NG unconditional loads, so the compiler waits for
+    // the OLDER register set only (s_waitcnt vmcnt(NA + NG)).  The staging plan walks (row, column) of the padded-tall
+    // image incrementally, piece e = tid + 512 i sits at position (tid >> 3) + 64 i: no division per piece (three per
+    // piece before; per tile that index math was a longer dependent chain than the tile's 60 MFMAs).
+    const float* a_ptr = s.ptr; const float* g_ptr = a.g;
+    int a_C = s.C, a_c0 = s.c0, a_up = s.up, g_C = a.Cout, nB = a.B;
+    TDM_PIN(a_ptr); TDM_PIN(g_ptr); TDM_PIN(a_C); TDM_PIN(a_c0); TDM_PIN(a_up); TDM_PIN(g_C); TDM_PIN(nB);
+    const int Hs = G::H >> a_up, Ws = G::W >> a_up;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_ptr), 0, nB * Hs * Ws * a_C * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g_ptr), 0, Mtot * g_C * 4, 0x00020000);
+    const int a_col = a_c0 + ci0 + grp * 16 + pq * 4;   // float column of this thread's piece inside a pixel row of A
+    const int g_col = co0 + grp * 16 + pq * 4;
+    struct Stage { u32x4 pa[NA]; u32x4 pg[NG]; int pix; int nelem; };
     Stage s0, s1;
     auto prefetch = [&](Stage& st, int t) {
         const int m0 = t * TILE_PX;
         const int mlast = min(m0 + TILE_PX - 1, Mtot - 1);
-        const int PR0 = padded_row<HW>(m0) - 1;
+        const int tb0 = m0 / (G::H * G::W);
+        const int ty0 = (m0 - tb0 * (G::H * G::W)) / G::W;
+        const int PR0 = tb0 * G::HP + ty0;
         const int nrows = padded_row<HW>(mlast) - PR0 + 2;
         st.nelem = nrows * G::WP * 8;
         st.pix = 0;
-        st.ok = 0u;
         if (tid < TILE_PX) {   // staged-pixel index of tile pixel `tid`
             const int m = min(m0 + tid, Mtot - 1);
             const int b = m / (G::H * G::W);
@@ -642,39 +653,42 @@ __global__ __launch_bounds__(512) void wgrad_s16_kernel(WgradArgs a) {
             const int y = rem / G::W, x = rem - y * G::W;
             st.pix = (b * G::HP + y + 1 - PR0) * G::WP + x + 1;
         }
+        int pos = tid >> 3;
+        // opaque to the optimiser: otherwise the tile-invariant (row, column) of every piece is hoisted out of the tile
+        // loop, kept in registers across it and spilled
+        asm volatile("" : "+v"(pos));
+        int lr = pos / G::WP;
+        int pc = pos - lr * G::WP;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            int e = tid + 512 * i;
-            // opaque to the optimiser: otherwise the tile-invariant parts of src_offset (row / column of each piece,
-            // partial addresses) are hoisted out of the tile loop, kept in 24+ registers and spilled
-            asm volatile("" : "+v"(e));
-            const int go = (e < st.nelem) ? src_offset<HW>(s, PR0, e >> 3, a.B) : -1;
-            const bool ok = go >= 0;
-            st.ok |= ok ? (1u << i) : 0u;
-            st.pa[i] = reinterpret_cast<const u32x4*>(s.ptr + (ok ? go : 0) + ci0 + grp * 16)[pq];
+            int py = ty0 + lr, b = tb0;
+            if (py >= G::HP) { py -= G::HP; ++b; }
+            if (HW == 14 && py >= G::HP) { py -= G::HP; ++b; }
+            const bool ok = tid + 512 * i < st.nelem && py >= 1 && py <= G::H && pc >= 1 && pc <= G::W && b < nB;
+            const int off = __mul24(__mul24(__mul24(b, Hs) + ((py - 1) >> a_up), Ws) + ((pc - 1) >> a_up), a_C) + a_col;
+            st.pa[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? off * 4 : (int)0x80000000, 0, 0));
+            pc += 64 % G::WP;
+            lr += 64 / G::WP;
+            if (pc >= G::WP) { pc -= G::WP; ++lr; }
         }
 #pragma unroll
-        for (int i = 0; i < NG; ++i) {
+        for (int i = 0; i < NG; ++i) {   // pixels past the end are past num_records: zeros
             const int m = m0 + ((tid + 512 * i) >> 3);
-            const bool ok = m < Mtot;
-            st.ok |= ok ? (1u << (16 + i)) : 0u;
-            st.pg[i] = reinterpret_cast<const u32x4*>(a.g + (long)(ok ? m : 0) * a.Cout + co0 + grp * 16)[pq];
+            st.pg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, (__mul24(m, g_C) + g_col) * 4, 0, 0));
         }
     };
     char* const ad = (to_lo ? Alo : Ahi) + dcol;
     char* const gd = (to_lo ? Glo : Ghi) + dcol;
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
     auto stage = [&](const Stage& st) {
         __syncthreads();   // previous tile fully consumed
         if (tid < TILE_PX) pixoff[tid] = st.pix;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int e = tid + 512 * i;
-            if (e < st.nelem) *reinterpret_cast<u32x4*>(ad + (e >> 3) * 64) = ((st.ok >> i) & 1u) ? st.pa[i] : zero4;
+            if (e < st.nelem) *reinterpret_cast<u32x4*>(ad + (e >> 3) * 64) = st.pa[i];
         }
 #pragma unroll
-        for (int i = 0; i < NG; ++i)
-            *reinterpret_cast<u32x4*>(gd + ((tid + 512 * i) >> 3) * 64) = ((st.ok >> (16 + i)) & 1u) ? st.pg[i] : zero4;
+        for (int i = 0; i < NG; ++i) *reinterpret_cast<u32x4*>(gd + ((tid + 512 * i) >> 3) * 64) = st.pg[i];
         __syncthreads();
     };
     auto kstep = [&](int ks, int t0, int nt) {   // 16 pixels ks*16.., taps t0 .. t0+nt-1 -> acc[0..nt-1]
