@@ -380,18 +380,26 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     const int img0 = mbase / (G::H * G::W);         // image of the group's first pixel (scalar)
     const int mnext = (img0 + 1) * (G::H * G::W);   // a 32-pixel group touches at most two images
     struct Pre { float4 rt[NIT]; unsigned mk[NIT]; } p;   // rt: residual, else the time-bias row
+    // branch-free: absent inputs get an empty descriptor (num_records 0 -> zeros), so the requests are one straight run
+    // of loads (under uniform branches each request became a load + s_waitcnt vmcnt(0) + spill at N = 64)
+    const bool use_res = a.res != nullptr;
+    const bool use_tb = !use_res && a.tb_out != nullptr && a.out_s16 != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_rt = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(use_res ? a.res : a.tb_out), 0, use_res ? Mtot * N * 4 : (use_tb ? a.B * a.tb_out_stride * 4 : 0), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_mk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(a.relu_mask_in), 0, bwd ? Mtot * (N / 4) : 0, 0x00020000);
     auto preload = [&]() {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int e = it * 64 + lane_e;
-        const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
-        const int m = min(mbase + px, Mtot - 1);   // clamped: the walk skips pixels past the end
-        const unsigned o = (unsigned)m * N + c;
-        if (a.res != nullptr) p.rt[it] = gload4(a.res + o);
-        if (bwd) p.mk[it] = gload<unsigned char>(a.relu_mask_in + (o >> 2));
-        if (a.out_s16 != nullptr && a.tb_out != nullptr && a.res == nullptr)
-            p.rt[it] = gload4(a.tb_out + (unsigned)((img0 + (m >= mnext ? 1 : 0)) * a.tb_out_stride + c));
-    }
+        for (int it = 0; it < NIT; ++it) {
+            const int e = it * 64 + lane_e;
+            const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
+            const int m = min(mbase + px, Mtot - 1);   // clamped: the walk skips pixels past the end
+            const int o = m * N + c;
+            const int otb = (img0 + (m >= mnext ? 1 : 0)) * a.tb_out_stride + c;
+            const f32x4 r = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_rt, (use_res ? o : otb) * 4, 0, 0));
+            p.rt[it] = make_float4(r[0], r[1], r[2], r[3]);
+            p.mk[it] = __builtin_amdgcn_raw_buffer_load_b8(rs_mk, o >> 2, 0, 0);
+        }
     };
     if constexpr (NT == 1) preload();   // (wider tiles: after the accumulators have left their registers)
     stamp();                     // 6: tile inputs requested
@@ -504,8 +512,9 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         }
     };
     static_assert(NIT % GI == 0, "pass groups");
-    if (mbase + 32 <= Mtot) static_for<0, NIT / GI>([&](auto g) { walk(std::true_type{}, g); });
-    else static_for<0, NIT / GI>([&](auto g) { walk(std::false_type{}, g); });
+    // (scheduling barrier between groups: interleaving TWO groups costs more registers than the N = 64 budget has)
+    if (mbase + 32 <= Mtot) static_for<0, NIT / GI>([&](auto g) { walk(std::true_type{}, g); __builtin_amdgcn_sched_barrier(0); });
+    else static_for<0, NIT / GI>([&](auto g) { walk(std::false_type{}, g); __builtin_amdgcn_sched_barrier(0); });
     if (bwd && a.sums != nullptr) {
         // lanes with equal lane_e % (N/4) hold the same channel quad of different pixels: butterfly over the rest
 #pragma unroll
