@@ -789,6 +789,250 @@ __global__ __launch_bounds__(512) void wgrad_s16_kernel(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// weight gradient, producer / consumer form (default).  The kernel above runs load -> LDS write -> MFMA as three phases
+// that all 8 waves go through together (barriers), so the matrix pipe idles while a tile is staged (~16 % busy).  Here
+// a workgroup is 16 waves: waves 8..15 PRODUCE — they fetch tile k + 2 into registers and write tile k + 1 into the
+// other half of a double-buffered LDS image — while waves 0..7 CONSUME tile k (transposed LDS reads + MFMA).  One
+// barrier per 128-pixel tile; the staging work (index math, 47 KB of slow ds_write_b128) runs under the MFMAs.
+// ---------------------------------------------------------------------------
+constexpr int W2_TP = 128;   // pixels per tile
+template <int HW> struct W2Geo;
+template <> struct W2Geo<28> { static constexpr int NRW = 10; };   // staged rows: 128 pixels + halo + one image seam
+template <> struct W2Geo<14> { static constexpr int NRW = 15; };
+
+template <int HW>
+__global__ __launch_bounds__(1024) void wgrad2_s16_kernel(WgradArgs a) {
+    using G = Geo<HW>;
+    constexpr int NPX = W2Geo<HW>::NRW * G::WP;
+    constexpr int APL = NPX * 64;            // one plane (hi or lo) of the activation image
+    constexpr int GPL = W2_TP * 64;
+    constexpr int BUF = 2 * APL + 2 * GPL + W2_TP * (int)sizeof(int);
+    extern __shared__ float4 smem4[];
+    char* const lds = reinterpret_cast<char*>(smem4);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ci_tile = blockIdx.y % a.nci, co_tile = blockIdx.y / a.nci;
+    const int ci0 = ci_tile * 32, co0 = co_tile * 32;
+    const int Mtot = a.B * G::H * G::W;
+    const int ntiles = (Mtot + W2_TP - 1) / W2_TP;
+    const int taps = a.a.taps;
+    const int step = gridDim.x;
+    const int nk = (ntiles - (int)blockIdx.x + step - 1) / step;   // tiles of this workgroup: blockIdx.x + k * step
+    float* const slab = a.slab + (long)blockIdx.x * a.slab_stride;
+
+    if (wave >= 8) {
+        // ------------------------------- producers -------------------------------
+        const int ptid = tid - 512;
+        const ConvSrc& s = a.a;
+        const float* a_ptr = s.ptr; const float* g_ptr = a.g;
+        int a_C = s.C, a_c0 = s.c0, a_up = s.up, g_C = a.Cout, nB = a.B;
+        TDM_PIN(a_ptr); TDM_PIN(g_ptr); TDM_PIN(a_C); TDM_PIN(a_c0); TDM_PIN(a_up); TDM_PIN(g_C); TDM_PIN(nB);
+        const int Hs = G::H >> a_up, Ws = G::W >> a_up;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_ptr), 0, nB * Hs * Ws * a_C * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g_ptr), 0, Mtot * g_C * 4, 0x00020000);
+        // staging role: piece8 = ptid & 7 -> 16-channel group (piece8 >> 2), 16-byte piece of the group (piece8 & 3:
+        // 0,1 = hi halves, 2,3 = lo halves); destination plane / offset inside a 64-byte pixel row
+        const int piece8 = ptid & 7, grp = piece8 >> 2, pq = piece8 & 3;
+        const int dcol = grp * 32 + (pq & 1) * 16;
+        const int dplane_a = (pq >= 2) ? APL : 0, dplane_g = (pq >= 2) ? GPL : 0;
+        const int a_col = a_c0 + ci0 + grp * 16 + pq * 4;   // float column of this thread's piece inside a pixel row of A
+        const int g_col = co0 + grp * 16 + pq * 4;
+        constexpr int NA = (NPX * 8 + 511) / 512;
+        constexpr int NG = W2_TP * 8 / 512;
+        struct Stage { u32x4 pa[NA]; u32x4 pg[NG]; int pix; int nelem; };
+        Stage s0, s1;
+        auto prefetch = [&](Stage& st, int k) {
+            const int t = min((int)blockIdx.x + k * step, ntiles - 1);   // (past the end: re-read the last tile, never staged)
+            const int m0 = t * W2_TP;
+            const int mlast = min(m0 + W2_TP - 1, Mtot - 1);
+            const int tb0 = m0 / (G::H * G::W);
+            const int ty0 = (m0 - tb0 * (G::H * G::W)) / G::W;
+            const int PR0 = tb0 * G::HP + ty0;
+            const int nrows = padded_row<HW>(mlast) - PR0 + 2;
+            st.nelem = min(nrows, W2Geo<HW>::NRW) * G::WP * 8;
+            st.pix = 0;
+            if (ptid < W2_TP) {   // staged-pixel index of tile pixel `ptid`
+                const int m = min(m0 + ptid, Mtot - 1);
+                const int b = m / (G::H * G::W);
+                const int rem = m - b * (G::H * G::W);
+                const int y = rem / G::W, x = rem - y * G::W;
+                st.pix = (b * G::HP + y + 1 - PR0) * G::WP + x + 1;
+            }
+            int pos = ptid >> 3;
+            asm volatile("" : "+v"(pos));   // keeps the tile-invariant (row, column) of every piece from being hoisted and spilled
+            int lr = pos / G::WP;
+            int pc = pos - lr * G::WP;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                int py = ty0 + lr, b = tb0;
+                if (py >= G::HP) { py -= G::HP; ++b; }
+                if (HW == 14 && py >= G::HP) { py -= G::HP; ++b; }
+                const bool ok = ptid + 512 * i < st.nelem && py >= 1 && py <= G::H && pc >= 1 && pc <= G::W && b < nB;
+                const int off = __mul24(__mul24(__mul24(b, Hs) + ((py - 1) >> a_up), Ws) + ((pc - 1) >> a_up), a_C) + a_col;
+                st.pa[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? off * 4 : (int)0x80000000, 0, 0));
+                pc += 64 % G::WP;
+                lr += 64 / G::WP;
+                if (pc >= G::WP) { pc -= G::WP; ++lr; }
+            }
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {   // pixels past the end are past num_records: zeros
+                const int m = m0 + ((ptid + 512 * i) >> 3);
+                st.pg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, (__mul24(m, g_C) + g_col) * 4, 0, 0));
+            }
+        };
+        auto write = [&](const Stage& st, int buf) {
+            char* const base = lds + buf * BUF;
+            int* const pixoff = reinterpret_cast<int*>(base + 2 * APL + 2 * GPL);
+            if (ptid < W2_TP) pixoff[ptid] = st.pix;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int e = ptid + 512 * i;
+                if (e < st.nelem) *reinterpret_cast<u32x4*>(base + dplane_a + dcol + (e >> 3) * 64) = st.pa[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NG; ++i)
+                *reinterpret_cast<u32x4*>(base + 2 * APL + dplane_g + dcol + ((ptid + 512 * i) >> 3) * 64) = st.pg[i];
+        };
+        prefetch(s0, 0);
+        prefetch(s1, 1);
+        write(s0, 0);
+        __syncthreads();                       // tile 0 staged
+        for (int k = 0; k < nk; k += 2) {
+            // consumers: tile k from buffer 0
+            prefetch(s0, k + 2);
+            if (k + 1 < nk) write(s1, 1);
+            __syncthreads();
+            if (k + 1 >= nk) break;
+            // consumers: tile k + 1 from buffer 1
+            prefetch(s1, k + 3);
+            if (k + 2 < nk) write(s0, 0);
+            __syncthreads();
+        }
+        // the consumers' final reduction: same barrier count
+        const int nbar = (taps == 9) ? 10 : 2;
+        for (int i = 0; i < nbar; ++i) __syncthreads();
+        return;
+    }
+
+    // ------------------------------- consumers -------------------------------
+    const int g4 = lane >> 4, cb = g4 & 1, hh = g4 >> 1, q = (lane >> 2) & 3, pcq = lane & 3;
+    const int colb = (cb * 16 + pcq * 4) * 2;
+    const int tgrp = wave >> 2, wq = wave & 3;
+    const int tp0 = tgrp * 5, ntap = tgrp ? 4 : 5;
+    f32x16 acc[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    auto kstep = [&](const char* base, int ks, int t0, int nt) {   // 16 pixels ks*16.., taps t0 .. t0+nt-1 -> acc[0..nt-1]
+        const char* Ahi = base; const char* Alo = base + APL;
+        const char* Ghi = base + 2 * APL; const char* Glo = Ghi + GPL;
+        const int* pixoff = reinterpret_cast<const int*>(Glo + GPL);
+        const int p0 = ks * 16 + hh * 8 + q;
+        const int gb0 = p0 * 64 + colb, gb1 = (p0 + 4) * 64 + colb;
+        const bf16x8 gh = tr_pair(Ghi + gb0, Ghi + gb1);
+        const bf16x8 gl = tr_pair(Glo + gb0, Glo + gb1);
+        const int ab0 = pixoff[p0] * 64 + colb, ab1 = pixoff[p0 + 4] * 64 + colb;
+#pragma unroll
+        for (int d = 0; d < 5; ++d) {
+            if (d < nt) {
+                const int tp = t0 + d;
+                const int to = ((tp / 3 - 1) * G::WP + (tp % 3 - 1)) * 64;
+                const bf16x8 ah = tr_pair(Ahi + ab0 + to, Ahi + ab1 + to);
+                const bf16x8 al = tr_pair(Alo + ab0 + to, Alo + ab1 + to);
+                acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh, acc[d], 0, 0, 0);
+                acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl, acc[d], 0, 0, 0);
+                acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh, acc[d], 0, 0, 0);
+            }
+        }
+    };
+    auto compute = [&](int buf) {
+        const char* base = lds + buf * BUF;
+        if (taps == 9) {
+            kstep(base, wq * 2, tp0, ntap);
+            kstep(base, wq * 2 + 1, tp0, ntap);
+        } else {   // one tap, the centre of the padded-tall image: the 8 waves split the tile's 8 K-steps
+            kstep(base, wave, 4, 1);
+        }
+    };
+    __syncthreads();                           // tile 0 staged
+    for (int k = 0; k < nk; k += 2) {
+        compute(0);
+        __syncthreads();
+        if (k + 1 >= nk) break;
+        compute(1);
+        __syncthreads();
+    }
+
+    // partial sums of the waves that share a tap -> LDS -> fixed-order sum -> this workgroup's slab
+    float* red = reinterpret_cast<float*>(smem4);   // 8 waves x 1024 floats
+    if (taps == 9) {
+#pragma unroll
+        for (int d = 0; d < 5; ++d) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[d][r];
+            __syncthreads();
+            // tap d of group 0 (waves 0-3) and tap 5 + d of group 1 (waves 4-7; d < 4): 2 x 1024 outputs
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+                const int o = tid + 512 * k2;
+                const int grp2 = o >> 10, idx = o & 1023;
+                if (grp2 == 0 || d < 4) {
+                    const float* rb = red + grp2 * 4096 + idx;
+                    const float sum = (rb[0] + rb[1024]) + (rb[2048] + rb[3072]);
+                    const int r = idx >> 6, ln = idx & 63;
+                    const int ci = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+                    const int co = ln & 31;
+                    const int wt = grp2 * 5 + d;
+                    slab[a.w_off + (long)(wt * a.a.w_rows + a.a.w_r0 + ci0 + ci) * a.Cout + co0 + co] = sum;
+                }
+            }
+        }
+    } else {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[0][r];
+        __syncthreads();
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int idx = tid + 512 * k2;
+            float sum = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) sum += red[w8 * 1024 + idx];
+            const int r = idx >> 6, ln = idx & 63;
+            const int ci = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+            const int co = ln & 31;
+            slab[a.w_off + (long)(a.a.w_r0 + ci0 + ci) * a.Cout + co0 + co] = sum;
+        }
+    }
+}
+
+int g_wgrad_form = 2;   // 2 = producer / consumer kernel (default), 1 = the phase-serial kernel above (kept for A/B timing)
+
+template <int HW>
+int launch_wgrad2_t(const WgradArgs& a, int nslab, hipStream_t st) {
+    using G = Geo<HW>;
+    constexpr size_t lds = (size_t)2 * (2 * W2Geo<HW>::NRW * G::WP * 64 + 2 * W2_TP * 64 + W2_TP * sizeof(int));
+    static_assert(lds >= 8 * 1024 * sizeof(float), "final reduction needs 32 KB");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_s16_kernel<HW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            tdm_set_error("wgrad2_s16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return 100 + (int)e;
+        }
+        attr_set = true;
+    }
+    const int nco = a.Cout / 32;
+    hipLaunchKernelGGL((wgrad2_s16_kernel<HW>), dim3(nslab, a.nci * nco), dim3(1024), lds, st, a);
+    TDM_CHECK_LAUNCH("wgrad2_s16");
+    return 0;
+}
+
 template <int HW>
 int launch_wgrad_t(const WgradArgs& a, int nslab, hipStream_t st) {
     using G = Geo<HW>;
@@ -858,8 +1102,13 @@ int tdm_launch_wgrad_s16(const WgradArgs& a, int hw, int nslab, hipStream_t st) 
     TDM_REQUIRE((a.a.C % 16) == 0 && (a.a.c0 % 16) == 0 && a.a.tb == nullptr, "wgrad_s16: S16 source layout");
     TDM_REQUIRE(nslab >= 1 && nslab <= TDM_UNET_MAX_SLABS, "wgrad_s16: nslab %d", nslab);
     TDM_REQUIRE(a.B > 0 && (long)a.B * hw * hw * 96 < 2147483647L, "wgrad_s16: batch %d out of range", a.B);
-    if (hw == 28) return launch_wgrad_t<28>(a, nslab, st);
-    if (hw == 14) return launch_wgrad_t<14>(a, nslab, st);
+    if (g_wgrad_form == 2) {
+        if (hw == 28) return launch_wgrad2_t<28>(a, nslab, st);
+        if (hw == 14) return launch_wgrad2_t<14>(a, nslab, st);
+    } else {
+        if (hw == 28) return launch_wgrad_t<28>(a, nslab, st);
+        if (hw == 14) return launch_wgrad_t<14>(a, nslab, st);
+    }
     tdm_set_error("wgrad_s16: unsupported hw=%d", hw);
     return 1;
 }
