@@ -379,7 +379,8 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     const bool bwd = NT != 3 && a.relu_mask_in != nullptr;   // (N = 32 / 64 outputs only)
     const int img0 = mbase / (G::H * G::W);         // image of the group's first pixel (scalar)
     const int mnext = (img0 + 1) * (G::H * G::W);   // a 32-pixel group touches at most two images
-    struct Pre { float4 rt[NIT]; unsigned mk[NIT]; } p;   // rt: residual, else the time-bias row
+    constexpr int GI = 4;   // passes per group: 4 independent chains, 16 value registers
+    struct Pre { float4 rt[GI]; unsigned mk[GI]; } p;   // inputs of ONE group of passes; rt: residual, else the time-bias row
     // branch-free: absent inputs get an empty descriptor (num_records 0 -> zeros), so the requests are one straight run
     // of loads (under uniform branches each request became a load + s_waitcnt vmcnt(0) + spill at N = 64)
     const bool use_res = a.res != nullptr;
@@ -388,10 +389,10 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         const_cast<float*>(use_res ? a.res : a.tb_out), 0, use_res ? Mtot * N * 4 : (use_tb ? a.B * a.tb_out_stride * 4 : 0), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_mk = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char*>(a.relu_mask_in), 0, bwd ? Mtot * (N / 4) : 0, 0x00020000);
-    auto preload = [&]() {
+    auto preload = [&](int g) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int e = it * 64 + lane_e;
+        for (int it = 0; it < GI; ++it) {
+            const int e = (g * GI + it) * 64 + lane_e;
             const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
             const int m = min(mbase + px, Mtot - 1);   // clamped: the walk skips pixels past the end
             const int o = m * N + c;
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
             p.mk[it] = __builtin_amdgcn_raw_buffer_load_b8(rs_mk, o >> 2, 0, 0);
         }
     };
-    if constexpr (NT == 1) preload();   // (wider tiles: after the accumulators have left their registers)
+    preload(0);
     stamp();                     // 6: tile inputs requested
     __syncthreads();             // every wave is done with the operand images
     stamp();                     // 7
@@ -415,7 +416,6 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
                     make_float4(ac[nt][4 * g], ac[nt][4 * g + 1], ac[nt][4 * g + 2], ac[nt][4 * g + 3]);
     };
     to_lds(acc);
-    if constexpr (NT != 1) preload();
     stamp();                     // 8: transpose written
     // Everything of p has been requested: wait for it HERE, once.  The requests sit under uniform branches, so without
     // this the compiler guards every pass's first use of p.rt / p.mk with s_waitcnt vmcnt(0) — which on gfx9
@@ -425,7 +425,6 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     // "is this output wanted" branch then wraps NIT independent instruction chains that the scheduler can interleave.
     // Pass by pass, each chain (LDS read -> ReLU -> split -> store, ~30 dependent instructions) ran alone at one
     // instruction per ~10 cycles.  `full` (all 32 pixels exist) removes the per-lane_e bounds check from all but the last tile.
-    constexpr int GI = 4;   // passes per group: 4 independent chains, 16 value registers
     float4 sacc[2][2];      // [slot][kind] partial sums of this lane_e's channel quad (bwd only)
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl)
@@ -466,7 +465,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         if (a.res != nullptr) {
 #pragma unroll
             for (int k = 0; k < GI; ++k) {
-                const float4 rz = p.rt[I0 + k];
+                const float4 rz = p.rt[k];
                 v[k].x += rz.x; v[k].y += rz.y; v[k].z += rz.z; v[k].w += rz.w;
             }
         }
@@ -474,7 +473,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
 #pragma unroll
             for (int k = 0; k < GI; ++k) {
                 const int m = mbase + ((I0 + k) * 64 + lane_e) / (N / 4);
-                const unsigned mk = p.mk[I0 + k];
+                const unsigned mk = p.mk[k];
                 const float4 u = v[k];
                 const float4 mv = make_float4((mk & 1u) ? u.x : 0.f, (mk & 2u) ? u.y : 0.f, (mk & 4u) ? u.z : 0.f,
                                               (mk & 8u) ? u.w : 0.f);
@@ -494,7 +493,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
             if (a.tb_out != nullptr) {
 #pragma unroll
                 for (int k = 0; k < GI; ++k) {
-                    float4 tz = p.rt[I0 + k];
+                    float4 tz = p.rt[k];
                     if (a.res != nullptr) {   // both a residual and a time-bias row (no UNet launch; C-ABI layer tests): fetch in place
                         const int e = (I0 + k) * 64 + lane_e;
                         const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
@@ -513,8 +512,21 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     };
     static_assert(NIT % GI == 0, "pass groups");
     // (scheduling barrier between groups: interleaving TWO groups costs more registers than the N = 64 budget has)
-    if (mbase + 32 <= Mtot) static_for<0, NIT / GI>([&](auto g) { walk(std::true_type{}, g); __builtin_amdgcn_sched_barrier(0); });
-    else static_for<0, NIT / GI>([&](auto g) { walk(std::false_type{}, g); __builtin_amdgcn_sched_barrier(0); });
+    // (the inputs of group g + 1 are requested when group g is done: one group's worth of registers; the N = 64 budget
+    //  has no room for a whole tile's — they were spilled as they arrived, one memory round trip each)
+    auto groups = [&](auto full_c) {
+        static_for<0, NIT / GI>([&](auto g) {
+            constexpr int gi = decltype(g)::value;
+            if constexpr (gi > 0) {
+                preload(gi);
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): also retires the previous group's stores
+            }
+            walk(full_c, g);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    if (mbase + 32 <= Mtot) groups(std::true_type{});
+    else groups(std::false_type{});
     if (bwd && a.sums != nullptr) {
         // lanes with equal lane_e % (N/4) hold the same channel quad of different pixels: butterfly over the rest
 #pragma unroll
