@@ -68,14 +68,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// 8 waves per workgroup, each a 32-row x 64-column piece of the 128 x 128 tile (2 accumulators): half the registers of the
+// former 4-wave / 64 x 64 form, so two workgroups put FOUR waves on every SIMD (was two).  Same lesson as the conv kernel:
+// at two waves per SIMD the loop is bound by the latency of its own chains (split + LDS write, barrier, fragment reads).
+constexpr int NT_THREADS = 512;
+constexpr int NT_LDS = (4 * PLANE > 8 * 32 * EP * 4) ? 4 * PLANE : 8 * 32 * EP * 4;   // operand planes / epilogue transposes
+
 template <int NPROD>
-__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g, int ntx, int ntiles) {
+__global__ __launch_bounds__(NT_THREADS, 4) void gemm_nt_bf16_kernel(GemmArgs g, int ntx, int ntiles) {
     // planes: A hi, A lo, B hi, B lo  (lo planes unused when NPROD == 1)
-    __shared__ __attribute__((aligned(16))) char lds[4 * PLANE];
+    extern __shared__ float4 nt_smem4[];
+    char* lds = reinterpret_cast<char*>(nt_smem4);
     char* Ahi = lds; char* Alo = lds + PLANE; char* Bhi = lds + 2 * PLANE; char* Blo = lds + 3 * PLANE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, j = lane & 31;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;   // rows wm*32 .. +31, columns wn*64 .. +63
     // this workgroup's contiguous tile range [t_beg, t_end) of the XCD-ordered tile list
     const int slot = xcd_remap(blockIdx.x, gridDim.x);
     const int per = ntiles / gridDim.x, rem = ntiles % gridDim.x;
@@ -87,15 +94,15 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g, int ntx, 
     // issued unconditionally and back to back: out-of-range pieces read a clamped address and are zeroed from the
     // `ok` bits when they are split into LDS.  (Guarded loads with scalar tail paths compiled to branches with an
     // s_waitcnt vmcnt(0) between consecutive loads, i.e. the loads of a chunk were serialised.)  K % 4 == 0.
-    f32x4 pa[4], pb[4];
+    f32x4 pa[2], pb[2];
     unsigned ok = 0u;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto gload = [&](int tile, int k0) {
         const int i0 = (tile / ntx) * TM, j0 = (tile % ntx) * TN_;
         ok = 0u;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {   // 128 rows x 8 float4
-            const int f = tid + 256 * p;
+        for (int p = 0; p < 2; ++p) {   // 128 rows x 8 float4
+            const int f = tid + NT_THREADS * p;
             const int row = f >> 3, kq = f & 7;
             const int gk = k0 + kq * 4;
             const bool kin = gk < g.K;
@@ -111,20 +118,18 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g, int ntx, 
 
     for (int tile = t_beg; tile < t_end; ++tile) {
         const int i0 = (tile / ntx) * TM, j0 = (tile % ntx) * TN_;
-        f32x16 acc[2][2];
+        f32x16 acc[2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
 
         for (int c = 0; c < nchunk; ++c) {
             __syncthreads();
             if (!(g.ablate & 8) || c == 0) {
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int f = tid + 256 * p;
+                for (int p = 0; p < 2; ++p) {
+                    const int f = tid + NT_THREADS * p;
                     const int row = f >> 3, kq = f & 7;
                     put_split<NPROD>(Ahi, Alo, row * PITCH + kq * 8, ((ok >> p) & 1u) ? pa[p] : zero4);
                     put_split<NPROD>(Bhi, Blo, row * PITCH + kq * 8, ((ok >> (4 + p)) & 1u) ? pb[p] : zero4);
@@ -138,28 +143,24 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g, int ntx, 
             if (g.ablate & 2) continue;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 xh[2], xl[2], wh[2], wl[2];
+                bf16x8 xh, xl, wh[2], wl[2];
+                const int ao = (wm * 32 + j) * PITCH + ks * 32 + h * 16;
+                xh = *reinterpret_cast<const bf16x8*>(Ahi + ao);
+                if (NPROD == 3) xl = *reinterpret_cast<const bf16x8*>(Alo + ao);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const int ao = (wm * 64 + t * 32 + j) * PITCH + ks * 32 + h * 16;
                     const int bo = (wn * 64 + t * 32 + j) * PITCH + ks * 32 + h * 16;
-                    xh[t] = *reinterpret_cast<const bf16x8*>(Ahi + ao);
                     wh[t] = *reinterpret_cast<const bf16x8*>(Bhi + bo);
-                    if (NPROD == 3) {
-                        xl[t] = *reinterpret_cast<const bf16x8*>(Alo + ao);
-                        wl[t] = *reinterpret_cast<const bf16x8*>(Blo + bo);
-                    }
+                    if (NPROD == 3) wl[t] = *reinterpret_cast<const bf16x8*>(Blo + bo);
                 }
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {   // D[n][m]: weight rows are the MFMA A operand
-                        if (NPROD == 3) {
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[nt], xl[mt], acc[mt][nt], 0, 0, 0);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[nt], xh[mt], acc[mt][nt], 0, 0, 0);
-                        }
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[nt], xh[mt], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < 2; ++nt) {   // D[n][m]: weight rows are the MFMA A operand
+                    if (NPROD == 3) {
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[nt], xl, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[nt], xh, acc[nt], 0, 0, 0);
                     }
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[nt], xh, acc[nt], 0, 0, 0);
+                }
             }
         }
 
@@ -169,14 +170,13 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g, int ntx, 
         // with bf16x3 operands, 187 -> 131 us with plain bf16 operands)
         __syncthreads();   // all waves are done reading the operand planes
         float* T = reinterpret_cast<float*>(lds) + wave * (32 * EP);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     *reinterpret_cast<float4*>(T + j * EP + nt * 32 + 8 * q + 4 * h) =
-                        make_float4(acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]);
+                        make_float4(acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]);
             // (wave-private region: no barrier needed between this wave's writes and reads)
             const int c4 = lane & 15;
             const int n = j0 + wn * 64 + c4 * 4;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g, int ntx, 
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int rr = it * 4 + (lane >> 4);
-                const int m = i0 + wm * 64 + mt * 32 + rr;
+                const int m = i0 + wm * 32 + rr;
                 float4 v = *reinterpret_cast<const float4*>(T + rr * EP + c4 * 4);
                 if (m < g.M && nq > 0 && nq < 4 && !(g.ablate & 4)) {   // ragged last quad (N % 4 != 0): plain epilogue
                     const long o = (long)m * g.c_rs + n;
@@ -408,8 +408,12 @@ int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
         hipError_t e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
+        if (e == hipSuccess)
             e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<3>),
-                                                             256, 0);
+                                                             NT_THREADS, NT_LDS);
         if (e != hipSuccess || cus <= 0 || per_cu <= 0) {
             tdm_set_error("gemm_nt_bf16: occupancy query failed: %s", hipGetErrorString(e));
             return 100 + (int)e;
@@ -417,8 +421,8 @@ int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
         resident = cus * per_cu;
     }
     dim3 grid(ntiles < resident ? ntiles : resident);
-    if (nprod == 3) hipLaunchKernelGGL(gemm_nt_bf16_kernel<3>, grid, dim3(256), 0, st, g, ntx, ntiles);
-    else hipLaunchKernelGGL(gemm_nt_bf16_kernel<1>, grid, dim3(256), 0, st, g, ntx, ntiles);
+    if (nprod == 3) hipLaunchKernelGGL(gemm_nt_bf16_kernel<3>, grid, dim3(NT_THREADS), NT_LDS, st, g, ntx, ntiles);
+    else hipLaunchKernelGGL(gemm_nt_bf16_kernel<1>, grid, dim3(NT_THREADS), NT_LDS, st, g, ntx, ntiles);
     TDM_CHECK_LAUNCH("gemm_nt_bf16");
     return 0;
 }
