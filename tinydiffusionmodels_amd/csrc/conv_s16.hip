@@ -831,8 +831,12 @@ __global__ __launch_bounds__(1024) void wgrad2_s16_kernel(WgradArgs a) {
     const int ntiles = (Mtot + W2_TP - 1) / W2_TP;
     const int taps = a.a.taps;
     const int step = gridDim.x;
-    const int nk = (ntiles - (int)blockIdx.x + step - 1) / step;   // tiles of this workgroup: blockIdx.x + k * step
-    float* const slab = a.slab + (long)blockIdx.x * a.slab_stride;
+    // Workgroups of one XCD take NEIGHBOURING tiles at the same time (slot = contiguous range per XCD): a 128-pixel tile
+    // stages 10 rows for 4.6 rows of payload, and with blockIdx-ordered tiles the 2.2x halo re-reads went to eight
+    // different L2s, i.e. to HBM — the kernel was bandwidth-bound on its own halo.
+    const int slot = xcd_remap(blockIdx.x, gridDim.x);
+    const int nk = (ntiles - slot + step - 1) / step;   // tiles of this workgroup: slot + k * step
+    float* const slab = a.slab + (long)slot * a.slab_stride;
 
     if (wave >= 8) {
         // ------------------------------- producers -------------------------------
@@ -855,38 +859,64 @@ __global__ __launch_bounds__(1024) void wgrad2_s16_kernel(WgradArgs a) {
         constexpr int NG = W2_TP * 8 / 512;
         struct Stage { u32x4 pa[NA]; u32x4 pg[NG]; int pix; int nelem; };
         Stage s0, s1;
-        auto prefetch = [&](Stage& st, int k) {
-            const int t = min((int)blockIdx.x + k * step, ntiles - 1);   // (past the end: re-read the last tile, never staged)
-            const int m0 = t * W2_TP;
-            const int mlast = min(m0 + W2_TP - 1, Mtot - 1);
-            const int tb0 = m0 / (G::H * G::W);
-            const int ty0 = (m0 - tb0 * (G::H * G::W)) / G::W;
-            const int PR0 = tb0 * G::HP + ty0;
-            const int nrows = padded_row<HW>(mlast) - PR0 + 2;
-            st.nelem = min(nrows, W2Geo<HW>::NRW) * G::WP * 8;
-            st.pix = 0;
-            if (ptid < W2_TP) {   // staged-pixel index of tile pixel `ptid`
-                const int m = min(m0 + ptid, Mtot - 1);
-                const int b = m / (G::H * G::W);
-                const int rem = m - b * (G::H * G::W);
-                const int y = rem / G::W, x = rem - y * G::W;
-                st.pix = (b * G::HP + y + 1 - PR0) * G::WP + x + 1;
-            }
-            int pos = ptid >> 3;
-            asm volatile("" : "+v"(pos));   // keeps the tile-invariant (row, column) of every piece from being hoisted and spilled
-            int lr = pos / G::WP;
-            int pc = pos - lr * G::WP;
+        // Per-tile index work is what bounds this kernel once the phases overlap (the staging waves' address arithmetic
+        // competes with the MFMA waves for vector issue), so everything that does not depend on the tile is computed
+        // ONCE: piece e = ptid + 512 i sits at staged position (ptid >> 3) + 64 i = (row lr_i, column pc_i); its column
+        // offset and column validity are tile-invariant.  Per tile only the staged ROWS change: lanes 0..NRW-1 of each
+        // producer wave work out (offset, valid) of one row each and park the pair in a wave-private LDS table; a piece
+        // then costs one 8-byte LDS read, an add and a select.
+        constexpr int NRW = W2Geo<HW>::NRW;
+        int* const rowtab = reinterpret_cast<int*>(lds + 2 * BUF) + (wave - 8) * 32;   // [16 rows][offset, nelem-limit flag]
+        int lr_i[NA], col_i[NA];
+        unsigned colok = 0u;
+        {
+            int lr = (ptid >> 3) / G::WP;
+            int pc = (ptid >> 3) - lr * G::WP;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                int py = ty0 + lr, b = tb0;
-                if (py >= G::HP) { py -= G::HP; ++b; }
-                if (HW == 14 && py >= G::HP) { py -= G::HP; ++b; }
-                const bool ok = ptid + 512 * i < st.nelem && py >= 1 && py <= G::H && pc >= 1 && pc <= G::W && b < nB;
-                const int off = __mul24(__mul24(__mul24(b, Hs) + ((py - 1) >> a_up), Ws) + ((pc - 1) >> a_up), a_C) + a_col;
-                st.pa[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? off * 4 : (int)0x80000000, 0, 0));
+                lr_i[i] = min(lr, NRW - 1) * 8;                     // byte offset of the row's table entry
+                col_i[i] = (((pc - 1) >> a_up) * a_C + a_col) * 4;   // bytes
+                colok |= (pc >= 1 && pc <= G::W && lr < NRW) ? (1u << i) : 0u;
                 pc += 64 % G::WP;
                 lr += 64 / G::WP;
                 if (pc >= G::WP) { pc -= G::WP; ++lr; }
+            }
+        }
+        auto prefetch = [&](Stage& st, int k) {
+            const int t = min(slot + k * step, ntiles - 1);   // (past the end: re-read the last tile, never staged)
+            const int m0 = t * W2_TP;
+            const int mlast = min(m0 + W2_TP - 1, Mtot - 1);
+            const int tb0 = m0 / (G::H * G::W);
+            const int rem0 = m0 - tb0 * (G::H * G::W);
+            const int ty0 = rem0 / G::W;
+            const int x0 = rem0 - ty0 * G::W;
+            const int PR0 = tb0 * G::HP + ty0;
+            const int nrows = min(padded_row<HW>(mlast) - PR0 + 2, NRW);
+            st.nelem = nrows * G::WP * 8;
+            // row table: staged row r = lane is padded row PR0 + r of the tall image
+            if (lane < 16) {
+                int py = ty0 + lane, b = tb0;
+                if (py >= G::HP) { py -= G::HP; ++b; }
+                if (HW == 14 && py >= G::HP) { py -= G::HP; ++b; }
+                const bool ok = lane < nrows && py >= 1 && py <= G::H && b < nB;
+                const int off = __mul24(__mul24(__mul24(b, Hs) + ((py - 1) >> a_up), Ws), a_C) * 4;
+                *reinterpret_cast<int2*>(rowtab + lane * 2) = make_int2(ok ? off : (int)0x80000000, 0);
+            }
+            // staged-pixel index of tile pixel `ptid` (< 128): q = x0 + ptid columns past the start of row ty0
+            st.pix = 0;
+            if (ptid < W2_TP) {
+                const int q = x0 + min(ptid, mlast - m0);   // (pixels past the end: the last real one; their G rows read as zeros)
+                const int dr = (q * (HW == 28 ? 2341 : 4682)) >> 16;   // q / W for q < W + 128 (checked exhaustively)
+                const int x = q - dr * G::W;
+                int y = ty0 + dr, seam = 0;
+                if (y >= G::H) { y -= G::H; seam = G::HP; }             // into the next image: + one padded image of rows
+                st.pix = (seam + y + 1 - ty0) * G::WP + x + 1;
+            }
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int roff = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(rowtab) + lr_i[i]);
+                const bool ok = ((colok >> i) & 1u) != 0u;
+                st.pa[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? (roff + col_i[i]) : (int)0x80000000, 0, 0));
             }
 #pragma unroll
             for (int i = 0; i < NG; ++i) {   // pixels past the end are past num_records: zeros
@@ -938,6 +968,8 @@ __global__ __launch_bounds__(1024) void wgrad2_s16_kernel(WgradArgs a) {
     for (int k = 0; k < 5; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    // (ONE MFMA site per accumulator: tap ranges as compile-time constants would fold every tap offset into the reads'
+    //  offset fields, but the three instantiations then disagree on where the accumulators live — 388 bytes of spills)
     auto kstep = [&](const char* base, int ks, int t0, int nt) {   // 16 pixels ks*16.., taps t0 .. t0+nt-1 -> acc[0..nt-1]
         const char* Ahi = base; const char* Alo = base + APL;
         const char* Ghi = base + 2 * APL; const char* Glo = Ghi + GPL;
@@ -1027,7 +1059,7 @@ int g_wgrad_form = 2;   // 2 = producer / consumer kernel (default), 1 = the pha
 template <int HW>
 int launch_wgrad2_t(const WgradArgs& a, int nslab, hipStream_t st) {
     using G = Geo<HW>;
-    constexpr size_t lds = (size_t)2 * (2 * W2Geo<HW>::NRW * G::WP * 64 + 2 * W2_TP * 64 + W2_TP * sizeof(int));
+    constexpr size_t lds = (size_t)2 * (2 * W2Geo<HW>::NRW * G::WP * 64 + 2 * W2_TP * 64 + W2_TP * sizeof(int)) + 8 * 32 * sizeof(int);   // + row tables
     static_assert(lds >= 8 * 1024 * sizeof(float), "final reduction needs 32 KB");
     static bool attr_set = false;
     if (!attr_set) {
