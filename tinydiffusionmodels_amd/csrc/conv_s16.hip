@@ -813,13 +813,15 @@ template <int HW> struct W2Geo;
 template <> struct W2Geo<28> { static constexpr int NRW = 10; };   // staged rows: 128 pixels + halo + one image seam
 template <> struct W2Geo<14> { static constexpr int NRW = 15; };
 
-template <int HW>
+template <int HW, bool SK2>
 __global__ __launch_bounds__(1024) void wgrad2_s16_kernel(WgradArgs a) {
     using G = Geo<HW>;
     constexpr int NPX = W2Geo<HW>::NRW * G::WP;
     constexpr int APL = NPX * 64;            // one plane (hi or lo) of the activation image
     constexpr int GPL = W2_TP * 64;
-    constexpr int BUF = 2 * APL + 2 * GPL + W2_TP * (int)sizeof(int);
+    constexpr int G2O = 2 * APL + 2 * GPL;                     // second gradient image (fused 1x1 skip), SK2 only
+    constexpr int PXO = G2O + (SK2 ? 2 * GPL : 0);            // staged-pixel table
+    constexpr int BUF = PXO + W2_TP * (int)sizeof(int);
     extern __shared__ float4 smem4[];
     char* const lds = reinterpret_cast<char*>(smem4);
 
@@ -848,6 +850,9 @@ __global__ __launch_bounds__(1024) void wgrad2_s16_kernel(WgradArgs a) {
         const int Hs = G::H >> a_up, Ws = G::W >> a_up;
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_ptr), 0, nB * Hs * Ws * a_C * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g_ptr), 0, Mtot * g_C * 4, 0x00020000);
+        const float* g2_ptr = a.g2;
+        TDM_PIN(g2_ptr);
+        const __amdgpu_buffer_rsrc_t rsG2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g2_ptr), 0, SK2 ? Mtot * g_C * 4 : 0, 0x00020000);
         // staging role: piece8 = ptid & 7 -> 16-channel group (piece8 >> 2), 16-byte piece of the group (piece8 & 3:
         // 0,1 = hi halves, 2,3 = lo halves); destination plane / offset inside a 64-byte pixel row
         const int piece8 = ptid & 7, grp = piece8 >> 2, pq = piece8 & 3;
@@ -857,7 +862,7 @@ __global__ __launch_bounds__(1024) void wgrad2_s16_kernel(WgradArgs a) {
         const int g_col = co0 + grp * 16 + pq * 4;
         constexpr int NA = (NPX * 8 + 511) / 512;
         constexpr int NG = W2_TP * 8 / 512;
-        struct Stage { u32x4 pa[NA]; u32x4 pg[NG]; int pix; int nelem; };
+        struct Stage { u32x4 pa[NA]; u32x4 pg[NG]; u32x4 pg2[SK2 ? NG : 1]; int pix; int nelem; };
         Stage s0, s1;
         // Per-tile index work is what bounds this kernel once the phases overlap (the staging waves' address arithmetic
         // competes with the MFMA waves for vector issue), so everything that does not depend on the tile is computed
@@ -922,11 +927,13 @@ __global__ __launch_bounds__(1024) void wgrad2_s16_kernel(WgradArgs a) {
             for (int i = 0; i < NG; ++i) {   // pixels past the end are past num_records: zeros
                 const int m = m0 + ((ptid + 512 * i) >> 3);
                 st.pg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, (__mul24(m, g_C) + g_col) * 4, 0, 0));
+                if constexpr (SK2)
+                    st.pg2[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG2, (__mul24(m, g_C) + g_col) * 4, 0, 0));
             }
         };
         auto write = [&](const Stage& st, int buf) {
             char* const base = lds + buf * BUF;
-            int* const pixoff = reinterpret_cast<int*>(base + 2 * APL + 2 * GPL);
+            int* const pixoff = reinterpret_cast<int*>(base + PXO);
             if (ptid < W2_TP) pixoff[ptid] = st.pix;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
@@ -935,7 +942,10 @@ __global__ __launch_bounds__(1024) void wgrad2_s16_kernel(WgradArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < NG; ++i)
+            {
                 *reinterpret_cast<u32x4*>(base + 2 * APL + dplane_g + dcol + ((ptid + 512 * i) >> 3) * 64) = st.pg[i];
+                if constexpr (SK2) *reinterpret_cast<u32x4*>(base + G2O + dplane_g + dcol + ((ptid + 512 * i) >> 3) * 64) = st.pg2[i];
+            }
         };
         prefetch(s0, 0);
         prefetch(s1, 1);
@@ -973,7 +983,7 @@ __global__ __launch_bounds__(1024) void wgrad2_s16_kernel(WgradArgs a) {
     auto kstep = [&](const char* base, int ks, int t0, int nt) {   // 16 pixels ks*16.., taps t0 .. t0+nt-1 -> acc[0..nt-1]
         const char* Ahi = base; const char* Alo = base + APL;
         const char* Ghi = base + 2 * APL; const char* Glo = Ghi + GPL;
-        const int* pixoff = reinterpret_cast<const int*>(Glo + GPL);
+        const int* pixoff = reinterpret_cast<const int*>(base + PXO);
         const int p0 = ks * 16 + hh * 8 + q;
         const int gb0 = p0 * 64 + colb, gb1 = (p0 + 4) * 64 + colb;
         const bf16x8 gh = tr_pair(Ghi + gb0, Ghi + gb1);
@@ -989,6 +999,17 @@ __global__ __launch_bounds__(1024) void wgrad2_s16_kernel(WgradArgs a) {
                 acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh, acc[d], 0, 0, 0);
                 acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl, acc[d], 0, 0, 0);
                 acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh, acc[d], 0, 0, 0);
+            }
+        }
+        if constexpr (SK2) {
+            if (nt == 4) {   // tap group 1: its fifth accumulator takes the block's 1x1 skip conv (centre-tap pixels x G2)
+                const bf16x8 g2h = tr_pair(base + G2O + gb0, base + G2O + gb1);
+                const bf16x8 g2l = tr_pair(base + G2O + GPL + gb0, base + G2O + GPL + gb1);
+                const bf16x8 ah = tr_pair(Ahi + ab0, Ahi + ab1);
+                const bf16x8 al = tr_pair(Alo + ab0, Alo + ab1);
+                acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, g2h, acc[4], 0, 0, 0);
+                acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, g2l, acc[4], 0, 0, 0);
+                acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, g2h, acc[4], 0, 0, 0);
             }
         }
     };
@@ -1024,14 +1045,15 @@ __global__ __launch_bounds__(1024) void wgrad2_s16_kernel(WgradArgs a) {
             for (int k2 = 0; k2 < 4; ++k2) {
                 const int o = tid + 512 * k2;
                 const int grp2 = o >> 10, idx = o & 1023;
-                if (grp2 == 0 || d < 4) {
+                if (grp2 == 0 || d < 4 || SK2) {
                     const float* rb = red + grp2 * 4096 + idx;
                     const float sum = (rb[0] + rb[1024]) + (rb[2048] + rb[3072]);
                     const int r = idx >> 6, ln = idx & 63;
                     const int ci = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
                     const int co = ln & 31;
                     const int wt = grp2 * 5 + d;
-                    slab[a.w_off + (long)(wt * a.a.w_rows + a.a.w_r0 + ci0 + ci) * a.Cout + co0 + co] = sum;
+                    if (grp2 == 1 && d == 4) slab[a.w_off2 + (long)(a.a.w_r0 + ci0 + ci) * a.Cout + co0 + co] = sum;   // 1x1 skip
+                    else slab[a.w_off + (long)(wt * a.a.w_rows + a.a.w_r0 + ci0 + ci) * a.Cout + co0 + co] = sum;
                 }
             }
         }
@@ -1056,14 +1078,14 @@ __global__ __launch_bounds__(1024) void wgrad2_s16_kernel(WgradArgs a) {
 
 int g_wgrad_form = 2;   // 2 = producer / consumer kernel (default), 1 = the phase-serial kernel above (kept for A/B timing)
 
-template <int HW>
+template <int HW, bool SK2>
 int launch_wgrad2_t(const WgradArgs& a, int nslab, hipStream_t st) {
     using G = Geo<HW>;
-    constexpr size_t lds = (size_t)2 * (2 * W2Geo<HW>::NRW * G::WP * 64 + 2 * W2_TP * 64 + W2_TP * sizeof(int)) + 8 * 32 * sizeof(int);   // + row tables
+    constexpr size_t lds = (size_t)2 * (2 * W2Geo<HW>::NRW * G::WP * 64 + (SK2 ? 4 : 2) * W2_TP * 64 + W2_TP * sizeof(int)) + 8 * 32 * sizeof(int);   // + row tables
     static_assert(lds >= 8 * 1024 * sizeof(float), "final reduction needs 32 KB");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_s16_kernel<HW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_s16_kernel<HW, SK2>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             tdm_set_error("wgrad2_s16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1072,7 +1094,7 @@ int launch_wgrad2_t(const WgradArgs& a, int nslab, hipStream_t st) {
         attr_set = true;
     }
     const int nco = a.Cout / 32;
-    hipLaunchKernelGGL((wgrad2_s16_kernel<HW>), dim3(nslab, a.nci * nco), dim3(1024), lds, st, a);
+    hipLaunchKernelGGL((wgrad2_s16_kernel<HW, SK2>), dim3(nslab, a.nci * nco), dim3(1024), lds, st, a);
     TDM_CHECK_LAUNCH("wgrad2_s16");
     return 0;
 }
@@ -1146,9 +1168,10 @@ int tdm_launch_wgrad_s16(const WgradArgs& a, int hw, int nslab, hipStream_t st) 
     TDM_REQUIRE((a.a.C % 16) == 0 && (a.a.c0 % 16) == 0 && a.a.tb == nullptr, "wgrad_s16: S16 source layout");
     TDM_REQUIRE(nslab >= 1 && nslab <= TDM_UNET_MAX_SLABS, "wgrad_s16: nslab %d", nslab);
     TDM_REQUIRE(a.B > 0 && (long)a.B * hw * hw * 96 < 2147483647L, "wgrad_s16: batch %d out of range", a.B);
+    TDM_REQUIRE(a.g2 == nullptr || (g_wgrad_form == 2 && a.a.taps == 9), "wgrad_s16: the fused 1x1 gradient rides on the 3x3 producer/consumer kernel");
     if (g_wgrad_form == 2) {
-        if (hw == 28) return launch_wgrad2_t<28>(a, nslab, st);
-        if (hw == 14) return launch_wgrad2_t<14>(a, nslab, st);
+        if (hw == 28) return a.g2 ? launch_wgrad2_t<28, true>(a, nslab, st) : launch_wgrad2_t<28, false>(a, nslab, st);
+        if (hw == 14) return a.g2 ? launch_wgrad2_t<14, true>(a, nslab, st) : launch_wgrad2_t<14, false>(a, nslab, st);
     } else {
         if (hw == 28) return launch_wgrad_t<28>(a, nslab, st);
         if (hw == 14) return launch_wgrad_t<14>(a, nslab, st);

@@ -114,6 +114,12 @@ struct WgradArgs {
     int B;
     int ntiles;
     int nci;            // number of 32-channel ci tiles
+    // S16 producer / consumer kernel only: the 1x1 skip conv of the same residual block reads the same activation tensor;
+    // its weight gradient dWskip[ci][co] = sum_p A[p][ci] * G2[p][co] rides on the 3x3 launch (the centre-tap fragments are
+    // staged anyway; tap group 1 has a free fifth accumulator).  g2: [M][Cout] S16 or nullptr; w_off2: slab offset of the
+    // 1x1 weight tensor (rows a.w_r0 .. as for the 3x3 tensor).
+    const float* g2;
+    int w_off2;
 };
 int tdm_launch_wgrad(const WgradArgs& a, int hw, int nslab, hipStream_t st);
 int tdm_launch_wgrad_bf16(const WgradArgs& a, int hw, int nslab, hipStream_t st);   // bf16x3 split operands

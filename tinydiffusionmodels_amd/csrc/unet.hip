@@ -259,8 +259,10 @@ int conv_s16_1(hipStream_t st, const Ws& ws, int hw, int B, const float* in_s16,
     return tdm_launch_conv_s16(a, hw, N, st);
 }
 int wgrad_s16(hipStream_t st, int hw, int B, const float* act_s16, int C, int c_used, int up, int taps,
-              const float* g_s16, int Cout, float* slabs, int w_off, int w_rows, int w_r0, int nslab) {
+              const float* g_s16, int Cout, float* slabs, int w_off, int w_rows, int w_r0, int nslab,
+              const float* g2_s16 = nullptr, int w_off2 = 0) {
     WgradArgs a{};
+    a.g2 = g2_s16; a.w_off2 = w_off2;   // the block's 1x1 skip weight gradient, fused into this 3x3 launch
     a.a = s16_src(act_s16, C, c_used, up, taps, nullptr, 0);
     a.a.w_rows = w_rows; a.a.w_r0 = w_r0;
     a.g = g_s16; a.Cout = Cout; a.slab = slabs; a.slab_stride = TDM_UNET_NPARAM; a.w_off = w_off; a.b_off = -1; a.B = B;
@@ -326,10 +328,9 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     TDM_TRY(conv_s16_1(st, w, 28, B, w.dc2s_4, 32, 9, kPack.dg[W_RB4C2], 32, nullptr, 0,
                        S16Out{nullptr, nullptr, nullptr, w.dh4s, nullptr, w.m1[3], w.gsum}));   // + ReLU backward of a1
     TDM_TRY(tdm_launch_image_sums(w.gsum, w.S[3], w.S2[3], B, 784, 32, st));
-    TDM_TRY(wgrad_s16(st, 28, B, w.h3s, 64, 64, 1, 9, w.dh4s, 32, slabs, r4.c1w, 96, 0, NS));
-    TDM_TRY(wgrad_s16(st, 28, B, w.h1s, 32, 32, 0, 9, w.dh4s, 32, slabs, r4.c1w, 96, 64, NS));
-    TDM_TRY(wgrad_s16(st, 28, B, w.h3s, 64, 64, 1, 1, w.dout4s, 32, slabs, r4.skw, 96, 0, NS));
-    TDM_TRY(wgrad_s16(st, 28, B, w.h1s, 32, 32, 0, 1, w.dout4s, 32, slabs, r4.skw, 96, 64, NS));
+    // rb4.conv1 and rb4.skip read the same concat: the 1x1 gradients ride on the 3x3 launches (fifth accumulator of tap group 1)
+    TDM_TRY(wgrad_s16(st, 28, B, w.h3s, 64, 64, 1, 9, w.dh4s, 32, slabs, r4.c1w, 96, 0, NS, w.dout4s, r4.skw));
+    TDM_TRY(wgrad_s16(st, 28, B, w.h1s, 32, 32, 0, 9, w.dh4s, 32, slabs, r4.c1w, 96, 64, NS, w.dout4s, r4.skw));
     {
         ConvArgs a{};
         a.nsrc = 2;
@@ -353,8 +354,7 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     TDM_TRY(conv_s16_1(st, w, 14, B, w.dc2s_2, 64, 9, kPack.dg[W_RB2C2], 64, nullptr, 0,
                        S16Out{nullptr, nullptr, nullptr, w.dh2s, nullptr, w.m1[1], w.gsum}));
     TDM_TRY(tdm_launch_image_sums(w.gsum, w.S[1], w.S2[1], B, 196, 64, st));
-    TDM_TRY(wgrad_s16(st, 14, B, w.p1s, 32, 32, 0, 9, w.dh2s, 64, slabs, r2.c1w, 32, 0, NS2));
-    TDM_TRY(wgrad_s16(st, 14, B, w.p1s, 32, 32, 0, 1, w.dout2s, 64, slabs, r2.skw, 32, 0, NS2));
+    TDM_TRY(wgrad_s16(st, 14, B, w.p1s, 32, 32, 0, 9, w.dh2s, 64, slabs, r2.c1w, 32, 0, NS2, w.dout2s, r2.skw));   // + rb2.skip
     {
         ConvArgs a{};
         a.nsrc = 2;
