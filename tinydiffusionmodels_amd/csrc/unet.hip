@@ -293,7 +293,7 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
     TDM_TRY(conv_s16_1(st, w, 14, B, w.h2s, 64, 9, kPack.fwd[W_RB3C1], 64, P + r3.c1b, 1,
                        S16Out{nullptr, save ? w.m1[2] : nullptr, nullptr, w.a1s_3, w.tb + 96}));
     TDM_TRY(conv_s16_1(st, w, 14, B, w.a1s_3, 64, 9, kPack.fwd[W_RB3C2], 64, P + r3.c2b, 1,
-                       S16Out{w.h3, save ? w.m2[2] : nullptr, w.h2, w.h3s, nullptr}));
+                       S16Out{save ? w.h3 : nullptr, save ? w.m2[2] : nullptr, w.h2, w.h3s, nullptr}));   // (fp32 h3: block-output accessor only)
     // rb4 on cat([up2(h3), h1])
     {
         ConvArgs a{};
