@@ -147,7 +147,7 @@ __device__ __forceinline__ void gstore_s16_o(float* s16, unsigned o, int c, cons
     gstore<tdm_bf16x4>(base + 32, lo);
 }
 
-template <int HW, int NT, bool SKIP>
+template <int HW, int NT, bool SKIP, bool PROBE>
 __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kernel(ConvArgs ka) {
     using G = Geo<HW>;
     static_assert(G::NR * G::WP * 4 <= NPIN * CONV_THREADS, "staging plan too small");
@@ -166,14 +166,16 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: everything derived from it stays scalar
     const int h = lane >> 5, j = lane & 31;
     const int t = xcd_remap(blockIdx.x, gridDim.x);
-    // phase probe (ablate & 16, tools/phase_probe.py): thread 0 stamps the shader clock at phase boundaries into the
-    // int64 table [blockIdx.x][16] that the caller appended BEHIND the B*H*W*N floats of aux
+    // phase probe (PROBE instantiation, launched when ablate & 16; tools/phase_probe.py): thread 0 stamps the shader clock
+    // at phase boundaries into the int64 table [blockIdx.x][16] that the caller appended BEHIND the B*H*W*N floats of aux
     int nstamp = 0;
     auto stamp = [&]() {
-        if ((a.ablate & 16) && tid == 0 && nstamp < 16)
-            gstore<long long>(reinterpret_cast<long long*>(a.aux + (long)a.B * G::H * G::W * N) + (long)blockIdx.x * 16 + nstamp,
-                              (long long)__builtin_readcyclecounter());
-        ++nstamp;
+        if constexpr (PROBE) {
+            if ((a.ablate & 16) && tid == 0 && nstamp < 16)
+                gstore<long long>(reinterpret_cast<long long*>(a.aux + (long)a.B * G::H * G::W * N) + (long)blockIdx.x * 16 + nstamp,
+                                  (long long)__builtin_readcyclecounter());
+            ++nstamp;
+        }
     };
     stamp();
     const int Mtot = a.B * G::H * G::W;
@@ -186,13 +188,20 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     const int nelem = nrows * G::WP * 4;      // 16-byte pieces of one chunk
     const int mbase = m0 + wave * 32;         // this wave's M tile (scalar)
 
-    int aoff;
+    int aoff;   // LDS byte offset of this lane's pixel (centre tap) in the staged image
     {
-        const int m = min(mbase + j, Mtot - 1);
-        const int b = m / (G::H * G::W);
-        const int rem = m - b * (G::H * G::W);
-        const int y = rem / G::W, x = rem - y * G::W;
-        aoff = ((b * G::HP + y + 1 - PR0) * G::WP + x + 1) * PIXB + h * 16;
+        // (image, row, column) of the M tile's first pixel are scalar; a lane is q = x0 + j columns further: q / W by
+        // multiply-shift (exact for q < W + 128), no per-lane constant divisions
+        const int mb = min(mbase, Mtot - 1);
+        const int b0 = mb / (G::H * G::W);
+        const int rem0 = mb - b0 * (G::H * G::W);
+        const int y0 = rem0 / G::W, x0 = rem0 - y0 * G::W;
+        const int q = x0 + min(j, Mtot - 1 - mb);       // (pixels past the end: the last real one)
+        const int dr = (q * (HW == 28 ? 2341 : 4682)) >> 16;
+        const int x = q - dr * G::W;
+        int y = y0 + dr, rowb = (b0 - tb0) * G::HP;
+        if (y >= G::H) { y -= G::H; rowb += G::HP; }
+        aoff = ((rowb + y + 1 - ty0) * G::WP + x + 1) * PIXB + h * 16;
     }
 
     // accumulators start from the conv bias (register quad g of N tile nt = channels nt*32 + 8g + 4h .. +3 of the lane's
@@ -231,24 +240,37 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     // beyond num_records and the hardware returns zeros — no exec-mask branch per load, no zero-initialised
     // destination, and (straight-line code) exact vmcnt(n) waits, so the second register set really stays in flight
     // while the first is staged.
-    auto prefetch_in = [&](uint4 (&pin)[NPIN], int (&goff)[NPIN], int& plan_src, int c) {
+    auto prefetch_in = [&](uint4 (&pin)[NPIN], int (&goff)[NPIN], int& plan_src, const int (&goff_other)[NPIN], int plan_other, int c) {
         const int si = (c >= nc0) ? 1 : 0;
         const int ch = si ? c - nc0 : c;
         const PinnedSrc s = a.src(si);
         const int up = s.up, Hs = G::H >> up, Ws = G::W >> up;
-        if (plan_src != si) {
-            // staged position of piece e = tid + 512 i is (tid >> 2) + 128 i: walk (row, column) of the padded-tall image
-            // incrementally — no division per element (src_offset's three cost ~1/3 of a 32 -> 32 launch in index math)
-            int lr = (tid >> 2) / G::WP;
-            int pc = (tid >> 2) - lr * G::WP;
+        if (plan_src != si && plan_other == si) {   // the other register set already holds this source's plan
 #pragma unroll
-            for (int i = 0; i < NPIN; ++i) {
-                int py = ty0 + lr, b = tb0;
+            for (int i = 0; i < NPIN; ++i) goff[i] = goff_other[i];
+            plan_src = si;
+        }
+        if (plan_src != si) {
+            // Staged position of piece e = tid + 512 i is (tid >> 2) + 128 i = (row lr, column pc) of the padded-tall image,
+            // walked incrementally (no division per piece).  What depends on the ROW — image, validity, the three
+            // multiplications of the source offset — is worked out once per row by lanes 0..31 of each wave and parked in
+            // a wave-private LDS table; a piece then costs one LDS read, the column offset and a select.
+            int* const rowtab = reinterpret_cast<int*>(wl + 9 * NT * 2048 + (SKIP ? NT * 2048 : 0)) + wave * 32;
+            if (lane < 32) {
+                int py = ty0 + lane, b = tb0;
                 if (py >= G::HP) { py -= G::HP; ++b; }
                 if (HW == 14 && py >= G::HP) { py -= G::HP; ++b; }   // 26 staged rows span up to three images at 14x14
-                const bool ok = tid + CONV_THREADS * i < nelem && py >= 1 && py <= G::H && pc >= 1 && pc <= G::W && b < a.B;
-                const int off = __mul24(__mul24(__mul24(b, Hs) + ((py - 1) >> up), Ws) + ((pc - 1) >> up), s.C) + s.c0;
-                goff[i] = ok ? (off + (tid & 3) * 4) * 4 : (int)0x80000000;   // byte offset, or out of range
+                const bool ok = lane < nrows && py >= 1 && py <= G::H && b < a.B;
+                rowtab[lane] = ok ? __mul24(__mul24(__mul24(b, Hs) + ((py - 1) >> up), Ws), s.C) * 4 : (int)0x80000000;
+            }
+            int lr = (tid >> 2) / G::WP;
+            int pc = (tid >> 2) - lr * G::WP;
+            const int cbase = (s.c0 + (tid & 3) * 4) * 4;
+#pragma unroll
+            for (int i = 0; i < NPIN; ++i) {
+                const int roff = rowtab[lr];                       // (lr <= 31 for both geometries)
+                const bool ok = roff >= 0 && pc >= 1 && pc <= G::W;
+                goff[i] = ok ? roff + __mul24((pc - 1) >> up, s.C) * 4 + cbase : (int)0x80000000;   // byte offset, or out of range
                 pc += STEP % G::WP;
                 lr += STEP / G::WP;
                 if (pc >= G::WP) { pc -= G::WP; ++lr; }
@@ -328,22 +350,22 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     };
 
     const bool pf = !(a.ablate & 1);
-    prefetch_in(pinA, goffA, planA, 0);
+    prefetch_in(pinA, goffA, planA, goffB, planB, 0);
     prefetch_w(0);
     if constexpr (NT == 1 && !SKIP) {
-        if (nchunks > 1) prefetch_in(pinB, goffB, planB, 1);
+        if (nchunks > 1) prefetch_in(pinB, goffB, planB, goffA, planA, 1);
         stamp();
         for (int c = 0; c < nchunks; c += 2) {
             stage(pinA);                                                  // chunk c
             stamp();
-            if (c + 2 < nchunks && pf) prefetch_in(pinA, goffA, planA, c + 2);
+            if (c + 2 < nchunks && pf) prefetch_in(pinA, goffA, planA, goffB, planB, c + 2);
             if (c + 1 < nchunks && pf) prefetch_w(c + 1);
             compute(c);
             stamp();
             if (c + 1 >= nchunks) break;
             stage(pinB);                                                  // chunk c + 1
             stamp();
-            if (c + 3 < nchunks && pf) prefetch_in(pinB, goffB, planB, c + 3);
+            if (c + 3 < nchunks && pf) prefetch_in(pinB, goffB, planB, goffA, planA, c + 3);
             if (c + 2 < nchunks && pf) prefetch_w(c + 2);
             compute(c + 1);
             stamp();
@@ -353,7 +375,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         // budget of four waves per SIMD, so these widths prefetch one chunk ahead
         for (int c = 0; c < nchunks; ++c) {
             stage(pinA);
-            if (c + 1 < nchunks && pf) { prefetch_in(pinA, goffA, planA, c + 1); prefetch_w(c + 1); }
+            if (c + 1 < nchunks && pf) { prefetch_in(pinA, goffA, planA, goffB, planB, c + 1); prefetch_w(c + 1); }
             compute(c);
         }
     }
@@ -559,19 +581,20 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         }
     }
     stamp();   // stores issued
-    if (a.ablate & 16) __builtin_amdgcn_s_waitcnt(0);   // (probe only) stores acknowledged
+    if constexpr (PROBE) if (a.ablate & 16) __builtin_amdgcn_s_waitcnt(0);   // stores acknowledged
     stamp();
 }
 
 template <int HW, int NT, bool SKIP>
 int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     using G = Geo<HW>;
-    constexpr size_t lds_op = (size_t)G::NR * G::WP * PIXB + (size_t)9 * NT * 2048 + (SKIP ? (size_t)NT * 2048 : 0);
+    constexpr size_t lds_op = (size_t)G::NR * G::WP * PIXB + (size_t)9 * NT * 2048 + (SKIP ? (size_t)NT * 2048 : 0) +
+                              (size_t)(CONV_THREADS / 64) * 32 * sizeof(int);   // operand images + the waves' row tables
     constexpr size_t lds_epi = (size_t)(CONV_THREADS / 64) * 32 * (NT * 32 + 4) * sizeof(float);   // per-wave transpose blocks
     constexpr size_t lds = lds_op > lds_epi ? lds_op : lds_epi;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<HW, NT, SKIP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<HW, NT, SKIP, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 110000);
         if (e != hipSuccess) {
             tdm_set_error("conv_s16: hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
@@ -583,7 +606,20 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     const int ntiles = (int)((Mtot + TILE_PX - 1) / TILE_PX);
     // ablate & 32 (probe): one workgroup per CU (LDS request > half of 160 KB) — phase times without a co-resident workgroup
     const size_t lds_req = (a.ablate & 32) ? (size_t)110000 : lds;
-    hipLaunchKernelGGL((conv_s16_kernel<HW, NT, SKIP>), dim3(ntiles), dim3(CONV_THREADS), lds_req, st, a);
+    if constexpr (HW == 28 && NT == 1 && !SKIP) {
+        if (a.ablate & 16) {   // the instrumented instantiation (diagnostics only)
+            static bool probe_attr = false;
+            if (!probe_attr) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<HW, NT, SKIP, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 110000);
+                probe_attr = true;
+            }
+            hipLaunchKernelGGL((conv_s16_kernel<HW, NT, SKIP, true>), dim3(ntiles), dim3(CONV_THREADS), lds_req, st, a);
+            TDM_CHECK_LAUNCH("conv_s16(probe)");
+            return 0;
+        }
+    }
+    hipLaunchKernelGGL((conv_s16_kernel<HW, NT, SKIP, false>), dim3(ntiles), dim3(CONV_THREADS), lds_req, st, a);
     TDM_CHECK_LAUNCH("conv_s16");
     return 0;
 }
