@@ -694,11 +694,9 @@ __global__ __launch_bounds__(EW_BLOCK) void out_bwd_s16_kernel(const float* __re
     float4 gw = make_float4(0.f, 0.f, 0.f, 0.f), g_c2 = gw, g_sk = gw;
     float gb = 0.f;
     const int64_t total = M * 8;
-    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+    const int64_t S = (int64_t)gridDim.x * EW_BLOCK;
+    auto finish = [&](int64_t i, float d, const float4& hv, unsigned am) {
         const int64_t m = i >> 3;
-        const float d = deps[m];
-        const float4 hv = reinterpret_cast<const float4*>(h4)[i];
-        const unsigned am = a2m[i];
         float4 o;
         o.x = d * wv.x; o.y = d * wv.y; o.z = d * wv.z; o.w = d * wv.w;
         if (dout != nullptr) reinterpret_cast<float4*>(dout)[i] = o;
@@ -709,7 +707,20 @@ __global__ __launch_bounds__(EW_BLOCK) void out_bwd_s16_kernel(const float* __re
         g_c2.x += mk.x; g_c2.y += mk.y; g_c2.z += mk.z; g_c2.w += mk.w;
         g_sk.x += o.x; g_sk.y += o.y; g_sk.z += o.z; g_sk.w += o.w;
         if (c4 == 0) gb += d;
+    };
+    int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x;
+    // four independent items in flight per thread (one workgroup per slab = one wave per SIMD: latency-bound otherwise)
+    for (; i + 3 * S < total; i += 4 * S) {
+        float d[4]; float4 hv[4]; unsigned am[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t k = i + u * S;
+            d[u] = deps[k >> 3]; hv[u] = reinterpret_cast<const float4*>(h4)[k]; am[u] = a2m[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) finish(i + u * S, d[u], hv[u], am[u]);
     }
+    for (; i < total; i += S) finish(i, deps[i >> 3], reinterpret_cast<const float4*>(h4)[i], a2m[i]);
     float* dst = slab + (long)blockIdx.x * slab_stride;
     const float sb = block_sum(gb, shb);
     quad_reduce_store(gw, shw, 8, dst + w_off);
@@ -728,7 +739,22 @@ __global__ __launch_bounds__(EW_BLOCK) void relu_mask_s16_kernel(const float* __
     const int c4 = threadIdx.x % C4;             // fixed per thread: the grid stride is a multiple of C4
     float4 gm = make_float4(0.f, 0.f, 0.f, 0.f), gu = gm;
     const int64_t total = M * C4;
-    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+    const int64_t S = (int64_t)gridDim.x * EW_BLOCK;
+    int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x;
+    // four independent items in flight per thread (one workgroup per slab = one wave per SIMD: the loop is latency-bound)
+    for (; i + 3 * S < total; i += 4 * S) {
+        float4 d[4]; unsigned mk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { d[u] = reinterpret_cast<const float4*>(dout)[i + u * S]; mk[u] = am[i + u * S]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 o = mask4(d[u], mk[u]);
+            tdm_store_s16_4(dc_s16, (i + u * S) / C4, C, c4 * 4, o);
+            gm.x += o.x; gm.y += o.y; gm.z += o.z; gm.w += o.w;
+            gu.x += d[u].x; gu.y += d[u].y; gu.z += d[u].z; gu.w += d[u].w;
+        }
+    }
+    for (; i < total; i += S) {
         const float4 d = reinterpret_cast<const float4*>(dout)[i];
         const float4 o = mask4(d, am[i]);
         tdm_store_s16_4(dc_s16, i / C4, C, c4 * 4, o);
@@ -751,24 +777,35 @@ __global__ __launch_bounds__(EW_BLOCK) void split_dcat_mask_s16_kernel(const flo
     __shared__ float4 sh[EW_BLOCK];
     float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t total = (int64_t)B * 196 * 16;
-    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
-        const int c4 = (int)(i & 15);
+    const int64_t S = (int64_t)gridDim.x * EW_BLOCK;
+    const int c4 = threadIdx.x & 15;   // (the grid stride is a multiple of 16)
+    struct Item { float4 v00, v01, v10, v11; unsigned am; };
+    auto fetch = [&](int64_t i, Item& it) {
         const int64_t p = i >> 4;
         const int xo = (int)(p % 14);
         const int64_t q = p / 14;
         const int yo = (int)(q % 14);
         const int64_t b = q / 14;
         const float4* src = reinterpret_cast<const float4*>(dcat) + ((b * 28 + 2 * yo) * 28 + 2 * xo) * 24 + c4;
-        const float4 v00 = src[0], v01 = src[24], v10 = src[28 * 24], v11 = src[28 * 24 + 24];
-        const unsigned am = a2m[i];
+        it.v00 = src[0]; it.v01 = src[24]; it.v10 = src[28 * 24]; it.v11 = src[28 * 24 + 24];
+        it.am = a2m[i];
+    };
+    auto finish = [&](int64_t i, const Item& it) {
         float4 d;
-        d.x = ((v00.x + v01.x) + v10.x) + v11.x; d.y = ((v00.y + v01.y) + v10.y) + v11.y;
-        d.z = ((v00.z + v01.z) + v10.z) + v11.z; d.w = ((v00.w + v01.w) + v10.w) + v11.w;
+        d.x = ((it.v00.x + it.v01.x) + it.v10.x) + it.v11.x; d.y = ((it.v00.y + it.v01.y) + it.v10.y) + it.v11.y;
+        d.z = ((it.v00.z + it.v01.z) + it.v10.z) + it.v11.z; d.w = ((it.v00.w + it.v01.w) + it.v10.w) + it.v11.w;
         reinterpret_cast<float4*>(dout3)[i] = d;
-        const float4 o = mask4(d, am);
-        tdm_store_s16_4(dc_s16, p, 64, c4 * 4, o);
+        const float4 o = mask4(d, it.am);
+        tdm_store_s16_4(dc_s16, i >> 4, 64, c4 * 4, o);
         gm.x += o.x; gm.y += o.y; gm.z += o.z; gm.w += o.w;
+    };
+    int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x;
+    for (; i + S < total; i += 2 * S) {   // two items (eight 16-byte loads) in flight per thread
+        Item a, b2;
+        fetch(i, a); fetch(i + S, b2);
+        finish(i, a); finish(i + S, b2);
     }
+    for (; i < total; i += S) { Item a; fetch(i, a); finish(i, a); }
     quad_reduce_store(gm, sh, 16, slab + (long)blockIdx.x * slab_stride + b_masked_off);
 }
 
@@ -783,22 +820,39 @@ __global__ __launch_bounds__(EW_BLOCK) void combine_dh1_mask_s16_kernel(const fl
     __shared__ float4 sh[EW_BLOCK];
     float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t total = (int64_t)B * 784 * 8;
-    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
-        const int c4 = (int)(i & 7);
+    const int64_t S = (int64_t)gridDim.x * EW_BLOCK;
+    const int c4 = threadIdx.x & 7;   // (the grid stride is a multiple of 8)
+    auto fetch = [&](int64_t i, float4& dc, float4& dp, unsigned& am) {
         const int64_t p = i >> 3;
         const int x = (int)(p % 28);
         const int64_t q = p / 28;
         const int y = (int)(q % 28);
         const int64_t b = q / 28;
-        const float4 dc = reinterpret_cast<const float4*>(dcat)[p * 24 + 16 + c4];
-        const float4 dp = reinterpret_cast<const float4*>(dp1)[((b * 14 + (y >> 1)) * 14 + (x >> 1)) * 8 + c4];
-        const unsigned am = a2m[i];
+        dc = reinterpret_cast<const float4*>(dcat)[p * 24 + 16 + c4];
+        dp = reinterpret_cast<const float4*>(dp1)[((b * 14 + (y >> 1)) * 14 + (x >> 1)) * 8 + c4];
+        am = a2m[i];
+    };
+    auto finish = [&](int64_t i, const float4& dc, const float4& dp, unsigned am) {
         float4 d;
         d.x = dc.x + 0.25f * dp.x; d.y = dc.y + 0.25f * dp.y; d.z = dc.z + 0.25f * dp.z; d.w = dc.w + 0.25f * dp.w;
         reinterpret_cast<float4*>(dout1)[i] = d;
         const float4 o = mask4(d, am);
-        tdm_store_s16_4(dc_s16, p, 32, c4 * 4, o);
+        tdm_store_s16_4(dc_s16, i >> 3, 32, c4 * 4, o);
         gm.x += o.x; gm.y += o.y; gm.z += o.z; gm.w += o.w;
+    };
+    int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x;
+    // four independent items in flight per thread (one workgroup per slab = one wave per SIMD: latency-bound otherwise)
+    for (; i + 3 * S < total; i += 4 * S) {
+        float4 dc[4], dp[4]; unsigned am[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fetch(i + u * S, dc[u], dp[u], am[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) finish(i + u * S, dc[u], dp[u], am[u]);
+    }
+    for (; i < total; i += S) {
+        float4 dc, dp; unsigned am;
+        fetch(i, dc, dp, am);
+        finish(i, dc, dp, am);
     }
     quad_reduce_store(gm, sh, 8, slab + (long)blockIdx.x * slab_stride + b_masked_off);
 }
