@@ -552,33 +552,43 @@ __global__ __launch_bounds__(EW_BLOCK) void conv_first_s16_kernel(const float* _
                                                                   float* __restrict__ a1, unsigned char* __restrict__ a1m,
                                                                   float* __restrict__ a1_s16, float* __restrict__ s, int B) {
     const int64_t total = (int64_t)B * 784 * 8;
+    // the thread's channel quad is fixed (the grid stride is a multiple of 8): its 9 tap weights, biases and skip weights
+    // are loaded once; the 9 input taps of an item are unconditional clamped loads (a branch per tap serialised them)
+    const int c4 = threadIdx.x & 7;
+    float4 wv[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) wv[tap] = *reinterpret_cast<const float4*>(w1 + tap * 32 + c4 * 4);
+    const float4 b1v = *reinterpret_cast<const float4*>(b1 + c4 * 4);
+    const float4 wsv = *reinterpret_cast<const float4*>(ws + c4 * 4);
+    const float4 bsv = *reinterpret_cast<const float4*>(bs + c4 * 4);
     for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
-        const int c4 = (int)(i & 7);
         const int64_t m = i >> 3;
         const int b = (int)(m / 784);
         const int rem = (int)(m - (int64_t)b * 784);
         const int y = rem / 28, xx = rem - y * 28;
-        float4 acc = *reinterpret_cast<const float4*>(b1 + c4 * 4);
-        float xc = 0.f;
+        const float* xb = x + (int64_t)b * 784;
+        float xv[9];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int yy = y + tap / 3 - 1, xq = xx + tap % 3 - 1;
-            float xv = 0.f;
-            if (yy >= 0 && yy < 28 && xq >= 0 && xq < 28) xv = x[(int64_t)b * 784 + yy * 28 + xq];
-            if (tap == 4) xc = xv;
-            const float4 wv = *reinterpret_cast<const float4*>(w1 + tap * 32 + c4 * 4);
-            acc.x = fmaf(xv, wv.x, acc.x); acc.y = fmaf(xv, wv.y, acc.y);
-            acc.z = fmaf(xv, wv.z, acc.z); acc.w = fmaf(xv, wv.w, acc.w);
+            const bool ok = yy >= 0 && yy < 28 && xq >= 0 && xq < 28;
+            const float v = xb[ok ? yy * 28 + xq : rem];
+            xv[tap] = ok ? v : 0.f;
         }
+        const float4 t4 = *reinterpret_cast<const float4*>(tb + (int64_t)b * tb_stride + c4 * 4);
+        float4 acc = b1v;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            acc.x = fmaf(xv[tap], wv[tap].x, acc.x); acc.y = fmaf(xv[tap], wv[tap].y, acc.y);
+            acc.z = fmaf(xv[tap], wv[tap].z, acc.z); acc.w = fmaf(xv[tap], wv[tap].w, acc.w);
+        }
+        const float xc = xv[4];
         acc.x = acc.x < 0.f ? 0.f : acc.x; acc.y = acc.y < 0.f ? 0.f : acc.y;
         acc.z = acc.z < 0.f ? 0.f : acc.z; acc.w = acc.w < 0.f ? 0.f : acc.w;
         if (a1 != nullptr) *reinterpret_cast<float4*>(a1 + m * 32 + c4 * 4) = acc;
         if (a1m != nullptr)
             a1m[i] = (unsigned char)((acc.x > 0.f ? 1 : 0) | (acc.y > 0.f ? 2 : 0) | (acc.z > 0.f ? 4 : 0) | (acc.w > 0.f ? 8 : 0));
-        const float4 t4 = *reinterpret_cast<const float4*>(tb + (int64_t)b * tb_stride + c4 * 4);
         tdm_store_s16_4(a1_s16, m, 32, c4 * 4, make_float4(acc.x + t4.x, acc.y + t4.y, acc.z + t4.z, acc.w + t4.w));
-        const float4 wsv = *reinterpret_cast<const float4*>(ws + c4 * 4);
-        const float4 bsv = *reinterpret_cast<const float4*>(bs + c4 * 4);
         float4 sv;
         sv.x = fmaf(xc, wsv.x, bsv.x); sv.y = fmaf(xc, wsv.y, bsv.y);
         sv.z = fmaf(xc, wsv.z, bsv.z); sv.w = fmaf(xc, wsv.w, bsv.w);
