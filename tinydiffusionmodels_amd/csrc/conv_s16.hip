@@ -156,6 +156,10 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     // prefetch load, around every uniform branch of the epilogue.  Everything the kernel uses is copied ONCE into
     // scalars the optimiser cannot rematerialise (opaque asm), about 60 SGPRs.
     PinnedArgs a(ka);
+    // rank-1 residual (ConvArgs::r1_*): only the 28x28 N = 32 instantiation (rb1.conv2) carries its registers
+    constexpr bool R1 = HW == 28 && NT == 1 && !SKIP;
+    const float* r1_x = R1 ? ka.r1_x : nullptr; const float* r1_w = ka.r1_w; const float* r1_b = ka.r1_b;
+    if constexpr (R1) { TDM_PIN(r1_x); TDM_PIN(r1_w); TDM_PIN(r1_b); }
     constexpr int N = NT * 32;
     constexpr int TILE_B = G::NR * G::WP * PIXB;
     extern __shared__ float4 smem4[];
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     const int img0 = mbase / (G::H * G::W);         // image of the group's first pixel (scalar)
     const int mnext = (img0 + 1) * (G::H * G::W);   // a 32-pixel group touches at most two images
     constexpr int GI = 4;   // passes per group: 4 independent chains, 16 value registers
-    struct Pre { float4 rt[GI]; unsigned mk[GI]; } p;   // inputs of ONE group of passes; rt: residual, else the time-bias row
+    struct Pre { float4 rt[GI]; unsigned mk[GI]; float rx[R1 ? GI : 1]; } p;   // inputs of ONE group of passes; rt: residual, else the time-bias row
     // branch-free: absent inputs get an empty descriptor (num_records 0 -> zeros), so the requests are one straight run
     // of loads (under uniform branches each request became a load + s_waitcnt vmcnt(0) + spill at N = 64)
     const bool use_res = a.res != nullptr;
@@ -411,6 +415,8 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         const_cast<float*>(use_res ? a.res : a.tb_out), 0, use_res ? Mtot * N * 4 : (use_tb ? a.B * a.tb_out_stride * 4 : 0), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_mk = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char*>(a.relu_mask_in), 0, bwd ? Mtot * (N / 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(r1_x), 0, r1_x != nullptr ? Mtot * 4 : 0, 0x00020000);
     auto preload = [&](int g) {
 #pragma unroll
         for (int it = 0; it < GI; ++it) {
@@ -422,6 +428,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
             const f32x4 r = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_rt, (use_res ? o : otb) * 4, 0, 0));
             p.rt[it] = make_float4(r[0], r[1], r[2], r[3]);
             p.mk[it] = __builtin_amdgcn_raw_buffer_load_b8(rs_mk, o >> 2, 0, 0);
+            if constexpr (R1) p.rx[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rx, m * 4, 0, 0));
         }
     };
     preload(0);
@@ -489,6 +496,15 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
             for (int k = 0; k < GI; ++k) {
                 const float4 rz = p.rt[k];
                 v[k].x += rz.x; v[k].y += rz.y; v[k].z += rz.z; v[k].w += rz.w;
+            }
+        }
+        if constexpr (R1) if (r1_x != nullptr) {   // rank-1 residual: the one-input-channel skip conv, recomputed (same fma as conv_first)
+#pragma unroll
+            for (int k = 0; k < GI; ++k) {
+                const int c = (((I0 + k) * 64 + lane_e) % (N / 4)) * 4;
+                const float4 w4 = gload4(r1_w + c), b4 = gload4(r1_b + c);
+                v[k].x += fmaf(p.rx[k], w4.x, b4.x); v[k].y += fmaf(p.rx[k], w4.y, b4.y);
+                v[k].z += fmaf(p.rx[k], w4.z, b4.z); v[k].w += fmaf(p.rx[k], w4.w, b4.w);
             }
         }
         if (bwd) {   // ReLU backward of the tensor this gradient belongs to + the sums its bias gradients need
@@ -1183,6 +1199,8 @@ int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st) {
         TDM_REQUIRE(a.src[i].wp != nullptr && (((uintptr_t)a.src[i].wp) & 15) == 0, "conv_s16: packed weights missing");
     }
     TDM_REQUIRE(a.out != nullptr || a.out_s16 != nullptr, "conv_s16: no output");
+    TDM_REQUIRE(a.r1_x == nullptr || (hw == 28 && N == 32 && a.skip_out == nullptr && a.res == nullptr && a.r1_w != nullptr && a.r1_b != nullptr),
+                "conv_s16: the rank-1 residual is built for the 28x28 N = 32 kernel without another residual");
     TDM_REQUIRE(a.B > 0 && (long)a.B * hw * hw * 96 < 2147483647L, "conv_s16: batch %d out of range", a.B);
     if (a.skip_out != nullptr) {   // fused 1x1 skip conv: built for the one geometry that uses it (rb4: 96 -> 32 @ 28x28)
         TDM_REQUIRE(hw == 28 && N == 32 && a.skip_wp != nullptr && a.skip_bias != nullptr, "conv_s16: fused skip needs hw=28, N=32");

@@ -592,7 +592,7 @@ __global__ __launch_bounds__(EW_BLOCK) void conv_first_s16_kernel(const float* _
         float4 sv;
         sv.x = fmaf(xc, wsv.x, bsv.x); sv.y = fmaf(xc, wsv.y, bsv.y);
         sv.z = fmaf(xc, wsv.z, bsv.z); sv.w = fmaf(xc, wsv.w, bsv.w);
-        *reinterpret_cast<float4*>(s + m * 32 + c4 * 4) = sv;
+        if (s != nullptr) *reinterpret_cast<float4*>(s + m * 32 + c4 * 4) = sv;
     }
 }
 

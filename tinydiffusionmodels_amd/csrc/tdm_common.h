@@ -86,6 +86,12 @@ struct ConvArgs {
     const unsigned short* skip_wp;
     const float* skip_bias;
     float* skip_out;
+    // Rank-1 residual (S16 kernel): rb1's skip conv has ONE input channel, so its output s[m][c] = fma(x[m], w[c], b[c]) is
+    // recomputed in the epilogue from 4 bytes per pixel instead of being written and re-read as a [M][N] fp32 tensor
+    // (51 MB each way at B = 512).  r1_x: [M] or nullptr; r1_w, r1_b: [N].  Added after ReLU, like `res` (exclusive with it).
+    const float* r1_x;
+    const float* r1_w;
+    const float* r1_b;
 };
 
 // hw in {28,14}; N in {32,64,96}; dgrad: transposed convolution with the forward weights

@@ -279,10 +279,18 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
     TDM_TRY(tdm_launch_pack(P, kPack.pa, w.wpack, st));
     const BlockOff &r1 = kL.rb[0], &r2 = kL.rb[1], &r3 = kL.rb[2], &r4 = kL.rb[3];
     // rb1: conv1 (Cin = 1) writes a1 (mask) and split(a1 + tb) for conv2
+    // (rb1.skip has one input channel: its output is not materialised; rb1.conv2's epilogue recomputes it from x)
     TDM_TRY(tdm_launch_conv_first_s16(x, P + r1.c1w, P + r1.c1b, P + r1.skw, P + r1.skb, w.tb + 0, 192, nullptr,
-                                      save ? w.m1[0] : nullptr, w.a1s_1, w.s1, B, st));
-    TDM_TRY(conv_s16_1(st, w, 28, B, w.a1s_1, 32, 9, kPack.fwd[W_RB1C2], 32, P + r1.c2b, 1,
-                       S16Out{w.h1, save ? w.m2[0] : nullptr, w.s1, w.h1s, nullptr}));
+                                      save ? w.m1[0] : nullptr, w.a1s_1, nullptr, B, st));
+    {
+        ConvArgs a{};
+        a.nsrc = 1;
+        a.src[0] = s16_src(w.a1s_1, 32, 32, 0, 9, w.wpack + kPack.fwd[W_RB1C2], 0);
+        a.bias = P + r1.c2b; a.relu = 1; a.B = B;
+        a.out = w.h1; a.mask_out = save ? w.m2[0] : nullptr; a.out_s16 = w.h1s; a.tb_out_stride = 192;
+        a.r1_x = x; a.r1_w = P + r1.skw; a.r1_b = P + r1.skb;
+        TDM_TRY(tdm_launch_conv_s16(a, 28, 32, st));
+    }
     // rb2 on avg_pool2d(h1)
     TDM_TRY(tdm_launch_pool_skip_s16(w.h1, P + r2.skw, P + r2.skb, w.p1s, w.s2, B, st));   // pooling + rb2.skip (1x1)
     TDM_TRY(conv_s16_1(st, w, 14, B, w.p1s, 32, 9, kPack.fwd[W_RB2C1], 64, P + r2.c1b, 1,
