@@ -160,6 +160,8 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     constexpr bool R1 = HW == 28 && NT == 1 && !SKIP;
     const float* r1_x = R1 ? ka.r1_x : nullptr; const float* r1_w = ka.r1_w; const float* r1_b = ka.r1_b;
     if constexpr (R1) { TDM_PIN(r1_x); TDM_PIN(r1_w); TDM_PIN(r1_b); }
+    float* o1_out = R1 ? ka.o1_out : nullptr; const float* o1_w = ka.o1_w; const float* o1_b = ka.o1_b;   // fused 1x1 output conv (rb4.conv2)
+    if constexpr (R1) { TDM_PIN(o1_out); TDM_PIN(o1_w); TDM_PIN(o1_b); }
     constexpr int N = NT * 32;
     constexpr int TILE_B = G::NR * G::WP * PIXB;
     extern __shared__ float4 smem4[];
@@ -526,6 +528,18 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         if (a.out != nullptr) {
 #pragma unroll
             for (int k = 0; k < GI; ++k) if (ok[k]) gstore4(a.out + o[k], v[k]);
+        }
+        if constexpr (R1) if (o1_out != nullptr) {   // the model's 1x1 output conv: 8 consecutive lanes hold a pixel's 32 channels
+            const float4 w4 = gload4(o1_w + (lane_e & 7) * 4);
+            const float ob = gload<float>(o1_b);
+#pragma unroll
+            for (int k = 0; k < GI; ++k) {
+                float d = ((v[k].x * w4.x + v[k].y * w4.y) + v[k].z * w4.z) + v[k].w * w4.w;   // (conv_out_kernel's association)
+                d += __shfl_xor(d, 1);
+                d += __shfl_xor(d, 2);
+                d += __shfl_xor(d, 4);
+                if ((lane_e & 7) == 0 && ok[k]) gstore<float>(o1_out + (o[k] >> 5), d + ob);
+            }
         }
         if (a.out_s16 != nullptr) {
             if (a.tb_out != nullptr) {
@@ -1198,7 +1212,9 @@ int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st) {
         TDM_REQUIRE(a.src[i].tb == nullptr, "conv_s16: the time bias is pre-added by the producer of an S16 tensor");
         TDM_REQUIRE(a.src[i].wp != nullptr && (((uintptr_t)a.src[i].wp) & 15) == 0, "conv_s16: packed weights missing");
     }
-    TDM_REQUIRE(a.out != nullptr || a.out_s16 != nullptr, "conv_s16: no output");
+    TDM_REQUIRE(a.out != nullptr || a.out_s16 != nullptr || a.o1_out != nullptr, "conv_s16: no output");
+    TDM_REQUIRE(a.o1_out == nullptr || (hw == 28 && N == 32 && a.skip_out == nullptr && a.o1_w != nullptr && a.o1_b != nullptr),
+                "conv_s16: the fused output conv is built for the 28x28 N = 32 kernel");
     TDM_REQUIRE(a.r1_x == nullptr || (hw == 28 && N == 32 && a.skip_out == nullptr && a.res == nullptr && a.r1_w != nullptr && a.r1_b != nullptr),
                 "conv_s16: the rank-1 residual is built for the 28x28 N = 32 kernel without another residual");
     TDM_REQUIRE(a.B > 0 && (long)a.B * hw * hw * 96 < 2147483647L, "conv_s16: batch %d out of range", a.B);

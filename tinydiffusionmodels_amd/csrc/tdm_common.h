@@ -92,6 +92,12 @@ struct ConvArgs {
     const float* r1_x;
     const float* r1_w;
     const float* r1_b;
+    // Fused 1x1 output conv N -> 1 (src/mnist.py:87, same kernel instantiation): o1_out[m] = sum_c value[m][c] * o1_w[c]
+    // + o1_b[0] over the value that goes to `out` (after ReLU and residual), with conv_out_kernel's association, so the
+    // [M][32] tensor need not be written when nothing else reads it (sampling).  o1_out: [M] or nullptr.
+    const float* o1_w;
+    const float* o1_b;
+    float* o1_out;
 };
 
 // hw in {28,14}; N in {32,64,96}; dgrad: transposed convolution with the forward weights

@@ -314,9 +314,15 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
         a.skip_wp = w.wpack + kPack.fwd[W_RB4SK]; a.skip_bias = P + r4.skb; a.skip_out = w.s4;
         TDM_TRY(tdm_launch_conv_s16(a, 28, 32, st));
     }
-    TDM_TRY(conv_s16_1(st, w, 28, B, w.a1s_4, 32, 9, kPack.fwd[W_RB4C2], 32, P + r4.c2b, 1,
-                       S16Out{w.h4, save ? w.m2[3] : nullptr, w.s4, nullptr, nullptr}));
-    TDM_TRY(tdm_launch_conv_out(w.h4, P + kL.outw, P + kL.outb, eps, (int64_t)B * 784, st));
+    {   // rb4.conv2 + the model's 1x1 output conv in its epilogue; h4 itself is only written for the backward pass
+        ConvArgs a{};
+        a.nsrc = 1;
+        a.src[0] = s16_src(w.a1s_4, 32, 32, 0, 9, w.wpack + kPack.fwd[W_RB4C2], 0);
+        a.bias = P + r4.c2b; a.relu = 1; a.B = B;
+        a.out = save ? w.h4 : nullptr; a.mask_out = save ? w.m2[3] : nullptr; a.res = w.s4; a.tb_out_stride = 192;
+        a.o1_w = P + kL.outw; a.o1_b = P + kL.outb; a.o1_out = eps;
+        TDM_TRY(tdm_launch_conv_s16(a, 28, 32, st));
+    }
     return 0;
 }
 
