@@ -644,8 +644,9 @@ __global__ __launch_bounds__(EW_BLOCK) void pool_skip_s16_kernel(const float* __
                 const int64_t q = p / 14;
                 const int yo = (int)(q % 14);
                 const int64_t b = q / 14;
-                const float4* src = reinterpret_cast<const float4*>(h1) + ((b * 28 + 2 * yo) * 28 + 2 * xo) * 8 + c4;
-                const float4 v00 = src[0], v01 = src[8], v10 = src[28 * 8], v11 = src[28 * 8 + 8];
+                const int64_t m00 = (b * 28 + 2 * yo) * 28 + 2 * xo;   // h1 is read from its S16 twin (hi + lo): no fp32 copy exists
+                const float4 v00 = tdm_load_s16_4(h1, m00, 32, c4 * 4), v01 = tdm_load_s16_4(h1, m00 + 1, 32, c4 * 4);
+                const float4 v10 = tdm_load_s16_4(h1, m00 + 28, 32, c4 * 4), v11 = tdm_load_s16_4(h1, m00 + 29, 32, c4 * 4);
                 o.x = (((v00.x + v01.x) + v10.x) + v11.x) * 0.25f;
                 o.y = (((v00.y + v01.y) + v10.y) + v11.y) * 0.25f;
                 o.z = (((v00.z + v01.z) + v10.z) + v11.z) * 0.25f;
@@ -986,6 +987,28 @@ int tdm_launch_nhwc_to_nchw(const float* in, float* out, int B, int HWpix, int C
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_grid((int64_t)B * HWpix * C)), dim3(EW_BLOCK), 0, st, in, out, B,
                        HWpix, C);
     TDM_CHECK_LAUNCH("nhwc_to_nchw");
+    return 0;
+}
+
+namespace {
+__global__ __launch_bounds__(EW_BLOCK) void s16_to_nchw_kernel(const float* __restrict__ in_s16, float* __restrict__ out, int B,
+                                                               int HWpix, int C) {
+    const int C4 = C >> 2;
+    const int64_t total = (int64_t)B * HWpix * C4;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c4 = (int)(i % C4);
+        const int64_t m = i / C4;
+        const int64_t b = m / HWpix, p = m - b * HWpix;
+        const float4 v = tdm_load_s16_4(in_s16, m, C, c4 * 4);
+        float* o = out + (b * C + c4 * 4) * HWpix + p;
+        o[0] = v.x; o[HWpix] = v.y; o[2 * (int64_t)HWpix] = v.z; o[3 * (int64_t)HWpix] = v.w;
+    }
+}
+}  // namespace
+int tdm_launch_s16_to_nchw(const float* in_s16, float* out, int B, int HWpix, int C, hipStream_t st) {
+    hipLaunchKernelGGL(s16_to_nchw_kernel, dim3(ew_grid((int64_t)B * HWpix * (C / 4))), dim3(EW_BLOCK), 0, st, in_s16, out, B,
+                       HWpix, C);
+    TDM_CHECK_LAUNCH("s16_to_nchw");
     return 0;
 }
 

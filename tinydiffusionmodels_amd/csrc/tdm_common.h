@@ -180,6 +180,7 @@ int tdm_launch_conv_first_s16(const float* x, const float* w1, const float* b1, 
 // p1_s16 = split(avg_pool2d(h1, 2)), s2 = rb2.skip(p1) + bias (1x1, 32 -> 64, exact fp32 on the vector units)
 int tdm_launch_pool_skip_s16(const float* h1, const float* wsk, const float* bsk, float* p1_s16, float* s2, int B,
                              hipStream_t st);
+int tdm_launch_s16_to_nchw(const float* in_s16, float* out, int B, int HWpix, int C, hipStream_t st);   // accessor: hi + lo -> fp32 NCHW
 int tdm_launch_avgpool_s16(const float* in, float* out, float* out_s16, int B, int Hout, int C, hipStream_t st);
 int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, const unsigned char* a2m, float* dout,
                            float* dout_s16, float* dc2_s16, float* slab, long slab_stride, int w_off, int b_off,

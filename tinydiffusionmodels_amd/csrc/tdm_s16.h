@@ -28,3 +28,16 @@ __device__ __forceinline__ void tdm_store_s16_4(float* s16, long m, int C, int c
     *reinterpret_cast<tdm_bf16x4*>(base) = hi;
     *reinterpret_cast<tdm_bf16x4*>(base + 32) = lo;
 }
+
+// channels c..c+3 (c % 4 == 0) of pixel m of an S16 tensor, reassembled: hi + lo (>= 16 significant bits of the original)
+__device__ __forceinline__ float4 tdm_load_s16_4(const float* s16, long m, int C, int c) {
+    const char* base = reinterpret_cast<const char*>(s16 + m * C + (c & ~15)) + (c & 15) * 2;
+    const uint2 h = *reinterpret_cast<const uint2*>(base);
+    const uint2 l = *reinterpret_cast<const uint2*>(base + 32);
+    float4 v;
+    v.x = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16);
+    v.y = __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u);
+    v.z = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16);
+    v.w = __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u);
+    return v;
+}

@@ -287,12 +287,12 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
         a.nsrc = 1;
         a.src[0] = s16_src(w.a1s_1, 32, 32, 0, 9, w.wpack + kPack.fwd[W_RB1C2], 0);
         a.bias = P + r1.c2b; a.relu = 1; a.B = B;
-        a.out = w.h1; a.mask_out = save ? w.m2[0] : nullptr; a.out_s16 = w.h1s; a.tb_out_stride = 192;
+        a.out = nullptr; a.mask_out = save ? w.m2[0] : nullptr; a.out_s16 = w.h1s; a.tb_out_stride = 192;   // (h1 lives as S16 only)
         a.r1_x = x; a.r1_w = P + r1.skw; a.r1_b = P + r1.skb;
         TDM_TRY(tdm_launch_conv_s16(a, 28, 32, st));
     }
     // rb2 on avg_pool2d(h1)
-    TDM_TRY(tdm_launch_pool_skip_s16(w.h1, P + r2.skw, P + r2.skb, w.p1s, w.s2, B, st));   // pooling + rb2.skip (1x1)
+    TDM_TRY(tdm_launch_pool_skip_s16(w.h1s, P + r2.skw, P + r2.skb, w.p1s, w.s2, B, st));   // pooling + rb2.skip (1x1), from the S16 twin
     TDM_TRY(conv_s16_1(st, w, 14, B, w.p1s, 32, 9, kPack.fwd[W_RB2C1], 64, P + r2.c1b, 1,
                        S16Out{nullptr, save ? w.m1[1] : nullptr, nullptr, w.a1s_2, w.tb + 32}));
     TDM_TRY(conv_s16_1(st, w, 14, B, w.a1s_2, 64, 9, kPack.fwd[W_RB2C2], 64, P + r2.c2b, 1,
@@ -301,7 +301,7 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
     TDM_TRY(conv_s16_1(st, w, 14, B, w.h2s, 64, 9, kPack.fwd[W_RB3C1], 64, P + r3.c1b, 1,
                        S16Out{nullptr, save ? w.m1[2] : nullptr, nullptr, w.a1s_3, w.tb + 96}));
     TDM_TRY(conv_s16_1(st, w, 14, B, w.a1s_3, 64, 9, kPack.fwd[W_RB3C2], 64, P + r3.c2b, 1,
-                       S16Out{save ? w.h3 : nullptr, save ? w.m2[2] : nullptr, w.h2, w.h3s, nullptr}));   // (fp32 h3: block-output accessor only)
+                       S16Out{nullptr, save ? w.m2[2] : nullptr, w.h2, w.h3s, nullptr}));   // (h3 lives as S16 only)
     // rb4 on cat([up2(h3), h1])
     {
         ConvArgs a{};
@@ -518,9 +518,12 @@ int tdm_unet_get_activation(const float* ws, int64_t B, int which, float* out_nc
     TDM_CHECK_B(B);
     const Ws w = carve(const_cast<float*>(ws), B, 0);
     switch (which) {
-        case 0: return tdm_launch_nhwc_to_nchw(w.h1, out_nchw, (int)B, 784, 32, (hipStream_t)stream);
+        // (S16 pipeline: h1 and h3 exist only as their hi/lo twins — what the consuming convs read)
+        case 0: return g_conv_mode == 2 ? tdm_launch_s16_to_nchw(w.h1s, out_nchw, (int)B, 784, 32, (hipStream_t)stream)
+                                        : tdm_launch_nhwc_to_nchw(w.h1, out_nchw, (int)B, 784, 32, (hipStream_t)stream);
         case 1: return tdm_launch_nhwc_to_nchw(w.h2, out_nchw, (int)B, 196, 64, (hipStream_t)stream);
-        case 2: return tdm_launch_nhwc_to_nchw(w.h3, out_nchw, (int)B, 196, 64, (hipStream_t)stream);
+        case 2: return g_conv_mode == 2 ? tdm_launch_s16_to_nchw(w.h3s, out_nchw, (int)B, 196, 64, (hipStream_t)stream)
+                                        : tdm_launch_nhwc_to_nchw(w.h3, out_nchw, (int)B, 196, 64, (hipStream_t)stream);
         case 3: return tdm_launch_nhwc_to_nchw(w.h4, out_nchw, (int)B, 784, 32, (hipStream_t)stream);
     }
     tdm_set_error("get_activation: which=%d", which);
