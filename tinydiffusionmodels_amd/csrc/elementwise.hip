@@ -551,9 +551,11 @@ __global__ __launch_bounds__(EW_BLOCK) void conv_first_s16_kernel(const float* _
                                                                   const float* __restrict__ tb, int tb_stride,
                                                                   float* __restrict__ a1, unsigned char* __restrict__ a1m,
                                                                   float* __restrict__ a1_s16, float* __restrict__ s, int B) {
-    const int64_t total = (int64_t)B * 784 * 8;
-    // the thread's channel quad is fixed (the grid stride is a multiple of 8): its 9 tap weights, biases and skip weights
-    // are loaded once; the 9 input taps of an item are unconditional clamped loads (a branch per tap serialised them)
+    // The kernel was VALU-bound (~250 instructions per output quad: 64-bit index math, a bounds-checked address per tap).
+    // Now: 32-bit indices; the thread's channel quad is fixed (the grid stride is a multiple of 8), so its 9 tap weights,
+    // biases and skip weights are loaded once; the 9 input taps are buffer loads at constant pixel offsets (reads before or
+    // past the tensor return 0) masked by 3 row + 3 column validity bits.
+    const int total = B * 784 * 8;
     const int c4 = threadIdx.x & 7;
     float4 wv[9];
 #pragma unroll
@@ -561,21 +563,21 @@ __global__ __launch_bounds__(EW_BLOCK) void conv_first_s16_kernel(const float* _
     const float4 b1v = *reinterpret_cast<const float4*>(b1 + c4 * 4);
     const float4 wsv = *reinterpret_cast<const float4*>(ws + c4 * 4);
     const float4 bsv = *reinterpret_cast<const float4*>(bs + c4 * 4);
-    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
-        const int64_t m = i >> 3;
-        const int b = (int)(m / 784);
-        const int rem = (int)(m - (int64_t)b * 784);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, B * 784 * 4, 0x00020000);
+    for (int i = blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += gridDim.x * EW_BLOCK) {
+        const int m = i >> 3;
+        const int b = m / 784;
+        const int rem = m - b * 784;
         const int y = rem / 28, xx = rem - y * 28;
-        const float* xb = x + (int64_t)b * 784;
         float xv[9];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yy = y + tap / 3 - 1, xq = xx + tap % 3 - 1;
-            const bool ok = yy >= 0 && yy < 28 && xq >= 0 && xq < 28;
-            const float v = xb[ok ? yy * 28 + xq : rem];
-            xv[tap] = ok ? v : 0.f;
-        }
-        const float4 t4 = *reinterpret_cast<const float4*>(tb + (int64_t)b * tb_stride + c4 * 4);
+        for (int tap = 0; tap < 9; ++tap)   // (m + offset < 0 only for taps above the first image: a negative = huge offset, reads 0)
+            xv[tap] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, (m + (tap / 3 - 1) * 28 + (tap % 3 - 1)) * 4, 0, 0));
+        const float4 t4 = *reinterpret_cast<const float4*>(tb + b * tb_stride + c4 * 4);
+        const bool r0 = y >= 1, r2 = y <= 26, c0 = xx >= 1, c2 = xx <= 26;
+        xv[0] = (r0 && c0) ? xv[0] : 0.f; xv[1] = r0 ? xv[1] : 0.f; xv[2] = (r0 && c2) ? xv[2] : 0.f;
+        xv[3] = c0 ? xv[3] : 0.f;                                    xv[5] = c2 ? xv[5] : 0.f;
+        xv[6] = (r2 && c0) ? xv[6] : 0.f; xv[7] = r2 ? xv[7] : 0.f; xv[8] = (r2 && c2) ? xv[8] : 0.f;
         float4 acc = b1v;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -585,14 +587,16 @@ __global__ __launch_bounds__(EW_BLOCK) void conv_first_s16_kernel(const float* _
         const float xc = xv[4];
         acc.x = acc.x < 0.f ? 0.f : acc.x; acc.y = acc.y < 0.f ? 0.f : acc.y;
         acc.z = acc.z < 0.f ? 0.f : acc.z; acc.w = acc.w < 0.f ? 0.f : acc.w;
-        if (a1 != nullptr) *reinterpret_cast<float4*>(a1 + m * 32 + c4 * 4) = acc;
+        if (a1 != nullptr) *reinterpret_cast<float4*>(a1 + (long)m * 32 + c4 * 4) = acc;
         if (a1m != nullptr)
             a1m[i] = (unsigned char)((acc.x > 0.f ? 1 : 0) | (acc.y > 0.f ? 2 : 0) | (acc.z > 0.f ? 4 : 0) | (acc.w > 0.f ? 8 : 0));
         tdm_store_s16_4(a1_s16, m, 32, c4 * 4, make_float4(acc.x + t4.x, acc.y + t4.y, acc.z + t4.z, acc.w + t4.w));
-        float4 sv;
-        sv.x = fmaf(xc, wsv.x, bsv.x); sv.y = fmaf(xc, wsv.y, bsv.y);
-        sv.z = fmaf(xc, wsv.z, bsv.z); sv.w = fmaf(xc, wsv.w, bsv.w);
-        if (s != nullptr) *reinterpret_cast<float4*>(s + m * 32 + c4 * 4) = sv;
+        if (s != nullptr) {
+            float4 sv;
+            sv.x = fmaf(xc, wsv.x, bsv.x); sv.y = fmaf(xc, wsv.y, bsv.y);
+            sv.z = fmaf(xc, wsv.z, bsv.z); sv.w = fmaf(xc, wsv.w, bsv.w);
+            *reinterpret_cast<float4*>(s + (long)m * 32 + c4 * 4) = sv;
+        }
     }
 }
 
