@@ -795,13 +795,11 @@ __global__ __launch_bounds__(EW_BLOCK) void split_dcat_mask_s16_kernel(const flo
     const int64_t S = (int64_t)gridDim.x * EW_BLOCK;
     const int c4 = threadIdx.x & 15;   // (the grid stride is a multiple of 16)
     struct Item { float4 v00, v01, v10, v11; unsigned am; };
-    auto fetch = [&](int64_t i, Item& it) {
-        const int64_t p = i >> 4;
-        const int xo = (int)(p % 14);
-        const int64_t q = p / 14;
-        const int yo = (int)(q % 14);
-        const int64_t b = q / 14;
-        const float4* src = reinterpret_cast<const float4*>(dcat) + ((b * 28 + 2 * yo) * 28 + 2 * xo) * 24 + c4;
+    auto fetch = [&](int64_t i, Item& it) {   // (32-bit index math)
+        const int p = (int)(i >> 4);
+        const int q = p / 14, xo = p - q * 14;
+        const int b = q / 14, yo = q - b * 14;
+        const float4* src = reinterpret_cast<const float4*>(dcat) + (unsigned)(((b * 28 + 2 * yo) * 28 + 2 * xo) * 24 + c4);
         it.v00 = src[0]; it.v01 = src[24]; it.v10 = src[28 * 24]; it.v11 = src[28 * 24 + 24];
         it.am = a2m[i];
     };
@@ -837,15 +835,13 @@ __global__ __launch_bounds__(EW_BLOCK) void combine_dh1_mask_s16_kernel(const fl
     const int64_t total = (int64_t)B * 784 * 8;
     const int64_t S = (int64_t)gridDim.x * EW_BLOCK;
     const int c4 = threadIdx.x & 7;   // (the grid stride is a multiple of 8)
-    auto fetch = [&](int64_t i, float4& dc, float4& dp, unsigned& am) {
-        const int64_t p = i >> 3;
-        const int x = (int)(p % 28);
-        const int64_t q = p / 28;
-        const int y = (int)(q % 28);
-        const int64_t b = q / 28;
-        dc = reinterpret_cast<const float4*>(dcat)[p * 24 + 16 + c4];
-        dp = reinterpret_cast<const float4*>(dp1)[((b * 14 + (y >> 1)) * 14 + (x >> 1)) * 8 + c4];
-        am = a2m[i];
+    auto fetch = [&](int64_t i, float4& dc, float4& dp, unsigned& am) {   // (32-bit index math: B * 784 * 24 < 2^31 / 4)
+        const int p = (int)(i >> 3);
+        const int q = p / 28, x = p - q * 28;
+        const int b = q / 28, y = q - b * 28;
+        dc = reinterpret_cast<const float4*>(dcat)[(unsigned)(p * 24 + 16 + c4)];
+        dp = reinterpret_cast<const float4*>(dp1)[(unsigned)(((b * 14 + (y >> 1)) * 14 + (x >> 1)) * 8 + c4)];
+        am = a2m[(unsigned)i];
     };
     auto finish = [&](int64_t i, const float4& dc, const float4& dp, unsigned am) {
         float4 d;
