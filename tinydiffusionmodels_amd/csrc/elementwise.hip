@@ -634,33 +634,40 @@ __global__ __launch_bounds__(EW_BLOCK) void pool_skip_s16_kernel(const float* __
     __shared__ float4 Wl[32 * 16];     // [ci][co quad]
     __shared__ float pooled[16][32];
     for (int i = threadIdx.x; i < 32 * 16; i += EW_BLOCK) Wl[i] = reinterpret_cast<const float4*>(wsk)[i];
-    const int64_t npix = (int64_t)B * 196;
+    const int npix = B * 196;
     const int px = threadIdx.x >> 4, cq = threadIdx.x & 15;
     const float4 bias = reinterpret_cast<const float4*>(bsk)[cq];
-    for (int64_t p0 = (int64_t)blockIdx.x * 16; p0 < npix; p0 += (int64_t)gridDim.x * 16) {
+    // software pipeline: the four S16 pixels of the NEXT trip are requested before the 32 x 64 products of the current one
+    const int lp = threadIdx.x >> 3, c4 = threadIdx.x & 7;   // pooling role (threads 0..127): pixel lp of the trip, channel quad c4
+    float4 v00, v01, v10, v11;
+    auto fetch = [&](int p0) {
+        const int p = p0 + lp;
+        v00 = v01 = v10 = v11 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (threadIdx.x < 128 && p < npix) {
+            const int q = p / 14, xo = p - q * 14;
+            const int b = q / 14, yo = q - b * 14;
+            const long m00 = (long)(b * 28 + 2 * yo) * 28 + 2 * xo;   // h1 is read from its S16 twin (hi + lo): no fp32 copy exists
+            v00 = tdm_load_s16_4(h1, m00, 32, c4 * 4); v01 = tdm_load_s16_4(h1, m00 + 1, 32, c4 * 4);
+            v10 = tdm_load_s16_4(h1, m00 + 28, 32, c4 * 4); v11 = tdm_load_s16_4(h1, m00 + 29, 32, c4 * 4);
+        }
+    };
+    const int step = gridDim.x * 16;
+    int p0 = blockIdx.x * 16;
+    if (p0 < npix) fetch(p0);
+    for (; p0 < npix; p0 += step) {
         __syncthreads();   // previous trip's pooled values consumed (and, first trip, Wl complete)
         if (threadIdx.x < 128) {
-            const int lp = threadIdx.x >> 3, c4 = threadIdx.x & 7;
-            const int64_t p = p0 + lp;
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < npix) {
-                const int xo = (int)(p % 14);
-                const int64_t q = p / 14;
-                const int yo = (int)(q % 14);
-                const int64_t b = q / 14;
-                const int64_t m00 = (b * 28 + 2 * yo) * 28 + 2 * xo;   // h1 is read from its S16 twin (hi + lo): no fp32 copy exists
-                const float4 v00 = tdm_load_s16_4(h1, m00, 32, c4 * 4), v01 = tdm_load_s16_4(h1, m00 + 1, 32, c4 * 4);
-                const float4 v10 = tdm_load_s16_4(h1, m00 + 28, 32, c4 * 4), v11 = tdm_load_s16_4(h1, m00 + 29, 32, c4 * 4);
-                o.x = (((v00.x + v01.x) + v10.x) + v11.x) * 0.25f;
-                o.y = (((v00.y + v01.y) + v10.y) + v11.y) * 0.25f;
-                o.z = (((v00.z + v01.z) + v10.z) + v11.z) * 0.25f;
-                o.w = (((v00.w + v01.w) + v10.w) + v11.w) * 0.25f;
-                tdm_store_s16_4(p1_s16, p, 32, c4 * 4, o);
-            }
+            float4 o;
+            o.x = (((v00.x + v01.x) + v10.x) + v11.x) * 0.25f;
+            o.y = (((v00.y + v01.y) + v10.y) + v11.y) * 0.25f;
+            o.z = (((v00.z + v01.z) + v10.z) + v11.z) * 0.25f;
+            o.w = (((v00.w + v01.w) + v10.w) + v11.w) * 0.25f;
+            if (p0 + lp < npix) tdm_store_s16_4(p1_s16, p0 + lp, 32, c4 * 4, o);
             *reinterpret_cast<float4*>(&pooled[lp][c4 * 4]) = o;
         }
         __syncthreads();
-        const int64_t p = p0 + px;
+        if (p0 + step < npix) fetch(p0 + step);
+        const int p = p0 + px;
         if (p < npix) {
             float4 acc = bias;
 #pragma unroll
@@ -670,7 +677,7 @@ __global__ __launch_bounds__(EW_BLOCK) void pool_skip_s16_kernel(const float* __
                 acc.x = fmaf(a, w4.x, acc.x); acc.y = fmaf(a, w4.y, acc.y);
                 acc.z = fmaf(a, w4.z, acc.z); acc.w = fmaf(a, w4.w, acc.w);
             }
-            reinterpret_cast<float4*>(s2)[p * 16 + cq] = acc;
+            reinterpret_cast<float4*>(s2)[(long)p * 16 + cq] = acc;
         }
     }
 }
