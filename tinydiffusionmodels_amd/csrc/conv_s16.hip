@@ -1017,15 +1017,16 @@ __global__ __launch_bounds__(1024) void wgrad2_s16_kernel(WgradArgs a) {
         prefetch(s1, 1);
         write(s0, 0);
         __syncthreads();                       // tile 0 staged
+        const bool idle = a.b_off == -3;   // probe: consumers only
         for (int k = 0; k < nk; k += 2) {
             // consumers: tile k from buffer 0
-            prefetch(s0, k + 2);
-            if (k + 1 < nk) write(s1, 1);
+            if (!idle) prefetch(s0, k + 2);
+            if (k + 1 < nk && !idle) write(s1, 1);
             __syncthreads();
             if (k + 1 >= nk) break;
             // consumers: tile k + 1 from buffer 1
-            prefetch(s1, k + 3);
-            if (k + 2 < nk) write(s0, 0);
+            if (!idle) prefetch(s1, k + 3);
+            if (k + 2 < nk && !idle) write(s0, 0);
             __syncthreads();
         }
         // the consumers' final reduction: same barrier count
@@ -1079,21 +1080,18 @@ __global__ __launch_bounds__(1024) void wgrad2_s16_kernel(WgradArgs a) {
             }
         }
     };
-    auto compute = [&](int buf) {
-        const char* base = lds + buf * BUF;
-        if (taps == 9) {
-            kstep(base, wq * 2, tp0, ntap);
-            kstep(base, wq * 2 + 1, tp0, ntap);
-        } else {   // one tap, the centre of the padded-tall image: the 8 waves split the tile's 8 K-steps
-            kstep(base, wave, 4, 1);
-        }
-    };
+    // ONE kstep site for every accumulator: with compute(0) / compute(1) (and the 1x1 path) as separate inlined sites the
+    // compiler gave each site its own accumulator registers and copied all 80 of them between sites every tile, each
+    // copy waiting out the MFMA that produced it (s_nop 9..11).  Buffer, K-step range and tap range are runtime values.
+    const int ks0 = (taps == 9) ? wq * 2 : wave;   // 3x3: 2 of the tile's 8 K-steps; 1x1: the 8 waves split them
+    const int nks = (taps == 9) ? 2 : 1;
+    const int kt0 = (taps == 9) ? tp0 : 4, knt = (taps == 9) ? ntap : 1;
+    const bool cidle = a.b_off == -2;   // probe: producers only
     __syncthreads();                           // tile 0 staged
-    for (int k = 0; k < nk; k += 2) {
-        compute(0);
-        __syncthreads();
-        if (k + 1 >= nk) break;
-        compute(1);
+    for (int k = 0; k < nk; ++k) {
+        const char* base = lds + (k & 1) * BUF;
+        if (!cidle)
+            for (int jk = 0; jk < nks; ++jk) kstep(base, ks0 + jk, kt0, knt);
         __syncthreads();
     }
 

@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include "tdm_common.h"
+#include <cstdlib>
 
 // ----------------------------- error plumbing --------------------------------
 static thread_local char g_err[512] = "";
@@ -641,6 +642,7 @@ int tdm_conv_wgrad_nhwc_s16_f32(const float* in, const float* tb, const float* d
     a.a = s16_src(in_s16, Cin, Cin, 0, taps, nullptr, 0);
     a.a.w_rows = Cin; a.a.w_r0 = 0;
     a.g = g_s16; a.Cout = Cout; a.slab = slabs; a.slab_stride = wlen; a.w_off = 0; a.b_off = -1; a.B = (int)B;
+    if (const char* pr = getenv("TDM_WGRAD_PROBE")) a.b_off = -atoi(pr);   // diagnostics: 2 = producers only, 3 = consumers only
     a.ntiles = (int)((M + 255) / 256);
     a.nci = Cin / 32;
     TDM_TRY(tdm_launch_wgrad_s16(a, HW, nslab, st));
