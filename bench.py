@@ -137,6 +137,24 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * args.steps / elapsed
 
+    # the step's one collective, timed alone (725,892 B per rank per step; ring-equivalent bandwidth)
+    allreduce = None
+    if world > 1:
+        gbuf = torch.zeros_like(trainer.state.grads)
+        for _ in range(5):
+            dist.all_reduce(gbuf, op=dist.ReduceOp.SUM)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            dist.all_reduce(gbuf, op=dist.ReduceOp.SUM)
+        sync()
+        tt = torch.tensor([(time.perf_counter() - t0) / 50], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        nbytes = gbuf.numel() * 4
+        allreduce = {"bytes": nbytes, "us": round(tt.item() * 1e6, 1),
+                     "ring_equiv_gbs": round(2.0 * (world - 1) / world * nbytes / tt.item() / 1e9, 2),
+                     "share_of_step": round(tt.item() / (elapsed / args.steps), 4)}
+
     out = {
         "metric": "DDPM train steps/sec, MNIST UNet b=512/GPU (512-image steps summed over GPUs)",
         "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -153,6 +171,8 @@ def main():
         "images_per_s": round(value * B_TRAIN, 1),
         "final_loss": loss_val,
     }
+    if allreduce is not None:
+        out["allreduce"] = allreduce
 
     if rank == 0:
         # ---- whole-step roofline fractions (algorithmic work / measured time) ----
