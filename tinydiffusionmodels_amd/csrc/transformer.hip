@@ -10,6 +10,7 @@
 // one wavefront per token row.
 #include <math.h>
 #include "tdm_common.h"
+#include <cstdlib>
 #include "tdm_transformer.h"
 
 namespace {
@@ -30,10 +31,12 @@ constexpr int LN_SLABS = 256;  // workgroup partials of the LayerNorm affine / b
 constexpr int CS_SLABS = 256;  // row-block partials of the bias gradients
 
 // Weight-gradient GEMMs contract over tokens (K = B*L, tens of thousands) into small [N][K] outputs:
-// each tensor gets its own split-K factor so that tiles x splits ~ 1024 workgroups fill the chip (512 measured slower).
+// each tensor gets its own split-K factor so that tiles x splits ~ 512 workgroups (fewer partial slabs to write and re-read;
+// TDM_TN_WGS overrides the target for sweeps).
 inline int wgrad_splitk(int N, int K) {
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-    int sk = (1024 + tiles - 1) / tiles;
+    static const int target = getenv("TDM_TN_WGS") ? atoi(getenv("TDM_TN_WGS")) : 512;   // sweep (8-wave NT kernel era): 384 5.65 ms, 512 5.50, 768 5.57, 1024 5.59, 1536 5.68 per step
+    int sk = (target + tiles - 1) / tiles;
     if (sk < 1) sk = 1;
     if (sk > 128) sk = 128;
     return sk;
