@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: DDPM train steps/s on the MNIST UNet at batch 512 per GPU
 (BASELINE.json configs[1]; data-parallel over N GPUs = configs[2]), plus the
-1000-step reverse-sampling rate at batch 4096 (configs[3]) as extra keys.
+1000-step reverse-sampling rate at batch 4096 (configs[3]) and the text denoiser
+(configs[4] shape) as extra keys.
 
     python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -9,8 +10,9 @@
 
 A "step" is the loop body of src/mnist.py:152-159 on one synthetic 512-image
 batch: draw t and noise, q_sample, UNet forward, MSE, backward, (RCCL
-all-reduce of the flat gradient), AdamW.  Inputs are resident in HBM before
-the timed region.  Rank 0 prints ONE JSON line."""
+all-reduce of the flat gradient), AdamW — one hipGraph replay per step (device-side
+Philox draws and AdamW step count; at N > 1: replay + all-reduce + AdamW).  Inputs are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line."""
 import argparse
 import json
 import os
@@ -30,44 +32,167 @@ TRAIN_FLOP_PER_SAMPLE = 3 * FWD_FLOP_PER_SAMPLE
 TRAIN_BYTES_PER_SAMPLE = 5_901_168 + 18_816
 OPT_BYTES_PER_STEP = 7 * 725_892
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16
 PEAK_HBM_GBS = 8000.0
 
+# Per-launch work of the default train step, in the order of tdm_unet_launch_name(id):
+# (FLOP per sample, bytes per sample, bytes per call).  FLOP = 2 * taps * Cin * Cout * pixels of the convs the
+# launch computes (fused 1x1 convs included); bytes = every tensor the launch reads or writes, counted once
+# (fp32 / S16 tensors 4 B per element, byte masks 1 B per 4 elements) — the traffic floor of the launch AS BUILT.
+_C3 = lambda ci, co, px: 2 * 9 * ci * co * px
+_C1 = lambda ci, co, px: 2 * ci * co * px
+_T28, _T14 = lambda c: 784 * c * 4, lambda c: 196 * c * 4     # one fp32 / S16 tensor per sample
+_M28, _M14 = lambda c: 784 * c // 4, lambda c: 196 * c // 4   # one byte mask per sample
+LAUNCH_WORK = [
+    (0, 776, 0),                                                             # timebias
+    (0, 0, 181_473 * 4 + 1_451_520),                                         # pack_weights (read fp32, write bf16 hi/lo x 2 dirs)
+    (_C3(1, 32, 784), 3136 + _T28(32) + _M28(32), 0),                        # rb1.conv1
+    (_C3(32, 32, 784) + _C1(1, 32, 784), 2 * _T28(32) + _M28(32) + 3136, 0),  # rb1.conv2 (+ rank-1 skip)
+    (_C1(32, 64, 196), _T28(32) + _T14(32) + _T14(64), 0),                   # avgpool + rb2.skip
+    (_C3(32, 64, 196), _T14(32) + _T14(64) + _M14(64), 0),                   # rb2.conv1
+    (_C3(64, 64, 196), 4 * _T14(64) + _M14(64), 0),                          # rb2.conv2 (in, res, h2, h2s)
+    (_C3(64, 64, 196), 2 * _T14(64) + _M14(64), 0),                          # rb3.conv1
+    (_C3(64, 64, 196), 3 * _T14(64) + _M14(64), 0),                          # rb3.conv2 (in, res, h3s)
+    (_C3(96, 32, 784) + _C1(96, 32, 784), _T14(64) + 3 * _T28(32) + _M28(32), 0),   # rb4.conv1 + skip
+    (_C3(32, 32, 784) + _C1(32, 1, 784), 3 * _T28(32) + _M28(32) + 3136, 0),  # rb4.conv2 + out
+    (2 * _C1(32, 1, 784), 3136 + 3 * _T28(32) + _M28(32), 0),                # out conv bwd
+    (_C3(32, 32, 784), 2 * _T28(32), 0),                                     # rb4.conv2 wgrad
+    (_C3(32, 32, 784), 2 * _T28(32) + _M28(32), 0),                          # rb4.conv2 dgrad
+    (0, 12_544, 0),                                                          # image_sums rb4
+    (_C3(64, 32, 784) + _C1(64, 32, 784), _T14(64) + 2 * _T28(32), 0),       # rb4.conv1 wgrad (up(h3) part)
+    (_C3(32, 32, 784) + _C1(32, 32, 784), 3 * _T28(32), 0),                  # rb4.conv1 wgrad (h1 part)
+    (_C3(32, 96, 784) + _C1(32, 96, 784), 2 * _T28(32) + _T28(96), 0),       # rb4.conv1 dgrad
+    (0, _T28(64) + _M14(64) + 2 * _T14(64), 0),                              # split_dcat_mask
+    (_C3(64, 64, 196), 2 * _T14(64), 0),                                     # rb3.conv2 wgrad
+    (_C3(64, 64, 196), 2 * _T14(64) + _M14(64), 0),                          # rb3.conv2 dgrad
+    (0, 6_272, 0),                                                           # image_sums rb3
+    (_C3(64, 64, 196), 2 * _T14(64), 0),                                     # rb3.conv1 wgrad
+    (_C3(64, 64, 196), 4 * _T14(64), 0),                                     # rb3.conv1 dgrad (in, res, dout2, dout2s)
+    (0, 2 * _T14(64) + _M14(64), 0),                                         # relu_mask rb2
+    (_C3(64, 64, 196), 2 * _T14(64), 0),                                     # rb2.conv2 wgrad
+    (_C3(64, 64, 196), 2 * _T14(64) + _M14(64), 0),                          # rb2.conv2 dgrad
+    (0, 6_272, 0),                                                           # image_sums rb2
+    (_C3(32, 64, 196) + _C1(32, 64, 196), _T14(32) + 2 * _T14(64), 0),       # rb2.conv1 wgrad
+    (_C3(64, 32, 196) + _C1(64, 32, 196), 2 * _T14(64) + _T14(32), 0),       # rb2.conv1 dgrad
+    (0, 3 * _T28(32) + _T14(32) + _M28(32), 0),                              # combine_dh1_mask
+    (_C3(32, 32, 784), 2 * _T28(32), 0),                                     # rb1.conv2 wgrad
+    (_C3(32, 32, 784), 2 * _T28(32) + _M28(32), 0),                          # rb1.conv2 dgrad
+    (0, 12_544, 0),                                                          # image_sums rb1
+    (0, 1_536, 0),                                                           # time_grad
+    (_C3(1, 32, 784) + _C1(1, 32, 784), 3136 + 2 * _T28(32), 0),             # rb1.conv1 wgrad
+    (0, 0, 4 * (256 * (320 + 9248 + 64 + 64 + 64 + 64 + 27648 + 9248 + 3104 + 33) + 128 * (18432 + 2048) + 64 * 3 * 36864) + 725_892),  # reduce
+]
+MFMA_LAUNCH = "conv_s16<", "wgrad2_s16<"    # launches whose FLOPs run on the matrix cores (bf16x3: 3 MFMA FLOP per FLOP)
 
-def cpu_baseline(cores: int):
-    """The CPU oracle (a port of the reference's PyTorch-CPU path) timed on the
-    host: train step at B=512, 1 warm-up + 4 measured steps."""
+
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def cpu_baseline(cores_all: int):
+    """The CPU oracle (a port of the reference's PyTorch-CPU path) timed on this host.
+    `value`: train steps/s at the metric's batch (512).  `points`: the protocol's configurations — MNIST train
+    B=64 (BASELINE config 1), p_sample B=25 / B=64, text denoiser train B=32 and p_sample B=10 — at 8 threads
+    and at all cores of this box's share, 3 warm-up + 10 (train) / 20 (p_sample) measured steps, median."""
     from oracle import ddpm_oracle as O           # checker / baseline only
-    torch.set_num_threads(cores)
-    p = O.unet_init_params(0)
     tabs = O.make_tables()
-    g = torch.Generator().manual_seed(1234)
-    x0 = torch.rand(B_TRAIN, 1, 28, 28, generator=g) * 2 - 1
-    m = {k: torch.zeros_like(v) for k, v in p.items()}
-    v = {k: torch.zeros_like(x) for k, x in p.items()}
-    times = []
-    for step in range(1, 6):
-        t0 = time.perf_counter()
-        t = torch.randint(0, 1000, (B_TRAIN,), generator=g)
-        noise = torch.randn(B_TRAIN, 1, 28, 28, generator=g)
-        _, grads = O.unet_loss_and_grads(p, x0, t, noise, tabs)
-        for k in p:
-            p[k], m[k], v[k] = O.adamw_step(p[k], grads[k], m[k], v[k], step)
-        times.append(time.perf_counter() - t0)
-    med = sorted(times[1:])[len(times[1:]) // 2]
-    return {"value": round(1.0 / med, 4), "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": "4 train steps at B=512 (1 warm-up), fp32 PyTorch-CPU oracle, median"}
+
+    def train_rate(B, threads, warm, meas):
+        torch.set_num_threads(threads)
+        p = O.unet_init_params(0)
+        g = torch.Generator().manual_seed(1234)
+        x0 = torch.rand(B, 1, 28, 28, generator=g) * 2 - 1
+        m = {k: torch.zeros_like(v) for k, v in p.items()}
+        v = {k: torch.zeros_like(x) for k, x in p.items()}
+        times = []
+        for step in range(1, warm + meas + 1):
+            t0 = time.perf_counter()
+            t = torch.randint(0, 1000, (B,), generator=g)
+            noise = torch.randn(B, 1, 28, 28, generator=g)
+            _, grads = O.unet_loss_and_grads(p, x0, t, noise, tabs)
+            for k in p:
+                p[k], m[k], v[k] = O.adamw_step(p[k], grads[k], m[k], v[k], step)
+            times.append(time.perf_counter() - t0)
+        return _median(times[warm:])
+
+    def psample_rate(B, threads):
+        torch.set_num_threads(threads)
+        p = O.unet_init_params(0)
+        g = torch.Generator().manual_seed(99)
+        x = torch.randn(B, 1, 28, 28, generator=g)
+        t = torch.full((B,), 500, dtype=torch.long)
+        times = []
+        with torch.no_grad():
+            for _ in range(23):
+                t0 = time.perf_counter()
+                x = O.p_sample(p, x, t, torch.randn(B, 1, 28, 28, generator=g), tabs)
+                times.append(time.perf_counter() - t0)
+        return _median(times[3:])
+
+    def text_rates(threads):
+        torch.set_num_threads(threads)
+        p = O.transformer_init_params(256, seed=7)
+        g = torch.Generator().manual_seed(7)
+        x0 = torch.randn(32, 128, 256, generator=g) * 0.02
+        times = []
+        for _ in range(3 + 6):
+            t0 = time.perf_counter()
+            t = torch.randint(0, 1000, (32,), generator=g)
+            noise = torch.randn(32, 128, 256, generator=g)
+            _, grads = O.transformer_loss_and_grads(p, x0, t, noise, tabs)
+            for k in p:
+                O.adamw_step(p[k], grads[k], torch.zeros_like(p[k]), torch.zeros_like(p[k]), 1, lr=1e-4, weight_decay=1e-4)
+            times.append(time.perf_counter() - t0)
+        tr = _median(times[3:])
+        x = torch.randn(10, 128, 256, generator=g)
+        tt = torch.full((10,), 500, dtype=torch.long)
+        times = []
+        with torch.no_grad():
+            for _ in range(13):
+                t0 = time.perf_counter()
+                x = O.text_p_sample(p, x, tt, torch.randn(10, 128, 256, generator=g), tabs)
+                times.append(time.perf_counter() - t0)
+        return tr, _median(times[3:])
+
+    points = []
+    for threads in sorted({min(8, cores_all), cores_all}):
+        s64 = train_rate(64, threads, 3, 10)
+        p25, p64 = psample_rate(25, threads), psample_rate(64, threads)
+        ttr, tps = text_rates(threads)
+        points.append({"threads": threads,
+                       "mnist_train_b64": {"ms_per_step": round(1e3 * s64, 2), "steps_per_s": round(1 / s64, 3), "img_per_s": round(64 / s64, 1)},
+                       "mnist_p_sample_b25": {"ms_per_step": round(1e3 * p25, 2), "img_per_s_1000_step": round(25 / (1000 * p25), 3)},
+                       "mnist_p_sample_b64": {"ms_per_step": round(1e3 * p64, 2), "img_per_s_1000_step": round(64 / (1000 * p64), 3)},
+                       "text_train_b32_l128_d256": {"ms_per_step": round(1e3 * ttr, 1), "tokens_per_s": round(32 * 128 / ttr, 0)},
+                       "text_p_sample_b10": {"ms_per_step": round(1e3 * tps, 2)}})
+    s512 = train_rate(B_TRAIN, cores_all, 1, 4)
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": round(1.0 / s512, 4), "unit": "steps/s", "cores": cores_all, "kind": "port", "cpu": cpu_model,
+            "sample": "4 train steps at B=512 (1 warm-up), fp32 PyTorch-CPU oracle, median; points: BASELINE.md §2 protocol "
+                      "(3 warm-up + 10 train / 20 p_sample steps, median; text train 3 + 6)",
+            "points": points}
 
 
-def time_kernel(fn, iters=20, warm=3):
-    for _ in range(warm):
-        fn()
+def time_events(fn, iters, warm=3):
+    """Average ms per call of fn(i) over `iters` back-to-back calls, HIP events on the launch stream."""
+    for i in range(warm):
+        fn(i)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
-        fn()
+    for i in range(iters):
+        fn(i)
     e1.record()
     e1.synchronize()
-    return e0.elapsed_time(e1) / iters   # ms
+    return e0.elapsed_time(e1) / iters
 
 
 def main():
@@ -78,8 +203,11 @@ def main():
     ap.add_argument("--sample-steps", type=int, default=100, help="reverse steps timed at B=4096 (0 = skip)")
     ap.add_argument("--text-steps", type=int, default=20, help="text-denoiser train steps timed (0 = skip)")
     ap.add_argument("--gemm-mode", type=int, default=1, choices=[0, 1, 2],
-                    help="transformer linear layers: 1 = bf16x3 split MFMA (default), 2 = plain bf16 MFMA, 0 = fp32 MFMA")
+                    help="transformer linear layers of the headline text figure: 1 = bf16x3 split MFMA (parity path, default), "
+                         "2 = plain bf16 MFMA, 0 = fp32 MFMA; modes 1 and 2 are both reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-launch-table", action="store_true", help="skip the per-launch replay timing")
+    ap.add_argument("--no-graph", action="store_true", help="issue the train step's launches eagerly instead of one hipGraph replay")
     ap.add_argument("--conv-mode", type=int, default=2, choices=[0, 1, 2],
                     help="UNet conv arithmetic: 2 = bf16x3 split MFMA over pre-split tensors (default), "
                          "1 = bf16x3 splitting while staging, 0 = exact fp32 MFMA")
@@ -103,17 +231,18 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from tinydiffusionmodels_amd import _lib, unet_engine as E
+    from tinydiffusionmodels_amd import _lib, dp, unet_engine as E
     from tinydiffusionmodels_amd.mnist import SimpleUNet, DDPMTrainer, reverse_diffusion
 
+    L = _lib.lib()
     E.check_layout_against_library()
-    _lib.check(_lib.lib().tdm_set_conv_mode(args.conv_mode))
+    _lib.check(L.tdm_set_conv_mode(args.conv_mode))
     torch.manual_seed(0)                       # identical default init on every rank (+ broadcast in the trainer)
     model = SimpleUNet().to(dev)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     x0 = torch.rand(B_TRAIN, 1, 28, 28, device=dev, generator=gen) * 2 - 1
-    torch.manual_seed(4321 + rank)             # rank-distinct t / noise streams
-    trainer = DDPMTrainer(model, batch_size=B_TRAIN, lr=1e-3)
+    torch.manual_seed(4321 + rank)             # rank-distinct t / noise streams (seeds the trainer's Philox key)
+    trainer = DDPMTrainer(model, batch_size=B_TRAIN, lr=1e-3, graph=not args.no_graph)
 
     def sync():
         torch.cuda.synchronize()
@@ -121,7 +250,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 2)):       # (>= 2: the first step runs eagerly, the second captures the graph)
         trainer.step(x0)
     sync()
     t0 = time.perf_counter()
@@ -140,21 +269,22 @@ def main():
     # the step's one collective, timed alone (725,892 B per rank per step; ring-equivalent bandwidth)
     allreduce = None
     if world > 1:
-        gbuf = torch.zeros_like(trainer.state.grads)
+        gbuf = torch.zeros_like(trainer.grads)
         for _ in range(5):
-            dist.all_reduce(gbuf, op=dist.ReduceOp.SUM)
+            dp.allreduce_grads_(gbuf)
         sync()
         t0 = time.perf_counter()
         for _ in range(50):
-            dist.all_reduce(gbuf, op=dist.ReduceOp.SUM)
+            dp.allreduce_grads_(gbuf)
         sync()
         tt = torch.tensor([(time.perf_counter() - t0) / 50], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         nbytes = gbuf.numel() * 4
         allreduce = {"bytes": nbytes, "us": round(tt.item() * 1e6, 1),
                      "ring_equiv_gbs": round(2.0 * (world - 1) / world * nbytes / tt.item() / 1e9, 2),
-                     "share_of_step": round(tt.item() / (elapsed / args.steps), 4)}
+                     "share_of_step": round(tt.item() / (elapsed / args.steps), 4), "via": dp.collective_name()}
 
+    graph_on = trainer.state.graph is not None
     out = {
         "metric": "DDPM train steps/sec, MNIST UNet b=512/GPU (512-image steps summed over GPUs)",
         "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -164,10 +294,12 @@ def main():
                       "fp32 tensors and accumulation; conv operands split into bf16 hi+lo, hi*hi + hi*lo + lo*hi on bf16 MFMA "
                       "(16 mantissa bits per operand, predicted noise within 2e-5 of the fp32 reference (1.3e-5 on the golden batch; bound 1e-3))",
         "data": "synthetic",
-        "config": {"workload": "MNIST DDPM UNet train step (q_sample+fwd+MSE+bwd+AdamW), batch 512 per GPU, "
+        "config": {"workload": "MNIST DDPM UNet train step (device-drawn t/noise + q_sample + fwd + MSE + bwd + AdamW), batch 512 per GPU, "
                                "1000-step linear beta schedule, " +
                                ("exact fp32 MFMA conv kernels" if args.conv_mode == 0 else "bf16x3 split-MFMA conv kernels"),
-                   "batch_per_gpu": B_TRAIN, "global_batch": B_TRAIN * world, "parallelism": f"dp{world}"},
+                   "batch_per_gpu": B_TRAIN, "global_batch": B_TRAIN * world, "parallelism": f"dp{world}",
+                   "step_issue": ("one hipGraph replay" + ("" if trainer.state.graph_whole else " + all-reduce + AdamW launches")) if graph_on
+                   else "eager launches from one C-ABI call", "collective": dp.collective_name()},
         "images_per_s": round(value * B_TRAIN, 1),
         "final_loss": loss_val,
     }
@@ -181,56 +313,90 @@ def main():
         byts = TRAIN_BYTES_PER_SAMPLE * B_TRAIN + OPT_BYTES_PER_STEP
         out["step_roofline"] = {"tflops": round(flops / step_s / 1e12, 2),
                                 "frac_f32_mfma": round(flops / step_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                                "gbs": round(byts / step_s / 1e9, 1),
+                                "frac_bf16_mfma_issue": round(3 * flops / step_s / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                                "gbs": round(byts / step_s / 1e9, 1), "algorithmic_bytes": byts,
                                 "frac_hbm": round(byts / step_s / 1e9 / PEAK_HBM_GBS, 4)}
-        # ---- dominant kernel (26 % of the step): the implicit-GEMM conv kernel, timed ALONE with events on
-        # the launch stream on the rb4.conv1 shape (96->32 3x3 @28x28, B=512: 43,352,064 FLOP and
-        # (96+32)*4*784 = 401,408 B per sample).  In the default arithmetic (bf16x3
-        # split MFMA over pre-split tensors) its binding roof is HBM (MFMA floor 26.6 us = HBM floor 25.7 us).
-        L = _lib.lib()
-        cin, cout, hw = 96, 32, 28
-        xin = torch.randn(B_TRAIN, hw, hw, cin, device=dev)
-        w = torch.randn(3, 3, cin, cout, device=dev) * 0.05
-        bias = torch.zeros(cout, device=dev)
-        yout = torch.empty(B_TRAIN, hw, hw, cout, device=dev)
-        woff = (9 * cin * cout + 63) & ~63
-        scratch = torch.empty(woff + B_TRAIN * hw * hw * cin + 128, device=dev)
-        kname = {0: "conv_mfma_kernel<28,1,fwd>", 1: "conv_bf16x3_kernel<28,1>", 2: "conv_s16_kernel<28,1>"}[args.conv_mode]
 
-        def conv_call(inp, flags):
-            if args.conv_mode == 0:
-                _lib.check(L.tdm_conv_nhwc_f32(_lib.ptr(xin), _lib.ptr(w), _lib.ptr(bias), None, None, _lib.ptr(yout),
-                                               None, B_TRAIN, hw, cin, cout, 3, 1, _lib.stream()))
-            elif args.conv_mode == 1:
-                _lib.check(L.tdm_conv_nhwc_bf16x3_f32(_lib.ptr(xin), _lib.ptr(w), _lib.ptr(bias), None, None,
-                                                      _lib.ptr(yout), None, _lib.ptr(scratch), B_TRAIN, hw, cin, cout,
-                                                      3, 1, _lib.stream()))
-            else:
-                _lib.check(L.tdm_conv_nhwc_s16_f32(_lib.ptr(inp), _lib.ptr(w), _lib.ptr(bias), None, None,
-                                                   _lib.ptr(yout), None, None, None, _lib.ptr(scratch), B_TRAIN, hw,
-                                                   cin, cout, 3, flags, _lib.stream()))
-        conv_call(xin, 1)                                   # mode 2: packs weights + pre-splits the input once
-        xs16 = scratch[woff:woff + B_TRAIN * hw * hw * cin]
-        ms = time_kernel(lambda: conv_call(xs16, 1 | 4 | 8))
-        kflop = 2 * 9 * cin * cout * hw * hw * B_TRAIN
-        kbytes = (cin + cout) * 4 * hw * hw * B_TRAIN
+    # ---- every launch of the step timed ALONE with HIP events on the launch stream (tdm_unet_replay_launch_f32):
+    #      the launch's in-pipeline arguments on two fully populated workspaces (1.3 GB each, alternated, so that the
+    #      256 MB Infinity Cache cannot serve one launch's inputs to the next) ----
+    if rank == 0 and args.conv_mode == 2 and not args.no_launch_table:
+        nl = L.tdm_unet_launch_count()
+        assert nl == len(LAUNCH_WORK), (nl, len(LAUNCH_WORK))
+        sts = [trainer.state, E.TrainState(trainer.flat, B_TRAIN)]
+        gn = torch.Generator(device=dev).manual_seed(5)
+        tt_ = torch.randint(0, 1000, (B_TRAIN,), device=dev, generator=gn)
+        nz = torch.randn(B_TRAIN, 1, 28, 28, device=dev, generator=gn)
+        for st in sts:
+            E.loss_and_grad(trainer.flat, st, x0, nz, tt_)
+        slabs = E.slabs_for(dev)
+        gscratch = torch.empty_like(trainer.grads)
+        rows = []
+        for lid in range(nl):
+            def call(i, lid=lid):
+                st = sts[i & 1]
+                _lib.check(L.tdm_unet_replay_launch_f32(_lib.ptr(trainer.flat), _lib.ptr(st.x_noisy), _lib.ptr(tt_), _lib.ptr(st.eps),
+                                                        _lib.ptr(st.deps), _lib.ptr(gscratch), _lib.ptr(st.ws.ws), _lib.ptr(slabs),
+                                                        B_TRAIN, lid, _lib.stream()), "replay")
+            ms = time_events(call, 20)
+            name = L.tdm_unet_launch_name(lid).decode()
+            fl, bps, bpc = LAUNCH_WORK[lid]
+            fl, by = fl * B_TRAIN, bps * B_TRAIN + bpc
+            row = {"id": lid, "launch": name, "us": round(ms * 1e3, 2), "bytes": by, "flop": fl,
+                   "hbm_frac": round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+            if any(k in name for k in MFMA_LAUNCH):
+                row["mfma_frac_bf16x3"] = round(3 * fl / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
+            rows.append(row)
+        total_us = sum(r["us"] for r in rows)
+        top = sorted(rows, key=lambda r: -r["us"])
+        out["launch_table"] = {"method": "each launch replayed alone 20x (3 warm-up), HIP events on the launch stream, two alternating "
+                                         "1.3 GB workspaces; bytes = tensors the launch reads + writes, once each",
+                               "sum_us": round(total_us, 1), "n_launches": nl, "top": top[:8],
+                               "conv_blocks": {"us": round(sum(r["us"] for r in rows if "conv_s16<" in r["launch"]), 1),
+                                               "bytes": sum(r["bytes"] for r in rows if "conv_s16<" in r["launch"])},
+                               "all_us": {str(r["id"]): r["us"] for r in rows}}
+        cb = out["launch_table"]["conv_blocks"]
+        cb["hbm_frac"] = round(cb["bytes"] / (cb["us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)
+        # ---- roofline: the dominant launch = rb4.conv1 with its fused skip conv, exactly as it runs in the step.
+        # Algorithmic bytes (SURVEY.md §8d convention, fp32 in + out elements of the conv): 96 in + 32 out channels of
+        # rb4.conv1 plus the 32 output channels of rb4.skip — the skip's input is the same concat and is not counted
+        # a second time (the per-conv sum of §8d would count it twice: 411 MB) — x 784 pixels x B.
+        r9 = next(r for r in rows if r["launch"].startswith("rb4.conv1 + rb4.skip fwd"))
+        kbytes = (96 + 32 + 32) * 4 * 784 * B_TRAIN
+        ms9 = r9["us"] * 1e-3
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")     # PMC FETCH_SIZE/WRITE_SIZE, see file
-        if args.conv_mode == 2 and os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r02_conv_traffic.json")     # PMC FETCH_SIZE/WRITE_SIZE of this kernel, see file
+        if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        if args.conv_mode == 0:
-            ach = kflop / (ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic}
-        else:
-            ach = kbytes / (ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                               "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
-                               "mfma_tflops_bf16": round(3 * kflop / (ms * 1e-3) / 1e12, 1), "mfma_peak_bf16": 2500.0}
-        out["roofline"].update({"kernel": kname + " (rb4.conv1 shape 96->32 3x3 @28x28, B=512)",
-                                "ms_per_launch": round(ms, 4), "flop_per_launch": kflop,
-                                "algorithmic_bytes_per_launch": kbytes})
-        del xin, yout
+        ach = kbytes / (ms9 * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
+                           "kernel": "conv_s16_kernel<28,1,true,false>: rb4.conv1 3x3 96->32 + fused rb4.skip 1x1 96->32 @28x28, B=512, "
+                                     "in-pipeline arguments (two K sources: up2(h3) S16 + h1 S16; outputs: S16 twin + time bias, ReLU byte mask, skip fp32)",
+                           "ms_per_launch": round(ms9, 4), "flop_per_launch": r9["flop"], "algorithmic_bytes_per_launch": kbytes,
+                           "tensor_bytes_per_launch": r9["bytes"],
+                           "mfma_tflops_bf16": round(3 * r9["flop"] / (ms9 * 1e-3) / 1e12, 1), "mfma_peak_bf16": PEAK_BF16_MFMA_TFLOPS,
+                           "timing": "HIP events on the launch stream, 20 launches alternating two workspaces; profiles/ holds the rocprofv3 "
+                                     "kernel-trace average of the same kernel from the same command"}
+        del sts, gscratch
+
+    # ---- the same step in the exact-fp32 arithmetic (--conv-mode 0), for the record ----
+    if rank == 0 and world == 1 and args.conv_mode == 2:
+        _lib.check(L.tdm_set_conv_mode(0))
+        tr0 = DDPMTrainer(model, batch_size=B_TRAIN, lr=1e-3, graph=False, broadcast=False)
+        for _ in range(3):
+            tr0.step(x0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(15):
+            tr0.step(x0)
+        torch.cuda.synchronize()
+        el0 = (time.perf_counter() - t0) / 15
+        out["fp32_mode"] = {"conv_mode": 0, "steps_per_s": round(1 / el0, 2), "ms_per_step": round(1e3 * el0, 3),
+                            "tflops": round(TRAIN_FLOP_PER_SAMPLE * B_TRAIN / el0 / 1e12, 1),
+                            "frac_f32_mfma": round(TRAIN_FLOP_PER_SAMPLE * B_TRAIN / el0 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+        del tr0
+        _lib.check(L.tdm_set_conv_mode(2))
 
     # ---- 1000-step sampling rate at B=4096 (configs[3]); sharded over ranks, no collectives ----
     if args.sample_steps > 0:
@@ -247,21 +413,25 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = tt.item()
         ms_rev = 1e3 * el / args.sample_steps
+        sbytes = 1_967_056 * B_SAMPLE + 725_892 + 4 * 784 * 4 * B_SAMPLE
         out["sampling"] = {"batch_per_gpu": B_SAMPLE, "ms_per_reverse_step": round(ms_rev, 3),
                            "reverse_steps_timed": args.sample_steps, "hipgraph": args.sample_steps >= 16,
+                           "noise": "Philox4x32-10 drawn inside the update kernel; step index in device memory",
                            "imgs_per_s_1000_step": round(world * B_SAMPLE / (ms_rev * 1e-3 * 1000), 2),
-                           "tflops": round(FWD_FLOP_PER_SAMPLE * B_SAMPLE / (ms_rev * 1e-3) / 1e12, 2)}
+                           "tflops": round(FWD_FLOP_PER_SAMPLE * B_SAMPLE / (ms_rev * 1e-3) / 1e12, 2),
+                           "frac_hbm": round(sbytes / (ms_rev * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
         del xs
+        model._samplers.clear()
 
     # ---- text denoiser train step (configs[4] shape: B=256/GPU, L=128, D=256; the reference's train mode,
     #      dropout 0.1 = src/shakespeare.py:490 default; the dropout-0 time is reported next to it) ----
     if args.text_steps > 0:
         from tinydiffusionmodels_amd.shakespeare import TinyTransformer, DenoiserTrainer
         Bt, Lt, Dt = 256, 128, 256
-        _lib.check(_lib.lib().tdm_set_gemm_mode(args.gemm_mode))
         xt = torch.randn(Bt, Lt, Dt, device=dev, generator=torch.Generator(device=dev).manual_seed(7 + rank)) * 0.02
 
-        def time_text(p_drop):
+        def time_text(p_drop, gemm_mode, steps):
+            _lib.check(L.tdm_set_gemm_mode(gemm_mode))
             torch.manual_seed(0)
             tmodel = TinyTransformer(Dt, dropout=p_drop).to(dev)
             tmodel.train()
@@ -270,7 +440,7 @@ def main():
                 ttr.step(xt)
             sync()
             t0 = time.perf_counter()
-            for _ in range(args.text_steps):
+            for _ in range(steps):
                 ttr.step(xt)
             sync()
             el = time.perf_counter() - t0
@@ -278,18 +448,26 @@ def main():
                 tt = torch.tensor([el], device=dev, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = tt.item()
-            return 1e3 * el / args.text_steps
+            return 1e3 * el / steps
 
-        ms_t = time_text(0.1)
-        ms_t0 = time_text(0.0)
-        tflop = 3 * 8_257_536 * Bt * Lt / (ms_t * 1e-3) / 1e12      # 8,257,536 FLOP/token fwd, x3 train
+        tflop_step = 3 * 8_257_536 * Bt * Lt / 1e12      # 8,257,536 FLOP/token fwd, x3 train
+        ms_t = time_text(0.1, args.gemm_mode, args.text_steps)
+        ms_t0 = time_text(0.0, args.gemm_mode, args.text_steps)
+        other = 2 if args.gemm_mode != 2 else 1
+        ms_o = time_text(0.1, other, args.text_steps)
+        names = {0: "fp32 MFMA GEMMs (exact)", 1: "bf16x3 split-operand MFMA GEMMs, fp32 accumulate (parity path: 3e-6 rel)",
+                 2: "plain bf16-operand MFMA GEMMs, fp32 accumulate (config 5's 'bf16 MFMA'; ~3e-3 rel, above the 1e-3 bound)"}
+        _lib.check(L.tdm_set_gemm_mode(args.gemm_mode))
         out["text_denoiser"] = {"batch_per_gpu": Bt, "seq_len": Lt, "dim": Dt, "dropout": 0.1, "ms_per_step": round(ms_t, 3),
                                 "ms_per_step_dropout0": round(ms_t0, 3),
                                 "steps_per_s": round(world * 1e3 / ms_t, 2),
-                                "tokens_per_s": round(world * Bt * Lt * 1e3 / ms_t, 0), "tflops": round(tflop, 2),
-                                "arithmetic": {0: "fp32 MFMA GEMMs (exact)", 1: "bf16x3 split-operand MFMA GEMMs, fp32 accumulate",
-                                               2: "plain bf16-operand MFMA GEMMs, fp32 accumulate"}[args.gemm_mode] +
-                                              "; fp32-MFMA attention, fp32 LayerNorm; counter-hash dropout masks"}
+                                "tokens_per_s": round(world * Bt * Lt * 1e3 / ms_t, 0), "tflops": round(tflop_step / (ms_t * 1e-3), 2),
+                                "frac_bf16_mfma": round(tflop_step / (ms_t * 1e-3) / PEAK_BF16_MFMA_TFLOPS, 4),
+                                "gemm_mode": args.gemm_mode,
+                                "arithmetic": names[args.gemm_mode] + "; fp32-MFMA attention, fp32 LayerNorm; counter-hash dropout masks",
+                                "other_gemm_mode": {"gemm_mode": other, "arithmetic": names[other], "ms_per_step": round(ms_o, 3),
+                                                    "tokens_per_s": round(world * Bt * Lt * 1e3 / ms_o, 0),
+                                                    "tflops": round(tflop_step / (ms_o * 1e-3), 2)}}
         del xt
         # rounding head of the same train step (row N1): logits + cross-entropy + the three gradients for the
         # 32,768 tokens of the batch against a GPT-2-sized vocabulary (synthetic table; V is not a multiple of 4)
@@ -300,14 +478,13 @@ def main():
         Wh = torch.randn(Vh, Dt, device=dev, generator=gh) * (1.0 / Dt ** 0.5)
         bh = torch.zeros(Vh, device=dev)
         idh = torch.randint(0, Vh, (Mh,), device=dev, generator=gh)
-        L_ = _lib.lib()
-        wsh = torch.empty(L_.tdm_round_workspace_floats(Mh, Vh, Dt), device=dev)
+        wsh = torch.empty(L.tdm_round_workspace_floats(Mh, Vh, Dt), device=dev)
         lossh, dxh, dWh, dbh = torch.empty(1, device=dev), torch.empty_like(xh), torch.empty_like(Wh), torch.empty_like(bh)
 
         def head():
-            _lib.check(L_.tdm_round_ce_loss_grad_f32(_lib.ptr(xh), _lib.ptr(Wh), _lib.ptr(bh), _lib.ptr(idh), 1.0, _lib.ptr(lossh),
-                                                     _lib.ptr(dxh), _lib.ptr(dWh), _lib.ptr(dbh), _lib.ptr(wsh), Mh, Vh, Dt,
-                                                     _lib.stream()), "round_ce")
+            _lib.check(L.tdm_round_ce_loss_grad_f32(_lib.ptr(xh), _lib.ptr(Wh), _lib.ptr(bh), _lib.ptr(idh), 1.0, _lib.ptr(lossh),
+                                                    _lib.ptr(dxh), _lib.ptr(dWh), _lib.ptr(dbh), _lib.ptr(wsh), Mh, Vh, Dt,
+                                                    _lib.stream()), "round_ce")
         head()
         sync()
         nh = max(1, args.text_steps // 3)
@@ -318,7 +495,7 @@ def main():
         ms_h = 1e3 * (time.perf_counter() - t0) / nh
         out["text_denoiser"]["rounding_head"] = {"vocab": Vh, "tokens": Mh, "ms": round(ms_h, 3),
                                                  "tflops": round(3 * 2.0 * Mh * Vh * Dt / (ms_h * 1e-3) / 1e12, 1),
-                                                 "logits_gb": round(Mh * 4.0 * ((Vh + 3) // 4 * 4) / 1e9, 2),
+                                                 "workspace_gb": round(wsh.numel() * 4 / 1e9, 2),
                                                  "loss": round(float(lossh.item()), 4)}
         del xh, Wh, bh, idh, wsh, dxh, dWh, dbh
 
@@ -330,6 +507,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        dp.shutdown()
         dist.destroy_process_group()
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TDM_VERSION 100
+#define TDM_VERSION 200
 #define TDM_TIMESTEPS 1000
 #define TDM_UNET_NPARAM 181473      /* SimpleUNet(), src/mnist.py:64-74 */
 #define TDM_UNET_NTENSOR 32         /* number of state_dict entries      */
@@ -87,6 +87,12 @@ int tdm_unet_bwd_f32(const float* params, const float* x, const float* deps, flo
  * which: 0=h1 (32,28,28) 1=h2 (64,14,14) 2=h3 (64,14,14) 3=h4 (32,28,28)     */
 int tdm_unet_get_activation(const float* ws, int64_t B, int which, float* out_nchw, void* stream);
 
+/* ReLU sign masks kept by a save != 0 forward (default arithmetic: one bit per element instead of the
+ * fp32 post-ReLU tensors), exchanged as one 0/1 byte per element, NCHW (B, C, H, W) of block 0..3's
+ * conv1 (which = 1) / conv2 (which = 2) output.  write = 0 reads them; write != 0 installs masks
+ * (tests: the reference's masks teacher-forced into tdm_unet_bwd_f32).                                */
+int tdm_unet_relu_mask_io(float* ws, int64_t B, int block, int which, uint8_t* mask_nchw, int write, void* stream);
+
 /* ---- a5: MSE + AdamW  (src/mnist.py:158, :148) ---------------------------- */
 /* loss = mean((pred-target)^2) -> loss_out[0]; dpred = 2*(pred-target)/n.
  * scratch: >= 1024 floats.                                                   */
@@ -113,6 +119,76 @@ int tdm_unet_loss_grad_f32(const float* params, const float* x0, const float* no
 int tdm_unet_p_sample_step_f32(const float* params, const float* x, const int64_t* t, const float* noise,
                                const float* tab_recip, const float* tab_eps, const float* tab_sigma,
                                int t_index, float* eps, float* x_out, float* ws, int64_t B, void* stream);
+
+/* ---- device-side randomness and step counting (hipGraph-replayable loops) ----
+ * The reference draws `t = torch.randint(0, timesteps, (B,))`, `noise = torch.randn_like(x0)`
+ * (src/mnist.py:154-155) and `torch.randn_like(x)` (:178) from the host-seeded generator.  The
+ * variants below draw the same distributions from Philox4x32-10 as a pure function of
+ * (seed, stream offset, element index) — csrc/tdm_philox.h — inside the kernel that consumes
+ * them.  rng_state: DEVICE int64[2] = {stream offset, 0}; every call advances the offset by one
+ * on the device (so a captured graph draws fresh numbers on every replay); [1] is scratch and
+ * must be 0 between calls.  The teacher-forced entry points above stay the parity path.       */
+/* out[i] = N(0,1) draw i of stream (seed, offset); n % 4 == 0 (tests / utilities)             */
+int tdm_philox_normal_f32(uint64_t seed, uint64_t offset, float* out, int64_t n, void* stream);
+/* raw generator words, 4 per counter (kind 0 = noise stream, 1 = step-index stream), device / host */
+int tdm_philox_u32(uint64_t seed, uint64_t offset, int kind, uint32_t* out, int64_t n, void* stream);
+int tdm_philox_u32_host(uint64_t seed, uint64_t offset, int kind, uint64_t idx, uint32_t* out4);
+/* t_out[b] ~ U{0..999}; noise_out ~ N(0,1); x_noisy_out = q_sample(x0, t, noise)  (src/mnist.py:154-156) */
+int tdm_ddpm_draw_q_sample_f32(const float* x0, const float* sqrt_acp, const float* sqrt_1m_acp, uint64_t seed,
+                               int64_t* rng_state, int64_t* t_out, float* noise_out, float* x_noisy_out,
+                               int64_t B, int64_t inner, void* stream);
+/* p_sample update (src/mnist.py:173-180) with z drawn in registers and the per-sample step index in
+ * DEVICE memory: out = recip[t] * (x - ceps[t] * eps) + sigma0[t] * z, then t_dev[b] = max(t_dev[b] - 1, 0).
+ * tab_sigma0 = sqrt(betas) with entry 0 set to 0 (the reference's `if t[0] == 0: return mean`).           */
+int tdm_p_sample_update_philox_f32(const float* x, const float* eps, const float* tab_recip, const float* tab_eps,
+                                   const float* tab_sigma0, int64_t* t_dev, uint64_t seed, int64_t* rng_state,
+                                   float* out, int64_t B, int64_t inner, void* stream);
+/* tdm_adamw_flat_f32 with the step count in DEVICE memory: step_state int64[2] = {steps taken, 0};
+ * the call performs step steps_taken + 1 and stores it (src/mnist.py:148,159).                         */
+int tdm_adamw_flat_devstep_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int64_t* step_state, float grad_scale,
+                               void* stream);
+/* tdm_unet_loss_grad_f32 with t and noise drawn on the device into t_buf (B) / noise (B,784)          */
+int tdm_unet_loss_grad_philox_f32(const float* params, const float* x0, const float* sqrt_acp,
+                                  const float* sqrt_1m_acp, uint64_t seed, int64_t* rng_state, int64_t* t_buf,
+                                  float* noise, float* x_noisy, float* eps, float* deps, float* loss_out,
+                                  float* grads, float* ws, float* slabs, int64_t B, void* stream);
+/* tdm_unet_p_sample_step_f32 with device-resident t and device-drawn noise: one reverse step of
+ * src/mnist.py:190-193 with no host-written scalar                                                   */
+int tdm_unet_p_sample_step_philox_f32(const float* params, const float* x, int64_t* t_dev, const float* tab_recip,
+                                      const float* tab_eps, const float* tab_sigma0, uint64_t seed,
+                                      int64_t* rng_state, float* eps, float* x_out, float* ws, int64_t B,
+                                      void* stream);
+
+/* ---- e: data-parallel collective (no reference counterpart: the reference trains
+ *      on one device, deployment/configs/mnist-training.yaml:5-6) ---------------------------------
+ * One process per GPU.  A context owns the RCCL communicator of its process; the unique id is made
+ * on rank 0 (tdm_comm_unique_id) and handed to the other ranks by the host's bootstrap channel
+ * (torchrun's store / any out-of-band byte transport).  Collectives are enqueued on the caller's
+ * stream and never synchronise it.  RCCL itself is loaded at the first comm call (dlopen).          */
+typedef struct tdm_ctx tdm_ctx;
+int tdm_ctx_create(int device, tdm_ctx** out);
+int tdm_ctx_destroy(tdm_ctx* ctx);
+int tdm_comm_unique_id_bytes(void);                 /* sizeof(ncclUniqueId) = 128 */
+int tdm_comm_unique_id(void* out_bytes);
+int tdm_comm_init(tdm_ctx* ctx, const void* unique_id, int rank, int world);
+int tdm_comm_rank(const tdm_ctx* ctx);
+int tdm_comm_world(const tdm_ctx* ctx);
+int tdm_comm_rccl_version(void);                    /* NCCL_VERSION_CODE of the loaded RCCL, -1 if unavailable */
+/* buf <- sum over ranks of buf (in place): the ONE collective of a train step, 725,892 B for the UNet */
+int tdm_allreduce_sum_f32(tdm_ctx* ctx, float* buf, int64_t n, void* stream);
+/* buf <- root's buf (identical replicas before the first step)                                       */
+int tdm_broadcast_f32(tdm_ctx* ctx, float* buf, int64_t n, int root, void* stream);
+
+/* ---- profiling: one launch of the train step at a time ------------------------
+ * The default train step is ~45 launches; each has an id and a name.  After a full
+ * tdm_unet_loss_grad_f32 call, tdm_unet_replay_launch_f32 re-issues launch `id` alone with the
+ * arguments it had inside the step (bench.py times every launch with events; PMC per kernel).   */
+int tdm_unet_launch_count(void);
+const char* tdm_unet_launch_name(int id);
+int tdm_unet_replay_launch_f32(const float* params, const float* x_noisy, const int64_t* t, float* eps,
+                               const float* deps, float* grads, float* ws, float* slabs, int64_t B, int id,
+                               void* stream);
 
 /* ---- per-layer entry points (tests / profiling) --------------------------- */
 /* generic NHWC 3x3 (pad 1) or 1x1 convolution as implicit GEMM on fp32 MFMA.

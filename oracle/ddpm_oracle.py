@@ -73,9 +73,13 @@ def residual_block(p: Dict[str, torch.Tensor], name: str, x: torch.Tensor, that:
                    inter: Optional[dict] = None) -> torch.Tensor:
     """src/mnist.py:56-61; `that` is (B,1,1,1) = t/1000."""
     h = F.relu(F.conv2d(x, p[f"{name}.conv1.weight"], p[f"{name}.conv1.bias"], padding=1))
+    if inter is not None:
+        inter[f"{name}.a1"] = h.detach()
     tb = F.linear(that, p[f"{name}.time_emb.weight"], p[f"{name}.time_emb.bias"]).view(that.shape[0], -1, 1, 1)
     h = h + tb
     h = F.relu(F.conv2d(h, p[f"{name}.conv2.weight"], p[f"{name}.conv2.bias"], padding=1))
+    if inter is not None:
+        inter[f"{name}.a2"] = h.detach()
     if f"{name}.skip.weight" in p:
         s = F.conv2d(x, p[f"{name}.skip.weight"], p[f"{name}.skip.bias"])
     else:
@@ -87,15 +91,17 @@ def unet_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor,
                  return_intermediates: bool = False):
     """src/mnist.py:76-87.  x (B,1,28,28) fp32, t (B,) int64 raw step index."""
     that = (t.float() / TIMESTEPS).view(-1, 1, 1, 1)
-    h1 = residual_block(p, "rb1", x, that)
-    h2 = residual_block(p, "rb2", F.avg_pool2d(h1, 2), that)
-    h3 = residual_block(p, "rb3", h2, that)
+    inter = {} if return_intermediates else None     # also the post-ReLU tensors rbN.a1 / rbN.a2 (their signs = ReLU masks)
+    h1 = residual_block(p, "rb1", x, that, inter)
+    h2 = residual_block(p, "rb2", F.avg_pool2d(h1, 2), that, inter)
+    h3 = residual_block(p, "rb3", h2, that, inter)
     h4 = F.interpolate(h3, scale_factor=2, mode="nearest")
     h4 = torch.cat([h4, h1], dim=1)
-    h4 = residual_block(p, "rb4", h4, that)
+    h4 = residual_block(p, "rb4", h4, that, inter)
     out = F.conv2d(h4, p["out.weight"], p["out.bias"])
     if return_intermediates:
-        return out, {"h1": h1, "h2": h2, "h3": h3, "h4": h4}
+        inter.update({"h1": h1, "h2": h2, "h3": h3, "h4": h4})
+        return out, inter
     return out
 
 
@@ -161,6 +167,58 @@ def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tenso
     denom = v.sqrt() / math.sqrt(bc2) + eps
     p = p - step_size * (m / denom)
     return p, m, v
+
+
+# --------------------------------------------------------------------------
+# device-side draws of the build (no reference counterpart: the reference uses torch's host-seeded generator,
+# src/mnist.py:154-155,178, whose CPU stream a device generator cannot reproduce — SURVEY.md §7 "RNG parity").
+# Restatement of csrc/tdm_philox.h: Philox4x32-10 (Salmon et al. 2011; known answer: counter 0, key 0 ->
+# 6627e8d5 e169c58d bc57ac4c 9b00dbd8), counter = (idx_lo, idx_hi | kind << 28, offset_lo, offset_hi).
+# --------------------------------------------------------------------------
+def philox4x32_10(ctr: np.ndarray, key: Tuple[int, int]) -> np.ndarray:
+    """ctr: (n,4) uint32 counters; returns (n,4) uint32 words."""
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), 0x9E3779B9, 0xBB67AE85
+    c = ctr.astype(np.uint64)
+    k0, k1 = key[0] & 0xFFFFFFFF, key[1] & 0xFFFFFFFF
+    mask = np.uint64(0xFFFFFFFF)
+    for r in range(10):
+        if r > 0:
+            k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+        p0 = M0 * c[:, 0]
+        p1 = M1 * c[:, 2]
+        hi0, lo0 = p0 >> np.uint64(32), p0 & mask
+        hi1, lo1 = p1 >> np.uint64(32), p1 & mask
+        c = np.stack([hi1 ^ c[:, 1] ^ np.uint64(k0), lo1, hi0 ^ c[:, 3] ^ np.uint64(k1), lo0], axis=1)
+    return c.astype(np.uint32)
+
+
+def philox_words(seed: int, offset: int, idx: np.ndarray, kind: int) -> np.ndarray:
+    idx = np.asarray(idx, dtype=np.uint64)
+    ctr = np.stack([idx & np.uint64(0xFFFFFFFF),
+                    ((idx >> np.uint64(32)) & np.uint64(0x0FFFFFFF)) | np.uint64(kind << 28),
+                    np.full(idx.shape, offset & 0xFFFFFFFF, dtype=np.uint64),
+                    np.full(idx.shape, (offset >> 32) & 0xFFFFFFFF, dtype=np.uint64)], axis=1)
+    return philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
+
+
+def philox_steps(seed: int, offset: int, B: int, nsteps: int = TIMESTEPS) -> torch.Tensor:
+    """t[b] = mulhi32(word0 of the step stream at counter b, nsteps)  (tdm_philox_step)."""
+    w = philox_words(seed, offset, np.arange(B), 1)[:, 0].astype(np.uint64)
+    return torch.from_numpy(((w * np.uint64(nsteps)) >> np.uint64(32)).astype(np.int64))
+
+
+def philox_normals(seed: int, offset: int, n: int) -> torch.Tensor:
+    """n (multiple of 4) N(0,1) draws: per float4 index two Box-Muller pairs over u = w * 2^-32 + 2^-33
+    (tdm_philox_normal4); fp32 arithmetic, so equal to the device values up to libm rounding."""
+    w = philox_words(seed, offset, np.arange(n // 4), 0).astype(np.float32)
+    u = w * np.float32(2.0 ** -32) + np.float32(2.0 ** -33)
+    r0 = np.sqrt(np.float32(-2.0) * np.log(u[:, 0]))
+    r1 = np.sqrt(np.float32(-2.0) * np.log(u[:, 2]))
+    a0 = (np.float32(2.0) * u[:, 1]).astype(np.float64) * np.pi
+    a1 = (np.float32(2.0) * u[:, 3]).astype(np.float64) * np.pi
+    out = np.stack([r0 * np.cos(a0).astype(np.float32), r0 * np.sin(a0).astype(np.float32),
+                    r1 * np.cos(a1).astype(np.float32), r1 * np.sin(a1).astype(np.float32)], axis=1)
+    return torch.from_numpy(out.reshape(-1).astype(np.float32))
 
 
 # --------------------------------------------------------------------------

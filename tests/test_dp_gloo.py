@@ -80,3 +80,99 @@ def test_shard_helpers_single_process():
     assert dp.world_info() == (0, 1)
     assert dp.allreduce_grads_(torch.ones(3)) == 1.0
     assert [dp.shard_chains(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+
+
+# ---- train() over a ragged epoch at world 3: collectives must pair up on every rank ----
+def _draws_for(x0):
+    """Deterministic per-sample (t, noise) keyed on the sample's content, so any rank / any process derives the same."""
+    key = (x0[:, 0, 0, 0].double() * 1e6).long().abs()
+    t = key % 1000
+    noise = torch.stack([torch.randn(1, 28, 28, generator=torch.Generator().manual_seed(int(k))) for k in key])
+    return t, noise
+
+
+def _make_oracle_stepper():
+    from tinydiffusionmodels_amd import dp, unet_engine as E
+    from tinydiffusionmodels_amd.mnist import DPStepper
+    from oracle import ddpm_oracle as O
+
+    class OracleStepper(DPStepper):
+        """DPStepper whose local gradient comes from the CPU oracle: exercises exactly the collective / weighting /
+        optimiser ordering DDPMTrainer inherits (src/mnist.py:152-159 under data parallelism)."""
+
+        def __init__(self, flat):
+            self.flat = flat
+            self.g = torch.zeros_like(flat)
+            self.m, self.v, self.nstep = torch.zeros_like(flat), torch.zeros_like(flat), 0
+            self.tabs = O.make_tables()
+            self.log = []
+
+        def local_loss_and_grad(self, x0, t, noise):
+            t, noise = _draws_for(x0)
+            loss, grads = O.unet_loss_and_grads(E.state_dict_from_flat(self.flat), x0, t, noise, self.tabs)
+            self.g.copy_(E.flat_from_state_dict(grads))
+            return loss
+
+        def grad_buffer(self):
+            return self.g
+
+        def optimizer_step(self, grad_scale):
+            self.nstep += 1
+            self.log.append((self.flat.clone(), self.g * grad_scale))
+            p, self.m, self.v = O.adamw_step(self.flat, self.g * grad_scale, self.m, self.v, self.nstep)
+            self.flat.copy_(p)
+
+    return OracleStepper
+
+
+def _train_worker(rank, world, port, out_dir, n, batch_size):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from tinydiffusionmodels_amd import dp, unet_engine as E
+    from tinydiffusionmodels_amd import mnist as M
+    from oracle import ddpm_oracle as O
+    dp.init_from_env("gloo")
+    flat = E.flat_from_state_dict(O.unet_init_params(seed=0))
+    stepper = _make_oracle_stepper()(flat)
+    data = torch.rand(n, 1, 28, 28, generator=torch.Generator().manual_seed(5)) * 2 - 1
+    dummy = torch.nn.Linear(1, 1)
+    M.train(dummy, "cpu", epochs=1, batch_size=batch_size, ckpt_path=os.path.join(out_dir, f"ckpt{rank}.pth"),
+            sample_every_epoch=False, data=data, log_every=0, trainer=stepper)
+    torch.save({"flat": stepper.flat, "log": stepper.log}, os.path.join(out_dir, f"t{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_ragged_epoch_world3_gloo(tmp_path):
+    """n = 20 samples, batch 3 per rank, world 3: global iterations of 9, 9 and 2 samples — in the last one rank 0
+    holds 2 samples and ranks 1-2 none.  Every rank must issue the same collectives (no hang / no mismatch), the
+    replicas must stay identical, and each step's reduced gradient must be the gradient of the mean loss over that
+    iteration's GLOBAL sample set (weights B_local / B_global, not a mean of per-rank means)."""
+    from oracle import ddpm_oracle as O
+    from tinydiffusionmodels_amd import unet_engine as E
+    n, bs, world = 20, 3, 3
+    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path), n, bs), nprocs=world, join=True)
+    runs = [torch.load(tmp_path / f"t{r}.pt") for r in range(world)]
+    assert all(len(r["log"]) == 3 for r in runs)                               # 3 optimiser steps on every rank
+    for r in runs[1:]:
+        assert torch.equal(r["flat"], runs[0]["flat"])                        # identical replicas after the epoch
+        for (p_a, g_a), (p_b, g_b) in zip(r["log"], runs[0]["log"]):
+            assert torch.equal(p_a, p_b) and torch.equal(g_a, g_b)
+    data = torch.rand(n, 1, 28, 28, generator=torch.Generator().manual_seed(5)) * 2 - 1
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(0))
+    tabs = O.make_tables()
+    for it, (p_before, g_used) in enumerate(runs[0]["log"]):
+        idx = perm[it * bs * world:(it + 1) * bs * world]
+        assert idx.numel() == (9, 9, 2)[it]
+        x0 = data[idx]
+        t, noise = _draws_for(x0)
+        _, grads = O.unet_loss_and_grads(E.state_dict_from_flat(p_before), x0, t, noise, tabs)
+        assert O.rel_err(g_used, E.flat_from_state_dict(grads)) < 1e-5, it
+    assert os.path.exists(tmp_path / "ckpt0.pth") and not os.path.exists(tmp_path / "ckpt1.pth")
+
+
+def test_global_batch_count():
+    from tinydiffusionmodels_amd import dp
+    assert [dp.global_batch_count(20, it, 3, 3) for it in range(4)] == [9, 9, 2, 0]
+    assert [dp.global_batch_count(60000, it, 128, 8) for it in (0, 57, 58, 59)] == [1024, 1024, 608, 0]

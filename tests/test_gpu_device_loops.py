@@ -1,0 +1,295 @@
+"""GPU tests of the host-free loops (through the C ABI): device-drawn Philox noise fused into q_sample and
+the p_sample update, the device-resident AdamW step count, the hipGraph-captured train step and reverse
+step, and the RCCL collective behind tdm_allreduce_sum_f32 (world 1 on a one-GPU box).
+
+The reference draws from torch's host generator (src/mnist.py:154-155,178), which no device stream can
+reproduce, so these paths are checked (a) bit-for-bit against the teacher-forced kernels of the parity
+tests fed the SAME draws, (b) against the numpy restatement of the generator in oracle/ddpm_oracle.py
+(integers bit-exact, normals to libm rounding), (c) statistically."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ddpm_oracle as O
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from tinydiffusionmodels_amd import _lib, unet_engine
+    lib = _lib.lib()
+    unet_engine.check_layout_against_library()
+    return lib
+
+
+@pytest.fixture(scope="module", autouse=True)
+def pinned_tables(golden_tables):
+    from tinydiffusionmodels_amd import schedule
+    schedule.set_tables(golden_tables)
+    yield golden_tables
+    schedule.set_tables(None)
+
+
+def _state(dev, offset=0):
+    return torch.tensor([offset, 0], dtype=torch.long, device=dev)
+
+
+# ---------------------------------------------------------------- generator
+@pytest.mark.parametrize("seed,offset", [(0, 0), (0x1234567890ABCDEF, 5), (2 ** 63 + 11, 2 ** 33 + 3)])
+def test_philox_words_device_host_oracle(dev, L, seed, offset):
+    from tinydiffusionmodels_amd import _lib
+    n = 4096
+    for kind in (0, 1):
+        out = torch.empty(n, dtype=torch.int32, device=dev)
+        _lib.check(L.tdm_philox_u32(seed, offset, kind, _lib.ptr(out), n, _lib.stream()))
+        got = out.cpu().numpy().view(np.uint32).reshape(-1, 4)
+        want = O.philox_words(seed, offset, np.arange(n // 4), kind)
+        assert np.array_equal(got, want)
+        h = (ctypes.c_uint32 * 4)()
+        L.tdm_philox_u32_host(seed, offset, kind, 777, h)
+        assert list(h) == want[777].tolist()
+        if seed == 0 and offset == 0 and kind == 0:   # Random123 known answer (counter 0, key 0)
+            assert [hex(v) for v in want[0]] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+
+
+def test_philox_normals_match_oracle_and_are_standard_normal(dev, L):
+    from tinydiffusionmodels_amd import _lib
+    n = 1 << 20
+    out = torch.empty(n, device=dev)
+    _lib.check(L.tdm_philox_normal_f32(99, 3, _lib.ptr(out), n, _lib.stream()))
+    z = out.cpu()
+    ref = O.philox_normals(99, 3, n)
+    assert (z - ref).abs().max().item() < 2e-5         # same integers, libm-level differences in log / sincos
+    zz = z.double()
+    assert abs(zz.mean().item()) < 4e-3 and abs(zz.var().item() - 1) < 6e-3
+    assert abs((zz ** 3).mean().item()) < 2e-2 and abs((zz ** 4).mean().item() - 3) < 5e-2
+    assert 4.0 < z.abs().max().item() < 7.0
+    # different offsets / seeds are different streams
+    out2 = torch.empty(n, device=dev)
+    _lib.check(L.tdm_philox_normal_f32(99, 4, _lib.ptr(out2), n, _lib.stream()))
+    assert abs(torch.corrcoef(torch.stack([out, out2]))[0, 1].item()) < 5e-3
+
+
+# ------------------------------------------------- fused draw + q_sample (train)
+@pytest.mark.parametrize("B", [1, 37, 512])
+def test_draw_q_sample_equals_teacher_forced_q_sample(dev, L, golden_tables, B):
+    from tinydiffusionmodels_amd import _lib
+    from tinydiffusionmodels_amd.mnist import q_sample
+    from tinydiffusionmodels_amd.schedule import device_tables
+    tabs = device_tables(dev)
+    seed, offset = 0xC0FFEE, 41
+    x0 = (torch.rand(B, 1, 28, 28, generator=torch.Generator().manual_seed(B)) * 2 - 1).to(dev)
+    st = _state(dev, offset)
+    t = torch.empty(B, dtype=torch.long, device=dev)
+    noise, xn = torch.empty_like(x0), torch.empty_like(x0)
+    _lib.check(L.tdm_ddpm_draw_q_sample_f32(_lib.ptr(x0), _lib.ptr(tabs["sqrt_alphas_cumprod"]),
+                                            _lib.ptr(tabs["sqrt_one_minus_alphas_cumprod"]), seed, _lib.ptr(st), _lib.ptr(t),
+                                            _lib.ptr(noise), _lib.ptr(xn), B, 784, _lib.stream()))
+    assert st.cpu().tolist() == [offset + 1, 0]                               # offset advanced on the device
+    assert torch.equal(t.cpu(), O.philox_steps(seed, offset, B))              # integer draws: bit-exact vs numpy
+    assert (noise.cpu().reshape(-1) - O.philox_normals(seed, offset, B * 784)).abs().max().item() < 2e-5
+    assert torch.equal(xn, q_sample(x0, t, noise))                            # same arithmetic as the parity kernel
+    assert torch.equal(xn.cpu(), O.q_sample(x0.cpu(), t.cpu(), noise.cpu(), golden_tables))
+    ref_noise = torch.empty_like(noise)
+    _lib.check(L.tdm_philox_normal_f32(seed, offset, _lib.ptr(ref_noise), B * 784, _lib.stream()))
+    assert torch.equal(noise, ref_noise)
+
+
+def test_step_index_draws_are_uniform(dev, L):
+    t = O.philox_steps(5, 0, 200000)
+    assert t.min().item() == 0 and t.max().item() == 999
+    counts = torch.bincount(t, minlength=1000).double()
+    chi2 = ((counts - 200.0) ** 2 / 200.0).sum().item()
+    assert 800 < chi2 < 1200                                                  # 999 dof: mean 999, sd 44.7
+
+
+# ------------------------------------------- fused draw + p_sample update (sampling)
+def test_p_update_philox_equals_teacher_forced_update(dev, L):
+    from tinydiffusionmodels_amd import _lib
+    from tinydiffusionmodels_amd.schedule import device_tables
+    tabs = device_tables(dev)
+    sigma0 = tabs["sigma"].clone()
+    sigma0[0] = 0.0
+    B, seed, offset = 9, 77, 1000
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 1, 28, 28, generator=g).to(dev)
+    eps = torch.randn(B, 1, 28, 28, generator=g).to(dev)
+    t0 = torch.tensor([999, 500, 2, 1, 0, 0, 17, 1, 333], dtype=torch.long, device=dev)
+    t = t0.clone()
+    st = _state(dev, offset)
+    out = torch.empty_like(x)
+    _lib.check(L.tdm_p_sample_update_philox_f32(_lib.ptr(x), _lib.ptr(eps), _lib.ptr(tabs["sqrt_recip_alphas"]),
+                                                _lib.ptr(tabs["eps_coef"]), _lib.ptr(sigma0), _lib.ptr(t), seed, _lib.ptr(st),
+                                                _lib.ptr(out), B, 784, _lib.stream()))
+    z = torch.empty_like(x)
+    _lib.check(L.tdm_philox_normal_f32(seed, offset, _lib.ptr(z), B * 784, _lib.stream()))
+    want = torch.empty_like(x)
+    _lib.check(L.tdm_p_sample_update_pert_f32(_lib.ptr(x), _lib.ptr(eps), _lib.ptr(z), _lib.ptr(tabs["sqrt_recip_alphas"]),
+                                              _lib.ptr(tabs["eps_coef"]), _lib.ptr(sigma0), _lib.ptr(t0), 1, _lib.ptr(want), B, 784,
+                                              _lib.stream()))
+    assert torch.equal(out, want)
+    assert torch.equal(t.cpu(), (t0.cpu() - 1).clamp(min=0)) and st.cpu().tolist() == [offset + 1, 0]
+    # rows at t == 0 are the posterior mean (the reference's `if t[0] == 0` branch): no noise term
+    mean = torch.empty_like(x)
+    _lib.check(L.tdm_p_sample_update_pert_f32(_lib.ptr(x), _lib.ptr(eps), None, _lib.ptr(tabs["sqrt_recip_alphas"]),
+                                              _lib.ptr(tabs["eps_coef"]), _lib.ptr(sigma0), _lib.ptr(t0), 0, _lib.ptr(mean), B, 784,
+                                              _lib.stream()))
+    assert torch.equal(out[4:6], mean[4:6])
+
+
+# --------------------------------------------------------- AdamW, device step count
+def test_adamw_device_step_count_equals_host_step(dev, L):
+    from tinydiffusionmodels_amd import unet_engine as E
+    g = torch.Generator().manual_seed(8)
+    n = E.NPARAM
+    p0 = torch.randn(n, generator=g).to(dev)
+    a, b = p0.clone(), p0.clone()
+    ma, va, mb, vb = (torch.zeros(n, device=dev) for _ in range(4))
+    state = torch.zeros(2, dtype=torch.long, device=dev)
+    for step in range(1, 6):
+        grad = (torch.randn(n, generator=g) * 10 ** float(torch.randint(-6, 1, (1,), generator=g))).to(dev)
+        E.adamw_step(a, grad, ma, va, step, lr=1e-3, grad_scale=0.5)
+        E.adamw_step_dev(b, grad, mb, vb, state, lr=1e-3, grad_scale=0.5)
+        assert state.cpu().tolist() == [step, 0]
+        assert (a - b).abs().max().item() <= 1e-9 + 2e-7 * a.abs().max().item(), step   # (device pow vs host libm pow)
+        assert torch.equal(ma, mb) and torch.equal(va, vb)
+    assert not torch.equal(a, p0)
+
+
+# ------------------------------------------------------------- captured train step
+def _fresh_trainer(dev, golden_dir, B, graph):
+    from tinydiffusionmodels_amd.mnist import SimpleUNet, DDPMTrainer
+    z = np.load(f"{golden_dir}/unet_forward.npz")
+    m = SimpleUNet()
+    m.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w.")})
+    m = m.to(dev)
+    torch.manual_seed(2024)                                     # governs the trainer's Philox seed
+    return m, DDPMTrainer(m, batch_size=B, lr=1e-3, graph=graph)
+
+
+def test_train_step_hipgraph_equals_eager_and_teacher_forced(dev, L, golden_dir, golden_tables):
+    """Six steps: graph replay vs the same launches issued eagerly -> bitwise equal parameters, losses and AdamW
+    step count; and the draws the device made (t, noise), fed to the teacher-forced entry point the parity tests
+    pin, give the same loss and gradient bitwise — so the captured step IS the parity-tested step
+    (src/mnist.py:152-159)."""
+    from tinydiffusionmodels_amd import unet_engine as E
+    B = 24
+    x0 = (torch.rand(B, 1, 28, 28, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(dev)
+    mg, tg = _fresh_trainer(dev, golden_dir, B, True)
+    me, te = _fresh_trainer(dev, golden_dir, B, False)
+    assert tg.seed == te.seed
+    for k in range(6):
+        before = me.flat.detach().clone()
+        lg = tg.step(x0).clone()
+        le = te.step(x0).clone()
+        assert torch.equal(lg, le), k
+        assert torch.equal(mg.flat, me.flat), k
+        # teacher-forced replay of the device's draws at the pre-step weights
+        st = E.TrainState(before, B)
+        E.loss_and_grad(before, st, x0, te.state.noise, te.state.t)
+        assert torch.equal(st.loss, le) and torch.equal(st.grads, te.grads), k
+    assert tg.state.graph is not None and te.state.graph is None
+    assert tg.steps_taken == te.steps_taken == 6
+    # the drawn t of the last step are the generator's integers (offset 5 = sixth call)
+    assert torch.equal(te.state.t.cpu(), O.philox_steps(te.seed, 5, B))
+    # and the oracle agrees with the device-drawn step end to end
+    p = {k: v.cpu() for k, v in E.state_dict_from_flat(before).items()}
+    loss_ref, _ = O.unet_loss_and_grads(p, x0.cpu(), te.state.t.cpu(), te.state.noise.cpu(), golden_tables)
+    assert abs(le.item() - loss_ref.item()) < 1e-4 * abs(loss_ref.item())
+
+
+def test_trainer_serves_ragged_batch_sizes_with_one_optimizer_state(dev, L, golden_dir):
+    """src/mnist.py:146-147 has no drop_last: the last batch of an epoch is smaller.  One trainer, two batch sizes,
+    shared AdamW moments / step count; the tail step weights the local gradient by B_local / global_batch."""
+    m, tr = _fresh_trainer(dev, golden_dir, 16, True)
+    g = torch.Generator().manual_seed(4)
+    xa = (torch.rand(16, 1, 28, 28, generator=g) * 2 - 1).to(dev)
+    xb = (torch.rand(5, 1, 28, 28, generator=g) * 2 - 1).to(dev)
+    for _ in range(3):
+        tr.step(xa)
+    p_before = m.flat.detach().clone()
+    tr.step(xb, global_batch=5)                                  # world 1: weight 5/5
+    assert tr.steps_taken == 4 and not torch.equal(m.flat, p_before)
+    assert tr.state.B == 5 and set(tr._states) == {16, 5}
+    assert tr._states[16].m is tr._states[5].m is tr.m
+    tr.step(xa)
+    assert tr.steps_taken == 5 and torch.isfinite(m.flat).all()
+
+
+# ------------------------------------------------------------ captured reverse step
+def test_graph_sampler_device_noise_equals_eager_chain_with_same_draws(dev, L, golden_dir):
+    """The hipGraph reverse loop with device-drawn noise (one C-ABI call per step) against the eager,
+    teacher-forced loop fed the SAME Philox draws: bitwise equal after 20 steps (src/mnist.py:190-193)."""
+    from tinydiffusionmodels_amd import _lib
+    from tinydiffusionmodels_amd.mnist import reverse_diffusion
+    m, _ = _fresh_trainer(dev, golden_dir, 4, False)
+    n, steps = 6, 20
+    x = torch.randn(n, 1, 28, 28, generator=torch.Generator().manual_seed(12)).to(dev)
+    torch.manual_seed(7)
+    with torch.no_grad():
+        got = reverse_diffusion(m, x, t_start=steps - 1, use_graph=True)
+    sampler = next(iter(m._samplers.values()))
+    assert sampler.graph is not None and sampler.rng_state.cpu().tolist() == [steps, 0]
+    assert sampler.t_vec.cpu().tolist() == [0] * n
+    zs = []
+    for k in range(steps):
+        z = torch.empty_like(x)
+        _lib.check(L.tdm_philox_normal_f32(sampler.seed, k, _lib.ptr(z), z.numel(), _lib.stream()))
+        zs.append(z)
+    with torch.no_grad():
+        want = reverse_diffusion(m, x, noises=zs, t_start=steps - 1, use_graph=False)
+    assert torch.equal(got, want)
+
+
+# ---------------------------------------------------------------- RCCL, world 1
+def test_native_rccl_world1_allreduce_broadcast_and_graph_capture(dev, L):
+    """tdm_ctx_create / tdm_comm_init / tdm_allreduce_sum_f32 over a real RCCL communicator of one rank (all a
+    one-GPU box allows): sum over one rank = identity, enqueued on the caller's stream, and capturable into a
+    hipGraph together with AdamW (the N-rank form of the train step).  Multi-rank arithmetic is covered on CPU
+    (gloo) by tests/test_dp_gloo.py and with two processes on this GPU by tests/test_gpu_dp.py."""
+    from tinydiffusionmodels_amd import dp, unet_engine as E
+    assert L.tdm_comm_rccl_version() >= 20000
+    uid = dp.NativeComm.make_unique_id()
+    assert len(uid) == L.tdm_comm_unique_id_bytes() == 128
+    comm = dp.NativeComm(0, 0, 1, uid)
+    assert L.tdm_comm_world(comm.ctx) == 1 and L.tdm_comm_rank(comm.ctx) == 0
+    buf = torch.randn(E.NPARAM, generator=torch.Generator().manual_seed(0)).to(dev)
+    want = buf.clone()
+    comm.allreduce_sum_(buf)
+    comm.broadcast_(buf, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(buf, want)
+    # inside a hipGraph, followed by the device-step AdamW
+    p = torch.zeros(E.NPARAM, device=dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    state = torch.zeros(2, dtype=torch.long, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        comm.allreduce_sum_(buf)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        comm.allreduce_sum_(buf)
+        E.adamw_step_dev(p, buf, m, v, state, lr=1e-3)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert state.cpu().tolist() == [3, 0] and torch.equal(buf, want) and torch.isfinite(p).all() and p.abs().max() > 0
+    comm.close()
+    # a context without a communicator refuses the collective with rc != 0 and a message (no abort, no hang)
+    from tinydiffusionmodels_amd import _lib
+    ctx = ctypes.c_void_p()
+    _lib.check(L.tdm_ctx_create(0, ctypes.byref(ctx)))
+    assert L.tdm_allreduce_sum_f32(ctx, _lib.ptr(buf), buf.numel(), _lib.stream()) != 0
+    assert b"not initialised" in L.tdm_last_error()
+    assert L.tdm_ctx_destroy(ctx) == 0

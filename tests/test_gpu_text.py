@@ -322,10 +322,57 @@ def test_denoiser_trainer_step_matches_oracle_adamw(dev, golden_tables, gemm_mod
     tr.step(x0.to(dev), t=t.to(dev), noise=noise.to(dev))
     sd = m.state_dict()
     lr = 1e-4
+    got, want, start = [], [], []
     for k in p:
         ref, _, _ = O.adamw_step(p[k], grads[k], torch.zeros_like(p[k]), torch.zeros_like(p[k]), 1, lr=lr,
                                  weight_decay=1e-4)
-        assert (sd[k].cpu() - ref).abs().max().item() < (0.05 if gemm_mode == 0 else 2.1) * lr, k
+        got.append(sd[k].cpu().reshape(-1)); want.append(ref.reshape(-1)); start.append(p[k].reshape(-1))
+    got, want, start = torch.cat(got), torch.cat(want), torch.cat(start)
+    err = (got - want).abs()
+    if gemm_mode == 0:
+        assert err.max().item() < 0.05 * lr
+    else:
+        # Adam's first step moves every element by lr * sign(g): bf16-level gradient noise flips that sign only where
+        # |g| is ~0.  Asserted: nearly all elements within 5 % of an lr-sized update, and the update as a whole agrees.
+        frac = (err < 0.05 * lr).float().mean().item()
+        rel_l2 = ((got - want).norm() / (want - start).norm()).item()
+        assert frac > (0.98 if gemm_mode == 1 else 0.90), frac
+        assert rel_l2 < (0.10 if gemm_mode == 1 else 0.30), rel_l2
+
+
+def test_full_size_properties_config5(dev, gemm_mode):
+    """BASELINE config 5 size (B=256, L=128, D=256; 32,768 tokens): sequences are independent (a slice of the batch
+    gives bitwise the same output), and the batch gradient of the mean loss equals the mean of the per-chunk
+    gradients (linearity; same arithmetic on both sides) — src/shakespeare.py:105-120, :230-236."""
+    if gemm_mode != 1:
+        pytest.skip("full-size properties run once, in the default (parity) arithmetic")
+    from tinydiffusionmodels_amd import transformer_engine as TE
+    dim, B, L = 256, 256, 128
+    m = _model(dim, dev)
+    m.eval()
+    g = torch.Generator(device=dev).manual_seed(21)
+    x0 = torch.randn(B, L, dim, device=dev, generator=g) * 0.02
+    noise = torch.randn(B, L, dim, device=dev, generator=g)
+    t = torch.randint(0, 1000, (B,), device=dev, generator=g)
+    with torch.no_grad():
+        full = m(x0, t)
+        part = m(x0[100:108].contiguous(), t[100:108].contiguous())
+    assert torch.isfinite(full).all()
+    assert torch.equal(full[100:108], part)
+    flat = m.flat.detach()
+    st = TE.TTTrainState(m.cfg, flat, B, L)
+    TE.tt_loss_and_grad(flat, st, x0, noise, t)
+    g_full, loss_full = st.grads.clone(), st.loss.clone()
+    st64 = TE.TTTrainState(m.cfg, flat, 64, L)
+    acc, lacc = torch.zeros_like(g_full), 0.0
+    for c in range(4):
+        s = slice(c * 64, (c + 1) * 64)
+        TE.tt_loss_and_grad(flat, st64, x0[s].contiguous(), noise[s].contiguous(), t[s].contiguous())
+        acc += st64.grads
+        lacc += st64.loss.item()
+    assert abs(loss_full.item() - lacc / 4) < 1e-5 * abs(loss_full.item())
+    assert O.rel_err(g_full, acc / 4) < 5e-5
+    del st, st64
 
 
 def test_train_mode_default_dropout_and_bad_rate(dev):

@@ -301,10 +301,21 @@ def test_unet_train_two_steps_golden(dev, lib, conv_mode, golden_dir):
             for k, v in grads.items():
                 assert O.rel_err(v.cpu(), g[f"s1.grad.{k}"]) < _gtol(), k
         sd = m.state_dict()
-        for k, v in sd.items():
-            # bf16x3 at B=4: a near-zero gradient element may flip sign (ReLU-mask flip), i.e. +lr vs -lr
-            bound = (0.05 if conv_mode == 0 else 2.1) * lr * step
-            assert (v.cpu() - g[f"s{step}.param.{k}"]).abs().max().item() < bound, (step, k)
+        got = torch.cat([v.cpu().reshape(-1) for v in sd.values()])
+        want = torch.cat([g[f"s{step}.param.{k}"].reshape(-1) for k in sd])
+        err = (got - want).abs()
+        if conv_mode == 0:
+            assert err.max().item() < 0.05 * lr * step, step
+        else:
+            # bf16x3 at B=4: the ~1e-5 forward difference flips a handful of near-zero ReLU pre-activations, and
+            # Adam's g / (|g| + eps) turns the resulting gradient differences on near-zero gradient ELEMENTS into
+            # O(lr) parameter differences there.  Asserted: all but a small fraction of the 181,473 parameters
+            # within 5 % of one lr-sized update, and the update as a whole agrees (relative L2 over what moved).
+            frac = (err < 0.05 * lr * step).float().mean().item()
+            assert frac > 0.98, (step, frac)
+            p0 = torch.cat([_weights(_load(golden_dir, "unet_forward.npz"))[k].reshape(-1) for k in sd])
+            rel_l2 = ((got - want).norm() / (want - p0).norm()).item()
+            assert rel_l2 < 0.10, (step, rel_l2)
 
 
 @pytest.mark.parametrize("B", [3, 37])
@@ -328,6 +339,112 @@ def test_unet_grads_oracle_and_autograd_bridge(dev, model, golden_dir, golden_ta
     for k, v in grads_ref.items():
         assert O.rel_err(got[k].cpu(), v) < _gtol(), k
     model.zero_grad()
+
+
+def _mask_io(ws, B, block, which, mask=None):
+    """Read (mask=None) or install the ReLU sign mask of block / conv `which` as a (B,C,H,W) uint8 tensor."""
+    from tinydiffusionmodels_amd import _lib
+    C, hw = ((32, 28), (64, 14), (64, 14), (32, 28))[block]
+    buf = torch.empty(B, C, hw, hw, dtype=torch.uint8, device=ws.ws.device) if mask is None else mask.contiguous()
+    _lib.check(_lib.lib().tdm_unet_relu_mask_io(_lib.ptr(ws.ws), B, block, which, _lib.ptr(buf), 0 if mask is None else 1,
+                                                _lib.stream()), "relu_mask_io")
+    return buf
+
+
+@pytest.mark.parametrize("B", [4, 37])
+def test_unet_grads_teacher_forced_relu_masks(dev, model, conv_mode, golden_dir, golden_tables, B):
+    """The claim behind _gtol(): in the default (bf16x3) arithmetic the end-to-end gradient differs from the
+    reference's by up to ~2e-3 ONLY because a few near-zero ReLU pre-activations change sign (a 1e-5 forward
+    difference).  Tested here: (1) the product's own masks differ from the oracle's in a handful of entries,
+    every one of them at a pre-activation within 1e-4 of zero; (2) with the ORACLE's masks installed in the
+    workspace (teacher forcing through the C ABI) the same backward kernels reproduce the reference gradients
+    to 2e-4 — 25x tighter than the end-to-end bound (src/mnist.py:158-159)."""
+    if conv_mode != 2:
+        pytest.skip("byte masks exist in the default (S16) pipeline; fp32 mode is held to 5e-5 end to end")
+    from tinydiffusionmodels_amd import _lib, unet_engine as E
+    from tinydiffusionmodels_amd.mnist import q_sample
+    p = _weights(_load(golden_dir, "unet_forward.npz"))
+    g = torch.Generator().manual_seed(100 + B)
+    x0 = torch.rand(B, 1, 28, 28, generator=g) * 2 - 1
+    t = torch.randint(0, 1000, (B,), generator=g)
+    noise = torch.randn(B, 1, 28, 28, generator=g)
+    _, grads_ref = O.unet_loss_and_grads(p, x0, t, noise, golden_tables)
+    xq_ref = O.q_sample(x0, t, noise, golden_tables)
+    _, inter = O.unet_forward(p, xq_ref, t, return_intermediates=True)
+    flat = model.flat.detach()
+    xq = q_sample(x0.to(dev), t.to(dev), noise.to(dev))
+    ws = E.UNetWorkspace(B, dev, training=True)
+    eps = E.unet_forward(flat, xq, t.to(dev), ws, save=True)
+    deps = (2.0 / eps.numel()) * (eps - noise.to(dev))
+    # (1) the product's masks vs the oracle's
+    flipped = total = 0
+    for blk, name in enumerate(("rb1", "rb2", "rb3", "rb4")):
+        for which in (1, 2):
+            a = inter[f"{name}.a{which}"]
+            mine = _mask_io(ws, B, blk, which).cpu().bool()
+            diff = mine != (a > 0)
+            flipped += int(diff.sum())
+            total += diff.numel()
+            assert (a[diff].abs() < 1e-4).all(), (name, which)      # only at the ReLU's kink
+    assert flipped <= max(8, total // 20000), (flipped, total)        # measured: a few per 10^5
+    e2e = E.state_dict_from_flat(E.unet_backward(flat, xq, deps, ws))
+    worst_e2e = max(O.rel_err(e2e[k].cpu(), v) for k, v in grads_ref.items())
+    # (2) teacher-forced masks
+    for blk, name in enumerate(("rb1", "rb2", "rb3", "rb4")):
+        for which in (1, 2):
+            _mask_io(ws, B, blk, which, (inter[f"{name}.a{which}"] > 0).to(torch.uint8).to(dev))
+    tf = E.state_dict_from_flat(E.unet_backward(flat, xq, deps, ws))
+    worst_tf = max(O.rel_err(tf[k].cpu(), v) for k, v in grads_ref.items())
+    print(f"B={B}: {flipped} of {total} mask entries flipped; grad rel err end-to-end {worst_e2e:.2e}, teacher-forced {worst_tf:.2e}")
+    assert worst_tf < 2e-4, worst_tf
+    assert worst_e2e < _gtol()
+    if flipped == 0:
+        assert worst_e2e < 2e-4
+
+
+def test_schedule_tables_of_this_host(lib, golden_dir):
+    """a1 on the box the tests run on, with the schedule NOT pinned: betas / alphas / alphas_cumprod are
+    host-independent and must be bit-equal to the reference's (src/mnist.py:28-31; SURVEY.md §8 a1 sha256);
+    the two sqrt tables go through the host's libm / MKL and may differ from the golden host's by 1 ulp
+    (the reference's own module globals would, too) — the count is printed."""
+    import hashlib
+    from tinydiffusionmodels_amd import schedule
+    g = _load(golden_dir, "schedule.npz")
+    own = schedule.make_tables()
+    want_sha = {"betas": "a455de8584c2913e", "alphas": "b32d9a7d2718af05", "alphas_cumprod": "b5555536933367c4"}
+    for k, h in want_sha.items():
+        assert torch.equal(own[k], g[k]), k
+        assert hashlib.sha256(own[k].numpy().tobytes()).hexdigest()[:16] == h, k
+    for k in ("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod"):
+        a, b = own[k].view(torch.int32), g[k].view(torch.int32)
+        ulp = (a - b).abs()
+        print(f"{k}: {int((ulp != 0).sum())} of 1000 entries differ from the golden host's, max {int(ulp.max())} ulp")
+        assert int(ulp.max()) <= 1, k
+
+
+def test_full_size_properties_b4096_sampler(dev, model, conv_mode):
+    """BASELINE config 4 size (B=4096 reverse steps): one reverse step is independent of the rest of the batch
+    (bitwise), the hipGraph-captured chain equals the eager chain bitwise (teacher-forced noise bank), and the
+    device-noise graph path stays finite (src/mnist.py:190-193)."""
+    if conv_mode != 2:
+        pytest.skip("full-size sampler properties run once, in the default arithmetic")
+    from tinydiffusionmodels_amd.mnist import reverse_diffusion, p_sample
+    B = 4096
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.randn(B, 1, 28, 28, device=dev, generator=g)
+    zs = [torch.randn(B, 1, 28, 28, device=dev, generator=g) for _ in range(4)]
+    with torch.no_grad():
+        t = torch.full((B,), 321, dtype=torch.long, device=dev)
+        full = p_sample(model, x, t, noise=zs[0])
+        sl = slice(2000, 2016)
+        part = p_sample(model, x[sl].contiguous(), t[sl].contiguous(), noise=zs[0][sl].contiguous())
+        assert torch.equal(full[sl], part)
+        a = reverse_diffusion(model, x, noises=zs, t_start=3, use_graph=False)
+        b = reverse_diffusion(model, x, noises=zs, t_start=3, use_graph=True)
+        assert torch.equal(a, b)
+        c = reverse_diffusion(model, x, t_start=15, use_graph=True)
+        assert torch.isfinite(c).all() and c.shape == x.shape
+    model._samplers.clear()
 
 
 # ------------------------------------------------------------------ sampling

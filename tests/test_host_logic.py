@@ -22,7 +22,7 @@ def test_library_exports_every_header_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/tdm_hip.h but not exported"
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
-    assert L.tdm_version() == 100
+    assert L.tdm_version() == 200
 
 
 def test_layout_matches_library_and_param_count():
@@ -147,3 +147,58 @@ def test_text_corpus_pipeline(tmp_path):
     allrows = torch.stack([train[i] for i in range(len(train))] + [val[i] for i in range(len(val))])
     assert sorted(map(tuple, allrows.tolist())) == sorted(map(tuple, torch.tensor(list(text.encode()))[: n_chunks * 16].view(-1, 16).tolist()))
     assert tok.batch_decode(torch.tensor([list(b"hello")])) == ["hello"]
+
+
+def test_philox_host_matches_oracle_restatement():
+    """csrc/tdm_philox.h evaluated on the host vs the numpy restatement in the oracle: Random123's known
+    answer, and random (seed, offset, index, kind) points — integer arithmetic, bit-exact."""
+    import ctypes
+    from oracle import ddpm_oracle as O
+    L = _lib.lib()
+    assert [hex(v) for v in O.philox4x32_10(np.zeros((1, 4), np.uint32), (0, 0))[0]] == \
+        ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    rng = np.random.default_rng(0)
+    out = (ctypes.c_uint32 * 4)()
+    for _ in range(50):
+        seed, off, idx = (int(v) for v in rng.integers(0, 2 ** 63, 3, dtype=np.uint64))
+        idx &= (1 << 60) - 1
+        kind = int(rng.integers(0, 2))
+        assert L.tdm_philox_u32_host(seed, off, kind, idx, out) == 0
+        assert list(out) == O.philox_words(seed, off, np.array([idx], dtype=np.uint64), kind)[0].tolist()
+    t = O.philox_steps(3, 9, 4096)
+    assert t.dtype == torch.int64 and 0 <= int(t.min()) and int(t.max()) <= 999
+    z = O.philox_normals(3, 9, 1 << 16)
+    assert abs(z.mean().item()) < 0.02 and abs(z.std().item() - 1) < 0.02
+
+
+def test_s16_pipeline_refuses_batches_beyond_its_32bit_addressing():
+    """The default conv arithmetic addresses with 24-bit pixel indices (B * 784 < 2^23): B = 16,384 must come back
+    as rc != 0 with a message — not as silently wrong reads (conv_s16.hip guards).  Argument checks
+    run before any pointer is touched, so this needs no GPU."""
+    L = _lib.lib()
+    assert L.tdm_get_conv_mode() == 2
+    for B in (16384, 10700):
+        assert L.tdm_unet_fwd_f32(None, None, None, None, None, B, 0, None) != 0
+        msg = L.tdm_last_error().decode()
+        assert "out of range" in msg and "10699" in msg, msg
+        assert L.tdm_unet_loss_grad_f32(*([None] * 13), B, None) != 0
+        assert L.tdm_conv_nhwc_s16_f32(*([None] * 10), B, 28, 32, 32, 3, 0, None) != 0
+        assert L.tdm_conv_wgrad_nhwc_s16_f32(*([None] * 5), B, 28, 32, 32, 3, None) != 0
+    # the largest admitted batch passes the range check and fails on the NULL pointers instead
+    assert L.tdm_unet_fwd_f32(None, None, None, None, None, 10699, 0, None) != 0
+    assert "NULL" in L.tdm_last_error().decode()
+    # the 64-bit-indexed arithmetics keep the 16,384 limit
+    _lib.check(L.tdm_set_conv_mode(0))
+    try:
+        assert L.tdm_unet_fwd_f32(None, None, None, None, None, 16384, 0, None) != 0
+        assert "NULL" in L.tdm_last_error().decode()
+        assert L.tdm_unet_fwd_f32(None, None, None, None, None, 16385, 0, None) != 0
+        assert "out of range" in L.tdm_last_error().decode()
+    finally:
+        _lib.check(L.tdm_set_conv_mode(2))
+
+
+def test_set_tables_retires_captured_samplers():
+    gen = schedule.schedule_generation()
+    schedule.set_tables(None)
+    assert schedule.schedule_generation() == gen + 1

@@ -33,6 +33,10 @@ _SIGS = {
     "tdm_unet_fwd_f32": ([c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_f], c_int),
     "tdm_unet_bwd_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_f], c_int),
     "tdm_unet_get_activation": ([c_f, c_i64, c_int, c_f, c_f], c_int),
+    "tdm_unet_relu_mask_io": ([c_f, c_i64, c_int, c_int, c_f, c_int, c_f], c_int),
+    "tdm_unet_launch_count": ([], c_int),
+    "tdm_unet_launch_name": ([c_int], ctypes.c_char_p),
+    "tdm_unet_replay_launch_f32": ([c_f] * 8 + [c_i64, c_int, c_f], c_int),
     "tdm_mse_fwd_bwd_f32": ([c_f, c_f, c_f, c_f, c_f, c_i64, c_f], c_int),
     "tdm_adamw_flat_f32": ([c_f, c_f, c_f, c_f, c_i64, c_float, c_float, c_float, c_float, c_float, c_i64,
                             c_float, c_f], c_int),
@@ -66,6 +70,25 @@ _SIGS = {
     "tdm_round_ce_loss_grad_f32": ([c_f, c_f, c_f, c_f, c_float, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_f], c_int),
     "tdm_round_logits_f32": ([c_f, c_f, c_f, c_f, c_i64, c_i64, c_int, c_int, c_f], c_int),
     "tdm_round_argmax_f32": ([c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_f], c_int),
+    "tdm_philox_normal_f32": ([c_u64, c_u64, c_f, c_i64, c_f], c_int),
+    "tdm_philox_u32": ([c_u64, c_u64, c_int, c_f, c_i64, c_f], c_int),
+    "tdm_philox_u32_host": ([c_u64, c_u64, c_int, c_u64, ctypes.POINTER(ctypes.c_uint32)], c_int),
+    "tdm_ddpm_draw_q_sample_f32": ([c_f, c_f, c_f, c_u64, c_f, c_f, c_f, c_f, c_i64, c_i64, c_f], c_int),
+    "tdm_p_sample_update_philox_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_u64, c_f, c_f, c_i64, c_i64, c_f], c_int),
+    "tdm_adamw_flat_devstep_f32": ([c_f, c_f, c_f, c_f, c_i64, c_float, c_float, c_float, c_float, c_float, c_f,
+                                    c_float, c_f], c_int),
+    "tdm_unet_loss_grad_philox_f32": ([c_f, c_f, c_f, c_f, c_u64] + [c_f] * 10 + [c_i64, c_f], c_int),
+    "tdm_unet_p_sample_step_philox_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_u64, c_f, c_f, c_f, c_f, c_i64, c_f], c_int),
+    "tdm_ctx_create": ([c_int, ctypes.POINTER(ctypes.c_void_p)], c_int),
+    "tdm_ctx_destroy": ([c_f], c_int),
+    "tdm_comm_unique_id_bytes": ([], c_int),
+    "tdm_comm_unique_id": ([ctypes.c_char_p], c_int),
+    "tdm_comm_init": ([c_f, ctypes.c_char_p, c_int, c_int], c_int),
+    "tdm_comm_rank": ([c_f], c_int),
+    "tdm_comm_world": ([c_f], c_int),
+    "tdm_comm_rccl_version": ([], c_int),
+    "tdm_allreduce_sum_f32": ([c_f, c_f, c_i64, c_f], c_int),
+    "tdm_broadcast_f32": ([c_f, c_f, c_i64, c_int, c_f], c_int),
     "tdm_gemm_f32": ([c_f, c_i64, c_i64, c_f, c_i64, c_i64, c_f, c_i64, c_f, c_f, c_int, c_int, c_int, c_int, c_int,
                       c_i64, c_f], c_int),
 }

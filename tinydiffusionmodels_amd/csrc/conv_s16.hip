@@ -1215,7 +1215,14 @@ int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st) {
                 "conv_s16: the fused output conv is built for the 28x28 N = 32 kernel");
     TDM_REQUIRE(a.r1_x == nullptr || (hw == 28 && N == 32 && a.skip_out == nullptr && a.res == nullptr && a.r1_w != nullptr && a.r1_b != nullptr),
                 "conv_s16: the rank-1 residual is built for the 28x28 N = 32 kernel without another residual");
-    TDM_REQUIRE(a.B > 0 && (long)a.B * hw * hw * 96 < 2147483647L, "conv_s16: batch %d out of range", a.B);
+    // 32-bit addressing limits of the S16 kernels: staged-row offsets are built with __mul24 on the pixel index
+    // (24-bit operands: B * hw * hw < 2^23) and held as SIGNED byte offsets with 0x80000000 = "padding"
+    // (every source / epilogue tensor < 2^31 bytes; implied by the pixel bound for <= 64 channels, checked for the rest)
+    TDM_REQUIRE(a.B > 0 && (long)a.B * hw * hw < TDM_S16_MAX_PIXELS,
+                "conv_s16: batch %d out of range (B * %d * %d must stay below 2^23 pixels: 32-bit S16 addressing)", a.B, hw, hw);
+    for (int i = 0; i < a.nsrc; ++i)
+        TDM_REQUIRE((long)a.B * (hw >> a.src[i].up) * (hw >> a.src[i].up) * a.src[i].C * 4 < 2147483647L,
+                    "conv_s16: source %d of batch %d exceeds 2^31 bytes", i, a.B);
     if (a.skip_out != nullptr) {   // fused 1x1 skip conv: built for the one geometry that uses it (rb4: 96 -> 32 @ 28x28)
         TDM_REQUIRE(hw == 28 && N == 32 && a.skip_wp != nullptr && a.skip_bias != nullptr, "conv_s16: fused skip needs hw=28, N=32");
         for (int i = 0; i < a.nsrc; ++i) TDM_REQUIRE(a.src[i].taps == 9, "conv_s16: fused skip rides on 3x3 sources");
@@ -1235,7 +1242,10 @@ int tdm_launch_wgrad_s16(const WgradArgs& a, int hw, int nslab, hipStream_t st) 
     TDM_REQUIRE(a.a.taps == 9 || a.a.taps == 1, "wgrad_s16: taps must be 9 or 1");
     TDM_REQUIRE((a.a.C % 16) == 0 && (a.a.c0 % 16) == 0 && a.a.tb == nullptr, "wgrad_s16: S16 source layout");
     TDM_REQUIRE(nslab >= 1 && nslab <= TDM_UNET_MAX_SLABS, "wgrad_s16: nslab %d", nslab);
-    TDM_REQUIRE(a.B > 0 && (long)a.B * hw * hw * 96 < 2147483647L, "wgrad_s16: batch %d out of range", a.B);
+    TDM_REQUIRE(a.B > 0 && (long)a.B * hw * hw < TDM_S16_MAX_PIXELS,
+                "wgrad_s16: batch %d out of range (B * %d * %d must stay below 2^23 pixels: 32-bit S16 addressing)", a.B, hw, hw);
+    TDM_REQUIRE((long)a.B * (hw >> a.a.up) * (hw >> a.a.up) * a.a.C * 4 < 2147483647L && (long)a.B * hw * hw * a.Cout * 4 < 2147483647L,
+                "wgrad_s16: a tensor of batch %d exceeds 2^31 bytes", a.B);
     TDM_REQUIRE(a.g2 == nullptr || (g_wgrad_form == 2 && a.a.taps == 9), "wgrad_s16: the fused 1x1 gradient rides on the 3x3 producer/consumer kernel");
     if (g_wgrad_form == 2) {
         if (hw == 28) return a.g2 ? launch_wgrad2_t<28, true>(a, nslab, st) : launch_wgrad2_t<28, false>(a, nslab, st);

@@ -1072,6 +1072,33 @@ int tdm_launch_combine_dh1_mask_s16(const float* dcat, const float* dp1, const u
     return 0;
 }
 
+// ReLU byte masks <-> one 0/1 byte per element in NCHW (test accessor: teacher-forced masks)
+namespace {
+__global__ __launch_bounds__(EW_BLOCK) void mask_io_kernel(unsigned char* __restrict__ packed, unsigned char* __restrict__ nchw,
+                                                           int B, int HWpix, int C, int write) {
+    const int C4 = C >> 2;
+    const int64_t total = (int64_t)B * HWpix * C4;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c4 = (int)(i % C4);
+        const int64_t m = i / C4;
+        const int64_t b = m / HWpix, p = m - b * HWpix;
+        unsigned char* e = nchw + (b * C + c4 * 4) * HWpix + p;
+        if (write) {
+            packed[i] = (unsigned char)((e[0] ? 1 : 0) | (e[HWpix] ? 2 : 0) | (e[2 * (int64_t)HWpix] ? 4 : 0) | (e[3 * (int64_t)HWpix] ? 8 : 0));
+        } else {
+            const unsigned mk = packed[i];
+            e[0] = mk & 1u; e[HWpix] = (mk >> 1) & 1u; e[2 * (int64_t)HWpix] = (mk >> 2) & 1u; e[3 * (int64_t)HWpix] = (mk >> 3) & 1u;
+        }
+    }
+}
+}  // namespace
+int tdm_launch_mask_io(unsigned char* packed, unsigned char* nchw, int B, int HWpix, int C, int write, hipStream_t st) {
+    hipLaunchKernelGGL(mask_io_kernel, dim3(ew_grid((int64_t)B * HWpix * (C / 4))), dim3(EW_BLOCK), 0, st, packed, nchw, B,
+                       HWpix, C, write);
+    TDM_CHECK_LAUNCH("mask_io");
+    return 0;
+}
+
 // ------------------------------- C ABI ---------------------------------------
 extern "C" {
 

@@ -1,0 +1,216 @@
+// Device-side randomness and device-side step counting for the DDPM loops, so that a whole
+// train step / reverse step is ONE hipGraph-replayable launch sequence with no host-written
+// scalars: the Philox offset, the reverse-step index and AdamW's step count all live in
+// device memory and are advanced by the kernels that consume them (last-arriving workgroup).
+//   * draw_q_sample_kernel: t ~ U{0..999}, noise ~ N(0,1), x_noisy = q_sample(x0, t, noise)
+//     (src/mnist.py:154-156) — replaces randint + randn + q_sample (three launches, one
+//     write + one read of the noise) by one pass;
+//   * p_update_philox_kernel: x_{t-1} = p_sample update with z drawn in registers
+//     (src/mnist.py:173-180), then t -= 1 — replaces randn + update + the t decrement;
+//   * adamw_devstep_kernel: torch.optim.AdamW with the bias corrections derived on the
+//     device from a device-resident step count (src/mnist.py:148,159).
+// The arithmetic of q_sample / the update / AdamW is the same as in elementwise.hip
+// (separately rounded mul / add, no FMA contraction).
+#include "tdm_common.h"
+#include "tdm_philox.h"
+#include <math.h>
+
+namespace {
+
+constexpr int RB = 256;
+inline int rng_grid(int64_t nwork) {
+    int64_t g = (nwork + RB - 1) / RB;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// true in exactly one workgroup: the one whose arrival completes the grid.  Every workgroup
+// calls it after its last read of the state the caller is about to advance.
+__device__ __forceinline__ bool last_block_arrives(unsigned* counter) {
+    __shared__ int is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned old = atomicAdd(counter, 1u);
+        is_last = (old == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    return is_last != 0;
+}
+
+__global__ __launch_bounds__(RB) void philox_normal_kernel(uint64_t seed, uint64_t offset, float* __restrict__ out, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * RB)
+        reinterpret_cast<float4*>(out)[i] = tdm_philox_normal4(seed, offset, (uint64_t)i);
+}
+
+__global__ __launch_bounds__(RB) void philox_u32_kernel(uint64_t seed, uint64_t offset, int kind, uint32_t* __restrict__ out,
+                                                       int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * RB) {
+        const tdm_u32x4 r = tdm_philox_at(seed, offset, (uint64_t)i, kind);
+        reinterpret_cast<uint4*>(out)[i] = make_uint4(r.x, r.y, r.z, r.w);
+    }
+}
+
+// state[0] = Philox offset of this call (advanced by 1 on exit), state[1] = arrival counter (0 between calls)
+__global__ __launch_bounds__(RB) void draw_q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ ta,
+                                                           const float* __restrict__ ts, uint64_t seed,
+                                                           int64_t* __restrict__ state, int64_t* __restrict__ t_out,
+                                                           float* __restrict__ noise_out, float* __restrict__ xn_out,
+                                                           int64_t B, int64_t inner4) {
+    const uint64_t offset = (uint64_t)state[0];
+    const int64_t n4 = B * inner4;
+    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * RB) {
+        const int64_t b = i / inner4;
+        const int64_t tt = tdm_philox_step(seed, offset, (uint64_t)b, TDM_TIMESTEPS);
+        if (i - b * inner4 == 0) t_out[b] = tt;
+        const float a = ta[tt], s = ts[tt];
+        const float4 x = reinterpret_cast<const float4*>(x0)[i];
+        const float4 n = tdm_philox_normal4(seed, offset, (uint64_t)i);
+        float4 o;
+        o.x = __fadd_rn(__fmul_rn(a, x.x), __fmul_rn(s, n.x));
+        o.y = __fadd_rn(__fmul_rn(a, x.y), __fmul_rn(s, n.y));
+        o.z = __fadd_rn(__fmul_rn(a, x.z), __fmul_rn(s, n.z));
+        o.w = __fadd_rn(__fmul_rn(a, x.w), __fmul_rn(s, n.w));
+        reinterpret_cast<float4*>(noise_out)[i] = n;
+        reinterpret_cast<float4*>(xn_out)[i] = o;
+    }
+    if (last_block_arrives(reinterpret_cast<unsigned*>(state + 1)) && threadIdx.x == 0) {
+        state[0] = (int64_t)(offset + 1);
+        *reinterpret_cast<unsigned*>(state + 1) = 0u;
+    }
+}
+
+__device__ __forceinline__ float p_upd(float x, float e, float z, float cr, float ce, float cs) {
+    return __fadd_rn(__fmul_rn(cr, __fsub_rn(x, __fmul_rn(ce, e))), __fmul_rn(cs, z));
+}
+
+// t: per-sample step index in DEVICE memory, decremented (floor 0) on exit; tsg[0] must be 0 so that the
+// t == 0 step returns the mean (src/mnist.py:176-177) without a host-side branch
+__global__ __launch_bounds__(RB) void p_update_philox_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                             const float* __restrict__ tr, const float* __restrict__ te,
+                                                             const float* __restrict__ tsg, int64_t* __restrict__ t,
+                                                             uint64_t seed, int64_t* __restrict__ state,
+                                                             float* __restrict__ out, int64_t B, int64_t inner4) {
+    const uint64_t offset = (uint64_t)state[0];
+    const int64_t n4 = B * inner4;
+    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * RB) {
+        const int64_t tt = t[i / inner4];
+        const float cr = tr[tt], ce = te[tt], cs = tsg[tt];
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        const float4 ev = reinterpret_cast<const float4*>(eps)[i];
+        const float4 zv = tdm_philox_normal4(seed, offset, (uint64_t)i);
+        float4 o;
+        o.x = p_upd(xv.x, ev.x, zv.x, cr, ce, cs);
+        o.y = p_upd(xv.y, ev.y, zv.y, cr, ce, cs);
+        o.z = p_upd(xv.z, ev.z, zv.z, cr, ce, cs);
+        o.w = p_upd(xv.w, ev.w, zv.w, cr, ce, cs);
+        reinterpret_cast<float4*>(out)[i] = o;
+    }
+    if (last_block_arrives(reinterpret_cast<unsigned*>(state + 1))) {
+        for (int64_t b = threadIdx.x; b < B; b += RB) {
+            const int64_t v = t[b] - 1;
+            t[b] = v < 0 ? 0 : v;
+        }
+        if (threadIdx.x == 0) {
+            state[0] = (int64_t)(offset + 1);
+            *reinterpret_cast<unsigned*>(state + 1) = 0u;
+        }
+    }
+}
+
+// AdamW with the step count in device memory: state[0] = steps taken so far (this call performs step state[0] + 1
+// and stores it), state[1] = arrival counter.  Same update as adamw_kernel (elementwise.hip); the scalar prologue
+// runs in double like torch's Python floats.
+__global__ __launch_bounds__(RB) void adamw_devstep_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                           float lr, float beta1, float beta2, float eps, float wd,
+                                                           int64_t* __restrict__ state, float gscale) {
+    __shared__ float sc[2];
+    const int64_t step = state[0] + 1;
+    if (threadIdx.x == 0) {
+        const double bc1 = 1.0 - pow((double)beta1, (double)step);
+        const double bc2 = 1.0 - pow((double)beta2, (double)step);
+        sc[0] = (float)((double)lr / bc1);
+        sc[1] = (float)sqrt(bc2);
+    }
+    __syncthreads();
+    const float step_size = sc[0], bc2_sqrt = sc[1];
+    const float decay = (float)(1.0 - (double)lr * (double)wd);
+    const float one_m_b1 = (float)(1.0 - (double)beta1), one_m_b2 = (float)(1.0 - (double)beta2);
+    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += (int64_t)gridDim.x * RB) {
+        const float gi = g[i] * gscale;
+        float pi = p[i] * decay;
+        float mi = m[i];
+        mi = mi + one_m_b1 * (gi - mi);
+        const float vi = v[i] * beta2 + one_m_b2 * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi = pi - step_size * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+    if (last_block_arrives(reinterpret_cast<unsigned*>(state + 1)) && threadIdx.x == 0) {
+        state[0] = step;
+        *reinterpret_cast<unsigned*>(state + 1) = 0u;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tdm_philox_normal_f32(uint64_t seed, uint64_t offset, float* out, int64_t n, void* stream) {
+    TDM_REQUIRE(out != nullptr && n > 0 && (n & 3) == 0, "philox_normal: n=%lld must be a positive multiple of 4", (long long)n);
+    hipLaunchKernelGGL(philox_normal_kernel, dim3(rng_grid(n / 4)), dim3(RB), 0, (hipStream_t)stream, seed, offset, out, n / 4);
+    TDM_CHECK_LAUNCH("philox_normal");
+    return 0;
+}
+
+int tdm_philox_u32(uint64_t seed, uint64_t offset, int kind, uint32_t* out, int64_t n, void* stream) {
+    TDM_REQUIRE(out != nullptr && n > 0 && (n & 3) == 0, "philox_u32: n=%lld must be a positive multiple of 4", (long long)n);
+    TDM_REQUIRE(kind == 0 || kind == 1, "philox_u32: kind %d", kind);
+    hipLaunchKernelGGL(philox_u32_kernel, dim3(rng_grid(n / 4)), dim3(RB), 0, (hipStream_t)stream, seed, offset, kind, out, n / 4);
+    TDM_CHECK_LAUNCH("philox_u32");
+    return 0;
+}
+
+int tdm_philox_u32_host(uint64_t seed, uint64_t offset, int kind, uint64_t idx, uint32_t* out4) {
+    TDM_REQUIRE(out4 != nullptr && (kind == 0 || kind == 1), "philox_u32_host: bad arguments");
+    const tdm_u32x4 r = tdm_philox_at(seed, offset, idx, kind);
+    out4[0] = r.x; out4[1] = r.y; out4[2] = r.z; out4[3] = r.w;
+    return 0;
+}
+
+int tdm_ddpm_draw_q_sample_f32(const float* x0, const float* sqrt_acp, const float* sqrt_1m_acp, uint64_t seed,
+                               int64_t* rng_state, int64_t* t_out, float* noise_out, float* x_noisy_out, int64_t B,
+                               int64_t inner, void* stream) {
+    TDM_REQUIRE(x0 && sqrt_acp && sqrt_1m_acp && rng_state && t_out && noise_out && x_noisy_out, "draw_q_sample: NULL pointer");
+    TDM_REQUIRE(B > 0 && inner > 0 && (inner & 3) == 0, "draw_q_sample: B=%lld inner=%lld (inner must be a multiple of 4)",
+                (long long)B, (long long)inner);
+    hipLaunchKernelGGL(draw_q_sample_kernel, dim3(rng_grid(B * inner / 4)), dim3(RB), 0, (hipStream_t)stream, x0, sqrt_acp,
+                       sqrt_1m_acp, seed, rng_state, t_out, noise_out, x_noisy_out, B, inner / 4);
+    TDM_CHECK_LAUNCH("draw_q_sample");
+    return 0;
+}
+
+int tdm_p_sample_update_philox_f32(const float* x, const float* eps, const float* tab_recip, const float* tab_eps,
+                                   const float* tab_sigma0, int64_t* t_dev, uint64_t seed, int64_t* rng_state, float* out,
+                                   int64_t B, int64_t inner, void* stream) {
+    TDM_REQUIRE(x && eps && tab_recip && tab_eps && tab_sigma0 && t_dev && rng_state && out, "p_sample_update_philox: NULL pointer");
+    TDM_REQUIRE(B > 0 && inner > 0 && (inner & 3) == 0, "p_sample_update_philox: B=%lld inner=%lld (inner must be a multiple of 4)",
+                (long long)B, (long long)inner);
+    hipLaunchKernelGGL(p_update_philox_kernel, dim3(rng_grid(B * inner / 4)), dim3(RB), 0, (hipStream_t)stream, x, eps,
+                       tab_recip, tab_eps, tab_sigma0, t_dev, seed, rng_state, out, B, inner / 4);
+    TDM_CHECK_LAUNCH("p_sample_update_philox");
+    return 0;
+}
+
+int tdm_adamw_flat_devstep_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, int64_t* step_state, float grad_scale, void* stream) {
+    TDM_REQUIRE(p && g && m && v && step_state && n > 0, "adamw_devstep: bad arguments (n=%lld)", (long long)n);
+    hipLaunchKernelGGL(adamw_devstep_kernel, dim3(rng_grid(n)), dim3(RB), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+                       beta2, eps, weight_decay, step_state, grad_scale);
+    TDM_CHECK_LAUNCH("adamw_devstep");
+    return 0;
+}
+
+}  // extern "C"

@@ -111,6 +111,9 @@ struct PackArgs { PackDesc d[TDM_MAX_PACK]; int n; };
 int tdm_launch_pack(const float* params, const PackArgs& pa, unsigned short* out, hipStream_t st);
 
 // S16 pipeline: pre-split sources, float4 epilogue (conv_s16.hip)
+// pixel-count limit of its 32-bit addressing (__mul24 on the pixel index): B * H * W < 2^23, i.e. B <= 10,699 at 28x28
+#define TDM_S16_MAX_PIXELS (1L << 23)
+#define TDM_S16_MAX_BATCH 10699
 int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st);
 int tdm_launch_to_s16(const float* in, const float* tb, int tb_stride, float* out, long M, int HWpix, int C,
                       hipStream_t st);
@@ -195,4 +198,5 @@ int tdm_launch_relu_mask_s16(const float* dout, const unsigned char* am, float* 
 // dh <- dh * (a1 > 0) in place (fp32) + S16 copy; S[b][c] = sum dh (unmasked), S2[b][c] = sum of the masked values
 int tdm_launch_time_grad_multi2(const float* const* S, const float* const* S2, float* const* d_tw, float* const* d_tb,
                                 float* const* d_b, const int* C, int n, const float* that, int B, hipStream_t st);
+int tdm_launch_mask_io(unsigned char* packed, unsigned char* nchw, int B, int HWpix, int C, int write, hipStream_t st);
 int tdm_launch_nhwc_to_nchw(const float* in, float* out, int B, int HWpix, int C, hipStream_t st);

@@ -272,17 +272,57 @@ int wgrad_s16(hipStream_t st, int hw, int B, const float* act_s16, int C, int c_
     return tdm_launch_wgrad_s16(a, hw, nslab, st);
 }
 
+// Every launch of the default (S16) train step has an id: tdm_unet_replay_launch_f32 re-issues ONE of them on a
+// workspace a full step has filled (bench.py times each launch alone with events; tools/ collect PMC per kernel).
+#define TDM_UNET_LAUNCHES(X)                                                                                             \
+    X(F_TIMEBIAS, "timebias") X(F_PACK, "pack_weights") X(F_CONV_FIRST, "rb1.conv1 (conv_first_s16)")                  \
+    X(F_RB1C2, "rb1.conv2 fwd 32->32 @28 (conv_s16<28,1>)") X(F_POOL_SKIP, "avgpool + rb2.skip (pool_skip_s16)")        \
+    X(F_RB2C1, "rb2.conv1 fwd 32->64 @14 (conv_s16<14,2>)") X(F_RB2C2, "rb2.conv2 fwd 64->64 @14 (conv_s16<14,2>)")     \
+    X(F_RB3C1, "rb3.conv1 fwd 64->64 @14 (conv_s16<14,2>)") X(F_RB3C2, "rb3.conv2 fwd 64->64 @14 (conv_s16<14,2>)")     \
+    X(F_RB4C1, "rb4.conv1 + rb4.skip fwd 96->32 @28 (conv_s16<28,1,skip>)")                                             \
+    X(F_RB4C2, "rb4.conv2 + out fwd 32->32 @28 (conv_s16<28,1>)")                                                       \
+    X(B_OUT_BWD, "out conv bwd + relu mask (out_bwd_s16)") X(B_WG_RB4C2, "rb4.conv2 wgrad (wgrad2_s16<28>)")            \
+    X(B_DG_RB4C2, "rb4.conv2 dgrad 32->32 @28 (conv_s16<28,1>)") X(B_SUMS4, "image_sums rb4")                           \
+    X(B_WG_RB4C1A, "rb4.conv1+skip wgrad, up(h3) part (wgrad2_s16<28,sk>)")                                             \
+    X(B_WG_RB4C1B, "rb4.conv1+skip wgrad, h1 part (wgrad2_s16<28,sk>)")                                                 \
+    X(B_DG_RB4C1, "rb4.conv1+skip dgrad 32->96 @28 (conv_s16<28,3>)") X(B_SPLIT_DCAT, "upsample bwd + relu mask (split_dcat_mask_s16)") \
+    X(B_WG_RB3C2, "rb3.conv2 wgrad (wgrad2_s16<14>)") X(B_DG_RB3C2, "rb3.conv2 dgrad 64->64 @14 (conv_s16<14,2>)")      \
+    X(B_SUMS3, "image_sums rb3") X(B_WG_RB3C1, "rb3.conv1 wgrad (wgrad2_s16<14>)")                                      \
+    X(B_DG_RB3C1, "rb3.conv1 dgrad 64->64 @14 (conv_s16<14,2>)") X(B_RELU_MASK2, "relu mask rb2 (relu_mask_s16)")       \
+    X(B_WG_RB2C2, "rb2.conv2 wgrad (wgrad2_s16<14>)") X(B_DG_RB2C2, "rb2.conv2 dgrad 64->64 @14 (conv_s16<14,2>)")      \
+    X(B_SUMS2, "image_sums rb2") X(B_WG_RB2C1, "rb2.conv1+skip wgrad (wgrad2_s16<14,sk>)")                              \
+    X(B_DG_RB2C1, "rb2.conv1+skip dgrad 64->32 @14 (conv_s16<14,1>)") X(B_COMBINE_DH1, "concat/pool bwd + relu mask (combine_dh1_mask_s16)") \
+    X(B_WG_RB1C2, "rb1.conv2 wgrad (wgrad2_s16<28>)") X(B_DG_RB1C2, "rb1.conv2 dgrad 32->32 @28 (conv_s16<28,1>)")      \
+    X(B_SUMS1, "image_sums rb1") X(B_TIME_GRAD, "time_emb + conv1 bias grads (time_grad)")                              \
+    X(B_FIRST_WGRAD, "rb1.conv1 + rb1.skip wgrad (first_wgrad)") X(B_REDUCE, "slab reduction (reduce_slabs)")
+enum UnetLaunch {
+#define X(id, name) L_##id,
+    TDM_UNET_LAUNCHES(X)
+#undef X
+    L_COUNT
+};
+const char* const kLaunchNames[L_COUNT] = {
+#define X(id, name) name,
+    TDM_UNET_LAUNCHES(X)
+#undef X
+};
+thread_local int g_only_launch = -1;   // >= 0: the S16 forward / backward issue only this launch
+#define RUN(id, call)                                                   \
+    do {                                                                \
+        if (g_only_launch < 0 || g_only_launch == (int)(L_##id)) TDM_TRY(call); \
+    } while (0)
+
 int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* eps, const Ws& w, int B, int save,
                      hipStream_t st) {
     const int tew[4] = {kL.rb[0].tew, kL.rb[1].tew, kL.rb[2].tew, kL.rb[3].tew};
     const int teb[4] = {kL.rb[0].teb, kL.rb[1].teb, kL.rb[2].teb, kL.rb[3].teb};
-    TDM_TRY(tdm_launch_timebias(t, P, tew, teb, w.that, w.tb, B, st));
-    TDM_TRY(tdm_launch_pack(P, kPack.pa, w.wpack, st));
+    RUN(F_TIMEBIAS, tdm_launch_timebias(t, P, tew, teb, w.that, w.tb, B, st));
+    RUN(F_PACK, tdm_launch_pack(P, kPack.pa, w.wpack, st));
     const BlockOff &r1 = kL.rb[0], &r2 = kL.rb[1], &r3 = kL.rb[2], &r4 = kL.rb[3];
     // rb1: conv1 (Cin = 1) writes a1 (mask) and split(a1 + tb) for conv2
     // (rb1.skip has one input channel: its output is not materialised; rb1.conv2's epilogue recomputes it from x)
-    TDM_TRY(tdm_launch_conv_first_s16(x, P + r1.c1w, P + r1.c1b, P + r1.skw, P + r1.skb, w.tb + 0, 192, nullptr,
-                                      save ? w.m1[0] : nullptr, w.a1s_1, nullptr, B, st));
+    RUN(F_CONV_FIRST, tdm_launch_conv_first_s16(x, P + r1.c1w, P + r1.c1b, P + r1.skw, P + r1.skb, w.tb + 0, 192, nullptr,
+                                                save ? w.m1[0] : nullptr, w.a1s_1, nullptr, B, st));
     {
         ConvArgs a{};
         a.nsrc = 1;
@@ -290,19 +330,19 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
         a.bias = P + r1.c2b; a.relu = 1; a.B = B;
         a.out = nullptr; a.mask_out = save ? w.m2[0] : nullptr; a.out_s16 = w.h1s; a.tb_out_stride = 192;   // (h1 lives as S16 only)
         a.r1_x = x; a.r1_w = P + r1.skw; a.r1_b = P + r1.skb;
-        TDM_TRY(tdm_launch_conv_s16(a, 28, 32, st));
+        RUN(F_RB1C2, tdm_launch_conv_s16(a, 28, 32, st));
     }
     // rb2 on avg_pool2d(h1)
-    TDM_TRY(tdm_launch_pool_skip_s16(w.h1s, P + r2.skw, P + r2.skb, w.p1s, w.s2, B, st));   // pooling + rb2.skip (1x1), from the S16 twin
-    TDM_TRY(conv_s16_1(st, w, 14, B, w.p1s, 32, 9, kPack.fwd[W_RB2C1], 64, P + r2.c1b, 1,
-                       S16Out{nullptr, save ? w.m1[1] : nullptr, nullptr, w.a1s_2, w.tb + 32}));
-    TDM_TRY(conv_s16_1(st, w, 14, B, w.a1s_2, 64, 9, kPack.fwd[W_RB2C2], 64, P + r2.c2b, 1,
-                       S16Out{w.h2, save ? w.m2[1] : nullptr, w.s2, w.h2s, nullptr}));
+    RUN(F_POOL_SKIP, tdm_launch_pool_skip_s16(w.h1s, P + r2.skw, P + r2.skb, w.p1s, w.s2, B, st));   // pooling + rb2.skip (1x1), from the S16 twin
+    RUN(F_RB2C1, conv_s16_1(st, w, 14, B, w.p1s, 32, 9, kPack.fwd[W_RB2C1], 64, P + r2.c1b, 1,
+                            S16Out{nullptr, save ? w.m1[1] : nullptr, nullptr, w.a1s_2, w.tb + 32}));
+    RUN(F_RB2C2, conv_s16_1(st, w, 14, B, w.a1s_2, 64, 9, kPack.fwd[W_RB2C2], 64, P + r2.c2b, 1,
+                            S16Out{w.h2, save ? w.m2[1] : nullptr, w.s2, w.h2s, nullptr}));
     // rb3 (identity skip)
-    TDM_TRY(conv_s16_1(st, w, 14, B, w.h2s, 64, 9, kPack.fwd[W_RB3C1], 64, P + r3.c1b, 1,
-                       S16Out{nullptr, save ? w.m1[2] : nullptr, nullptr, w.a1s_3, w.tb + 96}));
-    TDM_TRY(conv_s16_1(st, w, 14, B, w.a1s_3, 64, 9, kPack.fwd[W_RB3C2], 64, P + r3.c2b, 1,
-                       S16Out{nullptr, save ? w.m2[2] : nullptr, w.h2, w.h3s, nullptr}));   // (h3 lives as S16 only)
+    RUN(F_RB3C1, conv_s16_1(st, w, 14, B, w.h2s, 64, 9, kPack.fwd[W_RB3C1], 64, P + r3.c1b, 1,
+                            S16Out{nullptr, save ? w.m1[2] : nullptr, nullptr, w.a1s_3, w.tb + 96}));
+    RUN(F_RB3C2, conv_s16_1(st, w, 14, B, w.a1s_3, 64, 9, kPack.fwd[W_RB3C2], 64, P + r3.c2b, 1,
+                            S16Out{nullptr, save ? w.m2[2] : nullptr, w.h2, w.h3s, nullptr}));   // (h3 lives as S16 only)
     // rb4 on cat([up2(h3), h1])
     {
         ConvArgs a{};
@@ -313,7 +353,7 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
         a.mask_out = save ? w.m1[3] : nullptr; a.out_s16 = w.a1s_4; a.tb_out = w.tb + 160; a.tb_out_stride = 192;
         // rb4.skip (1x1 over the same concat) rides on this launch as a second accumulator: s4 = skip(cat) + bias
         a.skip_wp = w.wpack + kPack.fwd[W_RB4SK]; a.skip_bias = P + r4.skb; a.skip_out = w.s4;
-        TDM_TRY(tdm_launch_conv_s16(a, 28, 32, st));
+        RUN(F_RB4C1, tdm_launch_conv_s16(a, 28, 32, st));
     }
     {   // rb4.conv2 + the model's 1x1 output conv in its epilogue; h4 itself is only written for the backward pass
         ConvArgs a{};
@@ -322,7 +362,7 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
         a.bias = P + r4.c2b; a.relu = 1; a.B = B;
         a.out = save ? w.h4 : nullptr; a.mask_out = save ? w.m2[3] : nullptr; a.res = w.s4; a.tb_out_stride = 192;
         a.o1_w = P + kL.outw; a.o1_b = P + kL.outb; a.o1_out = eps;
-        TDM_TRY(tdm_launch_conv_s16(a, 28, 32, st));
+        RUN(F_RB4C2, tdm_launch_conv_s16(a, 28, 32, st));
     }
     return 0;
 }
@@ -337,53 +377,53 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     const int64_t M28 = (int64_t)B * 784, M14 = (int64_t)B * 196;
     const long NP = TDM_UNET_NPARAM;
     // ---- out conv + rb4 ----
-    TDM_TRY(tdm_launch_out_bwd_s16(deps, w.h4, P + kL.outw, w.m2[3], nullptr, w.dout4s, w.dc2s_4, slabs, NP, kL.outw,
-                                   kL.outb, r4.c2b, r4.skb, M28, NS, st));
-    TDM_TRY(wgrad_s16(st, 28, B, w.a1s_4, 32, 32, 0, 9, w.dc2s_4, 32, slabs, r4.c2w, 32, 0, NS));
-    TDM_TRY(conv_s16_1(st, w, 28, B, w.dc2s_4, 32, 9, kPack.dg[W_RB4C2], 32, nullptr, 0,
-                       S16Out{nullptr, nullptr, nullptr, w.dh4s, nullptr, w.m1[3], w.gsum}));   // + ReLU backward of a1
-    TDM_TRY(tdm_launch_image_sums(w.gsum, w.S[3], w.S2[3], B, 784, 32, st));
+    RUN(B_OUT_BWD, tdm_launch_out_bwd_s16(deps, w.h4, P + kL.outw, w.m2[3], nullptr, w.dout4s, w.dc2s_4, slabs, NP, kL.outw,
+                                          kL.outb, r4.c2b, r4.skb, M28, NS, st));
+    RUN(B_WG_RB4C2, wgrad_s16(st, 28, B, w.a1s_4, 32, 32, 0, 9, w.dc2s_4, 32, slabs, r4.c2w, 32, 0, NS));
+    RUN(B_DG_RB4C2, conv_s16_1(st, w, 28, B, w.dc2s_4, 32, 9, kPack.dg[W_RB4C2], 32, nullptr, 0,
+                               S16Out{nullptr, nullptr, nullptr, w.dh4s, nullptr, w.m1[3], w.gsum}));   // + ReLU backward of a1
+    RUN(B_SUMS4, tdm_launch_image_sums(w.gsum, w.S[3], w.S2[3], B, 784, 32, st));
     // rb4.conv1 and rb4.skip read the same concat: the 1x1 gradients ride on the 3x3 launches (fifth accumulator of tap group 1)
-    TDM_TRY(wgrad_s16(st, 28, B, w.h3s, 64, 64, 1, 9, w.dh4s, 32, slabs, r4.c1w, 96, 0, NS, w.dout4s, r4.skw));
-    TDM_TRY(wgrad_s16(st, 28, B, w.h1s, 32, 32, 0, 9, w.dh4s, 32, slabs, r4.c1w, 96, 64, NS, w.dout4s, r4.skw));
+    RUN(B_WG_RB4C1A, wgrad_s16(st, 28, B, w.h3s, 64, 64, 1, 9, w.dh4s, 32, slabs, r4.c1w, 96, 0, NS, w.dout4s, r4.skw));
+    RUN(B_WG_RB4C1B, wgrad_s16(st, 28, B, w.h1s, 32, 32, 0, 9, w.dh4s, 32, slabs, r4.c1w, 96, 64, NS, w.dout4s, r4.skw));
     {
         ConvArgs a{};
         a.nsrc = 2;
         a.src[0] = s16_src(w.dh4s, 32, 32, 0, 9, w.wpack + kPack.dg[W_RB4C1], 0);
         a.src[1] = s16_src(w.dout4s, 32, 32, 0, 1, w.wpack + kPack.dg[W_RB4SK], 0);
         a.out = w.dcat; a.B = B;
-        TDM_TRY(tdm_launch_conv_s16(a, 28, 96, st));
+        RUN(B_DG_RB4C1, tdm_launch_conv_s16(a, 28, 96, st));
     }
     // ---- rb3 ---- (upsample backward and the ReLU mask of rb3.conv2's output in one pass)
-    TDM_TRY(tdm_launch_split_dcat_mask_s16(w.dcat, w.m2[2], w.dout3, w.dc2s_3, slabs, NP, r3.c2b, B, NS, st));
-    TDM_TRY(wgrad_s16(st, 14, B, w.a1s_3, 64, 64, 0, 9, w.dc2s_3, 64, slabs, r3.c2w, 64, 0, NS4));
-    TDM_TRY(conv_s16_1(st, w, 14, B, w.dc2s_3, 64, 9, kPack.dg[W_RB3C2], 64, nullptr, 0,
-                       S16Out{nullptr, nullptr, nullptr, w.dh3s, nullptr, w.m1[2], w.gsum}));
-    TDM_TRY(tdm_launch_image_sums(w.gsum, w.S[2], w.S2[2], B, 196, 64, st));
-    TDM_TRY(wgrad_s16(st, 14, B, w.h2s, 64, 64, 0, 9, w.dh3s, 64, slabs, r3.c1w, 64, 0, NS4));
-    TDM_TRY(conv_s16_1(st, w, 14, B, w.dh3s, 64, 9, kPack.dg[W_RB3C1], 64, nullptr, 0,
-                       S16Out{w.dout2, nullptr, w.dout3, w.dout2s, nullptr}));   // + identity skip
+    RUN(B_SPLIT_DCAT, tdm_launch_split_dcat_mask_s16(w.dcat, w.m2[2], w.dout3, w.dc2s_3, slabs, NP, r3.c2b, B, NS, st));
+    RUN(B_WG_RB3C2, wgrad_s16(st, 14, B, w.a1s_3, 64, 64, 0, 9, w.dc2s_3, 64, slabs, r3.c2w, 64, 0, NS4));
+    RUN(B_DG_RB3C2, conv_s16_1(st, w, 14, B, w.dc2s_3, 64, 9, kPack.dg[W_RB3C2], 64, nullptr, 0,
+                               S16Out{nullptr, nullptr, nullptr, w.dh3s, nullptr, w.m1[2], w.gsum}));
+    RUN(B_SUMS3, tdm_launch_image_sums(w.gsum, w.S[2], w.S2[2], B, 196, 64, st));
+    RUN(B_WG_RB3C1, wgrad_s16(st, 14, B, w.h2s, 64, 64, 0, 9, w.dh3s, 64, slabs, r3.c1w, 64, 0, NS4));
+    RUN(B_DG_RB3C1, conv_s16_1(st, w, 14, B, w.dh3s, 64, 9, kPack.dg[W_RB3C1], 64, nullptr, 0,
+                               S16Out{w.dout2, nullptr, w.dout3, w.dout2s, nullptr}));   // + identity skip
     // ---- rb2 ----
-    TDM_TRY(tdm_launch_relu_mask_s16(w.dout2, w.m2[1], w.dc2s_2, slabs, NP, r2.c2b, r2.skb, M14, 64, NS, st));
-    TDM_TRY(wgrad_s16(st, 14, B, w.a1s_2, 64, 64, 0, 9, w.dc2s_2, 64, slabs, r2.c2w, 64, 0, NS4));
-    TDM_TRY(conv_s16_1(st, w, 14, B, w.dc2s_2, 64, 9, kPack.dg[W_RB2C2], 64, nullptr, 0,
-                       S16Out{nullptr, nullptr, nullptr, w.dh2s, nullptr, w.m1[1], w.gsum}));
-    TDM_TRY(tdm_launch_image_sums(w.gsum, w.S[1], w.S2[1], B, 196, 64, st));
-    TDM_TRY(wgrad_s16(st, 14, B, w.p1s, 32, 32, 0, 9, w.dh2s, 64, slabs, r2.c1w, 32, 0, NS2, w.dout2s, r2.skw));   // + rb2.skip
+    RUN(B_RELU_MASK2, tdm_launch_relu_mask_s16(w.dout2, w.m2[1], w.dc2s_2, slabs, NP, r2.c2b, r2.skb, M14, 64, NS, st));
+    RUN(B_WG_RB2C2, wgrad_s16(st, 14, B, w.a1s_2, 64, 64, 0, 9, w.dc2s_2, 64, slabs, r2.c2w, 64, 0, NS4));
+    RUN(B_DG_RB2C2, conv_s16_1(st, w, 14, B, w.dc2s_2, 64, 9, kPack.dg[W_RB2C2], 64, nullptr, 0,
+                               S16Out{nullptr, nullptr, nullptr, w.dh2s, nullptr, w.m1[1], w.gsum}));
+    RUN(B_SUMS2, tdm_launch_image_sums(w.gsum, w.S[1], w.S2[1], B, 196, 64, st));
+    RUN(B_WG_RB2C1, wgrad_s16(st, 14, B, w.p1s, 32, 32, 0, 9, w.dh2s, 64, slabs, r2.c1w, 32, 0, NS2, w.dout2s, r2.skw));   // + rb2.skip
     {
         ConvArgs a{};
         a.nsrc = 2;
         a.src[0] = s16_src(w.dh2s, 64, 64, 0, 9, w.wpack + kPack.dg[W_RB2C1], 0);
         a.src[1] = s16_src(w.dout2s, 64, 64, 0, 1, w.wpack + kPack.dg[W_RB2SK], 0);
         a.out = w.dp1; a.B = B;
-        TDM_TRY(tdm_launch_conv_s16(a, 14, 32, st));
+        RUN(B_DG_RB2C1, tdm_launch_conv_s16(a, 14, 32, st));
     }
     // ---- rb1 ---- (concat skip + avg-pool backward and the ReLU mask of rb1.conv2's output in one pass)
-    TDM_TRY(tdm_launch_combine_dh1_mask_s16(w.dcat, w.dp1, w.m2[0], w.dout1, w.dc2s_1, slabs, NP, r1.c2b, B, NS, st));
-    TDM_TRY(wgrad_s16(st, 28, B, w.a1s_1, 32, 32, 0, 9, w.dc2s_1, 32, slabs, r1.c2w, 32, 0, NS));
-    TDM_TRY(conv_s16_1(st, w, 28, B, w.dc2s_1, 32, 9, kPack.dg[W_RB1C2], 32, nullptr, 0,
-                       S16Out{w.dh1, nullptr, nullptr, nullptr, nullptr, w.m1[0], w.gsum}));   // dh1 <- masked, fp32 (rb1.conv1 wgrad)
-    TDM_TRY(tdm_launch_image_sums(w.gsum, w.S[0], w.S2[0], B, 784, 32, st));
+    RUN(B_COMBINE_DH1, tdm_launch_combine_dh1_mask_s16(w.dcat, w.dp1, w.m2[0], w.dout1, w.dc2s_1, slabs, NP, r1.c2b, B, NS, st));
+    RUN(B_WG_RB1C2, wgrad_s16(st, 28, B, w.a1s_1, 32, 32, 0, 9, w.dc2s_1, 32, slabs, r1.c2w, 32, 0, NS));
+    RUN(B_DG_RB1C2, conv_s16_1(st, w, 28, B, w.dc2s_1, 32, 9, kPack.dg[W_RB1C2], 32, nullptr, 0,
+                               S16Out{w.dh1, nullptr, nullptr, nullptr, nullptr, w.m1[0], w.gsum}));   // dh1 <- masked, fp32 (rb1.conv1 wgrad)
+    RUN(B_SUMS1, tdm_launch_image_sums(w.gsum, w.S[0], w.S2[0], B, 784, 32, st));
     {   // time_emb gradients of all four blocks + conv1 bias gradients of rb2..rb4, one launch
         const float* Sv[4] = {w.S[0], w.S[1], w.S[2], w.S[3]};
         const float* S2v[4] = {nullptr, w.S2[1], w.S2[2], w.S2[3]};
@@ -391,9 +431,9 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
         float* tbv[4] = {G + r1.teb, G + r2.teb, G + r3.teb, G + r4.teb};
         float* dbv[4] = {nullptr, G + r2.c1b, G + r3.c1b, G + r4.c1b};
         const int Cv[4] = {32, 64, 64, 32};
-        TDM_TRY(tdm_launch_time_grad_multi2(Sv, S2v, tw, tbv, dbv, Cv, 4, w.that, B, st));
+        RUN(B_TIME_GRAD, tdm_launch_time_grad_multi2(Sv, S2v, tw, tbv, dbv, Cv, 4, w.that, B, st));
     }
-    TDM_TRY(tdm_launch_first_wgrad(x, w.dh1, w.dout1, slabs, NP, r1.c1w, r1.c1b, r1.skw, r1.skb, B, NS, st));
+    RUN(B_FIRST_WGRAD, tdm_launch_first_wgrad(x, w.dh1, w.dout1, slabs, NP, r1.c1w, r1.c1b, r1.skw, r1.skb, B, NS, st));
     ReduceArgs ra{};
     int n = 0;
     auto sec = [&](int off, int len, int ns) { ra.sec[n].off = off; ra.sec[n].len = len; ra.sec[n].nslab = ns; ++n; };
@@ -404,7 +444,8 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     sec(r4.c1w, 27648, NS); sec(r4.c2w, 9216 + 32, NS); sec(r4.skw, 3072 + 32, NS);
     sec(kL.outw, 33, NS);
     ra.nsec = n;
-    return tdm_launch_reduce(slabs, NP, ra, G, st);
+    RUN(B_REDUCE, tdm_launch_reduce(slabs, NP, ra, G, st));
+    return 0;
 }
 
 constexpr int NSLAB = 256;
@@ -497,7 +538,15 @@ int tdm_unet_param_offsets(int32_t* offs) {
 int64_t tdm_unet_workspace_floats(int64_t B, int training) { return carve(nullptr, B, training).total; }
 int64_t tdm_unet_slab_floats(void) { return (int64_t)NSLAB * TDM_UNET_NPARAM; }
 
-#define TDM_CHECK_B(B) TDM_REQUIRE((B) >= 1 && (B) <= 16384, "batch %lld out of range [1, 16384]", (long long)(B))
+// Batch limit: 16384 for the fp32 / in-loader-split arithmetics (64-bit indexing); the default S16 pipeline addresses
+// with 32-bit offsets built from 24-bit pixel indices (conv_s16.hip), which caps it at 10,699 images of 28x28.
+#define TDM_CHECK_B(B)                                                                                                   \
+    TDM_REQUIRE((B) >= 1 && (B) <= (g_conv_mode == 2 ? TDM_S16_MAX_BATCH : 16384),                                        \
+                "batch %lld out of range [1, %d] (conv mode %d%s)", (long long)(B), g_conv_mode == 2 ? TDM_S16_MAX_BATCH : 16384, \
+                g_conv_mode, g_conv_mode == 2 ? ": 32-bit S16 addressing, B * 784 < 2^23" : "")
+#define TDM_CHECK_B_S16(B)                                                                                               \
+    TDM_REQUIRE((B) >= 1 && (B) <= TDM_S16_MAX_BATCH, "batch %lld out of range [1, %d] (32-bit S16 addressing)",        \
+                (long long)(B), TDM_S16_MAX_BATCH)
 
 int tdm_unet_fwd_f32(const float* params, const float* x, const int64_t* t, float* eps, float* ws, int64_t B, int save,
                      void* stream) {
@@ -531,6 +580,17 @@ int tdm_unet_get_activation(const float* ws, int64_t B, int which, float* out_nc
     return 1;
 }
 
+// ReLU sign masks of a save != 0 forward in the default (S16) pipeline, as one 0/1 byte per element in NCHW.
+// write != 0 installs masks instead (tests teacher-force the reference's masks into the backward pass).
+int tdm_unet_relu_mask_io(float* ws, int64_t B, int block, int which, uint8_t* mask_nchw, int write, void* stream) {
+    TDM_CHECK_B(B);
+    TDM_REQUIRE(g_conv_mode == 2, "relu_mask_io: byte masks exist in conv mode 2 only (mode %d keeps fp32 copies)", g_conv_mode);
+    TDM_REQUIRE(ws && mask_nchw && block >= 0 && block < 4 && (which == 1 || which == 2), "relu_mask_io: bad arguments");
+    const Ws w = carve(ws, B, 1);
+    const int C = kL.rb[block].cout, hwpix = (block == 0 || block == 3) ? 784 : 196;
+    return tdm_launch_mask_io(which == 1 ? w.m1[block] : w.m2[block], mask_nchw, (int)B, hwpix, C, write, (hipStream_t)stream);
+}
+
 int tdm_unet_loss_grad_f32(const float* params, const float* x0, const float* noise, const int64_t* t,
                            const float* sqrt_acp, const float* sqrt_1m_acp, float* x_noisy, float* eps, float* deps,
                            float* loss_out, float* grads, float* ws, float* slabs, int64_t B, void* stream) {
@@ -555,6 +615,54 @@ int tdm_unet_p_sample_step_f32(const float* params, const float* x, const int64_
     TDM_TRY(unet_forward(params, x, t, eps, w, (int)B, 0, (hipStream_t)stream));
     return tdm_p_sample_update_f32(x, eps, t_index == 0 ? nullptr : noise, tab_recip, tab_eps, tab_sigma, t_index, x_out,
                                    B * 784, stream);
+}
+
+// The train step with its randomness drawn on the device (src/mnist.py:152-158 incl. :154-155): one launch sequence,
+// no host-written scalar -> replayable as a hipGraph.  t_buf (B) int64 and noise (B,784) receive the draws.
+int tdm_unet_loss_grad_philox_f32(const float* params, const float* x0, const float* sqrt_acp, const float* sqrt_1m_acp,
+                                  uint64_t seed, int64_t* rng_state, int64_t* t_buf, float* noise, float* x_noisy,
+                                  float* eps, float* deps, float* loss_out, float* grads, float* ws, float* slabs, int64_t B,
+                                  void* stream) {
+    TDM_CHECK_B(B);
+    TDM_REQUIRE(params && x0 && rng_state && t_buf && noise && x_noisy && eps && deps && loss_out && grads && ws && slabs,
+                "unet_loss_grad_philox: NULL pointer");
+    const Ws w = carve(ws, B, 1);
+    hipStream_t st = (hipStream_t)stream;
+    TDM_TRY(tdm_ddpm_draw_q_sample_f32(x0, sqrt_acp, sqrt_1m_acp, seed, rng_state, t_buf, noise, x_noisy, B, 784, stream));
+    TDM_TRY(unet_forward(params, x_noisy, t_buf, eps, w, (int)B, 1, st));
+    TDM_TRY(tdm_mse_fwd_bwd_f32(eps, noise, loss_out, deps, w.scratch, B * 784, stream));
+    TDM_TRY(unet_backward(params, x_noisy, deps, grads, w, slabs, (int)B, st));
+    return 0;
+}
+
+// One reverse step with device-resident step index and device-drawn noise (src/mnist.py:191-193, :167-180):
+// eps = UNet(x, t_dev); x_out = update(x, eps, z ~ Philox); t_dev -= 1 (floor 0).  tab_sigma0[0] must be 0.
+int tdm_unet_p_sample_step_philox_f32(const float* params, const float* x, int64_t* t_dev, const float* tab_recip,
+                                      const float* tab_eps, const float* tab_sigma0, uint64_t seed, int64_t* rng_state,
+                                      float* eps, float* x_out, float* ws, int64_t B, void* stream) {
+    TDM_CHECK_B(B);
+    TDM_REQUIRE(params && x && t_dev && eps && x_out && ws && rng_state, "p_sample_step_philox: NULL pointer");
+    const Ws w = carve(ws, B, 0);
+    TDM_TRY(unet_forward(params, x, t_dev, eps, w, (int)B, 0, (hipStream_t)stream));
+    return tdm_p_sample_update_philox_f32(x, eps, tab_recip, tab_eps, tab_sigma0, t_dev, seed, rng_state, x_out, B, 784, stream);
+}
+
+// Profiling: re-issue ONE launch of the default train step (id in [0, tdm_unet_launch_count())) on a workspace that a
+// full tdm_unet_loss_grad_f32 call with the same arguments has filled.  Results are those of the full step's launch.
+int tdm_unet_launch_count(void) { return (int)L_COUNT; }
+const char* tdm_unet_launch_name(int id) { return (id >= 0 && id < (int)L_COUNT) ? kLaunchNames[id] : ""; }
+int tdm_unet_replay_launch_f32(const float* params, const float* x_noisy, const int64_t* t, float* eps, const float* deps,
+                               float* grads, float* ws, float* slabs, int64_t B, int id, void* stream) {
+    TDM_CHECK_B(B);
+    TDM_REQUIRE(g_conv_mode == 2, "replay_launch: the launch ids describe the default (S16) pipeline");
+    TDM_REQUIRE(id >= 0 && id < (int)L_COUNT, "replay_launch: id %d out of range", id);
+    TDM_REQUIRE(params && x_noisy && t && eps && deps && grads && ws && slabs, "replay_launch: NULL pointer");
+    const Ws w = carve(ws, B, 1);
+    g_only_launch = id;
+    int rc = unet_forward_s16(params, x_noisy, t, eps, w, (int)B, 1, (hipStream_t)stream);
+    if (rc == 0) rc = unet_backward_s16(params, x_noisy, deps, grads, w, slabs, (int)B, (hipStream_t)stream);
+    g_only_launch = -1;
+    return rc;
 }
 
 int tdm_set_conv_mode(int mode) {
@@ -595,7 +703,7 @@ int tdm_conv_nhwc_bf16x3_f32(const float* in, const float* w, const float* bias,
 int tdm_conv_nhwc_s16_f32(const float* in, const float* w, const float* bias, const float* res, const float* tb,
                           float* out, float* aux_relu_out, float* out_s16, const float* tb_out, float* scratch,
                           int64_t B, int HW, int Cin, int Cout, int ksize, int flags, void* stream) {
-    TDM_CHECK_B(B);
+    TDM_CHECK_B_S16(B);
     TDM_REQUIRE(ksize == 3 || ksize == 1, "conv: ksize %d", ksize);
     TDM_REQUIRE(scratch != nullptr, "conv_s16: scratch is NULL");
     hipStream_t st = (hipStream_t)stream;
@@ -625,7 +733,7 @@ int tdm_conv_nhwc_s16_f32(const float* in, const float* w, const float* bias, co
 // scratch >= B*HW*HW*(Cin + Cout) + 65 * ksize^2*Cin*Cout floats.
 int tdm_conv_wgrad_nhwc_s16_f32(const float* in, const float* tb, const float* dout, float* dw, float* scratch,
                                 int64_t B, int HW, int Cin, int Cout, int ksize, void* stream) {
-    TDM_CHECK_B(B);
+    TDM_CHECK_B_S16(B);
     TDM_REQUIRE(ksize == 3 || ksize == 1, "wgrad: ksize %d", ksize);
     TDM_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "wgrad_s16: Cin %d / Cout %d must be multiples of 32", Cin, Cout);
     hipStream_t st = (hipStream_t)stream;

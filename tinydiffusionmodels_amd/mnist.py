@@ -24,7 +24,7 @@ import torch.nn as nn
 from . import _lib
 from . import dp
 from . import unet_engine as E
-from .schedule import TIMESTEPS, cpu_tables, device_tables, linear_beta_schedule  # noqa: F401
+from .schedule import TIMESTEPS, cpu_tables, device_tables, linear_beta_schedule, schedule_generation  # noqa: F401
 from .utils import (get_samples_dir, get_vertex_checkpoint_path, load_checkpoint, save_checkpoint,
                     save_samples)
 
@@ -122,7 +122,7 @@ class SimpleUNet(nn.Module):
         return ws
 
     def _graph_sampler(self, n, device):
-        key = (n, str(device), self.flat.data_ptr())
+        key = (n, str(device), self.flat.data_ptr(), schedule_generation())   # (set_tables() retires captured tables)
         if key not in self._samplers:
             self._samplers.clear()                          # one resident sampler (buffers + graph) at a time
             self._samplers[key] = _GraphSampler(self, n, device)
@@ -233,6 +233,9 @@ class _GraphSampler:
         self.z = torch.empty_like(self.xa)
         self.t_vec = torch.zeros(n, device=dev, dtype=torch.long)
         self.kidx = torch.zeros(1, device=dev, dtype=torch.long)
+        # device-drawn noise (Philox stream keyed by a seed taken from torch's generator, offset advanced on the device)
+        self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self.rng_state = torch.zeros(2, device=dev, dtype=torch.long)
         self.ws = E.UNetWorkspace(n, dev, training=False)  # owned here: the graph holds its address
         self.bank = None
         self.graph = None
@@ -240,23 +243,28 @@ class _GraphSampler:
 
     def _one(self, a, b):
         if self.bank is None:
-            self.z.normal_()
-        else:   # teacher forcing inside the graph: z gathered from a resident bank by a device-side counter
-            torch.index_select(self.bank, 0, self.kidx, out=self.z.view(1, -1))
-            self.kidx.add_(1).clamp_(max=self.bank.shape[0] - 1)
+            # one C-ABI call per reverse step: UNet forward, update with z drawn in registers, t -= 1 — no ATen launch
+            _lib.check(_lib.lib().tdm_unet_p_sample_step_philox_f32(
+                _lib.ptr(self.model.flat.detach()), _lib.ptr(a), _lib.ptr(self.t_vec), _lib.ptr(self.tabs["sqrt_recip_alphas"]),
+                _lib.ptr(self.tabs["eps_coef"]), _lib.ptr(self.sigma0), self.seed, _lib.ptr(self.rng_state), _lib.ptr(self.eps),
+                _lib.ptr(b), _lib.ptr(self.ws.ws), self.n, _lib.stream()), "p_sample_step_philox")
+            return
+        # teacher forcing inside the graph: z gathered from a resident bank by a device-side counter
+        torch.index_select(self.bank, 0, self.kidx, out=self.z.view(1, -1))
+        self.kidx.add_(1).clamp_(max=self.bank.shape[0] - 1)
         _reverse_step_device_t(self.model.flat.detach(), self.ws, a, self.t_vec, self.z, self.eps, b, self.sigma0,
                                self.tabs)
         self.t_vec.sub_(1)
 
     def _capture(self):
-        saved = (self.xa.clone(), self.t_vec.clone(), self.kidx.clone())
+        saved = (self.xa.clone(), self.t_vec.clone(), self.kidx.clone(), self.rng_state.clone())
         side = torch.cuda.Stream(device=self.dev)          # warm-up off the capture stream, then restore
         side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(side):
             self._one(self.xa, self.xb)
             self._one(self.xb, self.xa)
         torch.cuda.current_stream(self.dev).wait_stream(side)
-        self.xa.copy_(saved[0]); self.t_vec.copy_(saved[1]); self.kidx.copy_(saved[2])
+        self.xa.copy_(saved[0]); self.t_vec.copy_(saved[1]); self.kidx.copy_(saved[2]); self.rng_state.copy_(saved[3])
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._one(self.xa, self.xb)
@@ -382,36 +390,145 @@ def synthetic_mnist(n: int, seed: int = 1234) -> torch.Tensor:
     return torch.rand(n, 1, 28, 28, generator=g) * 2 - 1
 
 
-class DDPMTrainer:
-    """The loop body of src/mnist.py:152-159 as one fused device-side step:
+class DPStepper:
+    """Collective + optimiser ordering of ONE data-parallel train step, independent of where the gradient
+    comes from (DDPMTrainer: the HIP kernels; the CPU tests: the oracle over gloo).
+
+    Equal shards (global_batch=None): per-rank mean-loss gradient, all-reduce(SUM), 1/world folded into AdamW.
+    Ragged tail (global_batch = samples ALL ranks hold in this iteration): each rank weights its mean-loss
+    gradient by B_local / global_batch before the SUM — ranks without samples contribute zeros but still join
+    the collective — which is exactly the gradient of the mean loss over the global batch.  No collective is
+    ever issued outside step() (construction included), so ranks cannot fall out of step with each other."""
+
+    def local_loss_and_grad(self, x0, t, noise):      # leaves the flat gradient in the buffer all-reduced below
+        raise NotImplementedError
+
+    def grad_buffer(self) -> torch.Tensor:
+        raise NotImplementedError
+
+    def optimizer_step(self, grad_scale: float) -> None:
+        raise NotImplementedError
+
+    def step(self, x0: Optional[torch.Tensor], t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
+             global_batch: Optional[int] = None):
+        b_local = 0 if x0 is None else int(x0.shape[0])
+        if global_batch is None and b_local == 0:
+            raise RuntimeError("a rank without samples needs global_batch (the tail iteration of an epoch)")
+        loss = self.local_loss_and_grad(x0, t, noise) if b_local else None
+        g = self.grad_buffer()
+        if global_batch is None:
+            scale = dp.allreduce_grads_(g)            # SUM over ranks; 1/world folded into AdamW
+        else:
+            if b_local:
+                g.mul_(b_local / float(global_batch))
+            else:
+                g.zero_()
+            dp.allreduce_grads_(g)
+            scale = 1.0
+        self.optimizer_step(scale)
+        return loss
+
+
+class DDPMTrainer(DPStepper):
+    """The loop body of src/mnist.py:152-159 as one device-side step:
     t ~ U{0..999}, noise ~ N(0,1), q_sample, UNet forward, MSE, backward,
     (data-parallel: one RCCL all-reduce of the flat 726 KB gradient), AdamW
-    with torch defaults (lr passed, betas (0.9,0.999), eps 1e-8, wd 0.01)."""
+    with torch defaults (lr passed, betas (0.9,0.999), eps 1e-8, wd 0.01).
+
+    With t / noise left to the trainer the whole step is ONE hipGraph replay: the draws come from a
+    device-side Philox stream, AdamW's step count lives in device memory, nothing is written by the host
+    (`graph=False` or TDM_TRAIN_GRAPH=0 runs the same launches eagerly).  At world > 1 the graph ends before
+    the collective (replay, all-reduce, AdamW = three host calls per step); TDM_GRAPH_COLLECTIVE=1 captures
+    the RCCL all-reduce and AdamW too.  Explicit t / noise (teacher forcing, parity tests) run eagerly.
+    One trainer serves every batch size (workspaces per size, optimiser state shared), and its constructor
+    issues no collective unless `broadcast` (default: rank 0's weights to every replica, once)."""
 
     def __init__(self, model: "SimpleUNet", batch_size: int, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.01):
+                 weight_decay: float = 0.01, graph: Optional[bool] = None, broadcast: bool = True):
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.flat = model.flat.detach()
         E._need_cuda(self.flat)
-        self.state = E.TrainState(self.flat, batch_size)
+        dev = self.flat.device
         self.rank, self.world = dp.world_info()
-        dp.broadcast_params_(self.flat, src=0)   # identical replicas: rank 0's weights everywhere
+        self.batch_size = batch_size
+        self.grads = torch.zeros(E.NPARAM, dtype=torch.float32, device=dev)
+        self.m = torch.zeros_like(self.grads)
+        self.v = torch.zeros_like(self.grads)
+        self.step_state = torch.zeros(2, dtype=torch.long, device=dev)     # {AdamW steps taken, scratch}
+        self.rng_state = torch.zeros(2, dtype=torch.long, device=dev)      # {Philox stream offset, scratch}
+        # rank-distinct draw streams: a seed from torch's generator (so torch.manual_seed governs it) mixed with the rank
+        self.seed = (int(torch.randint(0, 2 ** 62, (1,)).item()) ^ (self.rank * 0x9E3779B97F4A7C15)) & (2 ** 64 - 1)
+        self.use_graph = (os.environ.get("TDM_TRAIN_GRAPH", "1") != "0") if graph is None else bool(graph)
+        self.graph_collective = os.environ.get("TDM_GRAPH_COLLECTIVE", "0") == "1"
+        self._states = {}
+        self._cur = self._state(batch_size)
+        if broadcast:
+            dp.broadcast_params_(self.flat, src=0)   # identical replicas: rank 0's weights everywhere
 
-    def step(self, x0: torch.Tensor, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
-        """One optimisation step on batch x0 (B,1,28,28) already on the device.
-        Returns the loss as a 1-element device tensor (no host sync)."""
-        st = self.state
+    # ---- per-batch-size buffers; the optimiser state is shared ----
+    def _state(self, B: int) -> "E.TrainState":
+        st = self._states.get(B)
+        if st is None:
+            st = self._states[B] = E.TrainState(self.flat, B, grads=self.grads, m=self.m, v=self.v)
+        return st
+
+    @property
+    def state(self) -> "E.TrainState":
+        """Buffers of the most recent (initially: the constructor's) batch size."""
+        return self._cur
+
+    @property
+    def steps_taken(self) -> int:
+        return int(self.step_state[0].item())      # (host sync: checkpoints / tests only)
+
+    # ---- DPStepper interface ----
+    def grad_buffer(self):
+        return self.grads
+
+    def local_loss_and_grad(self, x0, t, noise):
+        st = self._cur = self._state(int(x0.shape[0]))
+        if t is None and noise is None:
+            return E.loss_and_grad_philox(self.flat, st, x0, self.seed, self.rng_state)
         if t is None:
             t = torch.randint(0, timesteps, (x0.shape[0],), device=x0.device)
         if noise is None:
             noise = torch.randn_like(x0)
-        loss = E.loss_and_grad(self.flat, st, x0, noise, t)
-        scale = dp.allreduce_grads_(st.grads)   # SUM over ranks (RCCL); 1/world folded into AdamW
-        st.step += 1
-        E.adamw_step(self.flat, st.grads, st.m, st.v, st.step, self.lr, self.betas, self.eps, self.weight_decay,
-                     grad_scale=scale)
-        return loss
+        return E.loss_and_grad(self.flat, st, x0, noise, t)
+
+    def optimizer_step(self, grad_scale: float) -> None:
+        E.adamw_step_dev(self.flat, self.grads, self.m, self.v, self.step_state, self.lr, self.betas, self.eps,
+                         self.weight_decay, grad_scale=grad_scale)
+
+    # ---- the hipGraph form of step() ----
+    def _capture(self, st: "E.TrainState") -> None:
+        whole = self.world == 1 or (self.graph_collective and dp.native_comm() is not None)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            E.loss_and_grad_philox(self.flat, st, st.x0, self.seed, self.rng_state)
+            if whole:
+                scale = dp.allreduce_grads_(self.grads)
+                self.optimizer_step(scale)
+        st.graph, st.graph_whole = g, whole
+
+    def step(self, x0: Optional[torch.Tensor], t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
+             global_batch: Optional[int] = None):
+        """One optimisation step on batch x0 (B,1,28,28) already on the device.
+        Returns the loss as a 1-element device tensor (no host sync)."""
+        if not (self.use_graph and t is None and noise is None and global_batch is None and x0 is not None):
+            return super().step(x0, t, noise, global_batch)
+        st = self._cur = self._state(int(x0.shape[0]))
+        if st.warm < 1:          # first step of a batch size runs eagerly (lazy kernel attributes, allocator warm-up)
+            st.warm += 1
+            return super().step(x0)
+        if x0.data_ptr() != st.x0.data_ptr():
+            st.x0.copy_(x0)      # the graph reads a fixed address
+        if st.graph is None:
+            self._capture(st)
+        st.graph.replay()
+        if not st.graph_whole:
+            self.optimizer_step(dp.allreduce_grads_(self.grads))
+        return st.loss
 
 
 def train(model: nn.Module,
@@ -423,40 +540,34 @@ def train(model: nn.Module,
           sample_every_epoch: bool = True,
           samples_per_epoch: int = 25,
           data: Optional[torch.Tensor] = None,
-          log_every: int = 50):
+          log_every: int = 50,
+          trainer: Optional[DPStepper] = None):
     """src/mnist.py:128-165.  `data`: optional (N,1,28,28) fp32 tensor in [-1,1]
     (default: MNIST IDX files under ./data).  The last batch of an epoch may be
-    partial, as with the reference's DataLoader (no drop_last)."""
+    partial, as with the reference's DataLoader (no drop_last); under data parallelism
+    the tail iteration weights every rank's gradient by its share of the global batch
+    (DPStepper), and a rank left without samples still joins the step's one collective.
+    `trainer`: a DPStepper to drive instead of the HIP DDPMTrainer (CPU tests)."""
     ckpt_path = get_vertex_checkpoint_path("image-model.pth") if "AIP_MODEL_DIR" in os.environ else ckpt_path
     if data is None:
         data = load_mnist_idx("./data")
     rank, world = dp.world_info()
     data = data.to(device)
     n = data.shape[0]
-    trainers = {}
-    opt_state = None
+    if trainer is None:
+        trainer = DDPMTrainer(model, batch_size, lr=lr)          # the ONLY broadcast of the run happens here
+    nb = (n + batch_size * world - 1) // (batch_size * world)
     for epoch in range(epochs):
         g = torch.Generator().manual_seed(epoch)          # same shuffle on every rank
         perm = torch.randperm(n, generator=g).to(device)
-        nb = (n + batch_size * world - 1) // (batch_size * world)
         last = None
         for it in range(nb):
             idx = dp.shard_batch_indices(perm, it, batch_size, rank, world)
-            if idx.numel() == 0:
-                idx = perm[:1]
-            x = data[idx]
-            B = x.shape[0]
-            if B not in trainers:
-                tr = trainers[B] = DDPMTrainer(model, B, lr=lr)
-                if opt_state is not None:               # partial last batch shares the optimiser state
-                    tr.state.m, tr.state.v = opt_state.m, opt_state.v
-                else:
-                    opt_state = tr.state
-            tr = trainers[B]
-            tr.state.step = opt_state.step
-            last = tr.step(x)
-            opt_state.step = tr.state.step
-            if log_every and (it + 1) % log_every == 0 and rank == 0:
+            gb = dp.global_batch_count(n, it, batch_size, world)
+            x = data[idx] if idx.numel() else None
+            loss = trainer.step(x, global_batch=None if gb == batch_size * world else gb)
+            last = loss if loss is not None else last
+            if log_every and (it + 1) % log_every == 0 and rank == 0 and last is not None:
                 print(f"Epoch {epoch + 1}/{epochs} it {it + 1}/{nb} loss={last.item():.4f}", flush=True)
         if rank == 0 and last is not None:
             print(f"Epoch {epoch + 1}/{epochs} done, loss={last.item():.4f}", flush=True)

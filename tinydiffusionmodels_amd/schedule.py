@@ -40,6 +40,12 @@ DERIVED_KEYS = ("sqrt_recip_alphas", "eps_coef", "sigma")
 
 _CPU_TABLES = None
 _DEV_TABLES: Dict[str, Dict[str, torch.Tensor]] = {}
+_GENERATION = 0
+
+
+def schedule_generation() -> int:
+    """Bumped by set_tables(): anything that captured device tables (hipGraph samplers) keys on it."""
+    return _GENERATION
 
 
 def cpu_tables() -> Dict[str, torch.Tensor]:
@@ -89,3 +95,5 @@ def set_tables(tables: Dict[str, torch.Tensor] = None) -> None:
             raise ValueError(f"set_tables: {k} has shape {tuple(new[k].shape)}, expected {tuple(cur[k].shape)}")
         cur[k].copy_(new[k])
     _DEV_TABLES.clear()
+    global _GENERATION
+    _GENERATION += 1

@@ -162,18 +162,27 @@ class TrainState:
     """Everything one rank needs for the fused DDPM train step
     (src/mnist.py:152-159): persistent buffers, AdamW moments, step count."""
 
-    def __init__(self, flat: torch.Tensor, B: int):
+    def __init__(self, flat: torch.Tensor, B: int, grads: Optional[torch.Tensor] = None, m: Optional[torch.Tensor] = None,
+                 v: Optional[torch.Tensor] = None):
         dev = flat.device
         self.B = B
         self.ws = UNetWorkspace(B, dev, training=True)
-        self.grads = torch.zeros(NPARAM, dtype=torch.float32, device=dev)
-        self.m = torch.zeros_like(self.grads)
-        self.v = torch.zeros_like(self.grads)
+        # flat gradient / AdamW moments: shared between the batch sizes of one trainer when passed in
+        self.grads = grads if grads is not None else torch.zeros(NPARAM, dtype=torch.float32, device=dev)
+        self.m = m if m is not None else torch.zeros_like(self.grads)
+        self.v = v if v is not None else torch.zeros_like(self.grads)
         self.x_noisy = torch.empty(B, 1, 28, 28, dtype=torch.float32, device=dev)
         self.eps = torch.empty_like(self.x_noisy)
         self.deps = torch.empty_like(self.x_noisy)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step = 0
+        # device-drawn step (tdm_unet_loss_grad_philox_f32): fixed-address batch, drawn t / noise; hipGraph of the step
+        self.x0 = torch.empty_like(self.x_noisy)
+        self.t = torch.zeros(B, dtype=torch.long, device=dev)
+        self.noise = torch.empty_like(self.x_noisy)
+        self.graph = None
+        self.graph_whole = False
+        self.warm = 0
 
 
 def loss_and_grad(flat: torch.Tensor, st: TrainState, x0: torch.Tensor, noise: torch.Tensor, t: torch.Tensor):
@@ -189,6 +198,34 @@ def loss_and_grad(flat: torch.Tensor, st: TrainState, x0: torch.Tensor, noise: t
             slabs_for(x0.device)]
     _lib.check(_lib.lib().tdm_unet_loss_grad_f32(*[_lib.ptr(a) for a in args], B, _lib.stream()), "unet_loss_grad")
     return st.loss
+
+
+def loss_and_grad_philox(flat: torch.Tensor, st: TrainState, x0: torch.Tensor, seed: int, rng_state: torch.Tensor):
+    """loss_and_grad with t ~ U{0..999} and noise ~ N(0,1) drawn on the device (src/mnist.py:154-155) from the Philox
+    stream (seed, rng_state[0]); the draws land in st.t / st.noise, the offset advances on the device."""
+    _need_cuda(flat, x0, rng_state)
+    tabs = device_tables(x0.device)
+    B = x0.shape[0]
+    if B != st.B:
+        raise RuntimeError("TrainState batch mismatch")
+    x0 = x0.contiguous()
+    _lib.check(_lib.lib().tdm_unet_loss_grad_philox_f32(
+        _lib.ptr(flat), _lib.ptr(x0), _lib.ptr(tabs["sqrt_alphas_cumprod"]), _lib.ptr(tabs["sqrt_one_minus_alphas_cumprod"]),
+        seed, _lib.ptr(rng_state), _lib.ptr(st.t), _lib.ptr(st.noise), _lib.ptr(st.x_noisy), _lib.ptr(st.eps),
+        _lib.ptr(st.deps), _lib.ptr(st.loss), _lib.ptr(st.grads), _lib.ptr(st.ws.ws), _lib.ptr(slabs_for(x0.device)), B,
+        _lib.stream()), "unet_loss_grad_philox")
+    return st.loss
+
+
+def adamw_step_dev(flat: torch.Tensor, grads: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step_state: torch.Tensor,
+                   lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
+                   weight_decay: float = 0.01, grad_scale: float = 1.0):
+    """adamw_step with the step count in device memory (step_state int64[2] = {steps taken, scratch}):
+    performs step steps_taken + 1 and stores it — no host-written scalar, hipGraph-replayable."""
+    _need_cuda(flat, grads, m, v, step_state)
+    _lib.check(_lib.lib().tdm_adamw_flat_devstep_f32(_lib.ptr(flat), _lib.ptr(grads), _lib.ptr(m), _lib.ptr(v), flat.numel(),
+                                                     lr, betas[0], betas[1], eps, weight_decay, _lib.ptr(step_state),
+                                                     grad_scale, _lib.stream()), "adamw_devstep")
 
 
 def adamw_step(flat: torch.Tensor, grads: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int,
