@@ -125,9 +125,9 @@ int tdm_unet_p_sample_step_f32(const float* params, const float* x, const int64_
  * (src/mnist.py:154-155) and `torch.randn_like(x)` (:178) from the host-seeded generator.  The
  * variants below draw the same distributions from Philox4x32-10 as a pure function of
  * (seed, stream offset, element index) — csrc/tdm_philox.h — inside the kernel that consumes
- * them.  rng_state: DEVICE int64[2] = {stream offset, 0}; every call advances the offset by one
- * on the device (so a captured graph draws fresh numbers on every replay); [1] is scratch and
- * must be 0 between calls.  The teacher-forced entry points above stay the parity path.       */
+ * them.  rng_state: DEVICE int64[2] = {stream offset, reserved}; every call advances the offset
+ * by one on the device, in a kernel enqueued behind the consumer (so a captured graph draws fresh
+ * numbers on every replay).  The teacher-forced entry points above stay the parity path.       */
 /* out[i] = N(0,1) draw i of stream (seed, offset); n % 4 == 0 (tests / utilities)             */
 int tdm_philox_normal_f32(uint64_t seed, uint64_t offset, float* out, int64_t n, void* stream);
 /* raw generator words, 4 per counter (kind 0 = noise stream, 1 = step-index stream), device / host */
@@ -143,8 +143,10 @@ int tdm_ddpm_draw_q_sample_f32(const float* x0, const float* sqrt_acp, const flo
 int tdm_p_sample_update_philox_f32(const float* x, const float* eps, const float* tab_recip, const float* tab_eps,
                                    const float* tab_sigma0, int64_t* t_dev, uint64_t seed, int64_t* rng_state,
                                    float* out, int64_t B, int64_t inner, void* stream);
-/* tdm_adamw_flat_f32 with the step count in DEVICE memory: step_state int64[2] = {steps taken, 0};
- * the call performs step steps_taken + 1 and stores it (src/mnist.py:148,159).                         */
+/* tdm_adamw_flat_f32 with the step count in DEVICE memory: step_state int64[4] = {steps taken, 0,
+ * beta1^steps, beta2^steps (doubles, maintained by the kernel)}, all zero before the first step; the call
+ * performs step steps_taken + 1 and stores it (src/mnist.py:148,159).  beta1 / beta2 must stay the same
+ * for the life of a state.                                                                              */
 int tdm_adamw_flat_devstep_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                                float beta2, float eps, float weight_decay, int64_t* step_state, float grad_scale,
                                void* stream);

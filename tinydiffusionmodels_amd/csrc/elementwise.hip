@@ -126,7 +126,9 @@ __global__ __launch_bounds__(EW_BLOCK) void to_unit_u8_kernel(const float* __res
 struct TeOffs { int w[4]; int b[4]; };
 __global__ __launch_bounds__(EW_BLOCK) void timebias_kernel(const int64_t* __restrict__ t,
                                                             const float* __restrict__ params, TeOffs o,
-                                                            float* __restrict__ that, float* __restrict__ tb, int B) {
+                                                            float* __restrict__ that, float* __restrict__ tb, int B,
+                                                            int64_t* __restrict__ bump) {
+    if (bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0) bump[0] += 1;
     const int total = B * 192;
     for (int i = blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += gridDim.x * EW_BLOCK) {
         const int b = i / 192, c = i - b * 192;
@@ -477,15 +479,17 @@ __global__ __launch_bounds__(FW_BLOCK) void first_wgrad_kernel(const float* __re
     };
     int64_t p = p0 + g;
     for (; p + 128 < p1; p += 256) {   // 2 pixels per trip: the 4 gradient loads are independent
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);   // dout1 == nullptr: the skip gradients come from elsewhere
         const float4 a0 = reinterpret_cast<const float4*>(dc1 + p * 32)[c4];
-        const float4 b0 = reinterpret_cast<const float4*>(dout1 + p * 32)[c4];
+        const float4 b0 = dout1 != nullptr ? reinterpret_cast<const float4*>(dout1 + p * 32)[c4] : z4;
         const float4 a1 = reinterpret_cast<const float4*>(dc1 + (p + 128) * 32)[c4];
-        const float4 b1 = reinterpret_cast<const float4*>(dout1 + (p + 128) * 32)[c4];
+        const float4 b1 = dout1 != nullptr ? reinterpret_cast<const float4*>(dout1 + (p + 128) * 32)[c4] : z4;
         one(p, a0, b0);
         one(p + 128, a1, b1);
     }
     for (; p < p1; p += 128)
-        one(p, reinterpret_cast<const float4*>(dc1 + p * 32)[c4], reinterpret_cast<const float4*>(dout1 + p * 32)[c4]);
+        one(p, reinterpret_cast<const float4*>(dc1 + p * 32)[c4],
+            dout1 != nullptr ? reinterpret_cast<const float4*>(dout1 + p * 32)[c4] : make_float4(0.f, 0.f, 0.f, 0.f));
     // lanes with the same c4 (lane & 7) hold different pixels: sum over lane bits 3..5
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
@@ -505,6 +509,7 @@ __global__ __launch_bounds__(FW_BLOCK) void first_wgrad_kernel(const float* __re
         for (int w = 0; w < 16; ++w) s += sh[w][k][cc];
         if (k < 9) dst[w1_off + k * 32 + cc] = s;
         else if (k == 9) dst[b1_off + cc] = s;
+        else if (dout1 == nullptr) continue;
         else if (k == 10) dst[ws_off + cc] = s;
         else dst[bs_off + cc] = s;
     }
@@ -708,15 +713,27 @@ __global__ __launch_bounds__(EW_BLOCK) void out_bwd_s16_kernel(const float* __re
                                                                const unsigned char* __restrict__ a2m, float* __restrict__ dout,
                                                                float* __restrict__ dout_s16, float* __restrict__ dc2_s16,
                                                                float* __restrict__ slab, long slab_stride, int w_off,
-                                                               int b_off, int c2b_off, int skb_off, int64_t M) {
+                                                               int b_off, int c2b_off, int skb_off, int64_t M,
+                                                               const float* __restrict__ eps, const float* __restrict__ noise,
+                                                               float* __restrict__ deps_out, float dscale, int loss_off) {
     __shared__ float4 shw[EW_BLOCK];
     __shared__ float shb[4];
     const int c4 = threadIdx.x & 7;
     const float4 wv = *reinterpret_cast<const float4*>(w + c4 * 4);
     float4 gw = make_float4(0.f, 0.f, 0.f, 0.f), g_c2 = gw, g_sk = gw;
-    float gb = 0.f;
+    float gb = 0.f, gl = 0.f;
     const int64_t total = M * 8;
     const int64_t S = (int64_t)gridDim.x * EW_BLOCK;
+    const bool fused = deps == nullptr;      // MSE backward fused: d = (eps - noise) * 2/M  (mse_kernel's arithmetic)
+    auto dval = [&](int64_t m) {
+        if (!fused) return deps[m];
+        const float df = eps[m] - noise[m];
+        if (c4 == 0) {
+            gl += df * df;
+            if (deps_out != nullptr) deps_out[m] = df * dscale;
+        }
+        return df * dscale;
+    };
     auto finish = [&](int64_t i, float d, const float4& hv, unsigned am) {
         const int64_t m = i >> 3;
         float4 o;
@@ -737,13 +754,17 @@ __global__ __launch_bounds__(EW_BLOCK) void out_bwd_s16_kernel(const float* __re
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t k = i + u * S;
-            d[u] = deps[k >> 3]; hv[u] = reinterpret_cast<const float4*>(h4)[k]; am[u] = a2m[k];
+            d[u] = dval(k >> 3); hv[u] = reinterpret_cast<const float4*>(h4)[k]; am[u] = a2m[k];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) finish(i + u * S, d[u], hv[u], am[u]);
     }
-    for (; i < total; i += S) finish(i, deps[i >> 3], reinterpret_cast<const float4*>(h4)[i], a2m[i]);
+    for (; i < total; i += S) finish(i, dval(i >> 3), reinterpret_cast<const float4*>(h4)[i], a2m[i]);
     float* dst = slab + (long)blockIdx.x * slab_stride;
+    if (fused && loss_off >= 0) {
+        const float sl = block_sum(gl, shb);
+        if (threadIdx.x == 0) dst[loss_off] = sl;
+    }
     const float sb = block_sum(gb, shb);
     quad_reduce_store(gw, shw, 8, dst + w_off);
     quad_reduce_store(g_c2, shw, 8, dst + c2b_off);
@@ -836,51 +857,91 @@ __global__ __launch_bounds__(EW_BLOCK) void combine_dh1_mask_s16_kernel(const fl
                                                                         const unsigned char* __restrict__ a2m,
                                                                         float* __restrict__ dout1, float* __restrict__ dc_s16,
                                                                         float* __restrict__ slab, long slab_stride,
-                                                                        int b_masked_off, int B) {
+                                                                        int b_masked_off, int B, const float* __restrict__ xin,
+                                                                        int ws_off, int bs_off) {
     __shared__ float4 sh[EW_BLOCK];
-    float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gm = make_float4(0.f, 0.f, 0.f, 0.f), gsw = gm, gsb = gm;
     const int64_t total = (int64_t)B * 784 * 8;
     const int64_t S = (int64_t)gridDim.x * EW_BLOCK;
     const int c4 = threadIdx.x & 7;   // (the grid stride is a multiple of 8)
-    auto fetch = [&](int64_t i, float4& dc, float4& dp, unsigned& am) {   // (32-bit index math: B * 784 * 24 < 2^31 / 4)
+    auto fetch = [&](int64_t i, float4& dc, float4& dp, unsigned& am, float& xv) {   // (32-bit index math: B * 784 * 24 < 2^31 / 4)
         const int p = (int)(i >> 3);
         const int q = p / 28, x = p - q * 28;
         const int b = q / 28, y = q - b * 28;
         dc = reinterpret_cast<const float4*>(dcat)[(unsigned)(p * 24 + 16 + c4)];
         dp = reinterpret_cast<const float4*>(dp1)[(unsigned)(((b * 14 + (y >> 1)) * 14 + (x >> 1)) * 8 + c4)];
         am = a2m[(unsigned)i];
+        xv = xin != nullptr ? xin[p] : 0.f;
     };
-    auto finish = [&](int64_t i, const float4& dc, const float4& dp, unsigned am) {
+    auto finish = [&](int64_t i, const float4& dc, const float4& dp, unsigned am, float xv) {
         float4 d;
         d.x = dc.x + 0.25f * dp.x; d.y = dc.y + 0.25f * dp.y; d.z = dc.z + 0.25f * dp.z; d.w = dc.w + 0.25f * dp.w;
-        reinterpret_cast<float4*>(dout1)[i] = d;
+        if (dout1 != nullptr) reinterpret_cast<float4*>(dout1)[i] = d;
         const float4 o = mask4(d, am);
         tdm_store_s16_4(dc_s16, i >> 3, 32, c4 * 4, o);
         gm.x += o.x; gm.y += o.y; gm.z += o.z; gm.w += o.w;
+        // rb1.skip (one input channel): dW[c] += x[m] * dout1[m][c], db[c] += dout1[m][c]  (first_wgrad_kernel's fma)
+        gsw.x = fmaf(xv, d.x, gsw.x); gsw.y = fmaf(xv, d.y, gsw.y); gsw.z = fmaf(xv, d.z, gsw.z); gsw.w = fmaf(xv, d.w, gsw.w);
+        gsb.x += d.x; gsb.y += d.y; gsb.z += d.z; gsb.w += d.w;
     };
     int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x;
     // four independent items in flight per thread (one workgroup per slab = one wave per SIMD: latency-bound otherwise)
     for (; i + 3 * S < total; i += 4 * S) {
-        float4 dc[4], dp[4]; unsigned am[4];
+        float4 dc[4], dp[4]; unsigned am[4]; float xv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) fetch(i + u * S, dc[u], dp[u], am[u]);
+        for (int u = 0; u < 4; ++u) fetch(i + u * S, dc[u], dp[u], am[u], xv[u]);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) finish(i + u * S, dc[u], dp[u], am[u]);
+        for (int u = 0; u < 4; ++u) finish(i + u * S, dc[u], dp[u], am[u], xv[u]);
     }
     for (; i < total; i += S) {
-        float4 dc, dp; unsigned am;
-        fetch(i, dc, dp, am);
-        finish(i, dc, dp, am);
+        float4 dc, dp; unsigned am; float xv;
+        fetch(i, dc, dp, am, xv);
+        finish(i, dc, dp, am, xv);
     }
-    quad_reduce_store(gm, sh, 8, slab + (long)blockIdx.x * slab_stride + b_masked_off);
+    float* dst = slab + (long)blockIdx.x * slab_stride;
+    quad_reduce_store(gm, sh, 8, dst + b_masked_off);
+    quad_reduce_store(gsw, sh, 8, (xin != nullptr && ws_off >= 0) ? dst + ws_off : nullptr);
+    quad_reduce_store(gsb, sh, 8, (xin != nullptr && bs_off >= 0) ? dst + bs_off : nullptr);
+}
+
+// time_emb / conv1-bias gradient partials of all four blocks from the per-group sums (GroupSumJobs, tdm_common.h):
+// d_tw[c] = sum_b that[b] * S[b][c], d_tb[c] = sum_b S[b][c] (S = unmasked sums), d_b(conv1)[c] = sum of the masked sums
+// (src/mnist.py:58-59 backward).  One workgroup per slab; a group's slot 0 / 1 belong to image img0 / img0 + 1.
+__global__ __launch_bounds__(EW_BLOCK) void group_sums_kernel(GroupSumJobs jb, const float* __restrict__ that, int B,
+                                                              float* __restrict__ slab, long slab_stride) {
+    __shared__ float4 sh[EW_BLOCK];
+    float* dst = slab + (long)blockIdx.x * slab_stride;
+    {
+        const int job = blockIdx.y;   // the four blocks' sums side by side: grid = (partial rows, 4)
+        const int C = jb.C[job], C4 = C >> 2, HW = jb.HWpix[job];
+        const long M = (long)B * HW;
+        const int G = (int)((M + 31) >> 5);
+        const int per = (G + gridDim.x - 1) / gridDim.x;
+        const int g0 = blockIdx.x * per, g1 = min(g0 + per, G);
+        const int c4 = threadIdx.x % C4, gi = threadIdx.x / C4, ng = EW_BLOCK / C4;
+        float4 aw = make_float4(0.f, 0.f, 0.f, 0.f), ab = aw, a2 = aw;
+        for (int g = g0 + gi; g < g1; g += ng) {
+            const int img0 = (int)(((long)g << 5) / HW);
+            const float t0 = that[img0], t1 = that[min(img0 + 1, B - 1)];
+            const float4* p = reinterpret_cast<const float4*>(jb.gs[job] + (long)g * 4 * C) + c4;   // [slot][kind][C]
+            const float4 s00 = p[0], s01 = p[C4], s10 = p[2 * C4], s11 = p[3 * C4];
+            aw.x += t0 * s00.x + t1 * s10.x; aw.y += t0 * s00.y + t1 * s10.y;
+            aw.z += t0 * s00.z + t1 * s10.z; aw.w += t0 * s00.w + t1 * s10.w;
+            ab.x += s00.x + s10.x; ab.y += s00.y + s10.y; ab.z += s00.z + s10.z; ab.w += s00.w + s10.w;
+            a2.x += s01.x + s11.x; a2.y += s01.y + s11.y; a2.z += s01.z + s11.z; a2.w += s01.w + s11.w;
+        }
+        quad_reduce_store(aw, sh, C4, dst + jb.tew[job]);
+        quad_reduce_store(ab, sh, C4, dst + jb.tew[job] + C);
+        quad_reduce_store(a2, sh, C4, jb.c1b[job] >= 0 ? dst + jb.c1b[job] : nullptr);
+    }
 }
 
 // ------------------------------- launchers -----------------------------------
 int tdm_launch_timebias(const int64_t* t, const float* params, const int* te_w_off, const int* te_b_off, float* that,
-                        float* tb, int B, hipStream_t st) {
+                        float* tb, int B, hipStream_t st, int64_t* bump) {
     TeOffs o;
     for (int i = 0; i < 4; ++i) { o.w[i] = te_w_off[i]; o.b[i] = te_b_off[i]; }
-    hipLaunchKernelGGL(timebias_kernel, dim3(ew_grid((int64_t)B * 192)), dim3(EW_BLOCK), 0, st, t, params, o, that, tb, B);
+    hipLaunchKernelGGL(timebias_kernel, dim3(ew_grid((int64_t)B * 192)), dim3(EW_BLOCK), 0, st, t, params, o, that, tb, B, bump);
     TDM_CHECK_LAUNCH("timebias");
     return 0;
 }
@@ -1043,10 +1104,20 @@ int tdm_launch_avgpool_s16(const float* in, float* out, float* out_s16, int B, i
 }
 int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, const unsigned char* a2, float* dout,
                            float* dout_s16, float* dc2_s16, float* slab, long slab_stride, int w_off, int b_off,
-                           int c2b_off, int skb_off, int64_t M, int nslab, hipStream_t st) {
+                           int c2b_off, int skb_off, int64_t M, int nslab, hipStream_t st, const float* eps,
+                           const float* noise, float* deps_out, int loss_off) {
+    TDM_REQUIRE(deps != nullptr || (eps != nullptr && noise != nullptr), "out_bwd_s16: needs deps, or eps and noise");
     hipLaunchKernelGGL(out_bwd_s16_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, deps, h4, w, a2, dout, dout_s16, dc2_s16,
-                       slab, slab_stride, w_off, b_off, c2b_off, skb_off, M);
+                       slab, slab_stride, w_off, b_off, c2b_off, skb_off, M, eps, noise, deps_out, 2.0f / (float)M, loss_off);
     TDM_CHECK_LAUNCH("out_bwd_s16");
+    return 0;
+}
+int tdm_launch_group_sums(const GroupSumJobs& jb, const float* that, int B, float* slab, long slab_stride, int nslab,
+                          hipStream_t st) {
+    for (int i = 0; i < 4; ++i)
+        TDM_REQUIRE(jb.gs[i] != nullptr && jb.C[i] % 16 == 0 && EW_BLOCK % (jb.C[i] / 4) == 0, "group_sums: job %d", i);
+    hipLaunchKernelGGL(group_sums_kernel, dim3(nslab, 4), dim3(EW_BLOCK), 0, st, jb, that, B, slab, slab_stride);
+    TDM_CHECK_LAUNCH("group_sums");
     return 0;
 }
 int tdm_launch_relu_mask_s16(const float* dout, const unsigned char* a, float* dc_s16, float* slab, long slab_stride,
@@ -1065,9 +1136,11 @@ int tdm_launch_split_dcat_mask_s16(const float* dcat, const unsigned char* a2, f
     return 0;
 }
 int tdm_launch_combine_dh1_mask_s16(const float* dcat, const float* dp1, const unsigned char* a2, float* dout1, float* dc_s16,
-                                    float* slab, long slab_stride, int b_masked_off, int B, int nslab, hipStream_t st) {
+                                    float* slab, long slab_stride, int b_masked_off, int B, int nslab, hipStream_t st,
+                                    const float* x, int ws_off, int bs_off) {
+    TDM_REQUIRE(dout1 != nullptr || x != nullptr, "combine_dh1_mask_s16: dout1 may only be dropped with the skip gradients fused");
     hipLaunchKernelGGL(combine_dh1_mask_s16_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, dcat, dp1, a2, dout1, dc_s16, slab,
-                       slab_stride, b_masked_off, B);
+                       slab_stride, b_masked_off, B, x, ws_off, bs_off);
     TDM_CHECK_LAUNCH("combine_dh1_mask_s16");
     return 0;
 }

@@ -25,18 +25,28 @@ inline int rng_grid(int64_t nwork) {
     return (int)g;
 }
 
-// true in exactly one workgroup: the one whose arrival completes the grid.  Every workgroup
-// calls it after its last read of the state the caller is about to advance.
-__device__ __forceinline__ bool last_block_arrives(unsigned* counter) {
-    __shared__ int is_last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned old = atomicAdd(counter, 1u);
-        is_last = (old == gridDim.x - 1) ? 1 : 0;
+// State advances (Philox offset, reverse-step index, AdamW step count) are made by a one-workgroup kernel launched
+// right AFTER the kernel that consumed the old values (stream order = every workgroup of the consumer has finished).
+// The first version let the consumer's last-arriving workgroup do it (one same-address atomic per workgroup): 709 / 2048
+// serialised atomics cost 17 us in AdamW and more in the B = 4096 update — three times the kernels' own time.
+__global__ __launch_bounds__(64) void bump_offset_kernel(int64_t* __restrict__ state) {
+    if (threadIdx.x == 0) state[0] += 1;
+}
+__global__ __launch_bounds__(RB) void bump_t_kernel(int64_t* __restrict__ state, int64_t* __restrict__ t, int64_t B) {
+    for (int64_t b = threadIdx.x; b < B; b += RB) {
+        const int64_t v = t[b] - 1;
+        t[b] = v < 0 ? 0 : v;
     }
-    __syncthreads();
-    return is_last != 0;
+    if (threadIdx.x == 0) state[0] += 1;
+}
+__global__ __launch_bounds__(64) void bump_adam_kernel(int64_t* __restrict__ state, float beta1, float beta2) {
+    if (threadIdx.x == 0) {
+        const double b1p = (state[0] == 0 ? 1.0 : __longlong_as_double(state[2])) * (double)beta1;
+        const double b2p = (state[0] == 0 ? 1.0 : __longlong_as_double(state[3])) * (double)beta2;
+        state[0] += 1;
+        state[2] = __double_as_longlong(b1p);
+        state[3] = __double_as_longlong(b2p);
+    }
 }
 
 __global__ __launch_bounds__(RB) void philox_normal_kernel(uint64_t seed, uint64_t offset, float* __restrict__ out, int64_t n4) {
@@ -52,7 +62,7 @@ __global__ __launch_bounds__(RB) void philox_u32_kernel(uint64_t seed, uint64_t 
     }
 }
 
-// state[0] = Philox offset of this call (advanced by 1 on exit), state[1] = arrival counter (0 between calls)
+// state[0] = Philox offset of this call (advanced afterwards by bump_offset_kernel / the next kernel of the step)
 __global__ __launch_bounds__(RB) void draw_q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ ta,
                                                            const float* __restrict__ ts, uint64_t seed,
                                                            int64_t* __restrict__ state, int64_t* __restrict__ t_out,
@@ -75,17 +85,13 @@ __global__ __launch_bounds__(RB) void draw_q_sample_kernel(const float* __restri
         reinterpret_cast<float4*>(noise_out)[i] = n;
         reinterpret_cast<float4*>(xn_out)[i] = o;
     }
-    if (last_block_arrives(reinterpret_cast<unsigned*>(state + 1)) && threadIdx.x == 0) {
-        state[0] = (int64_t)(offset + 1);
-        *reinterpret_cast<unsigned*>(state + 1) = 0u;
-    }
 }
 
 __device__ __forceinline__ float p_upd(float x, float e, float z, float cr, float ce, float cs) {
     return __fadd_rn(__fmul_rn(cr, __fsub_rn(x, __fmul_rn(ce, e))), __fmul_rn(cs, z));
 }
 
-// t: per-sample step index in DEVICE memory, decremented (floor 0) on exit; tsg[0] must be 0 so that the
+// t: per-sample step index in DEVICE memory (decremented afterwards by bump_t_kernel); tsg[0] must be 0 so that the
 // t == 0 step returns the mean (src/mnist.py:176-177) without a host-side branch
 __global__ __launch_bounds__(RB) void p_update_philox_kernel(const float* __restrict__ x, const float* __restrict__ eps,
                                                              const float* __restrict__ tr, const float* __restrict__ te,
@@ -107,35 +113,20 @@ __global__ __launch_bounds__(RB) void p_update_philox_kernel(const float* __rest
         o.w = p_upd(xv.w, ev.w, zv.w, cr, ce, cs);
         reinterpret_cast<float4*>(out)[i] = o;
     }
-    if (last_block_arrives(reinterpret_cast<unsigned*>(state + 1))) {
-        for (int64_t b = threadIdx.x; b < B; b += RB) {
-            const int64_t v = t[b] - 1;
-            t[b] = v < 0 ? 0 : v;
-        }
-        if (threadIdx.x == 0) {
-            state[0] = (int64_t)(offset + 1);
-            *reinterpret_cast<unsigned*>(state + 1) = 0u;
-        }
-    }
 }
 
 // AdamW with the step count in device memory: state[0] = steps taken so far (this call performs step state[0] + 1
-// and stores it), state[1] = arrival counter.  Same update as adamw_kernel (elementwise.hip); the scalar prologue
+// and stores it), state[1] = arrival counter, state[2..3] = beta1^steps, beta2^steps (doubles).  Same update as adamw_kernel (elementwise.hip); the scalar prologue
 // runs in double like torch's Python floats.
 __global__ __launch_bounds__(RB) void adamw_devstep_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                            float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                            float lr, float beta1, float beta2, float eps, float wd,
                                                            int64_t* __restrict__ state, float gscale) {
-    __shared__ float sc[2];
-    const int64_t step = state[0] + 1;
-    if (threadIdx.x == 0) {
-        const double bc1 = 1.0 - pow((double)beta1, (double)step);
-        const double bc2 = 1.0 - pow((double)beta2, (double)step);
-        sc[0] = (float)((double)lr / bc1);
-        sc[1] = (float)sqrt(bc2);
-    }
-    __syncthreads();
-    const float step_size = sc[0], bc2_sqrt = sc[1];
+    // beta^step as running products kept in the state (doubles, bit patterns in state[2..3]; 0 = "not started": 1.0):
+    // a double pow() per workgroup was most of this kernel's time (22 us for 726 KB of parameters)
+    const double b1p = (state[0] == 0 ? 1.0 : __longlong_as_double(state[2])) * (double)beta1;
+    const double b2p = (state[0] == 0 ? 1.0 : __longlong_as_double(state[3])) * (double)beta2;
+    const float step_size = (float)((double)lr / (1.0 - b1p)), bc2_sqrt = (float)sqrt(1.0 - b2p);
     const float decay = (float)(1.0 - (double)lr * (double)wd);
     const float one_m_b1 = (float)(1.0 - (double)beta1), one_m_b2 = (float)(1.0 - (double)beta2);
     for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += (int64_t)gridDim.x * RB) {
@@ -148,13 +139,23 @@ __global__ __launch_bounds__(RB) void adamw_devstep_kernel(float* __restrict__ p
         pi = pi - step_size * (mi / denom);
         p[i] = pi; m[i] = mi; v[i] = vi;
     }
-    if (last_block_arrives(reinterpret_cast<unsigned*>(state + 1)) && threadIdx.x == 0) {
-        state[0] = step;
-        *reinterpret_cast<unsigned*>(state + 1) = 0u;
-    }
 }
 
 }  // namespace
+
+// internal: the fused train step advances the offset in its next kernel (timebias) instead of a bump launch
+int tdm_launch_draw_q_sample(const float* x0, const float* sqrt_acp, const float* sqrt_1m_acp, uint64_t seed, int64_t* rng_state,
+                             int64_t* t_out, float* noise_out, float* x_noisy_out, int64_t B, int64_t inner, bool bump,
+                             hipStream_t st) {
+    hipLaunchKernelGGL(draw_q_sample_kernel, dim3(rng_grid(B * inner / 4)), dim3(RB), 0, st, x0, sqrt_acp, sqrt_1m_acp, seed,
+                       rng_state, t_out, noise_out, x_noisy_out, B, inner / 4);
+    TDM_CHECK_LAUNCH("draw_q_sample");
+    if (bump) {
+        hipLaunchKernelGGL(bump_offset_kernel, dim3(1), dim3(64), 0, st, rng_state);
+        TDM_CHECK_LAUNCH("bump_offset");
+    }
+    return 0;
+}
 
 extern "C" {
 
@@ -186,10 +187,8 @@ int tdm_ddpm_draw_q_sample_f32(const float* x0, const float* sqrt_acp, const flo
     TDM_REQUIRE(x0 && sqrt_acp && sqrt_1m_acp && rng_state && t_out && noise_out && x_noisy_out, "draw_q_sample: NULL pointer");
     TDM_REQUIRE(B > 0 && inner > 0 && (inner & 3) == 0, "draw_q_sample: B=%lld inner=%lld (inner must be a multiple of 4)",
                 (long long)B, (long long)inner);
-    hipLaunchKernelGGL(draw_q_sample_kernel, dim3(rng_grid(B * inner / 4)), dim3(RB), 0, (hipStream_t)stream, x0, sqrt_acp,
-                       sqrt_1m_acp, seed, rng_state, t_out, noise_out, x_noisy_out, B, inner / 4);
-    TDM_CHECK_LAUNCH("draw_q_sample");
-    return 0;
+    return tdm_launch_draw_q_sample(x0, sqrt_acp, sqrt_1m_acp, seed, rng_state, t_out, noise_out, x_noisy_out, B, inner, true,
+                                    (hipStream_t)stream);
 }
 
 int tdm_p_sample_update_philox_f32(const float* x, const float* eps, const float* tab_recip, const float* tab_eps,
@@ -201,6 +200,8 @@ int tdm_p_sample_update_philox_f32(const float* x, const float* eps, const float
     hipLaunchKernelGGL(p_update_philox_kernel, dim3(rng_grid(B * inner / 4)), dim3(RB), 0, (hipStream_t)stream, x, eps,
                        tab_recip, tab_eps, tab_sigma0, t_dev, seed, rng_state, out, B, inner / 4);
     TDM_CHECK_LAUNCH("p_sample_update_philox");
+    hipLaunchKernelGGL(bump_t_kernel, dim3(1), dim3(RB), 0, (hipStream_t)stream, rng_state, t_dev, B);
+    TDM_CHECK_LAUNCH("bump_t");
     return 0;
 }
 
@@ -210,6 +211,8 @@ int tdm_adamw_flat_devstep_f32(float* p, const float* g, float* m, float* v, int
     hipLaunchKernelGGL(adamw_devstep_kernel, dim3(rng_grid(n)), dim3(RB), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
                        beta2, eps, weight_decay, step_state, grad_scale);
     TDM_CHECK_LAUNCH("adamw_devstep");
+    hipLaunchKernelGGL(bump_adam_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_state, beta1, beta2);
+    TDM_CHECK_LAUNCH("bump_adam");
     return 0;
 }
 

@@ -145,6 +145,8 @@ struct ReduceSec {
     int off, len, nslab;
     long src_delta;        // slab 0 of this section starts at slabs + off + src_delta (default 0)
     long stride_override;  // distance between this section's slabs; 0 = the launch's common stride
+    float* dst;            // where the section's sums go; nullptr = out + off
+    float scale;           // factor applied to the sums; 0 = 1
 };
 #define TDM_MAX_SECS 64
 struct ReduceArgs {
@@ -156,8 +158,12 @@ int tdm_launch_reduce(const float* slabs, long stride, const ReduceArgs& ra, flo
 // ---------------------------------------------------------------------------
 // elementwise / small kernels (elementwise.hip)
 // ---------------------------------------------------------------------------
+// bump != nullptr: also bump[0] += 1 (the Philox offset of the fused train step, consumed by the preceding draw kernel)
 int tdm_launch_timebias(const int64_t* t, const float* params, const int* te_w_off, const int* te_b_off,
-                        float* that, float* tb, int B, hipStream_t st);
+                        float* that, float* tb, int B, hipStream_t st, int64_t* bump = nullptr);
+int tdm_launch_draw_q_sample(const float* x0, const float* sqrt_acp, const float* sqrt_1m_acp, uint64_t seed, int64_t* rng_state,
+                             int64_t* t_out, float* noise_out, float* x_noisy_out, int64_t B, int64_t inner, bool bump,
+                             hipStream_t st);
 int tdm_launch_conv_first(const float* x, const float* w1, const float* b1, const float* ws, const float* bs,
                           float* a1, float* s, int B, hipStream_t st);
 int tdm_launch_avgpool(const float* in, float* out, int B, int Hout, int C, hipStream_t st);
@@ -185,14 +191,25 @@ int tdm_launch_pool_skip_s16(const float* h1, const float* wsk, const float* bsk
                              hipStream_t st);
 int tdm_launch_s16_to_nchw(const float* in_s16, float* out, int B, int HWpix, int C, hipStream_t st);   // accessor: hi + lo -> fp32 NCHW
 int tdm_launch_avgpool_s16(const float* in, float* out, float* out_s16, int B, int Hout, int C, hipStream_t st);
+// deps == nullptr: the MSE backward is fused — d = (eps - noise) * 2/M is computed here (and written to deps_out when
+// given), and the slab partial of sum (eps - noise)^2 goes to slab offset loss_off (F.mse_loss, src/mnist.py:158)
 int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, const unsigned char* a2m, float* dout,
                            float* dout_s16, float* dc2_s16, float* slab, long slab_stride, int w_off, int b_off,
-                           int c2b_off, int skb_off, int64_t M, int nslab, hipStream_t st);
+                           int c2b_off, int skb_off, int64_t M, int nslab, hipStream_t st, const float* eps = nullptr,
+                           const float* noise = nullptr, float* deps_out = nullptr, int loss_off = -1);
+// time_emb weight / bias gradients of the four blocks and the conv1 bias gradients of rb2..rb4 as slab partials, straight
+// from the per-32-pixel-group sums the data-gradient launches wrote (ConvArgs::sums; one buffer per block)
+struct GroupSumJobs { const float* gs[4]; int C[4]; int HWpix[4]; int tew[4]; int c1b[4]; };
+int tdm_launch_group_sums(const GroupSumJobs& jb, const float* that, int B, float* slab, long slab_stride, int nslab,
+                          hipStream_t st);
 // dc_s16 = split(dout * (a > 0)); slab partial sums of the masked (and optionally unmasked) gradient per channel
 int tdm_launch_split_dcat_mask_s16(const float* dcat, const unsigned char* a2m, float* dout3, float* dc_s16, float* slab,
                                    long slab_stride, int b_masked_off, int B, int nslab, hipStream_t st);
+// x != nullptr: also the slab partials of rb1.skip's gradients (1 input channel: dW[c] = sum x[m] * dout1[m][c],
+// db[c] = sum dout1[m][c]) at ws_off / bs_off, so dout1 itself (nullable) need not be written for first_wgrad
 int tdm_launch_combine_dh1_mask_s16(const float* dcat, const float* dp1, const unsigned char* a2m, float* dout1, float* dc_s16,
-                                    float* slab, long slab_stride, int b_masked_off, int B, int nslab, hipStream_t st);
+                                    float* slab, long slab_stride, int b_masked_off, int B, int nslab, hipStream_t st,
+                                    const float* x = nullptr, int ws_off = -1, int bs_off = -1);
 int tdm_launch_relu_mask_s16(const float* dout, const unsigned char* am, float* dc_s16, float* slab, long slab_stride,
                              int b_masked_off, int b_unmasked_off, int64_t M, int C, int nslab, hipStream_t st);
 // dh <- dh * (a1 > 0) in place (fp32) + S16 copy; S[b][c] = sum dh (unmasked), S2[b][c] = sum of the masked values

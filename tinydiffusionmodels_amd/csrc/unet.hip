@@ -106,8 +106,10 @@ struct Ws {
     float *a1s_1, *h1s, *p1s, *a1s_2, *h2s, *a1s_3, *h3s, *a1s_4;
     float *dout4s, *dc2s_4, *dh4s, *dc2s_3, *dh3s, *dc2s_2, *dh2s, *dout2s, *dc2s_1, *S2[4];
     float* gsum;                    // per-32-pixel-group partial sums of a data-gradient launch (ConvArgs::sums)
+    float* gs[4];                   // ... one buffer per block in the S16 pipeline (consumed together by group_sums_kernel)
     unsigned char *m1[4], *m2[4];   // ReLU byte masks of conv1 / conv2 outputs of the 4 blocks (S16 pipeline, training)
     int64_t total;
+    int64_t* rng_bump = nullptr;    // set by the device-drawn train step: the forward's first kernel advances the Philox offset
 };
 
 Ws carve(float* base, int64_t B, int training) {
@@ -140,6 +142,8 @@ Ws carve(float* base, int64_t B, int training) {
         w.dout2s = take(M14 * 64); w.dc2s_1 = take(M28 * 32);
         for (int i = 0; i < 4; ++i) w.S2[i] = take(B * 64);
         w.gsum = take((M28 / 32 + 2) * 4 * 32 > (M14 / 32 + 2) * 4 * 64 ? (M28 / 32 + 2) * 4 * 32 : (M14 / 32 + 2) * 4 * 64);
+        w.gs[0] = w.gsum; w.gs[1] = take((M14 / 32 + 2) * 4 * 64); w.gs[2] = take((M14 / 32 + 2) * 4 * 64);
+        w.gs[3] = take((M28 / 32 + 2) * 4 * 32);
         // byte masks: one byte per 4 channels = (pixels * C / 4) bytes = pixels * C / 16 floats
         const int64_t mfl[4] = {M28 * 32 / 16, M14 * 64 / 16, M14 * 64 / 16, M28 * 32 / 16};
         for (int i = 0; i < 4; ++i) {
@@ -197,8 +201,12 @@ int wgrad(hipStream_t st, int hw, int B, const float* act, int C, int c_used, in
 
 int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* eps, const Ws& w, int B, int save,
                      hipStream_t st);
+// deps == nullptr: the train step's form — F.mse_loss forward + backward (src/mnist.py:158) is fused into the first
+// backward kernel (d = 2 (eps - noise) / n; loss partials travel through the slabs to loss_out)
+struct MseIn { const float* eps; const float* noise; float* deps_out; float* loss_out; };
+constexpr long SLAB_STRIDE = TDM_UNET_NPARAM + 64;   // S16 pipeline: [parameters | loss partial | pad]
 int unet_backward_s16(const float* P, const float* x, const float* deps, float* G, const Ws& w, float* slabs, int B,
-                      hipStream_t st);
+                      hipStream_t st, const MseIn* mse = nullptr);
 
 int unet_forward(const float* P, const float* x, const int64_t* t, float* eps, const Ws& w, int B, int save,
                  hipStream_t st) {
@@ -266,7 +274,7 @@ int wgrad_s16(hipStream_t st, int hw, int B, const float* act_s16, int C, int c_
     a.g2 = g2_s16; a.w_off2 = w_off2;   // the block's 1x1 skip weight gradient, fused into this 3x3 launch
     a.a = s16_src(act_s16, C, c_used, up, taps, nullptr, 0);
     a.a.w_rows = w_rows; a.a.w_r0 = w_r0;
-    a.g = g_s16; a.Cout = Cout; a.slab = slabs; a.slab_stride = TDM_UNET_NPARAM; a.w_off = w_off; a.b_off = -1; a.B = B;
+    a.g = g_s16; a.Cout = Cout; a.slab = slabs; a.slab_stride = SLAB_STRIDE; a.w_off = w_off; a.b_off = -1; a.B = B;
     a.ntiles = (int)(((long)B * hw * hw + 255) / 256);
     a.nci = c_used / 32;
     return tdm_launch_wgrad_s16(a, hw, nslab, st);
@@ -282,18 +290,18 @@ int wgrad_s16(hipStream_t st, int hw, int B, const float* act_s16, int C, int c_
     X(F_RB4C1, "rb4.conv1 + rb4.skip fwd 96->32 @28 (conv_s16<28,1,skip>)")                                             \
     X(F_RB4C2, "rb4.conv2 + out fwd 32->32 @28 (conv_s16<28,1>)")                                                       \
     X(B_OUT_BWD, "out conv bwd + relu mask (out_bwd_s16)") X(B_WG_RB4C2, "rb4.conv2 wgrad (wgrad2_s16<28>)")            \
-    X(B_DG_RB4C2, "rb4.conv2 dgrad 32->32 @28 (conv_s16<28,1>)") X(B_SUMS4, "image_sums rb4")                           \
+    X(B_DG_RB4C2, "rb4.conv2 dgrad 32->32 @28 (conv_s16<28,1>)")                                                        \
     X(B_WG_RB4C1A, "rb4.conv1+skip wgrad, up(h3) part (wgrad2_s16<28,sk>)")                                             \
     X(B_WG_RB4C1B, "rb4.conv1+skip wgrad, h1 part (wgrad2_s16<28,sk>)")                                                 \
     X(B_DG_RB4C1, "rb4.conv1+skip dgrad 32->96 @28 (conv_s16<28,3>)") X(B_SPLIT_DCAT, "upsample bwd + relu mask (split_dcat_mask_s16)") \
     X(B_WG_RB3C2, "rb3.conv2 wgrad (wgrad2_s16<14>)") X(B_DG_RB3C2, "rb3.conv2 dgrad 64->64 @14 (conv_s16<14,2>)")      \
-    X(B_SUMS3, "image_sums rb3") X(B_WG_RB3C1, "rb3.conv1 wgrad (wgrad2_s16<14>)")                                      \
+    X(B_WG_RB3C1, "rb3.conv1 wgrad (wgrad2_s16<14>)")                                                                   \
     X(B_DG_RB3C1, "rb3.conv1 dgrad 64->64 @14 (conv_s16<14,2>)") X(B_RELU_MASK2, "relu mask rb2 (relu_mask_s16)")       \
     X(B_WG_RB2C2, "rb2.conv2 wgrad (wgrad2_s16<14>)") X(B_DG_RB2C2, "rb2.conv2 dgrad 64->64 @14 (conv_s16<14,2>)")      \
-    X(B_SUMS2, "image_sums rb2") X(B_WG_RB2C1, "rb2.conv1+skip wgrad (wgrad2_s16<14,sk>)")                              \
+    X(B_WG_RB2C1, "rb2.conv1+skip wgrad (wgrad2_s16<14,sk>)")                                                           \
     X(B_DG_RB2C1, "rb2.conv1+skip dgrad 64->32 @14 (conv_s16<14,1>)") X(B_COMBINE_DH1, "concat/pool bwd + relu mask (combine_dh1_mask_s16)") \
     X(B_WG_RB1C2, "rb1.conv2 wgrad (wgrad2_s16<28>)") X(B_DG_RB1C2, "rb1.conv2 dgrad 32->32 @28 (conv_s16<28,1>)")      \
-    X(B_SUMS1, "image_sums rb1") X(B_TIME_GRAD, "time_emb + conv1 bias grads (time_grad)")                              \
+    X(B_GROUP_SUMS, "time_emb + conv1 bias grads from group sums (group_sums)")                                        \
     X(B_FIRST_WGRAD, "rb1.conv1 + rb1.skip wgrad (first_wgrad)") X(B_REDUCE, "slab reduction (reduce_slabs)")
 enum UnetLaunch {
 #define X(id, name) L_##id,
@@ -316,7 +324,7 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
                      hipStream_t st) {
     const int tew[4] = {kL.rb[0].tew, kL.rb[1].tew, kL.rb[2].tew, kL.rb[3].tew};
     const int teb[4] = {kL.rb[0].teb, kL.rb[1].teb, kL.rb[2].teb, kL.rb[3].teb};
-    RUN(F_TIMEBIAS, tdm_launch_timebias(t, P, tew, teb, w.that, w.tb, B, st));
+    RUN(F_TIMEBIAS, tdm_launch_timebias(t, P, tew, teb, w.that, w.tb, B, st, w.rng_bump));
     RUN(F_PACK, tdm_launch_pack(P, kPack.pa, w.wpack, st));
     const BlockOff &r1 = kL.rb[0], &r2 = kL.rb[1], &r3 = kL.rb[2], &r4 = kL.rb[3];
     // rb1: conv1 (Cin = 1) writes a1 (mask) and split(a1 + tb) for conv2
@@ -367,22 +375,35 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
     return 0;
 }
 
+// Slab buffer of the S16 pipeline: NSLAB weight-gradient slabs of SLAB_STRIDE floats (one per workgroup column of the
+// MFMA weight-gradient kernels), then EROWS compact rows of ESTRIDE floats for the partial sums the ELEMENTWISE producers
+// emit (bias / 1-channel-conv / time-embedding gradients, the loss): those kernels are bandwidth-bound only with ~4
+// workgroups per CU, i.e. up to 1024 partial rows, which would be 740 MB of full-width slabs for ~1 KB of payload each.
+constexpr int NSLAB = 256;
+constexpr int EROWS = 1024, ESTRIDE = 960;
+enum { E_OUT = 0, E_LOSS = 33, E_C2B4 = 64, E_SKB4 = 96, E_C2B3 = 128, E_C2B2 = 192, E_SKB2 = 256, E_C2B1 = 320, E_SKW1 = 352,
+       E_SKB1 = 384, E_TE1 = 416, E_TE2 = 480, E_TE3 = 608, E_TE4 = 736, E_C1B2 = 800, E_C1B3 = 864, E_C1B4 = 928 };
+constexpr long ESLAB_BASE = (long)NSLAB * SLAB_STRIDE;   // float offset of the compact rows inside the slab buffer
+
 int unet_backward_s16(const float* P, const float* x, const float* deps, float* G, const Ws& w, float* slabs, int B,
-                      hipStream_t st) {
-    constexpr int NS = 256;
+                      hipStream_t st, const MseIn* mse) {
+    constexpr int NS = NSLAB;
     // weight-gradient slabs of the 14x14 layers: with 2 / 4 (ci, co) channel-tile combinations per layer, 128 / 64
     // slabs make one round of 256 workgroups that each pipeline ~6 pixel tiles (256 slabs = 512-1024 workgroups of 1-3)
     constexpr int NS2 = 128, NS4 = 64;
+    constexpr int ER28 = 1024, ER14 = 512, ERG = 64;   // partial rows of the elementwise producers (28x28 / 14x14 / group sums)
     const BlockOff &r1 = kL.rb[0], &r2 = kL.rb[1], &r3 = kL.rb[2], &r4 = kL.rb[3];
     const int64_t M28 = (int64_t)B * 784, M14 = (int64_t)B * 196;
-    const long NP = TDM_UNET_NPARAM;
+    const long NP = SLAB_STRIDE;
+    float* const es = slabs + ESLAB_BASE;
+    TDM_REQUIRE(deps != nullptr || mse != nullptr, "unet_backward: no output gradient");
     // ---- out conv + rb4 ----
-    RUN(B_OUT_BWD, tdm_launch_out_bwd_s16(deps, w.h4, P + kL.outw, w.m2[3], nullptr, w.dout4s, w.dc2s_4, slabs, NP, kL.outw,
-                                          kL.outb, r4.c2b, r4.skb, M28, NS, st));
+    RUN(B_OUT_BWD, tdm_launch_out_bwd_s16(deps, w.h4, P + kL.outw, w.m2[3], nullptr, w.dout4s, w.dc2s_4, es, ESTRIDE, E_OUT,
+                                          E_OUT + 32, E_C2B4, E_SKB4, M28, ER28, st, deps ? nullptr : mse->eps,
+                                          deps ? nullptr : mse->noise, deps ? nullptr : mse->deps_out, deps ? -1 : E_LOSS));
     RUN(B_WG_RB4C2, wgrad_s16(st, 28, B, w.a1s_4, 32, 32, 0, 9, w.dc2s_4, 32, slabs, r4.c2w, 32, 0, NS));
     RUN(B_DG_RB4C2, conv_s16_1(st, w, 28, B, w.dc2s_4, 32, 9, kPack.dg[W_RB4C2], 32, nullptr, 0,
-                               S16Out{nullptr, nullptr, nullptr, w.dh4s, nullptr, w.m1[3], w.gsum}));   // + ReLU backward of a1
-    RUN(B_SUMS4, tdm_launch_image_sums(w.gsum, w.S[3], w.S2[3], B, 784, 32, st));
+                               S16Out{nullptr, nullptr, nullptr, w.dh4s, nullptr, w.m1[3], w.gs[3]}));   // + ReLU backward of a1
     // rb4.conv1 and rb4.skip read the same concat: the 1x1 gradients ride on the 3x3 launches (fifth accumulator of tap group 1)
     RUN(B_WG_RB4C1A, wgrad_s16(st, 28, B, w.h3s, 64, 64, 1, 9, w.dh4s, 32, slabs, r4.c1w, 96, 0, NS, w.dout4s, r4.skw));
     RUN(B_WG_RB4C1B, wgrad_s16(st, 28, B, w.h1s, 32, 32, 0, 9, w.dh4s, 32, slabs, r4.c1w, 96, 64, NS, w.dout4s, r4.skw));
@@ -395,20 +416,18 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
         RUN(B_DG_RB4C1, tdm_launch_conv_s16(a, 28, 96, st));
     }
     // ---- rb3 ---- (upsample backward and the ReLU mask of rb3.conv2's output in one pass)
-    RUN(B_SPLIT_DCAT, tdm_launch_split_dcat_mask_s16(w.dcat, w.m2[2], w.dout3, w.dc2s_3, slabs, NP, r3.c2b, B, NS, st));
+    RUN(B_SPLIT_DCAT, tdm_launch_split_dcat_mask_s16(w.dcat, w.m2[2], w.dout3, w.dc2s_3, es, ESTRIDE, E_C2B3, B, ER14, st));
     RUN(B_WG_RB3C2, wgrad_s16(st, 14, B, w.a1s_3, 64, 64, 0, 9, w.dc2s_3, 64, slabs, r3.c2w, 64, 0, NS4));
     RUN(B_DG_RB3C2, conv_s16_1(st, w, 14, B, w.dc2s_3, 64, 9, kPack.dg[W_RB3C2], 64, nullptr, 0,
-                               S16Out{nullptr, nullptr, nullptr, w.dh3s, nullptr, w.m1[2], w.gsum}));
-    RUN(B_SUMS3, tdm_launch_image_sums(w.gsum, w.S[2], w.S2[2], B, 196, 64, st));
+                               S16Out{nullptr, nullptr, nullptr, w.dh3s, nullptr, w.m1[2], w.gs[2]}));
     RUN(B_WG_RB3C1, wgrad_s16(st, 14, B, w.h2s, 64, 64, 0, 9, w.dh3s, 64, slabs, r3.c1w, 64, 0, NS4));
     RUN(B_DG_RB3C1, conv_s16_1(st, w, 14, B, w.dh3s, 64, 9, kPack.dg[W_RB3C1], 64, nullptr, 0,
                                S16Out{w.dout2, nullptr, w.dout3, w.dout2s, nullptr}));   // + identity skip
     // ---- rb2 ----
-    RUN(B_RELU_MASK2, tdm_launch_relu_mask_s16(w.dout2, w.m2[1], w.dc2s_2, slabs, NP, r2.c2b, r2.skb, M14, 64, NS, st));
+    RUN(B_RELU_MASK2, tdm_launch_relu_mask_s16(w.dout2, w.m2[1], w.dc2s_2, es, ESTRIDE, E_C2B2, E_SKB2, M14, 64, ER14, st));
     RUN(B_WG_RB2C2, wgrad_s16(st, 14, B, w.a1s_2, 64, 64, 0, 9, w.dc2s_2, 64, slabs, r2.c2w, 64, 0, NS4));
     RUN(B_DG_RB2C2, conv_s16_1(st, w, 14, B, w.dc2s_2, 64, 9, kPack.dg[W_RB2C2], 64, nullptr, 0,
-                               S16Out{nullptr, nullptr, nullptr, w.dh2s, nullptr, w.m1[1], w.gsum}));
-    RUN(B_SUMS2, tdm_launch_image_sums(w.gsum, w.S[1], w.S2[1], B, 196, 64, st));
+                               S16Out{nullptr, nullptr, nullptr, w.dh2s, nullptr, w.m1[1], w.gs[1]}));
     RUN(B_WG_RB2C1, wgrad_s16(st, 14, B, w.p1s, 32, 32, 0, 9, w.dh2s, 64, slabs, r2.c1w, 32, 0, NS2, w.dout2s, r2.skw));   // + rb2.skip
     {
         ConvArgs a{};
@@ -419,36 +438,49 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
         RUN(B_DG_RB2C1, tdm_launch_conv_s16(a, 14, 32, st));
     }
     // ---- rb1 ---- (concat skip + avg-pool backward and the ReLU mask of rb1.conv2's output in one pass)
-    RUN(B_COMBINE_DH1, tdm_launch_combine_dh1_mask_s16(w.dcat, w.dp1, w.m2[0], w.dout1, w.dc2s_1, slabs, NP, r1.c2b, B, NS, st));
+    // (rb1.skip has one input channel: its weight / bias gradients are sums over x * dout1 and dout1, taken here while
+    //  dout1 is in registers — the fp32 tensor itself is never written)
+    RUN(B_COMBINE_DH1, tdm_launch_combine_dh1_mask_s16(w.dcat, w.dp1, w.m2[0], nullptr, w.dc2s_1, es, ESTRIDE, E_C2B1, B, ER28, st,
+                                                       x, E_SKW1, E_SKB1));
     RUN(B_WG_RB1C2, wgrad_s16(st, 28, B, w.a1s_1, 32, 32, 0, 9, w.dc2s_1, 32, slabs, r1.c2w, 32, 0, NS));
     RUN(B_DG_RB1C2, conv_s16_1(st, w, 28, B, w.dc2s_1, 32, 9, kPack.dg[W_RB1C2], 32, nullptr, 0,
-                               S16Out{w.dh1, nullptr, nullptr, nullptr, nullptr, w.m1[0], w.gsum}));   // dh1 <- masked, fp32 (rb1.conv1 wgrad)
-    RUN(B_SUMS1, tdm_launch_image_sums(w.gsum, w.S[0], w.S2[0], B, 784, 32, st));
-    {   // time_emb gradients of all four blocks + conv1 bias gradients of rb2..rb4, one launch
-        const float* Sv[4] = {w.S[0], w.S[1], w.S[2], w.S[3]};
-        const float* S2v[4] = {nullptr, w.S2[1], w.S2[2], w.S2[3]};
-        float* tw[4] = {G + r1.tew, G + r2.tew, G + r3.tew, G + r4.tew};
-        float* tbv[4] = {G + r1.teb, G + r2.teb, G + r3.teb, G + r4.teb};
-        float* dbv[4] = {nullptr, G + r2.c1b, G + r3.c1b, G + r4.c1b};
-        const int Cv[4] = {32, 64, 64, 32};
-        RUN(B_TIME_GRAD, tdm_launch_time_grad_multi2(Sv, S2v, tw, tbv, dbv, Cv, 4, w.that, B, st));
+                               S16Out{w.dh1, nullptr, nullptr, nullptr, nullptr, w.m1[0], w.gs[0]}));   // dh1 <- masked, fp32 (rb1.conv1 wgrad)
+    {   // time_emb gradients of all four blocks + conv1 bias gradients of rb2..rb4 as partial rows, one launch
+        GroupSumJobs jb{};
+        const int Cv[4] = {32, 64, 64, 32}, hwv[4] = {784, 196, 196, 784};
+        const int tev[4] = {E_TE1, E_TE2, E_TE3, E_TE4}, c1bv[4] = {-1, E_C1B2, E_C1B3, E_C1B4};
+        for (int i = 0; i < 4; ++i) { jb.gs[i] = w.gs[i]; jb.C[i] = Cv[i]; jb.HWpix[i] = hwv[i]; jb.tew[i] = tev[i]; jb.c1b[i] = c1bv[i]; }
+        RUN(B_GROUP_SUMS, tdm_launch_group_sums(jb, w.that, B, es, ESTRIDE, ERG, st));
     }
-    RUN(B_FIRST_WGRAD, tdm_launch_first_wgrad(x, w.dh1, w.dout1, slabs, NP, r1.c1w, r1.c1b, r1.skw, r1.skb, B, NS, st));
+    RUN(B_FIRST_WGRAD, tdm_launch_first_wgrad(x, w.dh1, nullptr, slabs, NP, r1.c1w, r1.c1b, r1.skw, r1.skb, B, NS, st));
     ReduceArgs ra{};
     int n = 0;
     auto sec = [&](int off, int len, int ns) { ra.sec[n].off = off; ra.sec[n].len = len; ra.sec[n].nslab = ns; ++n; };
-    sec(r1.c1w, 288 + 32, NS); sec(r1.c2w, 9216 + 32, NS); sec(r1.skw, 32 + 32, NS);
-    sec(r2.c1w, 18432, NS2); sec(r2.c2w, 36864, NS4); sec(r2.c2w + 36864, 64, NS);   // weights | bias (elementwise producers)
-    sec(r2.skw, 2048, NS2); sec(r2.skw + 2048, 64, NS);
-    sec(r3.c1w, 36864, NS4); sec(r3.c2w, 36864, NS4); sec(r3.c2w + 36864, 64, NS);
-    sec(r4.c1w, 27648, NS); sec(r4.c2w, 9216 + 32, NS); sec(r4.skw, 3072 + 32, NS);
-    sec(kL.outw, 33, NS);
+    auto esec = [&](int off, int len, int e_off, int rows) {   // destination offset <- compact rows
+        sec(off, len, rows);
+        ra.sec[n - 1].src_delta = ESLAB_BASE + e_off - off; ra.sec[n - 1].stride_override = ESTRIDE;
+    };
+    // weight gradients (MFMA kernels, full-width slabs) + rb1.conv1 (first_wgrad)
+    sec(r1.c1w, 288 + 32, NS); sec(r1.c2w, 9216, NS);
+    sec(r2.c1w, 18432, NS2); sec(r2.c2w, 36864, NS4); sec(r2.skw, 2048, NS2);
+    sec(r3.c1w, 36864, NS4); sec(r3.c2w, 36864, NS4);
+    sec(r4.c1w, 27648, NS); sec(r4.c2w, 9216, NS); sec(r4.skw, 3072, NS);
+    // partial rows of the elementwise producers
+    esec(kL.outw, 33, E_OUT, ER28); esec(r4.c2b, 32, E_C2B4, ER28); esec(r4.skb, 32, E_SKB4, ER28);
+    esec(r3.c2b, 64, E_C2B3, ER14); esec(r2.c2b, 64, E_C2B2, ER14); esec(r2.skb, 64, E_SKB2, ER14);
+    esec(r1.c2b, 32, E_C2B1, ER28); esec(r1.skw, 32, E_SKW1, ER28); esec(r1.skb, 32, E_SKB1, ER28);
+    esec(r1.tew, 64, E_TE1, ERG); esec(r2.tew, 128, E_TE2, ERG); esec(r3.tew, 128, E_TE3, ERG); esec(r4.tew, 64, E_TE4, ERG);
+    esec(r2.c1b, 64, E_C1B2, ERG); esec(r3.c1b, 64, E_C1B3, ERG); esec(r4.c1b, 32, E_C1B4, ERG);
+    if (deps == nullptr) {   // loss = mean (eps - noise)^2
+        esec(0, 1, E_LOSS, ER28);
+        ra.sec[n - 1].dst = mse->loss_out; ra.sec[n - 1].scale = 1.0f / (float)M28;
+    }
     ra.nsec = n;
     RUN(B_REDUCE, tdm_launch_reduce(slabs, NP, ra, G, st));
     return 0;
 }
 
-constexpr int NSLAB = 256;
+
 
 int unet_backward(const float* P, const float* x, const float* deps, float* G, const Ws& w, float* slabs, int B,
                   hipStream_t st) {
@@ -526,6 +558,18 @@ int unet_backward(const float* P, const float* x, const float* deps, float* G, c
     return 0;
 }
 
+// F.mse_loss + backward of the whole network (src/mnist.py:158-159).  Default pipeline: the MSE rides in the first backward
+// kernel (no separate pass over eps / noise, no deps round trip); the other arithmetics keep the stand-alone kernels.
+int loss_and_backward(const float* P, const float* x_noisy, const float* noise, const float* eps, float* deps, float* loss_out,
+                      float* G, const Ws& w, float* slabs, int B, hipStream_t st) {
+    if (g_conv_mode == 2) {
+        const MseIn mi{eps, noise, deps, loss_out};
+        return unet_backward_s16(P, x_noisy, nullptr, G, w, slabs, B, st, &mi);
+    }
+    TDM_TRY(tdm_mse_fwd_bwd_f32(eps, noise, loss_out, deps, w.scratch, (int64_t)B * 784, (void*)st));
+    return unet_backward(P, x_noisy, deps, G, w, slabs, B, st);
+}
+
 }  // namespace
 
 extern "C" {
@@ -536,7 +580,7 @@ int tdm_unet_param_offsets(int32_t* offs) {
 }
 
 int64_t tdm_unet_workspace_floats(int64_t B, int training) { return carve(nullptr, B, training).total; }
-int64_t tdm_unet_slab_floats(void) { return (int64_t)NSLAB * TDM_UNET_NPARAM; }
+int64_t tdm_unet_slab_floats(void) { return (int64_t)NSLAB * SLAB_STRIDE + (int64_t)EROWS * ESTRIDE; }
 
 // Batch limit: 16384 for the fp32 / in-loader-split arithmetics (64-bit indexing); the default S16 pipeline addresses
 // with 32-bit offsets built from 24-bit pixel indices (conv_s16.hip), which caps it at 10,699 images of 28x28.
@@ -601,9 +645,7 @@ int tdm_unet_loss_grad_f32(const float* params, const float* x0, const float* no
     hipStream_t st = (hipStream_t)stream;
     TDM_TRY(tdm_q_sample_f32(x0, noise, t, sqrt_acp, sqrt_1m_acp, x_noisy, B, 784, stream));
     TDM_TRY(unet_forward(params, x_noisy, t, eps, w, (int)B, 1, st));
-    TDM_TRY(tdm_mse_fwd_bwd_f32(eps, noise, loss_out, deps, w.scratch, B * 784, stream));
-    TDM_TRY(unet_backward(params, x_noisy, deps, grads, w, slabs, (int)B, st));
-    return 0;
+    return loss_and_backward(params, x_noisy, noise, eps, deps, loss_out, grads, w, slabs, (int)B, st);
 }
 
 int tdm_unet_p_sample_step_f32(const float* params, const float* x, const int64_t* t, const float* noise,
@@ -626,13 +668,14 @@ int tdm_unet_loss_grad_philox_f32(const float* params, const float* x0, const fl
     TDM_CHECK_B(B);
     TDM_REQUIRE(params && x0 && rng_state && t_buf && noise && x_noisy && eps && deps && loss_out && grads && ws && slabs,
                 "unet_loss_grad_philox: NULL pointer");
-    const Ws w = carve(ws, B, 1);
+    Ws w = carve(ws, B, 1);
     hipStream_t st = (hipStream_t)stream;
-    TDM_TRY(tdm_ddpm_draw_q_sample_f32(x0, sqrt_acp, sqrt_1m_acp, seed, rng_state, t_buf, noise, x_noisy, B, 784, stream));
+    const bool fold = g_conv_mode == 2;   // the S16 forward's first kernel (timebias) advances the offset: one launch fewer
+    TDM_REQUIRE(sqrt_acp && sqrt_1m_acp, "unet_loss_grad_philox: NULL schedule table");
+    TDM_TRY(tdm_launch_draw_q_sample(x0, sqrt_acp, sqrt_1m_acp, seed, rng_state, t_buf, noise, x_noisy, B, 784, !fold, st));
+    if (fold) w.rng_bump = rng_state;
     TDM_TRY(unet_forward(params, x_noisy, t_buf, eps, w, (int)B, 1, st));
-    TDM_TRY(tdm_mse_fwd_bwd_f32(eps, noise, loss_out, deps, w.scratch, B * 784, stream));
-    TDM_TRY(unet_backward(params, x_noisy, deps, grads, w, slabs, (int)B, st));
-    return 0;
+    return loss_and_backward(params, x_noisy, noise, eps, deps, loss_out, grads, w, slabs, (int)B, st);
 }
 
 // One reverse step with device-resident step index and device-drawn noise (src/mnist.py:191-193, :167-180):

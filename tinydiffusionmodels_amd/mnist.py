@@ -455,7 +455,7 @@ class DDPMTrainer(DPStepper):
         self.grads = torch.zeros(E.NPARAM, dtype=torch.float32, device=dev)
         self.m = torch.zeros_like(self.grads)
         self.v = torch.zeros_like(self.grads)
-        self.step_state = torch.zeros(2, dtype=torch.long, device=dev)     # {AdamW steps taken, scratch}
+        self.step_state = torch.zeros(4, dtype=torch.long, device=dev)     # {AdamW steps taken, scratch, beta1^t, beta2^t}
         self.rng_state = torch.zeros(2, dtype=torch.long, device=dev)      # {Philox stream offset, scratch}
         # rank-distinct draw streams: a seed from torch's generator (so torch.manual_seed governs it) mixed with the rank
         self.seed = (int(torch.randint(0, 2 ** 62, (1,)).item()) ^ (self.rank * 0x9E3779B97F4A7C15)) & (2 ** 64 - 1)
@@ -477,6 +477,11 @@ class DDPMTrainer(DPStepper):
     def state(self) -> "E.TrainState":
         """Buffers of the most recent (initially: the constructor's) batch size."""
         return self._cur
+
+    def batch_buffer(self, B: int) -> torch.Tensor:
+        """The fixed-address (B,1,28,28) input buffer of batch size B: a batch written here (gather with out=, copy_)
+        and passed to step() is read in place by the captured step — no per-step staging copy."""
+        return self._state(B).x0
 
     @property
     def steps_taken(self) -> int:
@@ -564,7 +569,12 @@ def train(model: nn.Module,
         for it in range(nb):
             idx = dp.shard_batch_indices(perm, it, batch_size, rank, world)
             gb = dp.global_batch_count(n, it, batch_size, world)
-            x = data[idx] if idx.numel() else None
+            if idx.numel() == 0:
+                x = None
+            elif hasattr(trainer, "batch_buffer"):          # gather straight into the captured step's input buffer
+                x = torch.index_select(data, 0, idx, out=trainer.batch_buffer(idx.numel()))
+            else:
+                x = data[idx]
             loss = trainer.step(x, global_batch=None if gb == batch_size * world else gb)
             last = loss if loss is not None else last
             if log_every and (it + 1) % log_every == 0 and rank == 0 and last is not None:

@@ -220,9 +220,11 @@ def loss_and_grad_philox(flat: torch.Tensor, st: TrainState, x0: torch.Tensor, s
 def adamw_step_dev(flat: torch.Tensor, grads: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step_state: torch.Tensor,
                    lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
                    weight_decay: float = 0.01, grad_scale: float = 1.0):
-    """adamw_step with the step count in device memory (step_state int64[2] = {steps taken, scratch}):
+    """adamw_step with the step count in device memory (step_state int64[4] = {steps taken, scratch, beta1^t, beta2^t}):
     performs step steps_taken + 1 and stores it — no host-written scalar, hipGraph-replayable."""
     _need_cuda(flat, grads, m, v, step_state)
+    if step_state.numel() < 4 or step_state.dtype != torch.int64:
+        raise RuntimeError("adamw_step_dev: step_state must be an int64 tensor of 4 elements")
     _lib.check(_lib.lib().tdm_adamw_flat_devstep_f32(_lib.ptr(flat), _lib.ptr(grads), _lib.ptr(m), _lib.ptr(v), flat.numel(),
                                                      lr, betas[0], betas[1], eps, weight_decay, _lib.ptr(step_state),
                                                      grad_scale, _lib.stream()), "adamw_devstep")
