@@ -43,6 +43,11 @@ int tdm_q_sample_f32(const float* x0, const float* noise, const int64_t* t,
                      const float* sqrt_acp, const float* sqrt_1m_acp,
                      float* out, int64_t B, int64_t inner, void* stream);
 
+/* gradient of q_sample w.r.t. x0: out[b,i] = tab[t[b]] * x[b,i] with tab = sqrt_acp (learned embeddings get
+ * their diffusion-loss gradient through it, src/shakespeare.py:225-232)                                      */
+int tdm_scale_by_table_f32(const float* x, const int64_t* t, const float* tab, float* out, int64_t B,
+                           int64_t inner, void* stream);
+
 /* ---- a6: p_sample arithmetic  (src/mnist.py:169-180, shakespeare.py:343-352)
  * out = c_recip * (x - c_eps * eps) [+ c_sigma * noise]; the three scalars are
  * read on the device from 1000-entry tables at index t_index (uniform-t fast
@@ -271,6 +276,11 @@ int tdm_tt_p_sample_step_f32(const float* params, const float* x, const int64_t*
                              const float* tab_recip, const float* tab_eps, const float* tab_sigma,
                              int t_index, float* eps, float* x_out, float* ws,
                              int64_t B, int L, int D, int H, int depth, int ffn, void* stream);
+/* tdm_tt_p_sample_step_f32 with device-resident t and device-drawn noise (see tdm_unet_p_sample_step_philox_f32) */
+int tdm_tt_p_sample_step_philox_f32(const float* params, const float* x, int64_t* t_dev, const float* tab_recip,
+                                    const float* tab_eps, const float* tab_sigma0, uint64_t seed, int64_t* rng_state,
+                                    float* eps, float* x_out, float* ws, int64_t B, int L, int D, int H, int depth,
+                                    int ffn, void* stream);
 /* Arithmetic of the transformer's linear layers and their gradients:
  *   0 exact fp32 MFMA; 1 bf16x3 split operands, fp32 accumulate (default; ~1e-5 rel,
  *   meets the 1e-3 parity bound); 2 plain bf16 operands (throughput mode, ~3e-3 rel) */

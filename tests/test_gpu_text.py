@@ -375,6 +375,82 @@ def test_full_size_properties_config5(dev, gemm_mode):
     del st, st64
 
 
+def test_text_graph_sampler_equals_eager_chain_with_same_draws(dev, gemm_mode):
+    """The hipGraph text reverse loop (device-resident step index, Philox noise drawn inside the update kernel, one
+    C-ABI call per step) against the eager teacher-forced loop fed the SAME draws: bitwise equal
+    (src/shakespeare.py:382-385)."""
+    from tinydiffusionmodels_amd import _lib
+    from tinydiffusionmodels_amd.shakespeare import reverse_diffusion
+    dim, n, L, steps = 64, 3, 20, 18
+    m = _model(dim, dev)
+    m.eval()
+    x = torch.randn(n, L, dim, generator=torch.Generator().manual_seed(2)).to(dev)
+    torch.manual_seed(5)
+    got = reverse_diffusion(m, x, t_start=steps - 1, use_graph=True)
+    sampler = next(iter(m._samplers.values()))
+    assert sampler.graph is not None and sampler.rng_state.cpu().tolist()[0] == steps and sampler.t_vec.cpu().tolist() == [0] * n
+    zs = []
+    for k in range(steps):
+        z = torch.empty_like(x)
+        _lib.check(_lib.lib().tdm_philox_normal_f32(sampler.seed, k, _lib.ptr(z), z.numel(), _lib.stream()))
+        zs.append(z)
+    want = reverse_diffusion(m, x, noises=zs, t_start=steps - 1)
+    assert torch.equal(got, want)
+    odd = reverse_diffusion(m, x, t_start=16, use_graph=True)          # odd chain: first step eager, then graph replays
+    assert torch.isfinite(odd).all()
+    m._samplers.clear()
+
+
+def test_native_adamw_matches_torch_adamw_under_the_lr_schedule(dev):
+    """NativeAdamW (tdm_adamw_flat_f32 per parameter tensor) driven by the reference's warm-up / cosine LambdaLR
+    against torch.optim.AdamW on the same gradients (src/shakespeare.py:197-199, :159-167)."""
+    from tinydiffusionmodels_amd.shakespeare import NativeAdamW, get_cosine_schedule_with_warmup
+    g = torch.Generator().manual_seed(0)
+    shapes = [(1000,), (37, 16), (5, 3, 8)]
+    pa = [torch.nn.Parameter(torch.randn(*sh, generator=g).to(dev)) for sh in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = NativeAdamW(pa, lr=1e-3, weight_decay=1e-4)
+    ob = torch.optim.AdamW(pb, lr=1e-3, weight_decay=1e-4)
+    sa, sb = get_cosine_schedule_with_warmup(oa, 2, 8), get_cosine_schedule_with_warmup(ob, 2, 8)
+    for step in range(6):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(*a.shape, generator=g).to(dev) * 10 ** float(torch.randint(-4, 1, (1,), generator=g))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step(); sa.step(); sb.step()
+        assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"]
+        for a, b in zip(pa, pb):
+            assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item(), step
+    assert not torch.equal(pa[0].detach().cpu(), torch.randn(1000, generator=torch.Generator().manual_seed(0)))
+
+
+def test_q_sample_and_mse_autograd_bridges(dev, golden_tables):
+    """The two elementwise bridges of the native text train step against torch autograd on the same formula:
+    q_sample differentiable in x0 (gradient sqrt_acp[t] * g, src/shakespeare.py:37-44) and F.mse_loss (:236)."""
+    from tinydiffusionmodels_amd.shakespeare import _QSampleFunction, native_mse_loss
+    g = torch.Generator().manual_seed(3)
+    B, L, D = 5, 7, 16
+    x0 = torch.randn(B, L, D, generator=g)
+    noise = torch.randn(B, L, D, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    w = torch.randn(B, L, D, generator=g)
+    xr = x0.clone().requires_grad_(True)
+    ref = O.q_sample(xr, t, noise, golden_tables)
+    (ref * w).sum().backward()
+    xd = x0.to(dev).requires_grad_(True)
+    out = _QSampleFunction.apply(xd, t.to(dev), noise.to(dev))
+    (out * w.to(dev)).sum().backward()
+    assert torch.equal(out.detach().cpu(), ref.detach()) and torch.equal(xd.grad.cpu(), xr.grad)
+    pr = torch.randn(B, L, D, generator=g)
+    pr_ref = pr.clone().requires_grad_(True)
+    lref = F.mse_loss(pr_ref, noise)
+    (3.0 * lref).backward()
+    pd = pr.to(dev).requires_grad_(True)
+    ld = native_mse_loss(pd, noise.to(dev))
+    (3.0 * ld).backward()
+    assert abs(ld.item() - lref.item()) < 1e-6 * abs(lref.item())
+    assert O.rel_err(pd.grad.cpu(), pr_ref.grad) < 1e-6
+
+
 def test_train_mode_default_dropout_and_bad_rate(dev):
     from tinydiffusionmodels_amd.shakespeare import TinyTransformer
     m = TinyTransformer(32).to(dev)          # default dropout 0.1, like the reference

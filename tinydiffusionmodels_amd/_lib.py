@@ -64,6 +64,9 @@ _SIGS = {
     "tdm_dropout_keep_u8": ([c_float, c_u64, c_int, c_i64, c_i64, c_f], c_int),
     "tdm_tt_p_sample_step_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_i64, c_int, c_int, c_int,
                                   c_int, c_int, c_f], c_int),
+    "tdm_tt_p_sample_step_philox_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_u64, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int,
+                                         c_int, c_int, c_f], c_int),
+    "tdm_scale_by_table_f32": ([c_f, c_f, c_f, c_f, c_i64, c_i64, c_f], c_int),
     "tdm_embed_gather_f32": ([c_f, c_f, c_f, c_i64, c_int, c_int, c_f], c_int),
     "tdm_embed_scatter_add_f32": ([c_f, c_f, c_f, c_i64, c_int, c_int, c_float, c_f], c_int),
     "tdm_round_workspace_floats": ([c_i64, c_int, c_int], c_i64),

@@ -64,6 +64,16 @@ __global__ __launch_bounds__(EW_BLOCK) void q_sample_kernel(const float* __restr
     }
 }
 
+// out[b,i] = tab[t[b]] * x[b,i]: the gradient of q_sample w.r.t. x0 (d x_noisy / d x0 = sqrt_acp[t], src/shakespeare.py:41-44
+// differentiated) — learned embeddings receive their diffusion-loss gradient through it
+__global__ __launch_bounds__(EW_BLOCK) void scale_by_table_kernel(const float* __restrict__ x, const int64_t* __restrict__ t,
+                                                                  const float* __restrict__ tab, float* __restrict__ out,
+                                                                  int64_t B, int64_t inner) {
+    const int64_t total = B * inner;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK)
+        out[i] = __fmul_rn(tab[t[i / inner]], x[i]);
+}
+
 // ---- p_sample update --------------------------------------------------------
 // src/mnist.py:173-180: mean = c_recip * (x - c_eps * eps); out = mean + c_sigma * z
 __device__ __forceinline__ float p_update(float x, float e, float z, float cr, float ce, float cs, bool add) {
@@ -1182,6 +1192,15 @@ int tdm_q_sample_f32(const float* x0, const float* noise, const int64_t* t, cons
     hipLaunchKernelGGL(q_sample_kernel, dim3(ew_grid(work)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x0, noise, t,
                        sqrt_acp, sqrt_1m_acp, out, B, inner);
     TDM_CHECK_LAUNCH("q_sample");
+    return 0;
+}
+
+int tdm_scale_by_table_f32(const float* x, const int64_t* t, const float* tab, float* out, int64_t B, int64_t inner,
+                           void* stream) {
+    TDM_REQUIRE(x && t && tab && out && B > 0 && inner > 0, "scale_by_table: bad arguments");
+    hipLaunchKernelGGL(scale_by_table_kernel, dim3(ew_grid(B * inner)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, t, tab, out, B,
+                       inner);
+    TDM_CHECK_LAUNCH("scale_by_table");
     return 0;
 }
 

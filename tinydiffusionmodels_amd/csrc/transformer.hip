@@ -953,6 +953,21 @@ int tdm_tt_p_sample_step_f32(const float* params, const float* x, const int64_t*
                                    B * L * D, stream);
 }
 
+// One reverse step with device-resident step index and device-drawn noise (src/shakespeare.py:382-385, :343-352):
+// eps = TinyTransformer(x, t_dev); x_out = update(x, eps, z ~ Philox); t_dev -= 1 (floor 0).  tab_sigma0[0] must be 0.
+int tdm_tt_p_sample_step_philox_f32(const float* params, const float* x, int64_t* t_dev, const float* tab_recip,
+                                    const float* tab_eps, const float* tab_sigma0, uint64_t seed, int64_t* rng_state,
+                                    float* eps, float* x_out, float* ws, int64_t B, int L, int D, int H, int depth, int ffn,
+                                    void* stream) {
+    TDM_TRY(tt_check(B, L, D, H, depth, ffn));
+    TDM_REQUIRE(params && x && t_dev && eps && x_out && ws && rng_state, "tt_p_sample_step_philox: NULL pointer");
+    const TTLayout lay = tt_layout(D, depth, ffn);
+    const TTWs w = tt_carve(ws, B, L, D, H, depth, ffn, 0);
+    TDM_TRY(tt_forward(params, lay, x, t_dev, eps, w, B, L, D, H, depth, ffn, Drop{0.f, 0}, (hipStream_t)stream));
+    return tdm_p_sample_update_philox_f32(x, eps, tab_recip, tab_eps, tab_sigma0, t_dev, seed, rng_state, x_out, B,
+                                          (int64_t)L * D, stream);
+}
+
 int tdm_set_gemm_mode(int mode) {
     TDM_REQUIRE(mode >= 0 && mode <= 2, "gemm mode %d (0 = fp32 MFMA, 1 = bf16x3, 2 = bf16)", mode);
     g_gemm_mode = mode;

@@ -26,7 +26,7 @@ from . import _lib
 from . import dp
 from . import transformer_engine as TE
 from . import unet_engine as E
-from .schedule import TIMESTEPS, cpu_tables, device_tables, linear_beta_schedule  # noqa: F401
+from .schedule import TIMESTEPS, cpu_tables, device_tables, linear_beta_schedule, schedule_generation  # noqa: F401
 from .utils import get_samples_dir, get_vertex_checkpoint_path, load_checkpoint, save_checkpoint, save_samples
 
 T = TIMESTEPS  # number of diffusion steps (src/shakespeare.py:25)
@@ -237,6 +237,7 @@ class TinyTransformer(nn.Module):
         sd["time_emb.weight"], sd["time_emb.bias"] = te.weight.detach(), te.bias.detach()
         self.flat = nn.Parameter(TE.flat_from_state_dict(sd, dim, depth, TE.FFN))
         self._infer_ws = None
+        self._samplers = {}
         self.dropout_seed = None   # set to an int to force the seed of the next train-mode forwards (tests)
         self.last_dropout_seed = None
 
@@ -272,6 +273,83 @@ class TinyTransformer(nn.Module):
             return _TTFunction.apply(x, t, self.flat, self.cfg, p_drop, seed)
         return TE.tt_forward(self.cfg, self.flat.detach(), x, t, self._workspace(x.shape[0], x.shape[1], x.device), False,
                              p_drop=p_drop, seed=seed)
+
+
+class _QSampleFunction(torch.autograd.Function):
+    """q_sample (src/shakespeare.py:37-44) on the fused kernel, differentiable in x0: learned embeddings get the
+    diffusion-loss gradient d x_noisy / d x0 = sqrt_acp[t] through tdm_scale_by_table_f32 (:225-232)."""
+
+    @staticmethod
+    def forward(ctx, x0, t, noise):
+        E._need_cuda(x0, t, noise)
+        xc, tc, nc = x0.detach().contiguous(), t.contiguous(), noise.contiguous()
+        out = torch.empty_like(xc)
+        E.q_sample_into(xc, tc, nc, out)
+        ctx.save_for_backward(tc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (tc,) = ctx.saved_tensors
+        gc = g.contiguous()
+        dx0 = torch.empty_like(gc)
+        B = gc.shape[0]
+        _lib.check(_lib.lib().tdm_scale_by_table_f32(_lib.ptr(gc), _lib.ptr(tc), _lib.ptr(device_tables(gc.device)["sqrt_alphas_cumprod"]),
+                                                     _lib.ptr(dx0), B, gc.numel() // B, _lib.stream()), "scale_by_table")
+        return dx0, None, None
+
+
+class _MSEFunction(torch.autograd.Function):
+    """F.mse_loss(pred, target) (src/shakespeare.py:236) forward + backward in one native pass (tdm_mse_fwd_bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        E._need_cuda(pred, target)
+        pc, tc = pred.detach().contiguous(), target.contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=pc.device)
+        dpred = torch.empty_like(pc)
+        scratch = torch.empty(1024, dtype=torch.float32, device=pc.device)
+        _lib.check(_lib.lib().tdm_mse_fwd_bwd_f32(_lib.ptr(pc), _lib.ptr(tc), _lib.ptr(loss), _lib.ptr(dpred), _lib.ptr(scratch),
+                                                  pc.numel(), _lib.stream()), "mse")
+        ctx.dpred = dpred
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gl):
+        d = ctx.dpred
+        ctx.dpred = None
+        return d * gl, None
+
+
+def native_mse_loss(pred, target):
+    return _MSEFunction.apply(pred, target)
+
+
+class NativeAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW(params, lr, weight_decay) (src/shakespeare.py:197) with the update done by
+    tdm_adamw_flat_f32 — one launch per parameter tensor (the denoiser is ONE flat tensor).  A torch Optimizer
+    subclass so the reference's LambdaLR warm-up / cosine schedule drives `param_groups[0]['lr']` unchanged."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["m"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["v"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                if not p.is_contiguous():
+                    raise RuntimeError("NativeAdamW needs contiguous parameters")
+                E.adamw_step(p.data.view(-1), p.grad.contiguous().view(-1), st["m"].view(-1), st["v"].view(-1), st["step"],
+                             lr=group["lr"], betas=group["betas"], eps=group["eps"], weight_decay=group["weight_decay"])
+        return None
 
 
 class ByteTokenizer:
@@ -380,13 +458,83 @@ def p_sample(model, x, t, noise=None):
     return out
 
 
+class _TextGraphSampler:
+    """Persistent buffers + one captured two-step hipGraph of the text reverse loop for a (model, n, L) triple:
+    per reverse step ONE C-ABI call (denoiser forward, update with z drawn in registers, t -= 1 on the device)."""
+
+    def __init__(self, model: "TinyTransformer", n: int, L: int, dev):
+        from .schedule import device_tables as _dt
+        self.model, self.n, self.L, self.dev = model, n, L, dev
+        self.tabs = _dt(dev)
+        self.sigma0 = self.tabs["sigma"].clone()
+        self.sigma0[0] = 0.0                               # t == 0: x = mean (src/shakespeare.py:349-350)
+        D = model.cfg.dim
+        self.xa = torch.empty(n, L, D, device=dev)
+        self.xb = torch.empty_like(self.xa)
+        self.eps = torch.empty_like(self.xa)
+        self.t_vec = torch.zeros(n, device=dev, dtype=torch.long)
+        self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self.rng_state = torch.zeros(2, device=dev, dtype=torch.long)
+        self.ws = TE.TTWorkspace(model.cfg, n, L, dev, training=False)
+        self.graph = None
+
+    def _one(self, a, b):
+        cfg = self.model.cfg
+        _lib.check(_lib.lib().tdm_tt_p_sample_step_philox_f32(
+            _lib.ptr(self.model.flat.detach()), _lib.ptr(a), _lib.ptr(self.t_vec), _lib.ptr(self.tabs["sqrt_recip_alphas"]),
+            _lib.ptr(self.tabs["eps_coef"]), _lib.ptr(self.sigma0), self.seed, _lib.ptr(self.rng_state), _lib.ptr(self.eps),
+            _lib.ptr(b), _lib.ptr(self.ws.ws), self.n, self.L, cfg.dim, cfg.n_heads, cfg.depth, cfg.ffn, _lib.stream()),
+            "tt_p_sample_step_philox")
+
+    def _capture(self):
+        saved = (self.xa.clone(), self.t_vec.clone(), self.rng_state.clone())
+        side = torch.cuda.Stream(device=self.dev)          # warm-up off the capture stream, then restore
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            self._one(self.xa, self.xb)
+            self._one(self.xb, self.xa)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        self.xa.copy_(saved[0]); self.t_vec.copy_(saved[1]); self.rng_state.copy_(saved[2])
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._one(self.xa, self.xb)
+            self._one(self.xb, self.xa)
+
+    def run(self, x, nsteps, t_start):
+        self.xa.copy_(x)
+        self.t_vec.fill_(t_start)
+        left = nsteps
+        if left % 2 == 1:
+            self._one(self.xa, self.xb)
+            self.xa.copy_(self.xb)
+            left -= 1
+        if left > 0:
+            if self.graph is None:
+                self._capture()
+            for _ in range(left // 2):
+                self.graph.replay()
+        return self.xa.clone()
+
+
 @torch.no_grad()
-def reverse_diffusion(model: TinyTransformer, x: torch.Tensor, noises=None, t_start: int = T - 1) -> torch.Tensor:
+def reverse_diffusion(model: TinyTransformer, x: torch.Tensor, noises=None, t_start: int = T - 1,
+                      use_graph: Optional[bool] = None) -> torch.Tensor:
     """`for i in reversed(range(T)): x = p_sample(model, x, full(i))` (src/shakespeare.py:382-385,
-    :420-425) without per-step host syncs."""
+    :420-425) without per-step host syncs.  Default for chains of >= 16 steps with device-drawn noise: a
+    two-step hipGraph replayed (t_start + 1) / 2 times (step index and Philox offset in device memory).
+    `noises` (teacher forcing; noises[k] used at t = t_start - k) runs the eager loop."""
     E._need_cuda(x)
     n, L, _ = x.shape
     dev = x.device
+    nsteps = t_start + 1
+    if use_graph is None:
+        use_graph = noises is None and nsteps >= 16
+    if use_graph and noises is None:
+        key = (n, L, str(dev), model.flat.data_ptr(), schedule_generation())
+        if key not in model._samplers:
+            model._samplers.clear()
+            model._samplers[key] = _TextGraphSampler(model, n, L, dev)
+        return model._samplers[key].run(x.contiguous(), nsteps, t_start)
     flat = model.flat.detach()
     ws = model._workspace(n, L, dev)
     eps = torch.empty_like(x)
@@ -449,12 +597,13 @@ def train(model, rounding_fn, embedding_fn, data_loader, val_loader, device, ckp
           use_lr_scheduling=True, warmup_steps=100):
     """src/shakespeare.py:174-341 with the same control flow (cosine-warm-up LR,
     decaying rounding weight, validation pass, early stopping, `_best.pth`, final
-    checkpoint dict).  Denoiser, embedding lookup and rounding loss run on the native
-    kernels through autograd bridges; the optimiser is torch's AdamW over all parameters."""
+    checkpoint dict).  Every per-step tensor op is native: embedding gather / scatter-add, q_sample and its
+    x0-gradient, denoiser forward / backward, MSE, fused rounding cross-entropy, AdamW (NativeAdamW) — autograd only
+    chains the bridges."""
     params = list(model.parameters()) + list(rounding_fn.parameters())
     if use_learned_embeddings:
         params += list(embedding_fn.parameters())
-    optim = torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
+    optim = NativeAdamW(params, lr=lr, weight_decay=weight_decay)      # torch.optim.AdamW's update on tdm_adamw_flat_f32
     total_steps = len(data_loader) * epochs
     scheduler = get_cosine_schedule_with_warmup(optim, warmup_steps, total_steps) if use_lr_scheduling else None
     best_val_loss, patience_counter = float("inf"), 0
@@ -463,14 +612,9 @@ def train(model, rounding_fn, embedding_fn, data_loader, val_loader, device, ckp
         x0 = embedding_fn(token_ids) if use_learned_embeddings else embedding_fn[token_ids]
         t = torch.randint(0, T, (x0.shape[0],), device=device).long()
         noise = torch.randn_like(x0)
-        # q_sample with gradient to a learned x0: d(x_noisy)/d(x0) = sqrt_acp[t]
-        if x0.requires_grad:
-            a = device_tables(device)["sqrt_alphas_cumprod"][t].view(-1, 1, 1)
-            s = device_tables(device)["sqrt_one_minus_alphas_cumprod"][t].view(-1, 1, 1)
-            x_noisy = a * x0 + s * noise
-        else:
-            x_noisy = q_sample(x0, t, noise)
-        diff = F.mse_loss(model(x_noisy, t), noise)
+        # q_sample with gradient to a learned x0 (d x_noisy / d x0 = sqrt_acp[t]): native forward and backward
+        x_noisy = _QSampleFunction.apply(x0, t, noise) if x0.requires_grad else q_sample(x0, t, noise)
+        diff = native_mse_loss(model(x_noisy, t), noise)
         rnd = rounding_fn.cross_entropy(x0, token_ids)     # logits + cross-entropy, fused native call (row N1)
         return diff, rnd, diff + rw * rnd
 
