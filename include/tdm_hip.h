@@ -306,7 +306,10 @@ int tdm_embed_gather_f32(const float* table, const int64_t* ids, float* out, int
 int tdm_embed_scatter_add_f32(const float* g, const int64_t* ids, float* dtable, int64_t M, int V, int D,
                               float scale, void* stream);
 int64_t tdm_round_workspace_floats(int64_t M, int V, int D);
-/* rounding loss of src/shakespeare.py:239-240 and its gradients in one call:
+/* (The (M, V) logits live once in ws — written by the logits GEMM, whose epilogue also emits the log-sum-exp
+ *  partials, and read by the two gradient GEMMs, which regenerate softmax - onehot in their loaders; the
+ *  gradient tensor itself is never stored.)
+ * rounding loss of src/shakespeare.py:239-240 and its gradients in one call:
  *   loss_out[0] = cross_entropy(x W^T + b, ids)  (mean over the M tokens, unweighted)
  *   dx (M,D; may be NULL), dW (V,D), db (V) = gradients of  grad_scale * loss  (grad_scale = the
  *   rounding weight of :243); all three are overwritten.  ws: tdm_round_workspace_floats(M,V,D).  */
@@ -319,6 +322,10 @@ int tdm_round_logits_f32(const float* x, const float* W, const float* b, float* 
 /* out_ids[m] = argmax_v (x W^T + b)[m][v]   (decode, src/shakespeare.py:389-390) */
 int tdm_round_argmax_f32(const float* x, const float* W, const float* b, int64_t* out_ids, float* ws,
                          int64_t M, int V, int D, void* stream);
+/* out_ids[m] = argmax_v cos(x[m], E[v])  — the cosine-similarity fallback decode (src/shakespeare.py:393-401:
+ * F.normalize both sides, matmul, argmax).  E (V,D): embedding matrix.  ws: tdm_round_workspace_floats(M,V,D). */
+int tdm_cosine_argmax_f32(const float* x, const float* E, int64_t* out_ids, float* ws, int64_t M, int V, int D,
+                          void* stream);
 /* general strided fp32-MFMA GEMM (tests / profiling):
  * C[i][j] = sum_k A[i*a_rs + k*a_cs] * B[k*b_rs + j*b_cs] (+bias[j]) (+res[i][j]) (relu)      */
 int tdm_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs,

@@ -429,6 +429,14 @@ def rounding_ce_and_grads(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, ids
     return loss.detach(), xl.grad, Wl.grad, bl.grad
 
 
+def cosine_decode(x: torch.Tensor, embed_matrix: torch.Tensor) -> torch.Tensor:
+    """The cosine-similarity fallback decode of src/shakespeare.py:393-401: normalise both sides (F.normalize,
+    eps 1e-12), similarity matrix, argmax over the vocabulary."""
+    emb_norm = F.normalize(embed_matrix, dim=1)
+    x_norm = F.normalize(x, dim=-1)
+    return torch.matmul(x_norm, emb_norm.T).argmax(dim=-1)
+
+
 def text_p_sample(p, x, t, noise, tables, n_heads: int = 4, depth: int = 3):
     """src/shakespeare.py:343-352."""
     return p_sample_from_eps(x, t, transformer_forward(p, x, t, n_heads, depth), noise, tables)

@@ -315,6 +315,46 @@ def gen_text_head():
         out[f"{tag}.logits_head"] = logits.detach()[0, :2].clone()
         out[f"{tag}.dtable"] = emb.embeddings.weight.grad.clone()
         out[f"{tag}.dW"] = rnd.decoder.weight.grad.clone(); out[f"{tag}.db"] = rnd.decoder.bias.grad.clone()
+    # Cosine-similarity fallback decode: the lines live inside the reference's `sample()` (src/shakespeare.py:393-401), so
+    # that function itself is run, with its 1000-step loop short-circuited (p_sample patched to hand back a prepared
+    # final x at t = 0), a tokenizer stand-in that captures the token ids it is asked to decode, and the file writers
+    # patched out.  Both variants: learned embedding module, and a raw pre-trained matrix.
+    import contextlib
+    import io
+    for V, D, n, L, tag in ((1003, 32, 3, 16, "cos1003"), (2048, 64, 2, 64, "cos2048")):
+        torch.manual_seed(200 + V)
+        emb = S.LearnedEmbedding(V, D)
+        with torch.no_grad():
+            emb.embeddings.weight.mul_(25.0)
+        g = torch.Generator().manual_seed(V + 1)
+        ids = torch.randint(0, V, (n, L), generator=g)
+        x_final = emb.embeddings.weight.detach()[ids] * (0.5 + torch.rand(n, L, 1, generator=g)) + \
+            0.6 * torch.randn(n, L, D, generator=g)          # noisy, rescaled embeddings: not every token decodes to its id
+        captured = {}
+
+        class Tok:
+            def batch_decode(self, tokens, skip_special_tokens=True):
+                captured["tokens"] = tokens.clone()
+                return ["" for _ in range(tokens.shape[0])]
+
+        def fake_p_sample(model, x, t):
+            return x_final.clone() if int(t[0]) == 0 else x
+
+        saved = (S.p_sample, S.save_samples, S.get_samples_dir)
+        S.p_sample, S.save_samples, S.get_samples_dir = fake_p_sample, (lambda *a, **k: None), (lambda *a, **k: "/tmp/tdm_golden_samples")
+        try:
+            dummy = torch.nn.Linear(1, 1)
+            for variant, efn, learned in (("learned", emb, True), ("matrix", emb.embeddings.weight.detach().clone(), False)):
+                with contextlib.redirect_stdout(io.StringIO()):
+                    S.sample(dummy, dummy, efn, Tok(), "cpu", n_samples=n, seq_len=L, use_learned_rounding=False,
+                             use_learned_embeddings=learned, embed_dim=D)
+                out[f"{tag}.{variant}.tokens"] = captured["tokens"]
+        finally:
+            S.p_sample, S.save_samples, S.get_samples_dir = saved
+        assert torch.equal(out[f"{tag}.learned.tokens"], out[f"{tag}.matrix.tokens"])
+        out[f"{tag}.E"] = emb.embeddings.weight.detach().clone()
+        out[f"{tag}.x"] = x_final
+        out[f"{tag}.ids"] = ids
     np.savez(os.path.join(GOLD, "text_head.npz"), **_np(out))
     print("text head goldens written to", GOLD)
 

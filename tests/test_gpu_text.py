@@ -541,6 +541,65 @@ def test_rounding_ce_c_abi_vs_oracle(dev, gemm_mode, M, V, D):
     assert torch.equal(dW2, dW) and torch.equal(db2, db)      # deterministic (fixed-order slab sums)
 
 
+@pytest.mark.parametrize("tag", ["cos1003", "cos2048"])
+def test_cosine_decode_golden(dev, golden_dir, gemm_mode, tag):
+    """Native cosine-similarity decode (tdm_cosine_argmax_f32: row normalisation x2, MFMA similarity GEMM, row argmax) against
+    the token ids of the reference's fallback branch (src/shakespeare.py:393-401): integer output, compared exactly."""
+    if gemm_mode != 1:
+        pytest.skip("the rounding-head kernels always run the bf16x3 arithmetic")
+    from tinydiffusionmodels_amd.shakespeare import LearnedEmbedding, cosine_argmax, decode_tokens
+    g = _load(golden_dir, "text_head.npz")
+    x, E = g[f"{tag}.x"].to(dev), g[f"{tag}.E"].to(dev)
+    want = g[f"{tag}.learned.tokens"]
+    got = cosine_argmax(x, E).cpu()
+    if not torch.equal(got, want):      # a flip is only acceptable between two entries the reference itself cannot tell apart
+        sims = torch.matmul(F.normalize(g[f"{tag}.x"], dim=2), F.normalize(g[f"{tag}.E"], dim=1).T)
+        top2 = sims.topk(2, dim=-1).values
+        bad = got != want
+        assert ((top2[..., 0] - top2[..., 1])[bad] < 1e-6).all(), int(bad.sum())
+    V, D = E.shape
+    emb = LearnedEmbedding(V, D).to(dev)
+    emb.load_state_dict({"embeddings.weight": E})
+    assert torch.equal(decode_tokens(x, None, emb, use_learned_rounding=False, use_learned_embeddings=True).cpu(), got)
+    assert torch.equal(decode_tokens(x, None, E, use_learned_rounding=False, use_learned_embeddings=False).cpu(), got)
+    assert got.shape == want.shape and got.dtype == torch.int64
+
+
+def test_rounding_head_full_size_loss_is_consistent(dev, gemm_mode):
+    """Config-5 size rounding head (32,768 tokens x V = 50,257; logits stored once, softmax - onehot regenerated in the
+    gradient GEMMs' loaders): the loss equals the mean of a direct fp64 evaluation on a row sample, the bias gradient
+    sums to zero (each row of softmax - onehot does), and dx / dW are finite — a property test at a size the CPU
+    oracle cannot run (src/shakespeare.py:239-240)."""
+    if gemm_mode != 1:
+        pytest.skip("runs once")
+    from tinydiffusionmodels_amd import _lib
+    L_ = _lib.lib()
+    M, V, D = 32768, 50257, 256
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn(M, D, device=dev, generator=g) * 0.5
+    W = torch.randn(V, D, device=dev, generator=g) * (1.0 / D ** 0.5)
+    b = torch.randn(V, device=dev, generator=g) * 0.1
+    ids = torch.randint(0, V, (M,), device=dev, generator=g)
+    ws = torch.empty(L_.tdm_round_workspace_floats(M, V, D), device=dev)
+    loss, dx, dW, db = torch.empty(1, device=dev), torch.empty_like(x), torch.empty_like(W), torch.empty_like(b)
+    _lib.check(L_.tdm_round_ce_loss_grad_f32(_lib.ptr(x), _lib.ptr(W), _lib.ptr(b), _lib.ptr(ids), 1.0, _lib.ptr(loss), _lib.ptr(dx),
+                                             _lib.ptr(dW), _lib.ptr(db), _lib.ptr(ws), M, V, D, _lib.stream()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(dx).all() and torch.isfinite(dW).all() and torch.isfinite(db).all()
+    assert abs(db.double().sum().item()) < 1e-4
+    rows = torch.arange(0, M, 37, device=dev)
+    lg = x[rows].double() @ W.double().T + b.double()
+    ref_rows = torch.logsumexp(lg, dim=1) - lg[torch.arange(rows.numel(), device=dev), ids[rows]]
+    lse = ws[M * ((V + 3) // 4 * 4):][:M]            # workspace carve: logits [M][Vp] (a multiple of 64 floats) | lse [M]
+    # the loss over ALL rows vs the sampled fp64 mean: same distribution, 886 samples -> agree to a few percent
+    assert abs(loss.item() - ref_rows.mean().item()) < 0.02 * ref_rows.mean().item()
+    # and exactly on the sampled rows: dx of a row = sum_v p_v W_v - W_id  (fp64)
+    p = torch.softmax(lg[:8], dim=1)
+    dx_ref = (p @ W.double() - W.double()[ids[rows[:8]]]) / M
+    assert O.rel_err(dx[rows[:8]].double().cpu(), dx_ref.cpu()) < 1e-4
+    del ws
+
+
 def test_text_cli_train_then_sample_end_to_end(dev, gemm_mode, tmp_path, monkeypatch, capsys):
     """`python -m src.shakespeare --train` then `--sample` on a local corpus with the offline byte vocabulary:
     the reference's whole text loop (embedding lookup, q_sample, denoiser in train mode with dropout, rounding loss,

@@ -162,3 +162,13 @@ def test_host_schedules(golden_dir):
     g = _load(golden_dir, "text_denoiser.npz")
     assert g["cosine_warmup_10_100"].shape[0] == 100 and g["cosine_warmup_10_100"][0] == 0.0
     assert abs(g["rounding_weight_e20_w0.5"][0].item() - 0.5) < 1e-12
+
+
+@pytest.mark.parametrize("tag", ["cos1003", "cos2048"])
+def test_cosine_decode_oracle(golden_dir, tag):
+    """The oracle's cosine-similarity decode against the token ids the reference's own `sample()` produced through its
+    fallback branch (src/shakespeare.py:393-401; oracle/make_golden.py:gen_text_head runs that function)."""
+    g = _load(golden_dir, "text_head.npz")
+    tok = O.cosine_decode(g[f"{tag}.x"], g[f"{tag}.E"])
+    assert torch.equal(tok, g[f"{tag}.learned.tokens"]) and torch.equal(tok, g[f"{tag}.matrix.tokens"])
+    assert 0.5 < (tok == g[f"{tag}.ids"]).float().mean().item() < 1.0      # a real decode: most, not all, tokens recovered

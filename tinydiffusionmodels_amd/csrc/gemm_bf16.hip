@@ -74,7 +74,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 constexpr int NT_THREADS = 512;
 constexpr int NT_LDS = (4 * PLANE > 8 * 32 * EP * 4) ? 4 * PLANE : 8 * 32 * EP * 4;   // operand planes / epilogue transposes
 
-template <int NPROD>
+// softmax - onehot of 4 consecutive vocabulary entries v0 .. v0+3 of one token row, from stored logits
+__device__ __forceinline__ f32x4 ce_grad4(const f32x4 l, float lse, int tgt, int v0, int V, float scale) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (v0 + e < V) ? scale * (__expf(l[e] - lse) - (v0 + e == tgt ? 1.f : 0.f)) : 0.f;
+    return r;
+}
+
+template <int NPROD, bool CE, bool STATS>
 __global__ __launch_bounds__(NT_THREADS, 4) void gemm_nt_bf16_kernel(GemmArgs g, int ntx, int ntiles) {
     // planes: A hi, A lo, B hi, B lo  (lo planes unused when NPROD == 1)
     extern __shared__ float4 nt_smem4[];
@@ -118,6 +126,16 @@ __global__ __launch_bounds__(NT_THREADS, 4) void gemm_nt_bf16_kernel(GemmArgs g,
 
     for (int tile = t_beg; tile < t_end; ++tile) {
         const int i0 = (tile / ntx) * TM, j0 = (tile % ntx) * TN_;
+        float ce_l[2] = {0.f, 0.f};
+        int ce_t[2] = {0, 0};
+        if constexpr (CE) {   // this thread stages the same two A rows in every chunk of the tile
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int row = min(i0 + ((tid + NT_THREADS * p) >> 3), g.M - 1);
+                ce_l[p] = g.ce_lse[row];
+                ce_t[p] = (int)g.ce_ids[row];
+            }
+        }
         f32x16 acc[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -131,7 +149,9 @@ __global__ __launch_bounds__(NT_THREADS, 4) void gemm_nt_bf16_kernel(GemmArgs g,
                 for (int p = 0; p < 2; ++p) {
                     const int f = tid + NT_THREADS * p;
                     const int row = f >> 3, kq = f & 7;
-                    put_split<NPROD>(Ahi, Alo, row * PITCH + kq * 8, ((ok >> p) & 1u) ? pa[p] : zero4);
+                    f32x4 va = ((ok >> p) & 1u) ? pa[p] : zero4;
+                    if constexpr (CE) va = ((ok >> p) & 1u) ? ce_grad4(va, ce_l[p], ce_t[p], c * BK + kq * 4, g.ce_V, g.ce_scale) : zero4;
+                    put_split<NPROD>(Ahi, Alo, row * PITCH + kq * 8, va);
                     put_split<NPROD>(Bhi, Blo, row * PITCH + kq * 8, ((ok >> (4 + p)) & 1u) ? pb[p] : zero4);
                 }
             }
@@ -191,6 +211,27 @@ __global__ __launch_bounds__(NT_THREADS, 4) void gemm_nt_bf16_kernel(GemmArgs g,
                 const int rr = it * 4 + (lane >> 4);
                 const int m = i0 + wm * 32 + rr;
                 float4 v = *reinterpret_cast<const float4*>(T + rr * EP + c4 * 4);
+                if constexpr (STATS) {   // (max, sum exp) of this row's 64 columns + the target logit (cross-entropy partials)
+                    const float lv[4] = {v.x + bz.x, v.y + bz.y, v.z + bz.z, v.w + bz.w};
+                    float lm = -INFINITY;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (e < nq) lm = fmaxf(lm, lv[e]);
+#pragma unroll
+                    for (int o = 1; o <= 8; o <<= 1) lm = fmaxf(lm, __shfl_xor(lm, o));
+                    float sm = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (e < nq) sm += __expf(lv[e] - lm);
+#pragma unroll
+                    for (int o = 1; o <= 8; o <<= 1) sm += __shfl_xor(sm, o);
+                    if (m < g.M) {
+                        if (c4 == 0) {
+                            float* pp = g.ce_part + ((long)m * g.ce_nblk + ((j0 + wn * 64) >> 6)) * 2;
+                            pp[0] = lm; pp[1] = sm;
+                        }
+                        const int tg = (int)g.ce_ids[m] - n;
+                        if (tg >= 0 && tg < 4 && tg < nq) g.ce_tgt[m] = lv[tg];
+                    }
+                }
                 if (m < g.M && nq > 0 && nq < 4 && !(g.ablate & 4)) {   // ragged last quad (N % 4 != 0): plain epilogue
                     const long o = (long)m * g.c_rs + n;
                     const float vv[3] = {v.x + bz.x, v.y + bz.y, v.z + bz.z};
@@ -245,7 +286,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
 
 constexpr int TPL = 4 * 32 * 64;   // one [4 col blocks][32 tokens][32 cols] bf16 image = 8 KB
 
-template <int NPROD>
+template <int NPROD, bool CE>
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
     // C[i][j] = sum_k A(i,k) B(k,j) with A(i,k) = A[k*a_cs + i], B(k,j) = B[k*b_rs + j]  (a_rs = b_cs = 1)
     __shared__ __attribute__((aligned(16))) char lds[4 * TPL];
@@ -272,6 +313,8 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
     // next chunk's global loads, in flight during the MFMAs of the current one; unconditional and back to back
     // (out-of-range pieces read a clamped address, zeroed from `ok` at the LDS store); M % 4 == N % 4 == 0
     f32x4 pa[4], pb[4];
+    float ce_l[CE ? 4 : 1];   // lse / target id of the token rows of the prefetched chunk (CE form)
+    int ce_t[CE ? 4 : 1];
     unsigned ok = 0u;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto gload = [&](int k0) {
@@ -289,6 +332,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
             const long gkc = kin ? gk : kbeg;
             pa[p] = *reinterpret_cast<const f32x4*>(g.A + gkc * g.a_cs + (oa ? ia : 0));
             pb[p] = *reinterpret_cast<const f32x4*>(g.B + gkc * g.b_rs + (ob ? ib : 0));
+            if constexpr (CE) { ce_l[p] = g.ce_lse[gkc]; ce_t[p] = (int)g.ce_ids[gkc]; }
         }
     };
     if (kbeg < kend) gload(kbeg);
@@ -301,7 +345,8 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
             const int f = tid + 256 * p;
             const int mrow = f >> 5, c4 = f & 31;
             const int off = ((c4 >> 3) * 32 + mrow) * 64 + (c4 & 7) * 8;
-            const f32x4 va = ((ok >> p) & 1u) ? pa[p] : zero4;
+            f32x4 va = ((ok >> p) & 1u) ? pa[p] : zero4;
+            if constexpr (CE) va = ((ok >> p) & 1u) ? ce_grad4(va, ce_l[p], ce_t[p], i0 + c4 * 4, g.ce_V, g.ce_scale) : zero4;
             put_split<NPROD>(Ahi, Alo, off, va);
             put_split<NPROD>(Bhi, Blo, off, ((ok >> (4 + p)) & 1u) ? pb[p] : zero4);
             if (do_cs) { csum.x += va[0]; csum.y += va[1]; csum.z += va[2]; csum.w += va[3]; }
@@ -408,11 +453,15 @@ int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
         hipError_t e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<3, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<1, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
         if (e == hipSuccess)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<3>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<3, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
+        if (e == hipSuccess)
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<3, false, false>),
                                                              NT_THREADS, NT_LDS);
         if (e != hipSuccess || cus <= 0 || per_cu <= 0) {
             tdm_set_error("gemm_nt_bf16: occupancy query failed: %s", hipGetErrorString(e));
@@ -421,8 +470,17 @@ int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
         resident = cus * per_cu;
     }
     dim3 grid(ntiles < resident ? ntiles : resident);
-    if (nprod == 3) hipLaunchKernelGGL(gemm_nt_bf16_kernel<3>, grid, dim3(NT_THREADS), NT_LDS, st, g, ntx, ntiles);
-    else hipLaunchKernelGGL(gemm_nt_bf16_kernel<1>, grid, dim3(NT_THREADS), NT_LDS, st, g, ntx, ntiles);
+    TDM_REQUIRE(!(g.ce_lse != nullptr && g.ce_part != nullptr), "gemm_nt_bf16: one cross-entropy role per launch");
+    if (g.ce_lse != nullptr || g.ce_part != nullptr) {
+        TDM_REQUIRE(nprod == 3 && g.ce_ids != nullptr, "gemm_nt_bf16: the cross-entropy forms run in the bf16x3 arithmetic and need the target ids");
+        if (g.ce_lse != nullptr) hipLaunchKernelGGL((gemm_nt_bf16_kernel<3, true, false>), grid, dim3(NT_THREADS), NT_LDS, st, g, ntx, ntiles);
+        else {
+            TDM_REQUIRE(g.ce_tgt != nullptr && g.ce_nblk >= (g.N + 63) / 64 && g.res == nullptr && !g.relu && g.gate == nullptr && g.drop.thr == 0u,
+                        "gemm_nt_bf16: cross-entropy partials need a plain (bias-only) epilogue");
+            hipLaunchKernelGGL((gemm_nt_bf16_kernel<3, false, true>), grid, dim3(NT_THREADS), NT_LDS, st, g, ntx, ntiles);
+        }
+    } else if (nprod == 3) hipLaunchKernelGGL((gemm_nt_bf16_kernel<3, false, false>), grid, dim3(NT_THREADS), NT_LDS, st, g, ntx, ntiles);
+    else hipLaunchKernelGGL((gemm_nt_bf16_kernel<1, false, false>), grid, dim3(NT_THREADS), NT_LDS, st, g, ntx, ntiles);
     TDM_CHECK_LAUNCH("gemm_nt_bf16");
     return 0;
 }
@@ -438,8 +496,11 @@ int tdm_launch_gemm_tn_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
                 "gemm_tn_bf16: raw output only");
     const int sk = g.splitk > 1 ? g.splitk : 1;
     dim3 grid((g.N + TN_ - 1) / TN_, (g.M + TM - 1) / TM, sk);
-    if (nprod == 3) hipLaunchKernelGGL(gemm_tn_bf16_kernel<3>, grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL(gemm_tn_bf16_kernel<1>, grid, dim3(256), 0, st, g);
+    if (g.ce_lse != nullptr) {
+        TDM_REQUIRE(nprod == 3 && g.ce_ids != nullptr, "gemm_tn_bf16: the cross-entropy form runs in the bf16x3 arithmetic and needs the target ids");
+        hipLaunchKernelGGL((gemm_tn_bf16_kernel<3, true>), grid, dim3(256), 0, st, g);
+    } else if (nprod == 3) hipLaunchKernelGGL((gemm_tn_bf16_kernel<3, false>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, false>), grid, dim3(256), 0, st, g);
     TDM_CHECK_LAUNCH("gemm_tn_bf16");
     return 0;
 }

@@ -4,12 +4,16 @@
 //     logits = Linear(D, V)(x0);  rounding_loss = cross_entropy(logits, token_ids)
 // and the argmax decode of sampling (:387-390).
 //
-// First native version, sized for 288 GB of HBM rather than for a 16 GB card: the
-// (tokens x V) logits are materialised once in the caller's workspace (6.6 GB at 32,768
-// tokens x 50,257 entries) and overwritten in place by their gradient, so the head is three
-// MFMA GEMMs on the transformer's kernels (logits = x W^T + b; dx = g W; dW = g^T x with the
-// bias gradient from the same pass) plus one row-wise kernel (online log-sum-exp, then
-// softmax - onehot in place).  Fusing the row work into the GEMM epilogue / loaders is the follow-up.
+// Second version.  The (tokens x V) logits are written ONCE (6.6 GB at 32,768 tokens x 50,257 entries, in the
+// caller's workspace) and read twice; nothing else of that size exists:
+//   * logits = x W^T + b on the NT MFMA GEMM, whose epilogue also emits per (row, 64-column block) the pair
+//     (max, sum exp) and the target logit -> a tiny row kernel folds 786 pairs per row into lse and the loss;
+//   * dx = g W and dW = g^T x (+ db = column sums of g) read the stored LOGITS and regenerate
+//     g = scale * (softmax - onehot) = scale * (exp(l - lse) - [v == id]) in their loaders (GemmArgs::ce_*),
+//     so the gradient tensor is never written.
+// (The first version overwrote the logits with g in a separate row pass: written twice, read four times.)
+// Recomputing the logits inside the gradient GEMMs instead of storing them would cost two more bf16x3 GEMMs
+// (5 x 2.5 TFLOP of MFMA work instead of 3 x): slower than 20 GB of HBM traffic on this machine.
 #include <math.h>
 #include "tdm_common.h"
 #include "tdm_transformer.h"
@@ -43,35 +47,19 @@ __global__ __launch_bounds__(256) void embed_scatter_add_kernel(const float* __r
     }
 }
 
-// One workgroup per token row, two sweeps over the row in the same kernel:
-//   1. online (max, sum of exp) -> lse[m]; rowloss[m] = lse - logits[m][ids[m]]
-//   2. in place  logits[m][v] <- scale * (softmax(logits[m])[v] - [v == ids[m]]),  padding columns [V, ld) <- 0
-// The second sweep re-reads a 200 KB row the workgroup has just streamed (L2 hit), so HBM sees one read and one write
-// of the logits instead of the three reads + one write of separate statistics / gradient passes.
-constexpr int CE_BLOCK = 1024;   // 16 waves stream one 200 KB row: the kernel is latency-bound with fewer
-__global__ __launch_bounds__(CE_BLOCK) void ce_softmax_grad_kernel(float* __restrict__ logits, const int64_t* __restrict__ ids,
-                                                              float* __restrict__ lse, float* __restrict__ rowloss, long M,
-                                                              int V, long ld, float scale) {
-    __shared__ float redm[CE_BLOCK / 64], reds[CE_BLOCK / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ld4 = (int)(ld >> 2);
-    for (long m = blockIdx.x; m < M; m += gridDim.x) {
-        float* row = logits + m * ld;
-        long tgtl = ids[m];
-        tgtl = tgtl < 0 ? 0 : (tgtl >= V ? V - 1 : tgtl);   // never index out of bounds on a bad id
-        const int tgt = (int)tgtl;
+// lse[m] = log sum_v exp(logits[m][v]) from the (max, sum exp) pairs the logits GEMM wrote per 64-column block, and
+// rowloss[m] = lse[m] - logits[m][ids[m]]  (F.cross_entropy per token, src/shakespeare.py:240).  One wave per row.
+__global__ __launch_bounds__(256) void ce_lse_kernel(const float* __restrict__ part, const float* __restrict__ tgt,
+                                                     float* __restrict__ lse, float* __restrict__ rowloss, long M, int nblk) {
+    const int lane = threadIdx.x & 63;
+    for (long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (long)gridDim.x * 4) {
+        const float2* row = reinterpret_cast<const float2*>(part) + m * nblk;
         float mx = -INFINITY, sm = 0.f;
-        for (int q = threadIdx.x; q < ld4; q += CE_BLOCK) {
-            const float4 x = reinterpret_cast<const float4*>(row)[q];
-            const float r[4] = {x.x, x.y, x.z, x.w};
-            float lm = -INFINITY;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (q * 4 + e < V) lm = fmaxf(lm, r[e]);
-            if (lm > mx) { sm *= expf(mx - lm); mx = lm; }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (q * 4 + e < V) sm += expf(r[e] - mx);
+        for (int k = lane; k < nblk; k += 64) {
+            const float2 p = row[k];
+            if (p.x > mx) { sm = sm * expf(mx - p.x); mx = p.x; }
+            if (p.x != -INFINITY) sm += p.y * expf(p.x - mx);
         }
-        // combine the 256 (max, sum) pairs: wave shuffles, then the 4 waves through LDS
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
             const float om = __shfl_xor(mx, o), os = __shfl_xor(sm, o);
@@ -79,28 +67,25 @@ __global__ __launch_bounds__(CE_BLOCK) void ce_softmax_grad_kernel(float* __rest
             sm = (mx == -INFINITY ? 0.f : sm * expf(mx - nm)) + (om == -INFINITY ? 0.f : os * expf(om - nm));
             mx = nm;
         }
-        __syncthreads();
-        if (lane == 0) { redm[wave] = mx; reds[wave] = sm; }
-        __syncthreads();
-        float gm = redm[0];
-#pragma unroll
-        for (int w = 1; w < CE_BLOCK / 64; ++w) gm = fmaxf(gm, redm[w]);
-        float gs = 0.f;
-#pragma unroll
-        for (int w = 0; w < CE_BLOCK / 64; ++w) gs += redm[w] == -INFINITY ? 0.f : reds[w] * expf(redm[w] - gm);
-        const float l = gm + logf(gs);
-        if (threadIdx.x == 0) { lse[m] = l; rowloss[m] = l - row[tgt]; }
-        __syncthreads();   // row[tgt] is read before the row is overwritten
-        for (int q = threadIdx.x; q < ld4; q += CE_BLOCK) {
-            const float4 x = reinterpret_cast<const float4*>(row)[q];
-            float r[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int v = q * 4 + e;
-                r[e] = v < V ? scale * (expf(r[e] - l) - (v == tgt ? 1.f : 0.f)) : 0.f;
-            }
-            reinterpret_cast<float4*>(row)[q] = make_float4(r[0], r[1], r[2], r[3]);
+        if (lane == 0) {
+            const float l = mx + logf(sm);
+            lse[m] = l;
+            rowloss[m] = l - tgt[m];
         }
+    }
+}
+
+// y[r][:] = x[r][:] / max(||x[r]||_2, eps)   (F.normalize(x, dim=-1), eps 1e-12; src/shakespeare.py:398-399). Wave per row.
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restrict__ x, float* __restrict__ y, long R, int D) {
+    const int lane = threadIdx.x & 63;
+    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += (long)gridDim.x * 4) {
+        const float* xr = x + r * D;
+        float ss = 0.f;
+        for (int d = lane; d < D; d += 64) ss += xr[d] * xr[d];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        for (int d = lane; d < D; d += 64) y[r * D + d] = xr[d] * inv;
     }
 }
 
@@ -173,18 +158,22 @@ inline int round_splitk(int Vp, int D) {
     return sk < 1 ? 1 : (sk > 64 ? 64 : sk);
 }
 
-// workspace carve (floats): logits [M][Vp] | lse [M] | rowloss [M] | wT [D][Vp] | dW slabs [sk][Vp][D] | db slabs [sk][Vp]
-struct RoundWs { float *logits, *lse, *rowloss, *wT, *wslab, *bslab; long total; int Vp, sk; };
+// workspace carve (floats): logits [M][Vp] | lse [M] | rowloss [M] | target logit [M] | (max, sum exp) pairs [M][nblk][2] |
+// wT [D][Vp] | dW slabs [sk][Vp][D] | db slabs [sk][Vp] | xn [M][D] + [Vp]   (cosine decode: wT holds the normalised
+// table, xn the normalised rows and a zero bias)
+struct RoundWs { float *logits, *lse, *rowloss, *tgt, *part, *wT, *wslab, *bslab, *xn; long total; int Vp, sk, nblk; };
 RoundWs round_carve(float* base, long M, int V, int D) {
     RoundWs w{};
     long off = 0;
     auto take = [&](long n) { float* p = base ? base + off : nullptr; off += (n + 63) & ~63L; return p; };
     w.Vp = (int)pad4(V);
     w.sk = round_splitk(w.Vp, D);
-    w.logits = take(M * w.Vp); w.lse = take(M); w.rowloss = take(M);
+    w.nblk = ((V + 127) / 128) * 2;          // 64-column blocks the NT GEMM's 128-wide tiles cover
+    w.logits = take(M * w.Vp); w.lse = take(M); w.rowloss = take(M); w.tgt = take(M); w.part = take(M * w.nblk * 2);
     w.wT = take((long)D * w.Vp);
     w.wslab = take((long)w.sk * w.Vp * D);
     w.bslab = take((long)w.sk * ((w.Vp + 63) & ~63));
+    w.xn = take(M * D + w.Vp);               // cosine decode: normalised rows + a zero bias
     w.total = off;
     return w;
 }
@@ -237,16 +226,24 @@ int tdm_round_ce_loss_grad_f32(const float* x, const float* W, const float* b, c
     hipStream_t st = (hipStream_t)stream;
     const RoundWs w = round_carve(ws, M, V, D);
     const int Vp = w.Vp;
-    // logits = x W^T + b                                            (src/shakespeare.py:239)
-    TDM_TRY(logits_gemm(x, W, b, w.logits, M, V, Vp, D, st));
-    // cross-entropy, mean over tokens                               (src/shakespeare.py:240)
-    // g = grad_scale * (softmax - onehot) / M, in place over the logits; lse and the per-row loss on the way
-    hipLaunchKernelGGL(ce_softmax_grad_kernel, dim3((unsigned)(M < 16384 ? M : 16384)), dim3(CE_BLOCK), 0, st, w.logits, ids, w.lse,
-                       w.rowloss, (long)M, V, (long)Vp, grad_scale / (float)M);
-    TDM_CHECK_LAUNCH("ce_softmax_grad");
+    const float gscale = grad_scale / (float)M;
+    // logits = x W^T + b, with the cross-entropy partials in the epilogue            (src/shakespeare.py:239)
+    {
+        GemmArgs g{};
+        g.A = x; g.a_rs = D; g.a_cs = 1;
+        g.B = W; g.b_rs = 1; g.b_cs = D;
+        g.C = w.logits; g.c_rs = Vp; g.bias = b; g.M = (int)M; g.N = V; g.K = D; g.splitk = 1;
+        g.ce_part = w.part; g.ce_nblk = w.nblk; g.ce_tgt = w.tgt; g.ce_ids = ids;
+        TDM_TRY(tdm_launch_gemm_nt_bf16(g, 3, st));
+    }
+    // lse per token and the mean cross-entropy                                       (src/shakespeare.py:240)
+    hipLaunchKernelGGL(ce_lse_kernel, dim3((unsigned)((M + 3) / 4 < 4096 ? (M + 3) / 4 : 4096)), dim3(256), 0, st, w.part, w.tgt,
+                       w.lse, w.rowloss, (long)M, w.nblk);
+    TDM_CHECK_LAUNCH("ce_lse");
     hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, st, w.rowloss, loss_out, (long)M);
     TDM_CHECK_LAUNCH("ce_mean");
-    // dx = g W  (K-contiguous product on the transposed, zero-padded weight)
+    // dx = g W with g = grad_scale / M * (softmax - onehot) regenerated from the logits in the loader
+    // (K-contiguous product on the transposed, zero-padded weight)
     if (dx != nullptr) {
         dim3 tg((D + 31) / 32, (Vp + 31) / 32);
         hipLaunchKernelGGL(transpose_pad_kernel, tg, dim3(256), 0, st, W, w.wT, V, D, Vp);
@@ -255,9 +252,10 @@ int tdm_round_ce_loss_grad_f32(const float* x, const float* W, const float* b, c
         g.A = w.logits; g.a_rs = Vp; g.a_cs = 1;
         g.B = w.wT; g.b_rs = 1; g.b_cs = Vp;
         g.C = dx; g.c_rs = D; g.M = (int)M; g.N = D; g.K = Vp; g.splitk = 1;
+        g.ce_lse = w.lse; g.ce_ids = ids; g.ce_scale = gscale; g.ce_V = V;
         TDM_TRY(tdm_launch_gemm_nt_bf16(g, 3, st));
     }
-    // dW = g^T x (split over tokens) and db = column sums of g from the same pass
+    // dW = g^T x (split over tokens) and db = column sums of g from the same pass, g regenerated likewise
     {
         GemmArgs g{};
         g.A = w.logits; g.a_rs = 1; g.a_cs = Vp;
@@ -265,6 +263,7 @@ int tdm_round_ce_loss_grad_f32(const float* x, const float* W, const float* b, c
         g.C = w.wslab; g.c_rs = D; g.M = Vp; g.N = D; g.K = (int)M; g.splitk = w.sk;
         g.c_split_stride = (long)Vp * D;
         g.colsum = w.bslab; g.colsum_stride = (Vp + 63) & ~63;
+        g.ce_lse = w.lse; g.ce_ids = ids; g.ce_scale = gscale; g.ce_V = V;
         TDM_TRY(tdm_launch_gemm_tn_bf16(g, 3, st));
         ReduceArgs ra{};
         ra.nsec = 1;
@@ -290,6 +289,30 @@ int tdm_round_argmax_f32(const float* x, const float* W, const float* b, int64_t
     hipStream_t st = (hipStream_t)stream;
     const RoundWs w = round_carve(ws, M, V, D);
     TDM_TRY(logits_gemm(x, W, b, w.logits, M, V, w.Vp, D, st));
+    hipLaunchKernelGGL(row_argmax_kernel, dim3((unsigned)(M < 8192 ? M : 8192)), dim3(256), 0, st, w.logits, out_ids, (long)M, V,
+                       (long)w.Vp);
+    TDM_CHECK_LAUNCH("row_argmax");
+    return 0;
+}
+
+// Cosine-similarity decode (the reference's fallback when no rounding head is trained, src/shakespeare.py:393-401):
+// out_ids[m] = argmax_v <x[m] / max(|x[m]|, eps), E[v] / max(|E[v]|, eps)>: two row-normalisation passes, the logits GEMM
+// with a zero bias, the row argmax.  ws: tdm_round_workspace_floats(M, V, D).
+int tdm_cosine_argmax_f32(const float* x, const float* E, int64_t* out_ids, float* ws, int64_t M, int V, int D, void* stream) {
+    TDM_TRY(round_check(M, V, D));
+    TDM_REQUIRE(x && E && out_ids && ws, "cosine_argmax: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const RoundWs w = round_carve(ws, M, V, D);
+    float* En = w.wT;                      // [V][D]  (fits: the carve reserves D * Vp floats)
+    float* xn = w.xn;                      // [M][D] then the zero bias [Vp]
+    float* zb = xn + M * D;
+    hipLaunchKernelGGL(l2_normalize_kernel, dim3((unsigned)((V + 3) / 4 < 4096 ? (V + 3) / 4 : 4096)), dim3(256), 0, st, E, En, (long)V, D);
+    TDM_CHECK_LAUNCH("l2_normalize(table)");
+    hipLaunchKernelGGL(l2_normalize_kernel, dim3((unsigned)((M + 3) / 4 < 4096 ? (M + 3) / 4 : 4096)), dim3(256), 0, st, x, xn, (long)M, D);
+    TDM_CHECK_LAUNCH("l2_normalize(x)");
+    hipError_t e = hipMemsetAsync(zb, 0, (size_t)w.Vp * sizeof(float), st);
+    if (e != hipSuccess) { tdm_set_error("cosine_argmax: memset failed: %s", hipGetErrorString(e)); return 100 + (int)e; }
+    TDM_TRY(logits_gemm(xn, En, zb, w.logits, M, V, w.Vp, D, st));
     hipLaunchKernelGGL(row_argmax_kernel, dim3((unsigned)(M < 8192 ? M : 8192)), dim3(256), 0, st, w.logits, out_ids, (long)M, V,
                        (long)w.Vp);
     TDM_CHECK_LAUNCH("row_argmax");

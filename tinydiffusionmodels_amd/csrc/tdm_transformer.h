@@ -1,6 +1,7 @@
 // Internal declarations for the transformer-denoiser kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 #include "tdm_dropout.h"
 
 struct GemmArgs {
@@ -18,6 +19,14 @@ struct GemmArgs {
     // TN form only: colsum[z*colsum_stride + i] = sum over this split's k of A(i,k) (exact fp32; the bias gradient
     // when A = dY), written by the workgroups of tile column 0
     float* colsum; long colsum_stride;
+    // Cross-entropy fusion of the rounding head (rounding.hip, src/shakespeare.py:239-240), bf16 kernels only:
+    //  * ce_part != nullptr (NT, logits GEMM): besides C = logits, the epilogue writes per (row, 64-column block) the pair
+    //    (max, sum exp(v - max)) to ce_part[(row * ce_nblk + block) * 2] and the logit of the row's target id to ce_tgt[row];
+    //  * ce_lse != nullptr (NT as the A operand over k = vocabulary; TN as A(i = vocabulary, k = token)): A is read as
+    //    ce_scale * (exp(A - ce_lse[token]) - [vocabulary index == ce_ids[token]]) for vocabulary indices < ce_V, else 0 —
+    //    softmax - onehot is regenerated from the stored logits in the loader instead of being written back and re-read.
+    float* ce_part; int ce_nblk; float* ce_tgt;
+    const float* ce_lse; const int64_t* ce_ids; float ce_scale; int ce_V;
     int ablate;   // timing diagnostics (NT bf16 kernel; results are wrong when set): 1 no global loads after the first
                   // chunk, 2 no MFMA, 4 no epilogue stores, 8 no split / LDS stores after the first chunk
 };

@@ -558,12 +558,29 @@ def sample_diffusion_embeddings(model, embed_dim, device, n, seq_len):
 
 def decode_tokens(x, rounding_fn, embedding_fn, use_learned_rounding=True, use_learned_embeddings=True):
     """Token ids from final embeddings: rounding-head argmax, or the cosine-similarity
-    fallback (src/shakespeare.py:387-401).  Row N1: torch ops."""
+    fallback (src/shakespeare.py:387-401).  Row N1: both native."""
     if use_learned_rounding:
         return rounding_fn.argmax(x) if hasattr(rounding_fn, "argmax") else rounding_fn(x).argmax(dim=-1)
     embed_matrix = embedding_fn.get_embedding_matrix() if use_learned_embeddings else embedding_fn
-    sims = torch.matmul(F.normalize(x, dim=2), F.normalize(embed_matrix, dim=1).T)
-    return sims.argmax(dim=-1)
+    return cosine_argmax(x, embed_matrix)
+
+
+@torch.no_grad()
+def cosine_argmax(x: torch.Tensor, embed_matrix: torch.Tensor) -> torch.Tensor:
+    """argmax_v cos(x, E[v]) = (F.normalize(x, dim=2) @ F.normalize(E, dim=1).T).argmax(-1)  (src/shakespeare.py:393-401),
+    native: two row-normalisation kernels, the MFMA logits GEMM, the row argmax (tdm_cosine_argmax_f32)."""
+    E._need_cuda(x, embed_matrix)
+    V, D = embed_matrix.shape
+    if D % 4 != 0:
+        raise RuntimeError("cosine_argmax: the embedding dimension must be a multiple of 4")
+    xc = x.detach().reshape(-1, D).contiguous().float()
+    Ec = embed_matrix.detach().contiguous().float()
+    M = xc.shape[0]
+    out = torch.empty(M, dtype=torch.int64, device=xc.device)
+    ws = _round_workspace(M, V, D, xc.device)
+    _lib.check(_lib.lib().tdm_cosine_argmax_f32(_lib.ptr(xc), _lib.ptr(Ec), _lib.ptr(out), _lib.ptr(ws), M, V, D, _lib.stream()),
+               "cosine_argmax")
+    return out.view(x.shape[:-1])
 
 
 def sample(model, rounding_fn, embedding_fn, tokenizer, device, n_samples=4, seq_len=128,
