@@ -368,10 +368,15 @@ int launch_wgrad_t(const WgradArgs& a, int nslab, hipStream_t st) {
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, long stride,
                                                            ReduceArgs ra, float* __restrict__ out) {
     __shared__ float sh[4][64];
-    const ReduceSec s = ra.sec[blockIdx.y];
+    // 1-D grid of exactly the workgroups the sections need (a (max length, sections) grid launched 15,000 workgroups of
+    // which 2,800 had work: the empty ones cost a third of the kernel's time)
+    int si = 0;
+    while (si + 1 < ra.nsec && (int)blockIdx.x >= ra.blk0[si + 1]) ++si;
+    const ReduceSec s = ra.sec[si];
     if (s.stride_override != 0) stride = s.stride_override;
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-    for (int i0 = blockIdx.x * 64; i0 < s.len; i0 += gridDim.x * 64) {
+    {
+        const int i0 = ((int)blockIdx.x - ra.blk0[si]) * 64;
         const int i = i0 + e;
         float acc[8];
 #pragma unroll
@@ -434,8 +439,13 @@ int tdm_launch_reduce(const float* slabs, long stride, const ReduceArgs& ra, flo
     TDM_REQUIRE(ra.nsec >= 1 && ra.nsec <= TDM_MAX_SECS, "reduce: nsec %d", ra.nsec);
     int maxlen = 0;
     for (int i = 0; i < ra.nsec; ++i) maxlen = ra.sec[i].len > maxlen ? ra.sec[i].len : maxlen;
-    const int gx = (maxlen + 63) / 64;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, ra.nsec), dim3(256), 0, st, slabs, stride, ra, out);
+    (void)maxlen;
+    ReduceArgs rb = ra;
+    int nb = 0;
+    for (int i = 0; i < ra.nsec; ++i) { rb.blk0[i] = nb; nb += (ra.sec[i].len + 63) / 64; }
+    rb.blk0[ra.nsec] = nb;
+    TDM_REQUIRE(nb >= 1, "reduce: empty sections");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(nb), dim3(256), 0, st, slabs, stride, rb, out);
     TDM_CHECK_LAUNCH("reduce_slabs");
     return 0;
 }

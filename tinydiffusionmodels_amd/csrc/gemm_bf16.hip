@@ -20,6 +20,7 @@
 //           32][token][32 cols] images whose 64-byte pitch keeps the transposed reads
 //           conflict-free.
 #include "tdm_common.h"
+#include <cstdlib>
 #include "tdm_transformer.h"
 #include "tdm_s16.h"
 
@@ -68,11 +69,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-// 8 waves per workgroup, each a 32-row x 64-column piece of the 128 x 128 tile (2 accumulators): half the registers of the
-// former 4-wave / 64 x 64 form, so two workgroups put FOUR waves on every SIMD (was two).  Same lesson as the conv kernel:
-// at two waves per SIMD the loop is bound by the latency of its own chains (split + LDS write, barrier, fragment reads).
+// 8 waves per workgroup, each a (32 WM)-row x 64-column piece of the (128 WM) x 128 tile.
+//   WM = 1: 32 x 64 per wave (2 accumulators), <= 128 registers -> two workgroups = FOUR waves per SIMD.  (Same lesson as
+//           the conv kernel: at two waves per SIMD the small-tile loop is bound by the latency of its own chains.)
+//   WM = 2: 64 x 64 per wave (2 x 2 accumulators), one workgroup per CU.  The 32 x 64 form reads 96 B of LDS fragments per
+//           lane for 6 MFMAs — with four waves per SIMD that is exactly the CU's 128 B/clk of LDS bandwidth against the
+//           MFMA time, so the matrix pipe can never be more than about half busy; register blocking 2 x 2 reads 128 B for 12.
 constexpr int NT_THREADS = 512;
-constexpr int NT_LDS = (4 * PLANE > 8 * 32 * EP * 4) ? 4 * PLANE : 8 * 32 * EP * 4;   // operand planes / epilogue transposes
 
 // softmax - onehot of 4 consecutive vocabulary entries v0 .. v0+3 of one token row, from stored logits
 __device__ __forceinline__ f32x4 ce_grad4(const f32x4 l, float lse, int tgt, int v0, int V, float scale) {
@@ -82,15 +85,26 @@ __device__ __forceinline__ f32x4 ce_grad4(const f32x4 l, float lse, int tgt, int
     return r;
 }
 
-template <int NPROD, bool CE, bool STATS>
-__global__ __launch_bounds__(NT_THREADS, 4) void gemm_nt_bf16_kernel(GemmArgs g, int ntx, int ntiles) {
+template <int WM> struct NtCfg {
+    static constexpr int TMv = 128 * WM;
+    static constexpr int PLANE_A = TMv * PITCH, PLANE_B = 128 * PITCH;
+    static constexpr int OPER = 2 * PLANE_A + 2 * PLANE_B;
+    static constexpr int EPI = 8 * 32 * EP * 4;
+    static constexpr int LDS = OPER > EPI ? OPER : EPI;
+    static constexpr int NPA = 2 * WM;   // float4 pieces of A per thread and chunk
+};
+
+template <int NPROD, bool CE, bool STATS, int WM>
+__global__ __launch_bounds__(NT_THREADS, (WM == 1 ? 4 : 2)) void gemm_nt_bf16_kernel(GemmArgs g, int ntx, int ntiles) {
+    using Cf = NtCfg<WM>;
+    constexpr int TMv = Cf::TMv, NPA = Cf::NPA;
     // planes: A hi, A lo, B hi, B lo  (lo planes unused when NPROD == 1)
     extern __shared__ float4 nt_smem4[];
     char* lds = reinterpret_cast<char*>(nt_smem4);
-    char* Ahi = lds; char* Alo = lds + PLANE; char* Bhi = lds + 2 * PLANE; char* Blo = lds + 3 * PLANE;
+    char* Ahi = lds; char* Alo = lds + Cf::PLANE_A; char* Bhi = lds + 2 * Cf::PLANE_A; char* Blo = Bhi + Cf::PLANE_B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, j = lane & 31;
-    const int wm = wave >> 1, wn = wave & 1;   // rows wm*32 .. +31, columns wn*64 .. +63
+    const int wm = wave >> 1, wn = wave & 1;   // rows wm*32*WM .. , columns wn*64 .. +63
     // this workgroup's contiguous tile range [t_beg, t_end) of the XCD-ordered tile list
     const int slot = xcd_remap(blockIdx.x, gridDim.x);
     const int per = ntiles / gridDim.x, rem = ntiles % gridDim.x;
@@ -98,61 +112,73 @@ __global__ __launch_bounds__(NT_THREADS, 4) void gemm_nt_bf16_kernel(GemmArgs g,
     const int t_end = t_beg + per + (slot < rem ? 1 : 0);
     const int nchunk = (g.K + BK - 1) / BK;
 
-    // The next K-chunk's global loads, in flight while the current chunk is multiplied.  All 8 loads of a chunk are
+    // The next K-chunk's global loads, in flight while the current chunk is multiplied.  All loads of a chunk are
     // issued unconditionally and back to back: out-of-range pieces read a clamped address and are zeroed from the
     // `ok` bits when they are split into LDS.  (Guarded loads with scalar tail paths compiled to branches with an
     // s_waitcnt vmcnt(0) between consecutive loads, i.e. the loads of a chunk were serialised.)  K % 4 == 0.
-    f32x4 pa[2], pb[2];
+    f32x4 pa[NPA], pb[2];
     unsigned ok = 0u;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto gload = [&](int tile, int k0) {
-        const int i0 = (tile / ntx) * TM, j0 = (tile % ntx) * TN_;
+        const int i0 = (tile / ntx) * TMv, j0 = (tile % ntx) * TN_;
         ok = 0u;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {   // 128 rows x 8 float4
+        for (int p = 0; p < NPA; ++p) {   // TMv rows x 8 float4
             const int f = tid + NT_THREADS * p;
             const int row = f >> 3, kq = f & 7;
             const int gk = k0 + kq * 4;
-            const bool kin = gk < g.K;
-            const bool oa = kin && (i0 + row < g.M), ob = kin && (j0 + row < g.N);
+            const bool oa = gk < g.K && (i0 + row < g.M);
             ok |= (oa ? 1u : 0u) << p;
-            ok |= (ob ? 1u : 0u) << (4 + p);
-            const int gkc = kin ? gk : 0;
-            pa[p] = *reinterpret_cast<const f32x4*>(g.A + (long)min(i0 + row, g.M - 1) * g.a_rs + gkc);
-            pb[p] = *reinterpret_cast<const f32x4*>(g.B + (long)min(j0 + row, g.N - 1) * g.b_cs + gkc);
+            pa[p] = *reinterpret_cast<const f32x4*>(g.A + (long)min(i0 + row, g.M - 1) * g.a_rs + (gk < g.K ? gk : 0));
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {     // 128 rows x 8 float4
+            const int f = tid + NT_THREADS * p;
+            const int row = f >> 3, kq = f & 7;
+            const int gk = k0 + kq * 4;
+            const bool ob = gk < g.K && (j0 + row < g.N);
+            ok |= (ob ? 1u : 0u) << (8 + p);
+            pb[p] = *reinterpret_cast<const f32x4*>(g.B + (long)min(j0 + row, g.N - 1) * g.b_cs + (gk < g.K ? gk : 0));
         }
     };
     if (t_beg < t_end) gload(t_beg, 0);
 
     for (int tile = t_beg; tile < t_end; ++tile) {
-        const int i0 = (tile / ntx) * TM, j0 = (tile % ntx) * TN_;
-        float ce_l[2] = {0.f, 0.f};
-        int ce_t[2] = {0, 0};
-        if constexpr (CE) {   // this thread stages the same two A rows in every chunk of the tile
+        const int i0 = (tile / ntx) * TMv, j0 = (tile % ntx) * TN_;
+        float ce_l[NPA];
+        int ce_t[NPA];
+        if constexpr (CE) {   // this thread stages the same A rows in every chunk of the tile
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < NPA; ++p) {
                 const int row = min(i0 + ((tid + NT_THREADS * p) >> 3), g.M - 1);
                 ce_l[p] = g.ce_lse[row];
                 ce_t[p] = (int)g.ce_ids[row];
             }
         }
-        f32x16 acc[2];
+        f32x16 acc[WM][2];
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < WM; ++a)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
         for (int c = 0; c < nchunk; ++c) {
             __syncthreads();
             if (!(g.ablate & 8) || c == 0) {
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
+                for (int p = 0; p < NPA; ++p) {
                     const int f = tid + NT_THREADS * p;
                     const int row = f >> 3, kq = f & 7;
                     f32x4 va = ((ok >> p) & 1u) ? pa[p] : zero4;
                     if constexpr (CE) va = ((ok >> p) & 1u) ? ce_grad4(va, ce_l[p], ce_t[p], c * BK + kq * 4, g.ce_V, g.ce_scale) : zero4;
                     put_split<NPROD>(Ahi, Alo, row * PITCH + kq * 8, va);
-                    put_split<NPROD>(Bhi, Blo, row * PITCH + kq * 8, ((ok >> (4 + p)) & 1u) ? pb[p] : zero4);
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int f = tid + NT_THREADS * p;
+                    const int row = f >> 3, kq = f & 7;
+                    put_split<NPROD>(Bhi, Blo, row * PITCH + kq * 8, ((ok >> (8 + p)) & 1u) ? pb[p] : zero4);
                 }
             }
             __syncthreads();
@@ -163,10 +189,13 @@ __global__ __launch_bounds__(NT_THREADS, 4) void gemm_nt_bf16_kernel(GemmArgs g,
             if (g.ablate & 2) continue;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 xh, xl, wh[2], wl[2];
-                const int ao = (wm * 32 + j) * PITCH + ks * 32 + h * 16;
-                xh = *reinterpret_cast<const bf16x8*>(Ahi + ao);
-                if (NPROD == 3) xl = *reinterpret_cast<const bf16x8*>(Alo + ao);
+                bf16x8 xh[WM], xl[WM], wh[2], wl[2];
+#pragma unroll
+                for (int mt = 0; mt < WM; ++mt) {
+                    const int ao = (wm * 32 * WM + mt * 32 + j) * PITCH + ks * 32 + h * 16;
+                    xh[mt] = *reinterpret_cast<const bf16x8*>(Ahi + ao);
+                    if (NPROD == 3) xl[mt] = *reinterpret_cast<const bf16x8*>(Alo + ao);
+                }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int bo = (wn * 64 + t * 32 + j) * PITCH + ks * 32 + h * 16;
@@ -174,13 +203,15 @@ __global__ __launch_bounds__(NT_THREADS, 4) void gemm_nt_bf16_kernel(GemmArgs g,
                     if (NPROD == 3) wl[t] = *reinterpret_cast<const bf16x8*>(Blo + bo);
                 }
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {   // D[n][m]: weight rows are the MFMA A operand
-                    if (NPROD == 3) {
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[nt], xl, acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[nt], xh, acc[nt], 0, 0, 0);
+                for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {   // D[n][m]: weight rows are the MFMA A operand
+                        if (NPROD == 3) {
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[nt], xl[mt], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[nt], xh[mt], acc[mt][nt], 0, 0, 0);
+                        }
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[nt], xh[mt], acc[mt][nt], 0, 0, 0);
                     }
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[nt], xh, acc[nt], 0, 0, 0);
-                }
             }
         }
 
@@ -190,26 +221,27 @@ __global__ __launch_bounds__(NT_THREADS, 4) void gemm_nt_bf16_kernel(GemmArgs g,
         // with bf16x3 operands, 187 -> 131 us with plain bf16 operands)
         __syncthreads();   // all waves are done reading the operand planes
         float* T = reinterpret_cast<float*>(lds) + wave * (32 * EP);
-        {
+        const int c4 = lane & 15;
+        const int n = j0 + wn * 64 + c4 * 4;
+        const int nq = g.N - n;   // columns of this quad inside the matrix (>= 4: whole quad)
+        float4 bz = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias != nullptr && nq > 0) {
+            if (nq >= 4) bz = *reinterpret_cast<const float4*>(g.bias + n);
+            else { bz.x = g.bias[n]; if (nq > 1) bz.y = g.bias[n + 1]; if (nq > 2) bz.z = g.bias[n + 2]; }
+        }
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     *reinterpret_cast<float4*>(T + j * EP + nt * 32 + 8 * q + 4 * h) =
-                        make_float4(acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]);
+                        make_float4(acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]);
             // (wave-private region: no barrier needed between this wave's writes and reads)
-            const int c4 = lane & 15;
-            const int n = j0 + wn * 64 + c4 * 4;
-            const int nq = g.N - n;   // columns of this quad inside the matrix (>= 4: whole quad)
-            float4 bz = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g.bias != nullptr && nq > 0) {
-                if (nq >= 4) bz = *reinterpret_cast<const float4*>(g.bias + n);
-                else { bz.x = g.bias[n]; if (nq > 1) bz.y = g.bias[n + 1]; if (nq > 2) bz.z = g.bias[n + 2]; }
-            }
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int rr = it * 4 + (lane >> 4);
-                const int m = i0 + wm * 32 + rr;
+                const int m = i0 + wm * 32 * WM + mt * 32 + rr;
                 float4 v = *reinterpret_cast<const float4*>(T + rr * EP + c4 * 4);
                 if constexpr (STATS) {   // (max, sum exp) of this row's 64 columns + the target logit (cross-entropy partials)
                     const float lv[4] = {v.x + bz.x, v.y + bz.y, v.z + bz.z, v.w + bz.w};
@@ -438,6 +470,34 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 
 }  // namespace
 
+namespace {
+int g_nt_wm = 0;   // 0: pick per problem; 1 / 2: force the 128- / 256-row tile (TDM_GEMM_WM, A/B timing)
+
+template <int NPROD, bool CE, bool STATS, int WM>
+int launch_nt(const GemmArgs& g, hipStream_t st) {
+    using Cf = NtCfg<WM>;
+    static int resident = 0;   // workgroups the device holds at once (occupancy x CUs): the persistent grid
+    if (resident == 0) {
+        int dev = 0, cus = 0, per_cu = 0;
+        const void* fn = reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<NPROD, CE, STATS, WM>);
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, NT_THREADS, Cf::LDS);
+        if (e != hipSuccess || cus <= 0 || per_cu <= 0) {
+            tdm_set_error("gemm_nt_bf16: occupancy query failed: %s", hipGetErrorString(e));
+            return 100 + (int)e;
+        }
+        resident = cus * per_cu;
+    }
+    const int ntx = (g.N + TN_ - 1) / TN_, ntiles = ntx * ((g.M + Cf::TMv - 1) / Cf::TMv);
+    dim3 grid(ntiles < resident ? ntiles : resident);
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<NPROD, CE, STATS, WM>), grid, dim3(NT_THREADS), Cf::LDS, st, g, ntx, ntiles);
+    TDM_CHECK_LAUNCH("gemm_nt_bf16");
+    return 0;
+}
+}  // namespace
+
 // C[M][N] = A[M][K] B[N][K]^T ...: A(i,k) = A[i*a_rs + k], B(k,j) = B[j*b_cs + k]
 int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
     TDM_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm_nt_bf16: empty problem");
@@ -446,43 +506,28 @@ int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
                 "gemm_nt_bf16: leading dimensions and K must be multiples of 4");
     TDM_REQUIRE((((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.C) & 15) == 0, "gemm_nt_bf16: 16-byte alignment");
     TDM_REQUIRE(g.splitk <= 1, "gemm_nt_bf16: no split-K");
-    const int ntx = (g.N + TN_ - 1) / TN_, ntiles = ntx * ((g.M + TM - 1) / TM);
-    static int resident = 0;   // workgroups the device holds at once (occupancy x CUs): the persistent grid
-    if (resident == 0) {
-        int dev = 0, cus = 0, per_cu = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<3, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<1, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<3, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
-        if (e == hipSuccess)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<3, false, false>),
-                                                             NT_THREADS, NT_LDS);
-        if (e != hipSuccess || cus <= 0 || per_cu <= 0) {
-            tdm_set_error("gemm_nt_bf16: occupancy query failed: %s", hipGetErrorString(e));
-            return 100 + (int)e;
-        }
-        resident = cus * per_cu;
-    }
-    dim3 grid(ntiles < resident ? ntiles : resident);
     TDM_REQUIRE(!(g.ce_lse != nullptr && g.ce_part != nullptr), "gemm_nt_bf16: one cross-entropy role per launch");
+    static bool env_read = false;
+    if (!env_read) {
+        if (const char* e = getenv("TDM_GEMM_WM")) g_nt_wm = atoi(e);
+        env_read = true;
+    }
+    // 256-row tiles (64 x 64 per wave) when they still make at least one round of workgroups over the chip
+    const long tiles256 = (long)((g.N + TN_ - 1) / TN_) * ((g.M + 255) / 256);
+    // Measured (tools/time_gemm.py, M = 32768): the 256-row tile is NOT faster — N = 2048, K = 256: 185 us (128-row, four
+    // waves per SIMD) vs 201 us (256-row, two waves per SIMD); bf16 operands 135 vs 150 us; equal on the other layer shapes.
+    // Halving the waves per SIMD costs what the halved LDS fragment traffic buys.  It stays selectable (TDM_GEMM_WM=2).
+    (void)tiles256;
+    const bool big = g_nt_wm == 2;
     if (g.ce_lse != nullptr || g.ce_part != nullptr) {
         TDM_REQUIRE(nprod == 3 && g.ce_ids != nullptr, "gemm_nt_bf16: the cross-entropy forms run in the bf16x3 arithmetic and need the target ids");
-        if (g.ce_lse != nullptr) hipLaunchKernelGGL((gemm_nt_bf16_kernel<3, true, false>), grid, dim3(NT_THREADS), NT_LDS, st, g, ntx, ntiles);
-        else {
-            TDM_REQUIRE(g.ce_tgt != nullptr && g.ce_nblk >= (g.N + 63) / 64 && g.res == nullptr && !g.relu && g.gate == nullptr && g.drop.thr == 0u,
-                        "gemm_nt_bf16: cross-entropy partials need a plain (bias-only) epilogue");
-            hipLaunchKernelGGL((gemm_nt_bf16_kernel<3, false, true>), grid, dim3(NT_THREADS), NT_LDS, st, g, ntx, ntiles);
-        }
-    } else if (nprod == 3) hipLaunchKernelGGL((gemm_nt_bf16_kernel<3, false, false>), grid, dim3(NT_THREADS), NT_LDS, st, g, ntx, ntiles);
-    else hipLaunchKernelGGL((gemm_nt_bf16_kernel<1, false, false>), grid, dim3(NT_THREADS), NT_LDS, st, g, ntx, ntiles);
-    TDM_CHECK_LAUNCH("gemm_nt_bf16");
-    return 0;
+        if (g.ce_lse != nullptr) return big ? launch_nt<3, true, false, 2>(g, st) : launch_nt<3, true, false, 1>(g, st);
+        TDM_REQUIRE(g.ce_tgt != nullptr && g.ce_nblk >= (g.N + 63) / 64 && g.res == nullptr && !g.relu && g.gate == nullptr && g.drop.thr == 0u,
+                    "gemm_nt_bf16: cross-entropy partials need a plain (bias-only) epilogue");
+        return big ? launch_nt<3, false, true, 2>(g, st) : launch_nt<3, false, true, 1>(g, st);
+    }
+    if (nprod == 3) return big ? launch_nt<3, false, false, 2>(g, st) : launch_nt<3, false, false, 1>(g, st);
+    return big ? launch_nt<1, false, false, 2>(g, st) : launch_nt<1, false, false, 1>(g, st);
 }
 
 // C[M][N] = sum_k A[k][M]^T B[k][N]: A(i,k) = A[k*a_cs + i], B(k,j) = B[k*b_rs + j]; raw split-K output

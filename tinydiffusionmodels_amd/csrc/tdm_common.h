@@ -148,10 +148,11 @@ struct ReduceSec {
     float* dst;            // where the section's sums go; nullptr = out + off
     float scale;           // factor applied to the sums; 0 = 1
 };
-#define TDM_MAX_SECS 64
+#define TDM_MAX_SECS 40
 struct ReduceArgs {
     ReduceSec sec[TDM_MAX_SECS];
     int nsec;
+    int blk0[TDM_MAX_SECS + 1];   // filled by tdm_launch_reduce: first workgroup of each section in the 1-D grid
 };
 int tdm_launch_reduce(const float* slabs, long stride, const ReduceArgs& ra, float* out, hipStream_t st);
 
