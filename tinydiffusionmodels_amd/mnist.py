@@ -266,7 +266,7 @@ class _GraphSampler:
         torch.cuda.current_stream(self.dev).wait_stream(side)
         self.xa.copy_(saved[0]); self.t_vec.copy_(saved[1]); self.kidx.copy_(saved[2]); self.rng_state.copy_(saved[3])
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self._one(self.xa, self.xb)
             self._one(self.xb, self.xa)
         self.graph_has_bank = self.bank is not None
@@ -509,7 +509,7 @@ class DDPMTrainer(DPStepper):
     def _capture(self, st: "E.TrainState") -> None:
         whole = self.world == 1 or (self.graph_collective and dp.native_comm() is not None)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             E.loss_and_grad_philox(self.flat, st, st.x0, self.seed, self.rng_state)
             if whole:
                 scale = dp.allreduce_grads_(self.grads)

@@ -496,7 +496,7 @@ class _TextGraphSampler:
         torch.cuda.current_stream(self.dev).wait_stream(side)
         self.xa.copy_(saved[0]); self.t_vec.copy_(saved[1]); self.rng_state.copy_(saved[2])
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self._one(self.xa, self.xb)
             self._one(self.xb, self.xa)
 
