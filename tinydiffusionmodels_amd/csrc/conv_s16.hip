@@ -127,6 +127,9 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// staged rows of a 256 MT pixel tile: pixel rows it can touch (+1 for an unaligned start) + one image seam (2 halo rows)
+// + the top and bottom halo rows
+template <int HW, int MT> struct ConvRows { static constexpr int NR = (HW - 1 + 256 * MT + HW - 1) / HW + 4; };
 // registers of the fused 1x1 skip conv (ConvArgs::skip_out): exist only in the SKIP instantiation
 template <int NT, bool SKIP> struct SkipState {};
 template <int NT> struct SkipState<NT, true> { f32x16 acc2[NT]; uint4 psk; };
@@ -147,10 +150,19 @@ __device__ __forceinline__ void gstore_s16_o(float* s16, unsigned o, int c, cons
     gstore<tdm_bf16x4>(base + 32, lo);
 }
 
-template <int HW, int NT, bool SKIP, bool PROBE>
+// MT = M tiles (32 pixels each) per wave: the workgroup's tile is 256 MT pixels.  MT = 2 (28x28, N = 32 only): measured
+// per-round time of this kernel is a + b x (MFMAs per wave) with a fixed a = 4.5 us (first-load latency, prologue,
+// epilogue) and b set by the LDS fragment traffic — a wave reading ONE weight fragment pair for TWO pixel fragments halves
+// the rounds (and the fixed cost paid per round) and cuts the fragment bytes per MFMA by a quarter, at the same 4 waves
+// per SIMD (32 accumulator registers instead of 16; single prefetch set).
+template <int HW, int NT, bool SKIP, bool PROBE, int MT = 1>
 __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kernel(ConvArgs ka) {
     using G = Geo<HW>;
-    static_assert(G::NR * G::WP * 4 <= NPIN * CONV_THREADS, "staging plan too small");
+    constexpr int TPX = TILE_PX * MT;                                  // pixels of the workgroup's tile
+    constexpr int NRv = MT == 1 ? G::NR : ConvRows<HW, MT>::NR;        // staged rows of the padded-tall image
+    constexpr int NPINv = (NRv * G::WP * 4 + CONV_THREADS - 1) / CONV_THREADS;   // 16-byte input pieces per thread and K chunk
+    static_assert(NRv <= 32, "the per-wave row table has 32 entries");
+    static_assert(MT == 1 || (HW == 28 && NT == 1), "two M tiles per wave: built for the 28x28 N = 32 kernels");
     // The ~300-byte argument block does not stay in scalar registers by itself: the compiler re-reads a field from the
     // kernarg segment (s_load + s_waitcnt lgkmcnt(0), a scalar-cache round trip) next to almost every use — before each
     // prefetch load, around every uniform branch of the epilogue.  Everything the kernel uses is copied ONCE into
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     float* o1_out = R1 ? ka.o1_out : nullptr; const float* o1_w = ka.o1_w; const float* o1_b = ka.o1_b;   // fused 1x1 output conv (rb4.conv2)
     if constexpr (R1) { TDM_PIN(o1_out); TDM_PIN(o1_w); TDM_PIN(o1_b); }
     constexpr int N = NT * 32;
-    constexpr int TILE_B = G::NR * G::WP * PIXB;
+    constexpr int TILE_B = NRv * G::WP * PIXB;
     extern __shared__ float4 smem4[];
     char* tile = reinterpret_cast<char*>(smem4);
     char* wl = tile + TILE_B;
@@ -185,19 +197,21 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     };
     stamp();
     const int Mtot = a.B * G::H * G::W;
-    const int m0 = t * TILE_PX;
-    const int mlast = min(m0 + TILE_PX - 1, Mtot - 1);
+    const int m0 = t * TPX;
+    const int mlast = min(m0 + TPX - 1, Mtot - 1);
     const int tb0 = m0 / (G::H * G::W);                       // image and row of the tile's first pixel:
     const int ty0 = (m0 - tb0 * (G::H * G::W)) / G::W;        // the staged image starts at padded row PR0 = tb0 * HP + ty0
     const int PR0 = tb0 * G::HP + ty0;
     const int nrows = padded_row<HW>(mlast) - PR0 + 2;
     const int nelem = nrows * G::WP * 4;      // 16-byte pieces of one chunk
-    const int mbase = m0 + wave * 32;         // this wave's M tile (scalar)
+    const int mbase0 = m0 + wave * (32 * MT);   // this wave's first M tile (scalar); its MT tiles are consecutive
 
-    int aoff;   // LDS byte offset of this lane's pixel (centre tap) in the staged image
-    {
+    int aoff[MT];   // LDS byte offset of this lane's pixel (centre tap) in the staged image, per M tile
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
         // (image, row, column) of the M tile's first pixel are scalar; a lane is q = x0 + j columns further: q / W by
         // multiply-shift (exact for q < W + 128), no per-lane constant divisions
+        const int mbase = mbase0 + mt * 32;
         const int mb = min(mbase, Mtot - 1);
         const int b0 = mb / (G::H * G::W);
         const int rem0 = mb - b0 * (G::H * G::W);
@@ -207,13 +221,13 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         const int x = q - dr * G::W;
         int y = y0 + dr, rowb = (b0 - tb0) * G::HP;
         if (y >= G::H) { y -= G::H; rowb += G::HP; }
-        aoff = ((rowb + y + 1 - ty0) * G::WP + x + 1) * PIXB + h * 16;
+        aoff[mt] = ((rowb + y + 1 - ty0) * G::WP + x + 1) * PIXB + h * 16;
     }
 
     // accumulators start from the conv bias (register quad g of N tile nt = channels nt*32 + 8g + 4h .. +3 of the lane's
     // pixel): the loads are issued first thing and the epilogue has nothing left to add
-    f32x16 acc[NT];
-    auto init_acc = [&](f32x16 (&ac)[NT], const float* bias) {
+    f32x16 acc[MT][NT];
+    auto init_acc = [&](f32x16* ac, const float* bias) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -223,11 +237,13 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
                 ac[nt][4 * g] = bz.x; ac[nt][4 * g + 1] = bz.y; ac[nt][4 * g + 2] = bz.z; ac[nt][4 * g + 3] = bz.w;
             }
     };
-    init_acc(acc, a.bias);
-    SkipState<NT, SKIP> sk;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) init_acc(acc[mt], a.bias);
+    SkipState<MT * NT, SKIP> sk;
     if constexpr (SKIP) {
         sk.psk = make_uint4(0u, 0u, 0u, 0u);
-        init_acc(sk.acc2, a.skip_bias);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) init_acc(sk.acc2 + mt * NT, a.skip_bias);
     }
 
     // Software pipeline over K chunks, register-staged.  At N = 32 input pieces are prefetched TWO chunks ahead (two
@@ -238,22 +254,22 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     char* const sdst = tile + (tid >> 2) * PIXB + (tid & 3) * 16;
     const int nc0 = a.s0.nch >> 4;
     const int nchunks = nc0 + (a.nsrc > 1 ? (a.s1.nch >> 4) : 0);
-    int goffA[NPIN], goffB[NPIN];   // staging plans of the sources the two input sets were loaded from
+    int goffA[NPINv], goffB[NPINv];   // staging plans of the sources the two input sets were loaded from
     int planA = -1, planB = -1;
-    uint4 pinA[NPIN], pinB[NPIN], pwt[WN];
+    uint4 pinA[NPINv], pinB[NPINv], pwt[WN];
 
     // Inputs and weights come through buffer descriptors: a piece that is padding (or past the end) gets an offset
     // beyond num_records and the hardware returns zeros — no exec-mask branch per load, no zero-initialised
     // destination, and (straight-line code) exact vmcnt(n) waits, so the second register set really stays in flight
     // while the first is staged.
-    auto prefetch_in = [&](uint4 (&pin)[NPIN], int (&goff)[NPIN], int& plan_src, const int (&goff_other)[NPIN], int plan_other, int c) {
+    auto prefetch_in = [&](uint4 (&pin)[NPINv], int (&goff)[NPINv], int& plan_src, const int (&goff_other)[NPINv], int plan_other, int c) {
         const int si = (c >= nc0) ? 1 : 0;
         const int ch = si ? c - nc0 : c;
         const PinnedSrc s = a.src(si);
         const int up = s.up, Hs = G::H >> up, Ws = G::W >> up;
         if (plan_src != si && plan_other == si) {   // the other register set already holds this source's plan
 #pragma unroll
-            for (int i = 0; i < NPIN; ++i) goff[i] = goff_other[i];
+            for (int i = 0; i < NPINv; ++i) goff[i] = goff_other[i];
             plan_src = si;
         }
         if (plan_src != si) {
@@ -273,7 +289,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
             int pc = (tid >> 2) - lr * G::WP;
             const int cbase = (s.c0 + (tid & 3) * 4) * 4;
 #pragma unroll
-            for (int i = 0; i < NPIN; ++i) {
+            for (int i = 0; i < NPINv; ++i) {
                 const int roff = rowtab[lr];                       // (lr <= 31 for both geometries)
                 const bool ok = roff >= 0 && pc >= 1 && pc <= G::W;
                 goff[i] = ok ? roff + __mul24((pc - 1) >> up, s.C) * 4 + cbase : (int)0x80000000;   // byte offset, or out of range
@@ -286,7 +302,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.ptr), 0, a.B * Hs * Ws * s.C * 4, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < NPIN; ++i) {
+        for (int i = 0; i < NPINv; ++i) {
             const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i], ch << 6, 0));
             pin[i] = make_uint4(v[0], v[1], v[2], v[3]);
         }
@@ -310,10 +326,10 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
             sk.psk = make_uint4(v[0], v[1], v[2], v[3]);
         }
     };
-    auto stage = [&](const uint4 (&pin)[NPIN]) {
+    auto stage = [&](const uint4 (&pin)[NPINv]) {
         __syncthreads();      // everyone finished reading the previous chunk's LDS image
 #pragma unroll
-        for (int i = 0; i < NPIN; ++i)
+        for (int i = 0; i < NPINv; ++i)
             if (tid + CONV_THREADS * i < nelem) *reinterpret_cast<uint4*>(sdst + i * (STEP * PIXB)) = pin[i];
 #pragma unroll
         for (int i = 0; i < WN; ++i)
@@ -331,24 +347,34 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
             if (taps == 9 || tp == 4) {   // a 1x1 source uses the centre-tap site with packed tap 0
                 const int toff = ((tp / 3 - 1) * G::WP + (tp % 3 - 1)) * PIXB;
                 const int wt = (taps == 9) ? tp : 0;
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(tile + aoff + toff);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(tile + aoff + toff + 32);
+                bf16x8 ah[MT], al[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    ah[mt] = *reinterpret_cast<const bf16x8*>(tile + aoff[mt] + toff);
+                    al[mt] = *reinterpret_cast<const bf16x8*>(tile + aoff[mt] + toff + 32);
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const char* wb = wl + ((wt * NT + nt) * 2) * 1024 + lane * 16;
                     const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wb);
                     const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wb + 1024);
-                    // D[co][pixel]: weights are the A operand
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc[nt], 0, 0, 0);
+                    // D[co][pixel]: weights are the A operand (one weight fragment pair feeds all MT pixel tiles)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al[mt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[mt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[mt], acc[mt][nt], 0, 0, 0);
+                    }
                     if constexpr (SKIP) if (tp == 4) {   // the block's 1x1 skip conv reads exactly the centre-tap pixels
                         const char* sb = wl + 9 * NT * 2048 + (nt * 2) * 1024 + lane * 16;
                         const bf16x8 sh = *reinterpret_cast<const bf16x8*>(sb);
                         const bf16x8 sl = *reinterpret_cast<const bf16x8*>(sb + 1024);
-                        sk.acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh, al, sk.acc2[nt], 0, 0, 0);
-                        sk.acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sl, ah, sk.acc2[nt], 0, 0, 0);
-                        sk.acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh, ah, sk.acc2[nt], 0, 0, 0);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            sk.acc2[mt * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh, al[mt], sk.acc2[mt * NT + nt], 0, 0, 0);
+                            sk.acc2[mt * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sl, ah[mt], sk.acc2[mt * NT + nt], 0, 0, 0);
+                            sk.acc2[mt * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh, ah[mt], sk.acc2[mt * NT + nt], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -358,7 +384,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     const bool pf = !(a.ablate & 1);
     prefetch_in(pinA, goffA, planA, goffB, planB, 0);
     prefetch_w(0);
-    if constexpr (NT == 1 && !SKIP) {
+    if constexpr (NT == 1 && !SKIP && MT == 1) {
         if (nchunks > 1) prefetch_in(pinB, goffB, planB, goffA, planA, 1);
         stamp();
         for (int c = 0; c < nchunks; c += 2) {
@@ -405,8 +431,6 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     constexpr int EPI = N + 4;   // floats per staged pixel row: (N/4 + 1) x 16 B, an odd slot count
     constexpr int NIT = N / 8;   // passes per M tile: 32 * N/4 float4, 64 per instruction
     const bool bwd = NT != 3 && a.relu_mask_in != nullptr;   // (N = 32 / 64 outputs only)
-    const int img0 = mbase / (G::H * G::W);         // image of the group's first pixel (scalar)
-    const int mnext = (img0 + 1) * (G::H * G::W);   // a 32-pixel group touches at most two images
     constexpr int GI = 4;   // passes per group: 4 independent chains, 16 value registers
     struct Pre { float4 rt[GI]; unsigned mk[GI]; float rx[R1 ? GI : 1]; } p;   // inputs of ONE group of passes; rt: residual, else the time-bias row
     // branch-free: absent inputs get an empty descriptor (num_records 0 -> zeros), so the requests are one straight run
@@ -419,6 +443,13 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         const_cast<unsigned char*>(a.relu_mask_in), 0, bwd ? Mtot * (N / 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(r1_x), 0, r1_x != nullptr ? Mtot * 4 : 0, 0x00020000);
+    float* T = reinterpret_cast<float*>(smem4) + wave * (32 * EPI);
+    // The wave's MT M tiles go through the epilogue one after the other (same wave-private LDS block, same registers).
+    static_for<0, MT>([&](auto mtc) {
+    constexpr int mt = decltype(mtc)::value;
+    const int mbase = mbase0 + mt * 32;
+    const int img0 = mbase / (G::H * G::W);         // image of the group's first pixel (scalar)
+    const int mnext = (img0 + 1) * (G::H * G::W);   // a 32-pixel group touches at most two images
     auto preload = [&](int g) {
 #pragma unroll
         for (int it = 0; it < GI; ++it) {
@@ -435,10 +466,9 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     };
     preload(0);
     stamp();                     // 6: tile inputs requested
-    __syncthreads();             // every wave is done with the operand images
+    if constexpr (mt == 0) __syncthreads();   // every wave is done with the operand images
     stamp();                     // 7
-    float* T = reinterpret_cast<float*>(smem4) + wave * (32 * EPI);
-    auto to_lds = [&](const f32x16 (&ac)[NT]) {
+    auto to_lds = [&](const f32x16* ac) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -446,7 +476,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
                 *reinterpret_cast<float4*>(T + j_e * EPI + nt * 32 + 8 * g + 4 * h_e) =
                     make_float4(ac[nt][4 * g], ac[nt][4 * g + 1], ac[nt][4 * g + 2], ac[nt][4 * g + 3]);
     };
-    to_lds(acc);
+    to_lds(acc[mt]);
     stamp();                     // 8: transpose written
     // Everything of p has been requested: wait for it HERE, once.  The requests sit under uniform branches, so without
     // this the compiler guards every pass's first use of p.rt / p.mk with s_waitcnt vmcnt(0) — which on gfx9
@@ -600,7 +630,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     stamp();                     // 9
     stamp();                     // 10 (second M tile of the former 4-wave layout: none)
     if constexpr (SKIP) {   // second accumulator: skip_out = 1x1 conv (+ its bias, already accumulated), same transposed walk
-        to_lds(sk.acc2);
+        to_lds(sk.acc2 + mt * NT);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int e = it * 64 + lane_e;
@@ -610,21 +640,23 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
             if (m < Mtot) gstore4(a.skip_out + ((unsigned)m * N + c), v);
         }
     }
+    });   // M tiles
     stamp();   // stores issued
     if constexpr (PROBE) if (a.ablate & 16) __builtin_amdgcn_s_waitcnt(0);   // stores acknowledged
     stamp();
 }
 
-template <int HW, int NT, bool SKIP>
+template <int HW, int NT, bool SKIP, int MT = 1>
 int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     using G = Geo<HW>;
-    constexpr size_t lds_op = (size_t)G::NR * G::WP * PIXB + (size_t)9 * NT * 2048 + (SKIP ? (size_t)NT * 2048 : 0) +
+    constexpr int NRv = MT == 1 ? G::NR : ConvRows<HW, MT>::NR;
+    constexpr size_t lds_op = (size_t)NRv * G::WP * PIXB + (size_t)9 * NT * 2048 + (SKIP ? (size_t)NT * 2048 : 0) +
                               (size_t)(CONV_THREADS / 64) * 32 * sizeof(int);   // operand images + the waves' row tables
     constexpr size_t lds_epi = (size_t)(CONV_THREADS / 64) * 32 * (NT * 32 + 4) * sizeof(float);   // per-wave transpose blocks
     constexpr size_t lds = lds_op > lds_epi ? lds_op : lds_epi;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<HW, NT, SKIP, false>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<HW, NT, SKIP, false, MT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 110000);
         if (e != hipSuccess) {
             tdm_set_error("conv_s16: hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
@@ -633,10 +665,10 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st) {
         attr_set = true;
     }
     const long Mtot = (long)a.B * G::H * G::W;
-    const int ntiles = (int)((Mtot + TILE_PX - 1) / TILE_PX);
+    const int ntiles = (int)((Mtot + TILE_PX * MT - 1) / (TILE_PX * MT));
     // ablate & 32 (probe): one workgroup per CU (LDS request > half of 160 KB) — phase times without a co-resident workgroup
     const size_t lds_req = (a.ablate & 32) ? (size_t)110000 : lds;
-    if constexpr (HW == 28 && NT == 1 && !SKIP) {
+    if constexpr (HW == 28 && NT == 1 && !SKIP && MT == 1) {
         if (a.ablate & 16) {   // the instrumented instantiation (diagnostics only)
             static bool probe_attr = false;
             if (!probe_attr) {
@@ -649,9 +681,21 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st) {
             return 0;
         }
     }
-    hipLaunchKernelGGL((conv_s16_kernel<HW, NT, SKIP, false>), dim3(ntiles), dim3(CONV_THREADS), lds_req, st, a);
+    hipLaunchKernelGGL((conv_s16_kernel<HW, NT, SKIP, false, MT>), dim3(ntiles), dim3(CONV_THREADS), lds_req, st, a);
     TDM_CHECK_LAUNCH("conv_s16");
     return 0;
+}
+
+// 28x28, N = 32: 512-pixel tiles (two M tiles per wave) are built, bit-identical and selectable (tdm_set_conv_tile(2)),
+// but NOT the default: measured at B = 512 (tools/launch_times.py --tile 1|2) rb1.conv2 46.9 -> 51.6 us, rb4.conv2 49.8 ->
+// 50.7, the two data gradients 47.6 -> 47.9 / 43.2 -> 45.5 — a workgroup with twice the pixels lives twice as long, i.e. the
+// kernel's time is set by each wave's own instruction stream (time is linear in the tile count from 392 to 3136 tiles,
+// 26.5 ns per tile), not by a per-round fixed cost or the round quantisation, and the saved weight-fragment reads do not
+// show.  (The fused-skip form needs 64 accumulator registers per wave at MT = 2 and spills; it keeps 256-pixel tiles.)
+int g_conv_mt = 0;
+inline bool use_mt2(const ConvArgs& a) {
+    if ((a.ablate & 16) != 0) return false;                       // the phase probe instruments the one-tile form
+    return g_conv_mt == 2;
 }
 
 // ---------------------------------------------------------------------------
@@ -1228,7 +1272,7 @@ int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st) {
         for (int i = 0; i < a.nsrc; ++i) TDM_REQUIRE(a.src[i].taps == 9, "conv_s16: fused skip rides on 3x3 sources");
         return launch_conv_t<28, 1, true>(a, st);
     }
-    if (hw == 28 && N == 32) return launch_conv_t<28, 1, false>(a, st);
+    if (hw == 28 && N == 32) return use_mt2(a) ? launch_conv_t<28, 1, false, 2>(a, st) : launch_conv_t<28, 1, false>(a, st);
     if (hw == 28 && N == 64) return launch_conv_t<28, 2, false>(a, st);
     if (hw == 28 && N == 96) return launch_conv_t<28, 3, false>(a, st);
     if (hw == 14 && N == 32) return launch_conv_t<14, 1, false>(a, st);
@@ -1236,6 +1280,13 @@ int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st) {
     tdm_set_error("conv_s16: unsupported geometry hw=%d N=%d", hw, N);
     return 1;
 }
+
+extern "C" int tdm_set_conv_tile(int mt) {
+    TDM_REQUIRE(mt >= 0 && mt <= 2, "conv tile %d (0 = automatic, 1 = 256-pixel tiles, 2 = 512-pixel tiles for the 28x28 N = 32 kernels)", mt);
+    g_conv_mt = mt;
+    return 0;
+}
+extern "C" int tdm_get_conv_tile(void) { return g_conv_mt; }
 
 int tdm_launch_wgrad_s16(const WgradArgs& a, int hw, int nslab, hipStream_t st) {
     TDM_REQUIRE(a.Cout % 32 == 0 && a.nci >= 1, "wgrad_s16: Cout %d / nci %d", a.Cout, a.nci);
