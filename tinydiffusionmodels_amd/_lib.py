@@ -115,8 +115,14 @@ def lib() -> ctypes.CDLL:
                         f"{LIB_PATH} not found: build it with `python -m tinydiffusionmodels_amd.build` "
                         "(there is no CPU / eager fallback for the HIP path)")
                 L = ctypes.CDLL(LIB_PATH)
+                ab_mode = "TDM_HIP_LIB" in os.environ     # A/B timing against an older build: tolerate symbols it lacks
                 for name, (argtypes, restype) in _SIGS.items():
-                    fn = getattr(L, name)          # AttributeError if a symbol is missing
+                    try:
+                        fn = getattr(L, name)      # AttributeError if a symbol is missing
+                    except AttributeError:
+                        if ab_mode:
+                            continue
+                        raise
                     fn.argtypes = argtypes
                     fn.restype = restype
                 _lib = L

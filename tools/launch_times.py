@@ -23,7 +23,8 @@ def main():
     from tinydiffusionmodels_amd import _lib, unet_engine as E
     from tinydiffusionmodels_amd.mnist import SimpleUNet
     L = _lib.lib()
-    _lib.check(L.tdm_set_conv_tile(args.tile))
+    if args.tile:
+        _lib.check(L.tdm_set_conv_tile(args.tile))
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     model = SimpleUNet().to(dev)
