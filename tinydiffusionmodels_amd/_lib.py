@@ -46,6 +46,8 @@ _SIGS = {
     "tdm_conv_wgrad_nhwc_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int, c_f], c_int),
     "tdm_set_conv_mode": ([c_int], c_int),
     "tdm_get_conv_mode": ([], c_int),
+    "tdm_set_conv_ws": ([c_int], c_int),
+    "tdm_get_conv_ws": ([], c_int),
     "tdm_set_conv_tile": ([c_int], c_int),
     "tdm_get_conv_tile": ([], c_int),
     "tdm_conv_nhwc_bf16x3_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int, c_int, c_f],

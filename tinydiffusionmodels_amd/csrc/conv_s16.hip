@@ -646,6 +646,481 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     stamp();
 }
 
+// ---------------------------------------------------------------------------
+// Warp-specialised form of the N = 32 convolution (producer / consumer, persistent).  tools/phase_probe.py on the kernel
+// above: a workgroup lives 19.9 k cycles of which 8.0 k pass before its first MFMA (argument / plan prologue, then the
+// first chunk's HBM latency), 5.1 k in the epilogue and only 4.6 k in the two MFMA phases — and two co-resident
+// workgroups start together, so they wait together.  Here ONE workgroup of 16 waves owns a CU and walks tiles
+// slot, slot + G, ...: waves 8..15 PRODUCE (fetch the next K chunk into registers, write the one after the current
+// into the other half of a double-buffered operand image, and run the whole epilogue walk of the PREVIOUS tile out of
+// an LDS transpose block), waves 0..7 CONSUME (fragment reads + MFMA, then dump their accumulators into that block and
+// start the next tile at once).  One barrier per K chunk; no wave ever waits for HBM with accumulators in flight.
+// Same arithmetic, same operand layouts, same epilogue code as conv_s16_kernel<HW, 1, SKIP>: bit-identical results.
+// ---------------------------------------------------------------------------
+constexpr int WS_THREADS = 1024;
+template <int HW, bool SKIP> struct WsCfg {
+    using G = Geo<HW>;
+    static constexpr int TILE_B = G::NR * G::WP * PIXB;
+    static constexpr int WB = 9 * 2048 + (SKIP ? 2048 : 0);        // packed weights of one K chunk
+    static constexpr int WCH = 2;                                  // K chunks whose weights stay RESIDENT in LDS for the whole launch
+    static constexpr int WALL = WCH * WB;
+    static constexpr int OPB = (TILE_B + 63) & ~63;                // one operand buffer: the staged pixel image of a K chunk
+    static constexpr int EPI = 32 + 4;
+    static constexpr int TB = 8 * 32 * EPI * 4;                    // 8 transpose blocks (one per consumer wave)
+    static constexpr int LDS = WALL + 2 * OPB + TB + 8 * 32 * 4;   // + the loaders' row tables
+};
+
+template <int HW, bool SKIP>
+__global__ __launch_bounds__(WS_THREADS) void conv_ws_kernel(ConvArgs ka, int ntiles) {
+    using G = Geo<HW>;
+    using Cf = WsCfg<HW, SKIP>;
+    constexpr int NT = 1, N = 32, EPI = Cf::EPI, OPB = Cf::OPB, TILE_B = Cf::TILE_B;
+    constexpr int LTH = 256;                                   // loader threads (waves 8..11)
+    constexpr int NPINv = (G::NR * G::WP * 4 + LTH - 1) / LTH;
+    constexpr int STEP = LTH / 4;
+    PinnedArgs a(ka);
+    constexpr bool R1 = HW == 28 && !SKIP;
+    const float* r1_x = R1 ? ka.r1_x : nullptr; const float* r1_w = ka.r1_w; const float* r1_b = ka.r1_b;
+    if constexpr (R1) { TDM_PIN(r1_x); TDM_PIN(r1_w); TDM_PIN(r1_b); }
+    float* o1_out = R1 ? ka.o1_out : nullptr; const float* o1_w = ka.o1_w; const float* o1_b = ka.o1_b;
+    if constexpr (R1) { TDM_PIN(o1_out); TDM_PIN(o1_w); TDM_PIN(o1_b); }
+    extern __shared__ float4 smem4[];
+    char* const wall = reinterpret_cast<char*>(smem4);          // resident packed weights, chunk c at wall + c * WB
+    char* const lds = wall + Cf::WALL;                         // the two pixel-image buffers
+    float* const Tall = reinterpret_cast<float*>(lds + 2 * OPB);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int Mtot = a.B * G::H * G::W;
+    const int G_ = gridDim.x;
+    const int slot = xcd_remap(blockIdx.x, G_);
+    const int nk = slot < ntiles ? (ntiles - slot + G_ - 1) / G_ : 0;      // tiles of this workgroup: slot + k * G_
+    const int nc0 = a.s0.nch >> 4;
+    constexpr int nchunks = 2;                                             // K chunks per tile (the launcher checks it)
+    const int S = nk * nchunks;                                            // K-chunk steps of this workgroup
+    // one extra (virtual) tile after the last: its first steps only carry the epilogue of tile nk - 1
+    const int tail = SKIP ? 4 : 2;
+    // Barriers: one at the end of every step, plus one "T ready" barrier at the START of step (k >= 1, c == 0) and, with the
+    // fused skip conv, of step (k >= 1, c == 2): the consumers dump accumulators into the transpose blocks first thing in
+    // those steps, the walkers read them from then until the next dump (two whole steps later at the earliest).
+    const int Stot = S + (nk > 0 ? tail : 0);
+
+    // The packed weights of every K chunk (<= 36 KB: the 32-input-channel layers this kernel serves) are copied into LDS
+    // ONCE by all 16 waves — a per-chunk restaging like the one-role kernel's would be half of the loaders' work.
+    for (int c = 0; c < nchunks; ++c) {
+        const int si = (c >= nc0) ? 1 : 0;
+        const int ch = si ? c - nc0 : c;
+        const PinnedSrc s = a.src(si);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned short*>(s.wp) + (long)(s.wchunk0 + ch) * (s.taps * 1024), 0, s.taps * 2048, 0x00020000);
+        for (int e = tid; e < 9 * 128; e += WS_THREADS) {
+            const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, e * 16, 0, 0));
+            reinterpret_cast<u32x4*>(wall + c * Cf::WB)[e] = v;
+        }
+    }
+
+    if (wave < 8) {
+        // ------------------------------- consumers -------------------------------
+        f32x16 bias_acc, acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 bz = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias != nullptr) bz = gload4(a.bias + 8 * g + 4 * h);
+            bias_acc[4 * g] = bz.x; bias_acc[4 * g + 1] = bz.y; bias_acc[4 * g + 2] = bz.z; bias_acc[4 * g + 3] = bz.w;
+        }
+        acc = bias_acc;
+        f32x16 sbias, acc2, hold2;      // fused 1x1 skip conv (SKIP): second accumulator and its parked copy
+        if constexpr (SKIP) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bz = gload4(a.skip_bias + 8 * g + 4 * h);
+                sbias[4 * g] = bz.x; sbias[4 * g + 1] = bz.y; sbias[4 * g + 2] = bz.z; sbias[4 * g + 3] = bz.w;
+            }
+            acc2 = sbias; hold2 = sbias;
+        }
+        float* const T = Tall + wave * (32 * EPI);
+        auto to_lds = [&](const f32x16& ac) __attribute__((always_inline)) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(T + j * EPI + 8 * g + 4 * h) =
+                    make_float4(ac[4 * g], ac[4 * g + 1], ac[4 * g + 2], ac[4 * g + 3]);
+        };
+        __syncthreads();                                   // step 0 staged
+        int g = 0;
+        for (int k = 0; k <= nk; ++k) {
+            const int nch_k = (k < nk) ? nchunks : tail;
+            int aoff = 0;
+            if (k < nk) {
+                const int m0 = (slot + k * G_) * TILE_PX;
+                const int tb0 = m0 / (G::H * G::W);
+                const int ty0 = (m0 - tb0 * (G::H * G::W)) / G::W;
+                const int mb = min(m0 + wave * 32, Mtot - 1);
+                const int b0 = mb / (G::H * G::W);
+                const int rem0 = mb - b0 * (G::H * G::W);
+                const int y0 = rem0 / G::W, x0 = rem0 - y0 * G::W;
+                const int q = x0 + min(j, Mtot - 1 - mb);
+                const int dr = (q * (HW == 28 ? 2341 : 4682)) >> 16;
+                const int x = q - dr * G::W;
+                int y = y0 + dr, rowb = (b0 - tb0) * G::HP;
+                if (y >= G::H) { y -= G::H; rowb += G::HP; }
+                aoff = ((rowb + y + 1 - ty0) * G::WP + x + 1) * PIXB + h * 16;
+            }
+            for (int c = 0; c < nch_k; ++c, ++g) {
+                if (k >= 1 && c == 0) {                    // tile k - 1 is complete: hand its accumulators to the walkers
+                    to_lds(acc);
+                    acc = bias_acc;
+                    if constexpr (SKIP) { hold2 = acc2; acc2 = sbias; }
+                    __syncthreads();                       // T ready
+                }
+                if constexpr (SKIP) if (k >= 1 && c == 2) {
+                    to_lds(hold2);
+                    __syncthreads();                       // T ready (skip accumulator)
+                }
+                if (k < nk && !(a.ablate & 256)) {
+                    const char* tile = lds + (g & 1) * OPB;
+                    const char* wl = wall + c * Cf::WB;
+                    const int taps = (c >= nc0) ? a.s1.taps : a.s0.taps;
+#pragma unroll
+                    for (int tp = 0; tp < 9; ++tp) {
+                        if (taps == 9 || tp == 4) {
+                            const int toff = ((tp / 3 - 1) * G::WP + (tp % 3 - 1)) * PIXB;
+                            const int wt = (taps == 9) ? tp : 0;
+                            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(tile + aoff + toff);
+                            const bf16x8 al = *reinterpret_cast<const bf16x8*>(tile + aoff + toff + 32);
+                            const char* wb = wl + (wt * 2) * 1024 + lane * 16;
+                            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wb);
+                            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wb + 1024);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc, 0, 0, 0);
+                            if constexpr (SKIP) if (tp == 4) {
+                                const char* sb = wl + 9 * 2048 + lane * 16;
+                                const bf16x8 sh = *reinterpret_cast<const bf16x8*>(sb);
+                                const bf16x8 sl = *reinterpret_cast<const bf16x8*>(sb + 1024);
+                                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh, al, acc2, 0, 0, 0);
+                                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sl, ah, acc2, 0, 0, 0);
+                                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh, ah, acc2, 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        return;
+    }
+
+    if (wave < 12) {
+    // ------------------------------- loaders (waves 8..11): global -> registers -> operand buffers -------------------------------
+    const int ptid = tid - 512, pw = wave - 8;
+    // TWO register sets (chunk s lives in set s & 1): a chunk is requested two steps before it is written to LDS — with one
+    // step of distance every step waited out the HBM latency (the same finding as in the one-role kernel at N = 32)
+    struct LSet { int goff[NPINv]; int plan_tile, plan_src; uint4 pin[NPINv]; };
+    LSet L0, L1;
+    L0.plan_tile = L0.plan_src = L1.plan_tile = L1.plan_src = -1;
+    int* const rowtab = reinterpret_cast<int*>(lds + 2 * OPB + Cf::TB) + pw * 32;
+    static_assert(!SKIP, "the fused skip conv (six K chunks of weights) stays on the one-role kernel");
+    struct TileGeo { int m0, tb0, ty0, nrows; };
+    auto geo = [&](int k) __attribute__((always_inline)) {
+        TileGeo t;
+        t.m0 = (slot + k * G_) * TILE_PX;
+        const int mlast = min(t.m0 + TILE_PX - 1, Mtot - 1);
+        t.tb0 = t.m0 / (G::H * G::W);
+        t.ty0 = (t.m0 - t.tb0 * (G::H * G::W)) / G::W;
+        t.nrows = padded_row<HW>(mlast) - (t.tb0 * G::HP + t.ty0) + 2;
+        return t;
+    };
+    auto prefetch = [&](LSet& Ls, int s_) __attribute__((always_inline)) {   // global -> registers: K chunk (s_ % nchunks) of tile (s_ / nchunks)
+        const int k = s_ / nchunks, c = s_ - k * nchunks;
+        const int si = (c >= nc0) ? 1 : 0;
+        const int ch = si ? c - nc0 : c;
+        const PinnedSrc s = a.src(si);
+        const int up = s.up, Hs = G::H >> up, Ws = G::W >> up;
+        if (Ls.plan_tile != k || Ls.plan_src != si) {
+            const TileGeo t = geo(k);
+            if (lane < 32) {
+                int py = t.ty0 + lane, b = t.tb0;
+                if (py >= G::HP) { py -= G::HP; ++b; }
+                if (HW == 14 && py >= G::HP) { py -= G::HP; ++b; }
+                const bool ok = lane < t.nrows && py >= 1 && py <= G::H && b < a.B;
+                rowtab[lane] = ok ? __mul24(__mul24(__mul24(b, Hs) + ((py - 1) >> up), Ws), s.C) * 4 : (int)0x80000000;
+            }
+            int pt = ptid;
+            asm volatile("" : "+v"(pt));   // opaque: keeps the tile-invariant (row, column) of every piece out of registers between plans
+            int lr = (pt >> 2) / G::WP;
+            int pc = (pt >> 2) - lr * G::WP;
+            const int cbase = (s.c0 + (pt & 3) * 4) * 4;
+#pragma unroll
+            for (int i = 0; i < NPINv; ++i) {
+                const int roff = rowtab[min(lr, 31)];
+                const bool ok = roff >= 0 && pc >= 1 && pc <= G::W && lr < t.nrows;
+                Ls.goff[i] = ok ? roff + __mul24((pc - 1) >> up, s.C) * 4 + cbase : (int)0x80000000;
+                pc += STEP % G::WP;
+                lr += STEP / G::WP;
+                if (pc >= G::WP) { pc -= G::WP; ++lr; }
+            }
+            Ls.plan_tile = k; Ls.plan_src = si;
+        }
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.ptr), 0, a.B * Hs * Ws * s.C * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NPINv; ++i) {
+            const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, Ls.goff[i], ch << 6, 0));
+            Ls.pin[i] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    auto stage = [&](const LSet& Ls, int s_) __attribute__((always_inline)) {   // registers -> operand buffer (s_ & 1); every piece of the image is rewritten
+        char* const tile = lds + (s_ & 1) * OPB;
+        char* const sdst = tile + (ptid >> 2) * PIXB + (ptid & 3) * 16;
+#pragma unroll
+        for (int i = 0; i < NPINv; ++i)
+            if (ptid + LTH * i < G::NR * G::WP * 4) *reinterpret_cast<uint4*>(sdst + i * (STEP * PIXB)) = Ls.pin[i];
+    };
+
+    if (S > 0) prefetch(L0, 0);
+    if (S > 1) prefetch(L1, 1);
+    if (S > 0) stage(L0, 0);
+    if (S > 2) prefetch(L0, 2);
+    __syncthreads();                                   // step 0 staged
+    // Exactly two steps per tile (chunk c of tile k is step g = 2 k + c), written out straight-line: step (k, 0) stages chunk
+    // 2k + 1 from set 1 and refills it with chunk 2k + 3, step (k, 1) does the same with set 0 and chunks 2k + 2 / 2k + 4 —
+    // the waits in front of a set's LDS writes can then leave the OTHER set's eight loads in flight (vmcnt(8)); as a
+    // loop over steps with a parity branch the compiler waited for everything, i.e. one step of distance.
+    {
+        const bool ld = !(a.ablate & 64), stg = !(a.ablate & 512);
+        for (int k = 0; k <= nk; ++k) {
+            const int g = 2 * k;
+            if (k >= 1) __syncthreads();                                          // the consumers' "T ready" barrier
+            if (g + 1 < S && stg) stage(L1, g + 1);
+            if (g + 3 < S && ld) prefetch(L1, g + 3);
+            __syncthreads();
+            if (g + 2 < S && stg) stage(L0, g + 2);
+            if (g + 4 < S && ld) prefetch(L0, g + 4);
+            __syncthreads();
+        }
+    }
+    return;
+    }
+
+    // ------------------------------- walkers (waves 12..15): the epilogue, two consumer blocks each -------------------------------
+    const int pw2 = wave - 12;
+    // ---- epilogue walk of one 32-pixel x 32-channel block (the code of conv_s16_kernel's epilogue) ----
+    int lane_e = lane, j_e = j, h_e = h;
+    asm volatile("" : "+v"(lane_e), "+v"(j_e), "+v"(h_e));
+    (void)j_e; (void)h_e;
+    constexpr int NIT = N / 8, GI = 4;
+    static_assert(NIT == GI, "one group of passes per block at N = 32");
+    const bool bwd = a.relu_mask_in != nullptr;
+    const bool use_res = a.res != nullptr;
+    const bool use_tb = !use_res && a.tb_out != nullptr && a.out_s16 != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_rt = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(use_res ? a.res : a.tb_out), 0, use_res ? Mtot * N * 4 : (use_tb ? a.B * a.tb_out_stride * 4 : 0), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_mk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(a.relu_mask_in), 0, bwd ? Mtot * (N / 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(r1_x), 0, r1_x != nullptr ? Mtot * 4 : 0, 0x00020000);
+    struct Pre { float4 rt[GI]; unsigned mk[GI]; float rx[R1 ? GI : 1]; };
+    auto preload = [&](Pre& p, int mbase) __attribute__((always_inline)) {
+        const int img0 = mbase / (G::H * G::W);
+        const int mnext = (img0 + 1) * (G::H * G::W);
+#pragma unroll
+        for (int it = 0; it < GI; ++it) {
+            const int e = it * 64 + lane_e;
+            const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
+            const int m = min(mbase + px, Mtot - 1);
+            const int o = m * N + c;
+            const int otb = (img0 + (m >= mnext ? 1 : 0)) * a.tb_out_stride + c;
+            const f32x4 r = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_rt, (use_res ? o : otb) * 4, 0, 0));
+            p.rt[it] = make_float4(r[0], r[1], r[2], r[3]);
+            p.mk[it] = __builtin_amdgcn_raw_buffer_load_b8(rs_mk, o >> 2, 0, 0);
+            if constexpr (R1) p.rx[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rx, m * 4, 0, 0));
+        }
+    };
+    auto walk = [&](const Pre& p, const float* T, int mbase, auto full_c) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const int img0 = mbase / (G::H * G::W);
+        const int mnext = (img0 + 1) * (G::H * G::W);
+        float4 sacc[2][2];
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int kd = 0; kd < 2; ++kd) sacc[sl][kd] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v[GI];
+        unsigned o[GI];
+        bool ok[GI];
+#pragma unroll
+        for (int k = 0; k < GI; ++k) {
+            const int e = k * 64 + lane_e;
+            const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
+            v[k] = *reinterpret_cast<const float4*>(T + px * EPI + c);
+            o[k] = (unsigned)(mbase + px) * N + c;
+            ok[k] = FULL || mbase + px < Mtot;
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int k = 0; k < GI; ++k) {
+                v[k].x = fmaxf(v[k].x, 0.f); v[k].y = fmaxf(v[k].y, 0.f); v[k].z = fmaxf(v[k].z, 0.f); v[k].w = fmaxf(v[k].w, 0.f);
+            }
+        }
+        if (a.aux != nullptr) {
+#pragma unroll
+            for (int k = 0; k < GI; ++k) if (ok[k]) gstore4(a.aux + o[k], v[k]);
+        }
+        if (a.mask_out != nullptr) {
+#pragma unroll
+            for (int k = 0; k < GI; ++k)
+                if (ok[k])
+                    gstore<unsigned char>(a.mask_out + (o[k] >> 2),
+                                          (unsigned char)((v[k].x > 0.f ? 1 : 0) | (v[k].y > 0.f ? 2 : 0) |
+                                                          (v[k].z > 0.f ? 4 : 0) | (v[k].w > 0.f ? 8 : 0)));
+        }
+        if (a.res != nullptr) {
+#pragma unroll
+            for (int k = 0; k < GI; ++k) {
+                const float4 rz = p.rt[k];
+                v[k].x += rz.x; v[k].y += rz.y; v[k].z += rz.z; v[k].w += rz.w;
+            }
+        }
+        if constexpr (R1) if (r1_x != nullptr) {
+#pragma unroll
+            for (int k = 0; k < GI; ++k) {
+                const int c = ((k * 64 + lane_e) % (N / 4)) * 4;
+                const float4 w4 = gload4(r1_w + c), b4 = gload4(r1_b + c);
+                v[k].x += fmaf(p.rx[k], w4.x, b4.x); v[k].y += fmaf(p.rx[k], w4.y, b4.y);
+                v[k].z += fmaf(p.rx[k], w4.z, b4.z); v[k].w += fmaf(p.rx[k], w4.w, b4.w);
+            }
+        }
+        if (bwd) {
+#pragma unroll
+            for (int k = 0; k < GI; ++k) {
+                const int m = mbase + (k * 64 + lane_e) / (N / 4);
+                const unsigned mk = p.mk[k];
+                const float4 u = v[k];
+                const float4 mv = make_float4((mk & 1u) ? u.x : 0.f, (mk & 2u) ? u.y : 0.f, (mk & 4u) ? u.z : 0.f,
+                                              (mk & 8u) ? u.w : 0.f);
+                const bool s0 = ok[k] && m < mnext, s1 = ok[k] && m >= mnext;
+                sacc[0][0].x += s0 ? u.x : 0.f; sacc[0][0].y += s0 ? u.y : 0.f; sacc[0][0].z += s0 ? u.z : 0.f; sacc[0][0].w += s0 ? u.w : 0.f;
+                sacc[0][1].x += s0 ? mv.x : 0.f; sacc[0][1].y += s0 ? mv.y : 0.f; sacc[0][1].z += s0 ? mv.z : 0.f; sacc[0][1].w += s0 ? mv.w : 0.f;
+                sacc[1][0].x += s1 ? u.x : 0.f; sacc[1][0].y += s1 ? u.y : 0.f; sacc[1][0].z += s1 ? u.z : 0.f; sacc[1][0].w += s1 ? u.w : 0.f;
+                sacc[1][1].x += s1 ? mv.x : 0.f; sacc[1][1].y += s1 ? mv.y : 0.f; sacc[1][1].z += s1 ? mv.z : 0.f; sacc[1][1].w += s1 ? mv.w : 0.f;
+                v[k] = mv;
+            }
+        }
+        if (a.out != nullptr) {
+#pragma unroll
+            for (int k = 0; k < GI; ++k) if (ok[k]) gstore4(a.out + o[k], v[k]);
+        }
+        if constexpr (R1) if (o1_out != nullptr) {
+            const float4 w4 = gload4(o1_w + (lane_e & 7) * 4);
+            const float ob = gload<float>(o1_b);
+#pragma unroll
+            for (int k = 0; k < GI; ++k) {
+                float d = ((v[k].x * w4.x + v[k].y * w4.y) + v[k].z * w4.z) + v[k].w * w4.w;
+                d += __shfl_xor(d, 1);
+                d += __shfl_xor(d, 2);
+                d += __shfl_xor(d, 4);
+                if ((lane_e & 7) == 0 && ok[k]) gstore<float>(o1_out + (o[k] >> 5), d + ob);
+            }
+        }
+        if (a.out_s16 != nullptr) {
+            if (a.tb_out != nullptr) {
+#pragma unroll
+                for (int k = 0; k < GI; ++k) {
+                    float4 tz = p.rt[k];
+                    if (a.res != nullptr) {
+                        const int e = k * 64 + lane_e;
+                        const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
+                        const int m = min(mbase + px, Mtot - 1);
+                        tz = gload4(a.tb_out + (unsigned)((img0 + (m >= mnext ? 1 : 0)) * a.tb_out_stride + c));
+                    }
+                    v[k].x += tz.x; v[k].y += tz.y; v[k].z += tz.z; v[k].w += tz.w;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < GI; ++k) {
+                const int c = ((k * 64 + lane_e) % (N / 4)) * 4;
+                if (ok[k]) gstore_s16_o(a.out_s16, o[k], c, v[k]);
+            }
+        }
+        if (bwd && a.sums != nullptr) {
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                for (int kd = 0; kd < 2; ++kd) {
+                    float4 r = sacc[sl][kd];
+#pragma unroll
+                    for (int off = N / 4; off < 64; off <<= 1) {
+                        r.x += __shfl_xor(r.x, off); r.y += __shfl_xor(r.y, off);
+                        r.z += __shfl_xor(r.z, off); r.w += __shfl_xor(r.w, off);
+                    }
+                    if (lane_e < N / 4 && mbase < Mtot) {
+                        const unsigned grp = (unsigned)mbase >> 5;
+                        gstore4(a.sums + (unsigned)(((grp * 2 + sl) * 2 + kd) * N + lane_e * 4), r);
+                    }
+                }
+        }
+    };
+    auto walk_skip = [&](const float* T, int mbase) __attribute__((always_inline)) {     // skip_out = the second accumulator (+ its bias), plain stores
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = it * 64 + lane_e;
+            const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
+            const int m = mbase + px;
+            const float4 v = *reinterpret_cast<const float4*>(T + px * EPI + c);
+            if (m < Mtot) gstore4(a.skip_out + ((unsigned)m * N + c), v);
+        }
+    };
+
+    // Schedule (step = K chunk c of tile k):
+    //   start of (k + 1, 0):  consumers: T <- accumulators of tile k, "T ready" barrier
+    //   (k + 1, 0), (k + 1, 1): walkers walk their first / second block of tile k       [needs >= 2 chunks per tile]
+    //   SKIP: start of (k + 1, 2): T <- skip accumulator of tile k, barrier; (k + 1, 2), (k + 1, 3): walkers store it
+    //   the inputs of a walk (residual / mask / rank-1 input) are requested one step ahead
+    __syncthreads();                                   // step 0 staged
+    Pre pa, pb;
+    for (int k = 0; k <= nk; ++k) {
+        const int nch_k = (k < nk) ? nchunks : tail;
+        const int mb0 = (slot + (k - 1) * G_) * TILE_PX + (2 * pw2) * 32;      // first block of tile k - 1
+        for (int c = 0; c < nch_k; ++c) {
+            if (k >= 1 && c == 0) {
+                __syncthreads();                       // T ready
+                // opaque per tile: otherwise every per-lane offset of the walks is hoisted out of the tile loop, computed once
+                // (500 instructions) and parked in scratch (100 spilled registers)
+                asm volatile("" : "+v"(lane_e));
+                preload(pb, mb0 + 32);
+                __builtin_amdgcn_s_waitcnt(0x0F70 | 0x0008);   // vmcnt(8): pa (requested a step ago) has arrived; pb's loads may fly
+                if (a.ablate & 128) {}
+                else if (mb0 + 32 <= Mtot) walk(pa, Tall + (2 * pw2) * (32 * EPI), mb0, std::true_type{});
+                else walk(pa, Tall + (2 * pw2) * (32 * EPI), mb0, std::false_type{});
+            }
+            if (k >= 1 && c == 1) {
+                asm volatile("" : "+v"(lane_e));
+                __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0)
+                if (a.ablate & 128) {}
+                else if (mb0 + 64 <= Mtot) walk(pb, Tall + (2 * pw2 + 1) * (32 * EPI), mb0 + 32, std::true_type{});
+                else walk(pb, Tall + (2 * pw2 + 1) * (32 * EPI), mb0 + 32, std::false_type{});
+            }
+            if constexpr (SKIP) {
+                if (k >= 1 && c == 2) {
+                    __syncthreads();                   // T ready (skip accumulator)
+                    asm volatile("" : "+v"(lane_e));
+                    walk_skip(Tall + (2 * pw2) * (32 * EPI), mb0);
+                }
+                if (k >= 1 && c == 3) {
+                    asm volatile("" : "+v"(lane_e));
+                    walk_skip(Tall + (2 * pw2 + 1) * (32 * EPI), mb0 + 32);
+                }
+            }
+            if (k < nk && c == nch_k - 1) {            // next step starts tile k's epilogue: request its first block's inputs now
+                asm volatile("" : "+v"(lane_e));
+                preload(pa, (slot + k * G_) * TILE_PX + (2 * pw2) * 32);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 template <int HW, int NT, bool SKIP, int MT = 1>
 int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     using G = Geo<HW>;
@@ -697,6 +1172,40 @@ inline bool use_mt2(const ConvArgs& a) {
     if ((a.ablate & 16) != 0) return false;                       // the phase probe instruments the one-tile form
     return g_conv_mt == 2;
 }
+
+// warp-specialised N = 32 kernel: 1 = on (default), 0 = the one-role kernel (tdm_set_conv_ws; A/B and tests)
+int g_conv_ws = 0;   // opt-in (tdm_set_conv_ws): slower than the one-role kernel as of r2, see DESIGN.md section 5
+template <int HW, bool SKIP>
+int launch_conv_ws(const ConvArgs& a, hipStream_t st) {
+    using G = Geo<HW>;
+    using Cf = WsCfg<HW, SKIP>;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<HW, SKIP>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
+        if (e != hipSuccess || n <= 0) {
+            tdm_set_error("conv_ws: device query / LDS attribute (%d B) failed: %s", Cf::LDS, hipGetErrorString(e));
+            return 100 + (int)e;
+        }
+        cus = n;
+    }
+    const long Mtot = (long)a.B * G::H * G::W;
+    const int ntiles = (int)((Mtot + TILE_PX - 1) / TILE_PX);
+    const int grid = ntiles < cus ? ntiles : cus;
+    hipLaunchKernelGGL((conv_ws_kernel<HW, SKIP>), dim3(grid), dim3(WS_THREADS), Cf::LDS, st, a, ntiles);
+    TDM_CHECK_LAUNCH("conv_ws");
+    return 0;
+}
+inline bool use_ws(const ConvArgs& a) {
+    if (!g_conv_ws || (a.ablate & ~(64 | 128 | 256 | 512)) != 0 || g_conv_mt == 2 || a.skip_out != nullptr) return false;   // (64..512: role ablations, timing only)
+    const int nch = (a.src[0].nch >> 4) + (a.nsrc > 1 ? (a.src[1].nch >> 4) : 0);
+    return nch == 2;      // exactly two K chunks: their weights stay resident in LDS, and the hand-off schedule needs two steps per tile
+}
+
+
 
 // ---------------------------------------------------------------------------
 // weight gradient  dW[tap][ci][co] = sum_p A[p + tap][ci] * G[p][co]  (A, G are S16)
@@ -1272,6 +1781,8 @@ int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st) {
         for (int i = 0; i < a.nsrc; ++i) TDM_REQUIRE(a.src[i].taps == 9, "conv_s16: fused skip rides on 3x3 sources");
         return launch_conv_t<28, 1, true>(a, st);
     }
+    if (hw == 28 && N == 32 && use_ws(a)) return launch_conv_ws<28, false>(a, st);
+    if (hw == 14 && N == 32 && use_ws(a)) return launch_conv_ws<14, false>(a, st);
     if (hw == 28 && N == 32) return use_mt2(a) ? launch_conv_t<28, 1, false, 2>(a, st) : launch_conv_t<28, 1, false>(a, st);
     if (hw == 28 && N == 64) return launch_conv_t<28, 2, false>(a, st);
     if (hw == 28 && N == 96) return launch_conv_t<28, 3, false>(a, st);
@@ -1280,6 +1791,13 @@ int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st) {
     tdm_set_error("conv_s16: unsupported geometry hw=%d N=%d", hw, N);
     return 1;
 }
+
+extern "C" int tdm_set_conv_ws(int on) {
+    TDM_REQUIRE(on == 0 || on == 1, "conv_ws %d (0 = one-role N = 32 kernel, 1 = warp-specialised)", on);
+    g_conv_ws = on;
+    return 0;
+}
+extern "C" int tdm_get_conv_ws(void) { return g_conv_ws; }
 
 extern "C" int tdm_set_conv_tile(int mt) {
     TDM_REQUIRE(mt >= 0 && mt <= 2, "conv tile %d (0 = automatic, 1 = 256-pixel tiles, 2 = 512-pixel tiles for the 28x28 N = 32 kernels)", mt);
