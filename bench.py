@@ -463,7 +463,7 @@ def main():
                                 "tokens_per_s": round(world * Bt * Lt * 1e3 / ms_t, 0), "tflops": round(tflop_step / (ms_t * 1e-3), 2),
                                 "frac_bf16_mfma": round(tflop_step / (ms_t * 1e-3) / PEAK_BF16_MFMA_TFLOPS, 4),
                                 "gemm_mode": args.gemm_mode,
-                                "arithmetic": names[args.gemm_mode] + "; fp32-MFMA attention, fp32 LayerNorm; counter-hash dropout masks",
+                                "arithmetic": names[args.gemm_mode] + "; bf16x3-MFMA attention (split operands, fp32 accumulate), fp32 LayerNorm; counter-hash dropout masks",
                                 "other_gemm_mode": {"gemm_mode": other, "arithmetic": names[other], "ms_per_step": round(ms_o, 3),
                                                     "tokens_per_s": round(world * Bt * Lt * 1e3 / ms_o, 0),
                                                     "tflops": round(tflop_step / (ms_o * 1e-3), 2)}}

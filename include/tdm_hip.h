@@ -294,10 +294,23 @@ int tdm_tt_p_sample_step_philox_f32(const float* params, const float* x, int64_t
  *   meets the 1e-3 parity bound); 2 plain bf16 operands (throughput mode, ~3e-3 rel) */
 int tdm_set_gemm_mode(int mode);
 int tdm_get_gemm_mode(void);
-/* Attention kernels: 0 scalar fp32 (one thread per row), 1 fp32 MFMA (default). Both are
- * exact fp32 arithmetic; mode 0 is the cross-check for mode 1.                          */
+/* Attention kernels: 0 scalar fp32 (one thread per row), 1 fp32 MFMA, 2 bf16x3 MFMA (default:
+ * split bf16 operands, fp32 accumulate, ~1e-5 rel like gemm mode 1).  Modes 0 and 1 are exact
+ * fp32 arithmetic, the cross-checks for mode 2.                                           */
 int tdm_set_attn_mode(int mode);
 int tdm_get_attn_mode(void);
+/* Per-op self-attention core of nn.TransformerEncoderLayer (reference: src/shakespeare.py:108-111, the
+ * nn.MultiheadAttention inside the encoder layer) on the packed projection qkv[B][L][3 D] = q | k | v with
+ * heads as consecutive D/H slices: o[B][L][D] = softmax(q k^T / sqrt(D/H)) (dropout on the probabilities
+ * when p_drop > 0, mask site `site` of tdm_dropout_keep_u8) v;  lse[B H][L] = log-sum-exp of every score
+ * row (saved for the backward).  D/H in {8, 16, 32, 64}; runs in the selected attention mode.            */
+int tdm_attention_fwd_f32(const float* qkv, float* o, float* lse, int64_t B, int L, int D, int H, float p_drop,
+                          uint64_t seed, int site, void* stream);
+/* dqkv[B][L][3 D] = gradient of the above wrt qkv given dO[B][L][D] (every element written); Dvec[B H][L]
+ * is scratch.  Same p_drop / seed / site as the forward call.                                          */
+int tdm_attention_bwd_f32(const float* qkv, const float* o, const float* lse, const float* dO, float* dqkv,
+                          float* Dvec, int64_t B, int L, int D, int H, float p_drop, uint64_t seed, int site,
+                          void* stream);
 /* Host-side evaluation of the dropout mask (tests, oracle cross-check): keep_host[i] = 1 iff
  * flat element idx0 + i of dropout site `site` survives.  Sites in the order the reference's
  * forward reaches them: 0 input dropout (src/shakespeare.py:119); layer l: 1+4l attention

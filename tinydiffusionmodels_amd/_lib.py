@@ -65,6 +65,8 @@ _SIGS = {
     "tdm_tt_loss_grad_f32": ([c_f] * 13 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_float, c_u64, c_f], c_int),
     "tdm_set_attn_mode": ([c_int], c_int),
     "tdm_get_attn_mode": ([], c_int),
+    "tdm_attention_fwd_f32": ([c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_float, c_u64, c_int, c_f], c_int),
+    "tdm_attention_bwd_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_float, c_u64, c_int, c_f], c_int),
     "tdm_dropout_keep_u8": ([c_float, c_u64, c_int, c_i64, c_i64, c_f], c_int),
     "tdm_tt_p_sample_step_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_i64, c_int, c_int, c_int,
                                   c_int, c_int, c_f], c_int),

@@ -705,6 +705,18 @@ __global__ __launch_bounds__(WS_THREADS) void conv_ws_kernel(ConvArgs ka, int nt
     // fused skip conv, of step (k >= 1, c == 2): the consumers dump accumulators into the transpose blocks first thing in
     // those steps, the walkers read them from then until the next dump (two whole steps later at the earliest).
     const int Stot = S + (nk > 0 ? tail : 0);
+    // role probe (ablate & 1024; tools/ws_probe.py): lane 0 of waves 0 / 8 / 12 stamps the shader clock before and after every
+    // barrier into the int64 table [workgroup][3 roles][64] the caller appended behind the B*H*W*N floats of aux
+    int nstamp = 0;
+    auto stamp = [&](int role, int tag) __attribute__((always_inline)) {
+        if (a.ablate & 1024) {
+            if (lane == 0 && (wave == 0 || wave == 8 || wave == 12) && nstamp < 64)
+                gstore<long long>(reinterpret_cast<long long*>(a.aux + (long)a.B * G::H * G::W * N) + ((long)blockIdx.x * 3 + role) * 64 + nstamp,
+                                  ((long long)tag << 56) | ((long long)__builtin_readcyclecounter() & 0x00ffffffffffffffll));
+            ++nstamp;
+        }
+    };
+#define WS_BARRIER(role) do { stamp(role, 1); __syncthreads(); stamp(role, 2); } while (0)
 
     // The packed weights of every K chunk (<= 36 KB: the 32-input-channel layers this kernel serves) are copied into LDS
     // ONCE by all 16 waves — a per-chunk restaging like the one-role kernel's would be half of the loaders' work.
@@ -746,7 +758,7 @@ __global__ __launch_bounds__(WS_THREADS) void conv_ws_kernel(ConvArgs ka, int nt
                 *reinterpret_cast<float4*>(T + j * EPI + 8 * g + 4 * h) =
                     make_float4(ac[4 * g], ac[4 * g + 1], ac[4 * g + 2], ac[4 * g + 3]);
         };
-        __syncthreads();                                   // step 0 staged
+        WS_BARRIER(0);                                   // step 0 staged
         int g = 0;
         for (int k = 0; k <= nk; ++k) {
             const int nch_k = (k < nk) ? nchunks : tail;
@@ -771,11 +783,11 @@ __global__ __launch_bounds__(WS_THREADS) void conv_ws_kernel(ConvArgs ka, int nt
                     to_lds(acc);
                     acc = bias_acc;
                     if constexpr (SKIP) { hold2 = acc2; acc2 = sbias; }
-                    __syncthreads();                       // T ready
+                    WS_BARRIER(0);                       // T ready
                 }
                 if constexpr (SKIP) if (k >= 1 && c == 2) {
                     to_lds(hold2);
-                    __syncthreads();                       // T ready (skip accumulator)
+                    WS_BARRIER(0);                       // T ready (skip accumulator)
                 }
                 if (k < nk && !(a.ablate & 256)) {
                     const char* tile = lds + (g & 1) * OPB;
@@ -805,7 +817,7 @@ __global__ __launch_bounds__(WS_THREADS) void conv_ws_kernel(ConvArgs ka, int nt
                         }
                     }
                 }
-                __syncthreads();
+                WS_BARRIER(0);
             }
         }
         return;
@@ -882,7 +894,7 @@ __global__ __launch_bounds__(WS_THREADS) void conv_ws_kernel(ConvArgs ka, int nt
     if (S > 1) prefetch(L1, 1);
     if (S > 0) stage(L0, 0);
     if (S > 2) prefetch(L0, 2);
-    __syncthreads();                                   // step 0 staged
+    WS_BARRIER(1);                                   // step 0 staged
     // Exactly two steps per tile (chunk c of tile k is step g = 2 k + c), written out straight-line: step (k, 0) stages chunk
     // 2k + 1 from set 1 and refills it with chunk 2k + 3, step (k, 1) does the same with set 0 and chunks 2k + 2 / 2k + 4 —
     // the waits in front of a set's LDS writes can then leave the OTHER set's eight loads in flight (vmcnt(8)); as a
@@ -891,13 +903,15 @@ __global__ __launch_bounds__(WS_THREADS) void conv_ws_kernel(ConvArgs ka, int nt
         const bool ld = !(a.ablate & 64), stg = !(a.ablate & 512);
         for (int k = 0; k <= nk; ++k) {
             const int g = 2 * k;
-            if (k >= 1) __syncthreads();                                          // the consumers' "T ready" barrier
+            if (k >= 1) WS_BARRIER(1);                                          // the consumers' "T ready" barrier
             if (g + 1 < S && stg) stage(L1, g + 1);
+            stamp(1, 3);
             if (g + 3 < S && ld) prefetch(L1, g + 3);
-            __syncthreads();
+            WS_BARRIER(1);
             if (g + 2 < S && stg) stage(L0, g + 2);
+            stamp(1, 3);
             if (g + 4 < S && ld) prefetch(L0, g + 4);
-            __syncthreads();
+            WS_BARRIER(1);
         }
     }
     return;
@@ -1077,33 +1091,37 @@ __global__ __launch_bounds__(WS_THREADS) void conv_ws_kernel(ConvArgs ka, int nt
     //   (k + 1, 0), (k + 1, 1): walkers walk their first / second block of tile k       [needs >= 2 chunks per tile]
     //   SKIP: start of (k + 1, 2): T <- skip accumulator of tile k, barrier; (k + 1, 2), (k + 1, 3): walkers store it
     //   the inputs of a walk (residual / mask / rank-1 input) are requested one step ahead
-    __syncthreads();                                   // step 0 staged
+    WS_BARRIER(2);                                   // step 0 staged
     Pre pa, pb;
     for (int k = 0; k <= nk; ++k) {
         const int nch_k = (k < nk) ? nchunks : tail;
         const int mb0 = (slot + (k - 1) * G_) * TILE_PX + (2 * pw2) * 32;      // first block of tile k - 1
         for (int c = 0; c < nch_k; ++c) {
             if (k >= 1 && c == 0) {
-                __syncthreads();                       // T ready
+                WS_BARRIER(2);                       // T ready
                 // opaque per tile: otherwise every per-lane offset of the walks is hoisted out of the tile loop, computed once
                 // (500 instructions) and parked in scratch (100 spilled registers)
                 asm volatile("" : "+v"(lane_e));
+                if (!(a.ablate & 2048)) {
                 preload(pb, mb0 + 32);
                 __builtin_amdgcn_s_waitcnt(0x0F70 | 0x0008);   // vmcnt(8): pa (requested a step ago) has arrived; pb's loads may fly
+                }
+                stamp(2, 3);
                 if (a.ablate & 128) {}
                 else if (mb0 + 32 <= Mtot) walk(pa, Tall + (2 * pw2) * (32 * EPI), mb0, std::true_type{});
                 else walk(pa, Tall + (2 * pw2) * (32 * EPI), mb0, std::false_type{});
             }
             if (k >= 1 && c == 1) {
                 asm volatile("" : "+v"(lane_e));
-                __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0)
+                if (!(a.ablate & 2048)) __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0)
+                stamp(2, 3);
                 if (a.ablate & 128) {}
                 else if (mb0 + 64 <= Mtot) walk(pb, Tall + (2 * pw2 + 1) * (32 * EPI), mb0 + 32, std::true_type{});
                 else walk(pb, Tall + (2 * pw2 + 1) * (32 * EPI), mb0 + 32, std::false_type{});
             }
             if constexpr (SKIP) {
                 if (k >= 1 && c == 2) {
-                    __syncthreads();                   // T ready (skip accumulator)
+                    WS_BARRIER(2);                   // T ready (skip accumulator)
                     asm volatile("" : "+v"(lane_e));
                     walk_skip(Tall + (2 * pw2) * (32 * EPI), mb0);
                 }
@@ -1113,14 +1131,16 @@ __global__ __launch_bounds__(WS_THREADS) void conv_ws_kernel(ConvArgs ka, int nt
                 }
             }
             if (k < nk && c == nch_k - 1) {            // next step starts tile k's epilogue: request its first block's inputs now
+                stamp(2, 4);
                 asm volatile("" : "+v"(lane_e));
-                preload(pa, (slot + k * G_) * TILE_PX + (2 * pw2) * 32);
+                if (!(a.ablate & 2048)) preload(pa, (slot + k * G_) * TILE_PX + (2 * pw2) * 32);
             }
-            __syncthreads();
+            WS_BARRIER(2);
         }
     }
 }
 
+#undef WS_BARRIER
 template <int HW, int NT, bool SKIP, int MT = 1>
 int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     using G = Geo<HW>;
@@ -1200,7 +1220,7 @@ int launch_conv_ws(const ConvArgs& a, hipStream_t st) {
     return 0;
 }
 inline bool use_ws(const ConvArgs& a) {
-    if (!g_conv_ws || (a.ablate & ~(64 | 128 | 256 | 512)) != 0 || g_conv_mt == 2 || a.skip_out != nullptr) return false;   // (64..512: role ablations, timing only)
+    if (!g_conv_ws || (a.ablate & ~(64 | 128 | 256 | 512 | 1024 | 2048)) != 0 || g_conv_mt == 2 || a.skip_out != nullptr) return false;   // (64..512: role ablations, timing only)
     const int nch = (a.src[0].nch >> 4) + (a.nsrc > 1 ? (a.src[1].nch >> 4) : 0);
     return nch == 2;      // exactly two K chunks: their weights stay resident in LDS, and the hand-off schedule needs two steps per tile
 }

@@ -41,3 +41,6 @@ int tdm_launch_transpose(const float* in, float* out, int R, int Cn, hipStream_t
 // 2 dK/dV (out = dqkv, aux = D read)
 int tdm_launch_attn_mfma(int which, int hd, const float* qkv, const float* o, const float* lse, const float* dO, float* out,
                          float* aux, long B, int L, int D, int H, DropArgs dr, hipStream_t st);
+// the same three kernels on the bf16 matrix cores with split operands (attn_bf16.hip, ~1e-5 relative): the default
+int tdm_launch_attn_bf16(int which, int hd, const float* qkv, const float* o, const float* lse, const float* dO, float* out,
+                         float* aux, long B, int L, int D, int H, DropArgs dr, hipStream_t st);

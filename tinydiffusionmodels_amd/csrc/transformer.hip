@@ -18,8 +18,8 @@ namespace {
 // arithmetic of the linear layers: 0 exact fp32 MFMA, 1 bf16x3 split operands (default, meets the 1e-3
 // parity bound), 2 plain bf16 operands (throughput mode)
 int g_gemm_mode = 1;
-// attention: 0 scalar fp32 kernels (this file), 1 fp32 MFMA (attn_mfma.hip, default)
-int g_attn_mode = 1;
+// attention: 0 scalar fp32 kernels (this file), 1 fp32 MFMA (attn_mfma.hip), 2 bf16x3 MFMA (attn_bf16.hip, default)
+int g_attn_mode = 2;
 
 // train-mode dropout of one call: p = 0 -> off
 struct Drop {
@@ -658,6 +658,7 @@ int attn_launch(int which, const float* qkv, const float* o, const float* lse, c
 }
 int attn_dispatch(int which, int hd, const float* qkv, const float* o, const float* lse, const float* dO, float* out,
                   float* aux, long B, int L, int D, int H, DropArgs dr, hipStream_t st) {
+    if (g_attn_mode == 2) return tdm_launch_attn_bf16(which, hd, qkv, o, lse, dO, out, aux, B, L, D, H, dr, st);
     if (g_attn_mode == 1) return tdm_launch_attn_mfma(which, hd, qkv, o, lse, dO, out, aux, B, L, D, H, dr, st);
     switch (hd) {
         case 8: return attn_launch<8>(which, qkv, o, lse, dO, out, aux, B, L, D, H, dr, st);
@@ -976,11 +977,35 @@ int tdm_set_gemm_mode(int mode) {
 int tdm_get_gemm_mode(void) { return g_gemm_mode; }
 
 int tdm_set_attn_mode(int mode) {
-    TDM_REQUIRE(mode == 0 || mode == 1, "attention mode %d (0 = scalar fp32, 1 = fp32 MFMA)", mode);
+    TDM_REQUIRE(mode >= 0 && mode <= 2, "attention mode %d (0 = scalar fp32, 1 = fp32 MFMA, 2 = bf16x3 MFMA)", mode);
     g_attn_mode = mode;
     return 0;
 }
 int tdm_get_attn_mode(void) { return g_attn_mode; }
+
+// Per-op attention (nn.MultiheadAttention's core, src/shakespeare.py:108-111) in the selected attention mode, on the packed
+// projection qkv[B][L][3 D] (q | k | v, heads = consecutive head_dim slices): softmax(q k^T / sqrt(head_dim)) (dropout) v.
+int tdm_attention_fwd_f32(const float* qkv, float* o, float* lse, int64_t B, int L, int D, int H, float p_drop, uint64_t seed,
+                          int site, void* stream) {
+    TDM_REQUIRE(qkv != nullptr && o != nullptr && lse != nullptr && B >= 0 && L > 0 && H > 0 && D > 0 && D % H == 0,
+                "attention_fwd: bad arguments (B=%lld L=%d D=%d H=%d)", (long long)B, L, D, H);
+    TDM_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "attention_fwd: p_drop %g", (double)p_drop);
+    if (B == 0) return 0;
+    return attn_dispatch(0, D / H, qkv, nullptr, nullptr, nullptr, o, lse, B, L, D, H, tdm_drop_site(p_drop, seed, site),
+                         (hipStream_t)stream);
+}
+// gradients wrt the packed projection: dqkv[B][L][3 D] (every element written); Dvec[B H][L] is scratch (dO . O per row)
+int tdm_attention_bwd_f32(const float* qkv, const float* o, const float* lse, const float* dO, float* dqkv, float* Dvec,
+                          int64_t B, int L, int D, int H, float p_drop, uint64_t seed, int site, void* stream) {
+    TDM_REQUIRE(qkv != nullptr && o != nullptr && lse != nullptr && dO != nullptr && dqkv != nullptr && Dvec != nullptr &&
+                    B >= 0 && L > 0 && H > 0 && D > 0 && D % H == 0,
+                "attention_bwd: bad arguments (B=%lld L=%d D=%d H=%d)", (long long)B, L, D, H);
+    TDM_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "attention_bwd: p_drop %g", (double)p_drop);
+    if (B == 0) return 0;
+    const DropArgs da = tdm_drop_site(p_drop, seed, site);
+    TDM_TRY(attn_dispatch(1, D / H, qkv, o, lse, dO, dqkv, Dvec, B, L, D, H, da, (hipStream_t)stream));
+    return attn_dispatch(2, D / H, qkv, nullptr, lse, dO, dqkv, Dvec, B, L, D, H, da, (hipStream_t)stream);
+}
 
 // keep[i] = 1 if element idx0 + i of dropout site `site` survives (the mask the kernels regenerate in registers)
 int tdm_dropout_keep_u8(float p_drop, uint64_t seed, int site, int64_t idx0, int64_t n, uint8_t* keep_host) {

@@ -21,7 +21,7 @@ def run(hw, cin, cout, B, outs="s16"):
     out = {}
     for ws in (0, 1):
         _lib.check(L.tdm_set_conv_ws(ws))
-        for name, abl in ((("one-role", 0),) if ws == 0 else (("ws full", 0), ("no loads", 64), ("no loads/stage", 64 | 512), ("no walk", 128), ("no mfma", 256),
+        for name, abl in ((("one-role", 0),) if ws == 0 else (("ws full", 0), ("no preload", 2048), ("no preload/only walk", 2048 | 64 | 512 | 256), ("no loads", 64), ("no loads/stage", 64 | 512), ("no walk", 128), ("no mfma", 256),
                                                                 ("only mfma", 64 | 512 | 128), ("only walk", 64 | 512 | 256), ("only load+stage", 128 | 256), ("nothing", 64 | 512 | 128 | 256))):
             fl = 1 | 4 | 8 | (abl << 8)
             def f(): _lib.check(L.tdm_conv_nhwc_s16_f32(_lib.ptr(x16), _lib.ptr(w), _lib.ptr(b), _lib.ptr(res) if full else None, None,
