@@ -347,8 +347,15 @@ int tdm_round_argmax_f32(const float* x, const float* W, const float* b, int64_t
  * F.normalize both sides, matmul, argmax).  E (V,D): embedding matrix.  ws: tdm_round_workspace_floats(M,V,D). */
 int tdm_cosine_argmax_f32(const float* x, const float* E, int64_t* out_ids, float* ws, int64_t M, int V, int D,
                           void* stream);
-/* general strided fp32-MFMA GEMM (tests / profiling):
- * C[i][j] = sum_k A[i*a_rs + k*a_cs] * B[k*b_rs + j*b_cs] (+bias[j]) (+res[i][j]) (relu)      */
+/* "S16" tensors (the pre-split operand form of the bf16x3 kernels): same shape and byte size as the fp32
+ * tensor; every 64-byte group of 16 consecutive elements holds hi[16] | lo[16] as bf16 with hi = bf16(x),
+ * lo = bf16(x - hi).  out = S16 of in, n % 16 == 0 elements, 64-byte aligned.                           */
+int tdm_split_s16_f32(const float* in, float* out, int64_t n, void* stream);
+/* general strided GEMM of the transformer's linear layers in the selected gemm mode (tests / profiling):
+ * C[i][j] = sum_k A[i*a_rs + k*a_cs] * B[k*b_rs + j*b_cs] (+bias[j]) (+res[i][j]) (relu)
+ * `relu` is a flag word: bit 0 ReLU; bit 1 (bf16 modes): A and B are S16 tensors (K-contiguous form: K % 16
+ * == 0; token-major form: M, N % 16 == 0); bit 2 (bf16 modes, K-contiguous form): C is written as an S16
+ * tensor (N % 16 == 0).                                                                                */
 int tdm_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs,
                  float* C, int64_t c_rs, const float* bias, const float* res, int M, int N, int K,
                  int relu, int splitk, int64_t c_split_stride, void* stream);

@@ -260,6 +260,52 @@ def test_dropout_mask_host_function_matches_oracle():
         assert np.array_equal(buf.astype(bool), O.dropout_keep(p_drop, seed, site, (n,)).numpy())
 
 
+def _unsplit_s16(t):
+    """fp32 value hi + lo of every element of an S16 tensor (tdm_s16.h layout), on the CPU."""
+    raw = t.detach().cpu().contiguous().view(torch.int16).view(-1, 32)           # one 64-byte group: hi[16] | lo[16]
+    f = (raw.to(torch.int32) << 16).view(torch.float32)
+    return (f[:, :16].double() + f[:, 16:].double()).float().view(t.shape)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 64), (1000, 2048, 256), (130, 48, 2048), (257, 768, 256)])
+def test_s16_operands_give_the_same_gemm_bitwise(dev, gemm_mode, M, N, K):
+    """The pre-split ("S16") operand path of the bf16 GEMMs (tdm_split_s16_f32 + flag bits of tdm_gemm_f32): the loaders copy
+    what the fp32-input loaders would have computed, so the K-contiguous (forward / data-gradient) and token-major (weight-
+    gradient) products are BIT-IDENTICAL to the fp32-input kernels; an S16 output holds bf16(hi), bf16(x - hi) of the fp32 one."""
+    if gemm_mode == 0:
+        pytest.skip("S16 operands exist in the bf16 GEMM modes")
+    from tinydiffusionmodels_amd import _lib
+    L_ = _lib.lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(dev); W = (torch.randn(N, K, generator=g) * 0.1).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    A16, W16 = torch.empty_like(A), torch.empty_like(W)
+    _lib.check(L_.tdm_split_s16_f32(_lib.ptr(A), _lib.ptr(A16), A.numel(), _lib.stream()))
+    _lib.check(L_.tdm_split_s16_f32(_lib.ptr(W), _lib.ptr(W16), W.numel(), _lib.stream()))
+    assert O.rel_err(_unsplit_s16(A16), A.cpu()) < 2e-5
+    def nt(a, w, flags):
+        c = torch.empty(M, N, device=dev)
+        _lib.check(L_.tdm_gemm_f32(_lib.ptr(a), K, 1, _lib.ptr(w), 1, K, _lib.ptr(c), N, _lib.ptr(bias), None, M, N, K, flags, 1, 0, _lib.stream()))
+        return c
+    c_ref = nt(A, W, 1)
+    assert torch.equal(nt(A16, W16, 1 | 2), c_ref)
+    c16 = nt(A16, W16, 1 | 2 | 4)
+    want16 = torch.empty_like(c_ref)
+    _lib.check(L_.tdm_split_s16_f32(_lib.ptr(c_ref), _lib.ptr(want16), c_ref.numel(), _lib.stream()))
+    assert torch.equal(c16.view(torch.int32), want16.view(torch.int32))
+    # token-major (weight-gradient) form: dW[N][K] = dY[M][N]^T X[M][K]; M, N, K multiples of 16 for the S16 rows
+    Mt = (M // 16) * 16
+    dY = torch.randn(Mt, N, generator=g).to(dev); X = A[:Mt].contiguous()
+    dY16, X16 = torch.empty_like(dY), torch.empty_like(X)
+    _lib.check(L_.tdm_split_s16_f32(_lib.ptr(dY), _lib.ptr(dY16), dY.numel(), _lib.stream()))
+    _lib.check(L_.tdm_split_s16_f32(_lib.ptr(X), _lib.ptr(X16), X.numel(), _lib.stream()))
+    def tn(dy, x, flags):
+        c = torch.empty(N, K, device=dev)
+        _lib.check(L_.tdm_gemm_f32(_lib.ptr(dy), 1, N, _lib.ptr(x), K, 1, _lib.ptr(c), K, None, None, N, K, Mt, flags, 1, 0, _lib.stream()))
+        return c
+    assert torch.equal(tn(dY16, X16, 2), tn(dY, X, 0))
+
+
 @pytest.mark.parametrize("B,L,D,H,p_drop", [(2, 128, 256, 4, 0.0), (3, 37, 64, 4, 0.1), (1, 130, 128, 4, 0.0), (2, 96, 32, 4, 0.2),
                                             (1, 200, 64, 8, 0.1), (2, 64, 32, 1, 0.0)])
 def test_attention_per_op_vs_torch(dev, attn_mode, B, L, D, H, p_drop):

@@ -99,6 +99,7 @@ _SIGS = {
     "tdm_allreduce_sum_f32": ([c_f, c_f, c_i64, c_f], c_int),
     "tdm_broadcast_f32": ([c_f, c_f, c_i64, c_int, c_f], c_int),
     "tdm_cosine_argmax_f32": ([c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_f], c_int),
+    "tdm_split_s16_f32": ([c_f, c_f, c_i64, c_f], c_int),
     "tdm_gemm_f32": ([c_f, c_i64, c_i64, c_f, c_i64, c_i64, c_f, c_i64, c_f, c_f, c_int, c_int, c_int, c_int, c_int,
                       c_i64, c_f], c_int),
 }

@@ -156,16 +156,21 @@ __device__ __forceinline__ void accum_T_times(f32x16 (&out)[Cfg<HD>::NT], const 
 }
 
 // write the transposed accumulator tiles as rows: dst_row[32 t + 8 q + 4 h + (0..3)] = out[t][4 q + ..] * mul
+// dst_row (fp32) and / or dst16 (the S16 twin of the same [rows][ld] tensor: row m, columns col0 + d) may be null
 template <int HD>
-__device__ __forceinline__ void store_rows(float* __restrict__ dst_row, const f32x16 (&out)[Cfg<HD>::NT], int h, float mul) {
+__device__ __forceinline__ void store_rows(float* __restrict__ dst_row, float* __restrict__ dst16, long m, int ld, int col0,
+                                           const f32x16 (&out)[Cfg<HD>::NT], int h, float mul) {
 #pragma unroll
     for (int t = 0; t < Cfg<HD>::NT; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int d = 32 * t + 8 * q + 4 * h;
-            if (d < HD)
-                *reinterpret_cast<float4*>(dst_row + d) = make_float4(out[t][4 * q] * mul, out[t][4 * q + 1] * mul,
-                                                                      out[t][4 * q + 2] * mul, out[t][4 * q + 3] * mul);
+            if (d < HD) {
+                const float4 v = make_float4(out[t][4 * q] * mul, out[t][4 * q + 1] * mul, out[t][4 * q + 2] * mul,
+                                             out[t][4 * q + 3] * mul);
+                if (dst_row != nullptr) *reinterpret_cast<float4*>(dst_row + d) = v;
+                if (dst16 != nullptr) tdm_store_s16_4(dst16, m, ld, col0 + d, v);
+            }
         }
 }
 
@@ -176,8 +181,8 @@ __device__ __forceinline__ void clear_lds(char* lds, int bytes, int tid) {
 // ------------------------------------------------------------------ forward
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const float* __restrict__ qkv, float* __restrict__ o,
-                                                            float* __restrict__ lse, int L, int D, int H, float scale,
-                                                            DropArgs dr) {
+                                                            float* __restrict__ o16, float* __restrict__ lse, int L, int D,
+                                                            int H, float scale, DropArgs dr) {
     using C = Cfg<HD>;
     extern __shared__ float4 sm4[];
     char* Kr = reinterpret_cast<char*>(sm4);
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const float* __re
         }
     }
     if (qvalid) {
-        store_rows<HD>(o + ((long)b * L + qi) * D + hh * HD, acc_o, h, 1.f / l);
+        store_rows<HD>(o + ((long)b * L + qi) * D + hh * HD, o16, (long)b * L + qi, D, hh * HD, acc_o, h, 1.f / l);
         if (h == 0) lse[(long)bh * L + qi] = m + logf(l);
     }
 }
@@ -251,8 +256,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const float* __re
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                                const float* __restrict__ lse, const float* __restrict__ dO,
-                                                               float* __restrict__ dqkv, float* __restrict__ Dvec, int L,
-                                                               int D, int H, float scale, DropArgs dr) {
+                                                               float* __restrict__ dqkv, float* __restrict__ dqkv16,
+                                                               float* __restrict__ Dvec, int L, int D, int H, float scale,
+                                                               DropArgs dr) {
     using C = Cfg<HD>;
     extern __shared__ float4 sm4[];
     char* Kr = reinterpret_cast<char*>(sm4);
@@ -311,7 +317,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const float* _
         }
     }
     if (qvalid) {
-        store_rows<HD>(dqkv + ((long)b * L + qi) * 3 * D + hh * HD, acc_dq, h, scale);
+        store_rows<HD>(dqkv != nullptr ? dqkv + ((long)b * L + qi) * 3 * D + hh * HD : nullptr, dqkv16, (long)b * L + qi, 3 * D,
+                       hh * HD, acc_dq, h, scale);
         if (h == 0) Dvec[(long)bh * L + qi] = Di;
     }
 }
@@ -320,8 +327,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const float* _
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const float* __restrict__ qkv, const float* __restrict__ lse,
                                                                 const float* __restrict__ dO, const float* __restrict__ Dvec,
-                                                                float* __restrict__ dqkv, int L, int D, int H, float scale,
-                                                                DropArgs dr) {
+                                                                float* __restrict__ dqkv, float* __restrict__ dqkv16, int L,
+                                                                int D, int H, float scale, DropArgs dr) {
     using C = Cfg<HD>;
     extern __shared__ float4 sm4[];
     char* Qr = reinterpret_cast<char*>(sm4);
@@ -387,15 +394,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const float* 
         }
     }
     if (kvalid) {
-        float* dst = dqkv + ((long)b * L + kj) * 3 * D + hh * HD;
-        store_rows<HD>(dst + D, acc_dk, h, scale);
-        store_rows<HD>(dst + 2 * D, acc_dv, h, 1.f);
+        float* dst = dqkv != nullptr ? dqkv + ((long)b * L + kj) * 3 * D + hh * HD : nullptr;
+        store_rows<HD>(dst != nullptr ? dst + D : nullptr, dqkv16, (long)b * L + kj, 3 * D, D + hh * HD, acc_dk, h, scale);
+        store_rows<HD>(dst != nullptr ? dst + 2 * D : nullptr, dqkv16, (long)b * L + kj, 3 * D, 2 * D + hh * HD, acc_dv, h, 1.f);
     }
 }
 
 template <int HD>
-int attn_bf16_launch(int which, const float* qkv, const float* o, const float* lse, const float* dO, float* out, float* aux,
-                     long B, int L, int D, int H, DropArgs dr, hipStream_t st) {
+int attn_bf16_launch(int which, const float* qkv, const float* o, const float* lse, const float* dO, float* out, float* out16,
+                     float* aux, long B, int L, int D, int H, DropArgs dr, hipStream_t st) {
     using C = Cfg<HD>;
     const float scale = 1.0f / sqrtf((float)HD);
     dim3 grid((unsigned)(B * H), (L + QB - 1) / QB);
@@ -418,13 +425,13 @@ int attn_bf16_launch(int which, const float* qkv, const float* o, const float* l
         attr_set = true;
     }
     if (which == 0) {
-        hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD>), grid, dim3(256), lds_f, st, qkv, out, aux, L, D, H, scale, dr);
+        hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD>), grid, dim3(256), lds_f, st, qkv, out, out16, aux, L, D, H, scale, dr);
         TDM_CHECK_LAUNCH("attn_fwd_bf16");
     } else if (which == 1) {
-        hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<HD>), grid, dim3(256), lds_q, st, qkv, o, lse, dO, out, aux, L, D, H, scale, dr);
+        hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<HD>), grid, dim3(256), lds_q, st, qkv, o, lse, dO, out, out16, aux, L, D, H, scale, dr);
         TDM_CHECK_LAUNCH("attn_bwd_dq_bf16");
     } else {
-        hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<HD>), grid, dim3(256), lds_kv, st, qkv, lse, dO, aux, out, L, D, H, scale, dr);
+        hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<HD>), grid, dim3(256), lds_kv, st, qkv, lse, dO, aux, out, out16, L, D, H, scale, dr);
         TDM_CHECK_LAUNCH("attn_bwd_dkv_bf16");
     }
     return 0;
@@ -432,15 +439,18 @@ int attn_bf16_launch(int which, const float* qkv, const float* o, const float* l
 
 }  // namespace
 
-// which: 0 forward (out = O, aux = lse), 1 dQ (out = dqkv, aux = D written), 2 dK/dV (out = dqkv, aux = D read)
+// which: 0 forward (out = O, aux = lse), 1 dQ (out = dqkv, aux = D written), 2 dK/dV (out = dqkv, aux = D read);
+// out16 != nullptr: the S16 twin of `out` is written too (forward: `out` stays required; backward: `out` may be nullptr)
 int tdm_launch_attn_bf16(int which, int hd, const float* qkv, const float* o, const float* lse, const float* dO, float* out,
-                         float* aux, long B, int L, int D, int H, DropArgs dr, hipStream_t st) {
-    TDM_REQUIRE((D % 4) == 0 && (((uintptr_t)qkv | (uintptr_t)out) & 15) == 0, "attention: 16-byte alignment");
+                         float* out16, float* aux, long B, int L, int D, int H, DropArgs dr, hipStream_t st) {
+    TDM_REQUIRE((D % 4) == 0 && (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)out16) & 15) == 0, "attention: 16-byte alignment");
+    TDM_REQUIRE(out != nullptr || (which != 0 && out16 != nullptr), "attention: no output");
+    TDM_REQUIRE(out16 == nullptr || (D % 16) == 0, "attention: an S16 output needs D %% 16 == 0");
     switch (hd) {
-        case 8: return attn_bf16_launch<8>(which, qkv, o, lse, dO, out, aux, B, L, D, H, dr, st);
-        case 16: return attn_bf16_launch<16>(which, qkv, o, lse, dO, out, aux, B, L, D, H, dr, st);
-        case 32: return attn_bf16_launch<32>(which, qkv, o, lse, dO, out, aux, B, L, D, H, dr, st);
-        case 64: return attn_bf16_launch<64>(which, qkv, o, lse, dO, out, aux, B, L, D, H, dr, st);
+        case 8: return attn_bf16_launch<8>(which, qkv, o, lse, dO, out, out16, aux, B, L, D, H, dr, st);
+        case 16: return attn_bf16_launch<16>(which, qkv, o, lse, dO, out, out16, aux, B, L, D, H, dr, st);
+        case 32: return attn_bf16_launch<32>(which, qkv, o, lse, dO, out, out16, aux, B, L, D, H, dr, st);
+        case 64: return attn_bf16_launch<64>(which, qkv, o, lse, dO, out, out16, aux, B, L, D, H, dr, st);
     }
     tdm_set_error("attention: head_dim %d not supported (8, 16, 32, 64)", hd);
     return 1;

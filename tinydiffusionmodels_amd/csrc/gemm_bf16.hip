@@ -94,8 +94,17 @@ template <int WM> struct NtCfg {
     static constexpr int NPA = 2 * WM;   // float4 pieces of A per thread and chunk
 };
 
-template <int NPROD, bool CE, bool STATS, int WM>
+// a 16-byte piece kq (0..7) of a row's 32-element S16 chunk (hi0 hi0' lo0 lo0' hi1 hi1' lo1 lo1') goes to its plane as is
+template <int NPROD>
+__device__ __forceinline__ void put_s16(char* hi_plane, char* lo_plane, int row, int kq, const f32x4 v) {
+    const bool is_lo = (kq >> 1) & 1;
+    if (NPROD == 1 && is_lo) return;
+    *reinterpret_cast<f32x4*>((is_lo ? lo_plane : hi_plane) + row * PITCH + ((kq >> 2) * 16 + (kq & 1) * 8) * 2) = v;
+}
+
+template <int NPROD, bool CE, bool STATS, int WM, bool S16IN = false>
 __global__ __launch_bounds__(NT_THREADS, (WM == 1 ? 4 : 2)) void gemm_nt_bf16_kernel(GemmArgs g, int ntx, int ntiles) {
+    static_assert(!(S16IN && CE), "the cross-entropy loader regenerates its operand from fp32 logits");
     using Cf = NtCfg<WM>;
     constexpr int TMv = Cf::TMv, NPA = Cf::NPA;
     // planes: A hi, A lo, B hi, B lo  (lo planes unused when NPROD == 1)
@@ -172,13 +181,16 @@ __global__ __launch_bounds__(NT_THREADS, (WM == 1 ? 4 : 2)) void gemm_nt_bf16_ke
                     const int row = f >> 3, kq = f & 7;
                     f32x4 va = ((ok >> p) & 1u) ? pa[p] : zero4;
                     if constexpr (CE) va = ((ok >> p) & 1u) ? ce_grad4(va, ce_l[p], ce_t[p], c * BK + kq * 4, g.ce_V, g.ce_scale) : zero4;
-                    put_split<NPROD>(Ahi, Alo, row * PITCH + kq * 8, va);
+                    if constexpr (S16IN) put_s16<NPROD>(Ahi, Alo, row, kq, va);
+                    else put_split<NPROD>(Ahi, Alo, row * PITCH + kq * 8, va);
                 }
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const int f = tid + NT_THREADS * p;
                     const int row = f >> 3, kq = f & 7;
-                    put_split<NPROD>(Bhi, Blo, row * PITCH + kq * 8, ((ok >> (8 + p)) & 1u) ? pb[p] : zero4);
+                    const f32x4 vb = ((ok >> (8 + p)) & 1u) ? pb[p] : zero4;
+                    if constexpr (S16IN) put_s16<NPROD>(Bhi, Blo, row, kq, vb);
+                    else put_split<NPROD>(Bhi, Blo, row * PITCH + kq * 8, vb);
                 }
             }
             __syncthreads();
@@ -288,9 +300,17 @@ __global__ __launch_bounds__(NT_THREADS, (WM == 1 ? 4 : 2)) void gemm_nt_bf16_ke
                         v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
                     }
                     if (g.gate != nullptr) {
-                        const float4 gz = *reinterpret_cast<const float4*>(g.gate + o);
-                        v.x = gz.x > 0.f ? v.x * g.gate_scale : 0.f; v.y = gz.y > 0.f ? v.y * g.gate_scale : 0.f;
-                        v.z = gz.z > 0.f ? v.z * g.gate_scale : 0.f; v.w = gz.w > 0.f ? v.w * g.gate_scale : 0.f;
+                        if (g.gate_s16) {   // S16 gate (values >= 0): element nonzero <=> hi or lo nonzero
+                            const char* gb = reinterpret_cast<const char*>(g.gate + (o - (n & 15))) + (n & 15) * 2;
+                            const uint2 gh = *reinterpret_cast<const uint2*>(gb), gl = *reinterpret_cast<const uint2*>(gb + 32);
+                            const unsigned b0 = gh.x | gl.x, b1 = gh.y | gl.y;
+                            v.x = (b0 & 0xffffu) ? v.x * g.gate_scale : 0.f; v.y = (b0 >> 16) ? v.y * g.gate_scale : 0.f;
+                            v.z = (b1 & 0xffffu) ? v.z * g.gate_scale : 0.f; v.w = (b1 >> 16) ? v.w * g.gate_scale : 0.f;
+                        } else {
+                            const float4 gz = *reinterpret_cast<const float4*>(g.gate + o);
+                            v.x = gz.x > 0.f ? v.x * g.gate_scale : 0.f; v.y = gz.y > 0.f ? v.y * g.gate_scale : 0.f;
+                            v.z = gz.z > 0.f ? v.z * g.gate_scale : 0.f; v.w = gz.w > 0.f ? v.w * g.gate_scale : 0.f;
+                        }
                     }
                     if (g.drop.thr != 0u) {
                         const unsigned long long e = (unsigned long long)m * (unsigned)g.N + (unsigned)n;
@@ -299,7 +319,8 @@ __global__ __launch_bounds__(NT_THREADS, (WM == 1 ? 4 : 2)) void gemm_nt_bf16_ke
                         v.z = tdm_keep(g.drop, e + 2) ? v.z * g.drop.scale : 0.f;
                         v.w = tdm_keep(g.drop, e + 3) ? v.w * g.drop.scale : 0.f;
                     }
-                    *reinterpret_cast<float4*>(g.C + o) = v;
+                    if (g.C != nullptr) *reinterpret_cast<float4*>(g.C + o) = v;
+                    if (g.C16 != nullptr) tdm_store_s16_4(g.C16, m, (int)g.c_rs, n, v);
                 }
             }
         }
@@ -318,8 +339,9 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
 
 constexpr int TPL = 4 * 32 * 64;   // one [4 col blocks][32 tokens][32 cols] bf16 image = 8 KB
 
-template <int NPROD, bool CE>
+template <int NPROD, bool CE, bool S16IN = false>
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
+    static_assert(!(S16IN && CE), "the cross-entropy loader regenerates its operand from fp32 logits");
     // C[i][j] = sum_k A(i,k) B(k,j) with A(i,k) = A[k*a_cs + i], B(k,j) = B[k*b_rs + j]  (a_rs = b_cs = 1)
     __shared__ __attribute__((aligned(16))) char lds[4 * TPL];
     char* Ahi = lds; char* Alo = lds + TPL; char* Bhi = lds + 2 * TPL; char* Blo = lds + 3 * TPL;
@@ -370,6 +392,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
     if (kbeg < kend) gload(kbeg);
     const bool do_cs = g.colsum != nullptr && blockIdx.x == 0;
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);   // this thread's 4 A columns (c4 = tid & 31), rows tid>>5 (+8p)
+    float csum8[S16IN ? 8 : 1] = {};                  // S16 operands: the 8 columns of this thread's hi or lo piece
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();
 #pragma unroll
@@ -379,9 +402,27 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
             const int off = ((c4 >> 3) * 32 + mrow) * 64 + (c4 & 7) * 8;
             f32x4 va = ((ok >> p) & 1u) ? pa[p] : zero4;
             if constexpr (CE) va = ((ok >> p) & 1u) ? ce_grad4(va, ce_l[p], ce_t[p], i0 + c4 * 4, g.ce_V, g.ce_scale) : zero4;
-            put_split<NPROD>(Ahi, Alo, off, va);
-            put_split<NPROD>(Bhi, Blo, off, ((ok >> (4 + p)) & 1u) ? pb[p] : zero4);
-            if (do_cs) { csum.x += va[0]; csum.y += va[1]; csum.z += va[2]; csum.w += va[3]; }
+            if constexpr (S16IN) {
+                // piece c4 of the 128-column (512-byte) S16 row chunk: 16-column group c4 >> 2, pieces hi | hi' | lo | lo'
+                const int grp = c4 >> 2, sub = c4 & 3;
+                const int o16 = (((grp >> 1) * 32 + mrow) * 64) + ((grp & 1) * 16 + (sub & 1) * 8) * 2;
+                const f32x4 vb = ((ok >> (4 + p)) & 1u) ? pb[p] : zero4;
+                if (NPROD == 3 || sub < 2) {
+                    *reinterpret_cast<f32x4*>(((sub >> 1) ? Alo : Ahi) + o16) = va;
+                    *reinterpret_cast<f32x4*>(((sub >> 1) ? Blo : Bhi) + o16) = vb;
+                }
+                if (do_cs) {
+                    const uint4 u = __builtin_bit_cast(uint4, va);
+                    csum8[0] += __uint_as_float(u.x << 16); csum8[1] += __uint_as_float(u.x & 0xffff0000u);
+                    csum8[2] += __uint_as_float(u.y << 16); csum8[3] += __uint_as_float(u.y & 0xffff0000u);
+                    csum8[4] += __uint_as_float(u.z << 16); csum8[5] += __uint_as_float(u.z & 0xffff0000u);
+                    csum8[6] += __uint_as_float(u.w << 16); csum8[7] += __uint_as_float(u.w & 0xffff0000u);
+                }
+            } else {
+                put_split<NPROD>(Ahi, Alo, off, va);
+                put_split<NPROD>(Bhi, Blo, off, ((ok >> (4 + p)) & 1u) ? pb[p] : zero4);
+                if (do_cs) { csum.x += va[0]; csum.y += va[1]; csum.z += va[2]; csum.w += va[3]; }
+            }
         }
         __syncthreads();
         if (k0 + BK < kend) gload(k0 + BK);
@@ -412,7 +453,22 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
                 }
         }
     }
-    if (do_cs) {   // 8 row groups -> one sum per column, fixed order
+    if (S16IN && do_cs) {   // column c of the tile = hi piece + lo piece of its 16-column group, 8 row groups each, fixed order
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lds);   // [8 row groups][32 pieces][8]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = csum8[e];
+        __syncthreads();
+        if (tid < 128) {
+            const int grp = tid >> 4, w16 = tid & 15;               // column tid of the tile
+            const int ph = grp * 4 + (w16 >> 3), e = w16 & 7;       // its hi piece; the lo piece is ph + 2
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a += red[(k * 32 + ph) * 8 + e] + red[(k * 32 + ph + 2) * 8 + e];
+            float* dst = g.colsum + (long)blockIdx.z * g.colsum_stride;
+            if (i0 + tid < g.M) dst[i0 + tid] = a;
+        }
+    } else if (do_cs) {   // 8 row groups -> one sum per column, fixed order
         __syncthreads();
         float4* red = reinterpret_cast<float4*>(lds);
         red[tid] = csum;
@@ -473,13 +529,13 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 namespace {
 int g_nt_wm = 0;   // 0: pick per problem; 1 / 2: force the 128- / 256-row tile (TDM_GEMM_WM, A/B timing)
 
-template <int NPROD, bool CE, bool STATS, int WM>
+template <int NPROD, bool CE, bool STATS, int WM, bool S16IN = false>
 int launch_nt(const GemmArgs& g, hipStream_t st) {
     using Cf = NtCfg<WM>;
     static int resident = 0;   // workgroups the device holds at once (occupancy x CUs): the persistent grid
     if (resident == 0) {
         int dev = 0, cus = 0, per_cu = 0;
-        const void* fn = reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<NPROD, CE, STATS, WM>);
+        const void* fn = reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<NPROD, CE, STATS, WM, S16IN>);
         hipError_t e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
@@ -492,7 +548,7 @@ int launch_nt(const GemmArgs& g, hipStream_t st) {
     }
     const int ntx = (g.N + TN_ - 1) / TN_, ntiles = ntx * ((g.M + Cf::TMv - 1) / Cf::TMv);
     dim3 grid(ntiles < resident ? ntiles : resident);
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<NPROD, CE, STATS, WM>), grid, dim3(NT_THREADS), Cf::LDS, st, g, ntx, ntiles);
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<NPROD, CE, STATS, WM, S16IN>), grid, dim3(NT_THREADS), Cf::LDS, st, g, ntx, ntiles);
     TDM_CHECK_LAUNCH("gemm_nt_bf16");
     return 0;
 }
@@ -504,8 +560,15 @@ int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
     TDM_REQUIRE(g.a_cs == 1 && g.b_rs == 1, "gemm_nt_bf16: both operands must be K-contiguous");
     TDM_REQUIRE((g.a_rs % 4) == 0 && (g.b_cs % 4) == 0 && (g.c_rs % 4) == 0 && (g.K % 4) == 0,
                 "gemm_nt_bf16: leading dimensions and K must be multiples of 4");
-    TDM_REQUIRE((((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.C) & 15) == 0, "gemm_nt_bf16: 16-byte alignment");
+    TDM_REQUIRE((((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.C | (uintptr_t)g.C16) & 15) == 0, "gemm_nt_bf16: 16-byte alignment");
+    TDM_REQUIRE(g.C != nullptr || g.C16 != nullptr, "gemm_nt_bf16: no output");
     TDM_REQUIRE(g.splitk <= 1, "gemm_nt_bf16: no split-K");
+    TDM_REQUIRE(!g.s16_in || ((g.K % 16) == 0 && (g.a_rs % 16) == 0 && (g.b_cs % 16) == 0 && g.ce_lse == nullptr),
+                "gemm_nt_bf16: S16 operands need K and the leading dimensions to be multiples of 16 (K=%d)", g.K);
+    TDM_REQUIRE(g.C16 == nullptr || ((g.N % 16) == 0 && (g.c_rs % 16) == 0 && g.ce_part == nullptr),
+                "gemm_nt_bf16: an S16 output needs N and its leading dimension to be multiples of 16 (N=%d)", g.N);
+    TDM_REQUIRE(g.C != nullptr || (g.N % 4) == 0, "gemm_nt_bf16: an S16-only output needs N %% 4 == 0");
+    TDM_REQUIRE(!g.gate_s16 || (g.c_rs % 16) == 0, "gemm_nt_bf16: an S16 gate needs a leading dimension that is a multiple of 16");
     TDM_REQUIRE(!(g.ce_lse != nullptr && g.ce_part != nullptr), "gemm_nt_bf16: one cross-entropy role per launch");
     static bool env_read = false;
     if (!env_read) {
@@ -526,6 +589,7 @@ int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
                     "gemm_nt_bf16: cross-entropy partials need a plain (bias-only) epilogue");
         return big ? launch_nt<3, false, true, 2>(g, st) : launch_nt<3, false, true, 1>(g, st);
     }
+    if (g.s16_in) return nprod == 3 ? launch_nt<3, false, false, 1, true>(g, st) : launch_nt<1, false, false, 1, true>(g, st);
     if (nprod == 3) return big ? launch_nt<3, false, false, 2>(g, st) : launch_nt<3, false, false, 1>(g, st);
     return big ? launch_nt<1, false, false, 2>(g, st) : launch_nt<1, false, false, 1>(g, st);
 }
@@ -544,15 +608,68 @@ int tdm_launch_gemm_tn_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
     if (g.ce_lse != nullptr) {
         TDM_REQUIRE(nprod == 3 && g.ce_ids != nullptr, "gemm_tn_bf16: the cross-entropy form runs in the bf16x3 arithmetic and needs the target ids");
         hipLaunchKernelGGL((gemm_tn_bf16_kernel<3, true>), grid, dim3(256), 0, st, g);
+    } else if (g.s16_in) {
+        TDM_REQUIRE((g.a_cs % 16) == 0 && (g.b_rs % 16) == 0 && (g.M % 16) == 0 && (g.N % 16) == 0,
+                    "gemm_tn_bf16: S16 operands need M, N and the leading dimensions to be multiples of 16");
+        if (nprod == 3) hipLaunchKernelGGL((gemm_tn_bf16_kernel<3, false, true>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, false, true>), grid, dim3(256), 0, st, g);
     } else if (nprod == 3) hipLaunchKernelGGL((gemm_tn_bf16_kernel<3, false>), grid, dim3(256), 0, st, g);
     else hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, false>), grid, dim3(256), 0, st, g);
     TDM_CHECK_LAUNCH("gemm_tn_bf16");
     return 0;
 }
 
+namespace {
+// out (S16, [Cn][R], R % 16 == 0) = transpose of in[R][Cn]: a workgroup transposes a 32 x 32 block through LDS and writes
+// every output row's 32 elements as two 16-element S16 groups
+__global__ __launch_bounds__(256) void transpose_s16_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cn) {
+    __shared__ float t[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = by + ty + 8 * k, c = bx + tx;
+        t[ty + 8 * k][tx] = (r < R && c < Cn) ? in[(long)r * Cn + c] : 0.f;
+    }
+    __syncthreads();
+    // 32 output rows (c) x 8 quads of r: thread = (row c = tid >> 3, quad = tid & 7)
+    const int cr = threadIdx.x >> 3, q4 = (threadIdx.x & 7) * 4;
+    const int c = bx + cr, r0 = by + q4;
+    if (c < Cn && r0 < R) tdm_store_s16_4(out, c, R, r0, make_float4(t[q4][cr], t[q4 + 1][cr], t[q4 + 2][cr], t[q4 + 3][cr]));
+}
+__global__ __launch_bounds__(256) void split_s16_kernel(const float* __restrict__ in, float* __restrict__ out, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long e = i * 4;
+        tdm_bf16x4 hi, lo;
+        tdm_split4(reinterpret_cast<const float4*>(in)[i], hi, lo);
+        char* base = reinterpret_cast<char*>(out + (e & ~15L)) + (e & 15) * 2;
+        *reinterpret_cast<tdm_bf16x4*>(base) = hi;
+        *reinterpret_cast<tdm_bf16x4*>(base + 32) = lo;
+    }
+}
+}  // namespace
+
 int tdm_launch_transpose(const float* in, float* out, int R, int Cn, hipStream_t st) {
     dim3 grid((Cn + 31) / 32, (R + 31) / 32);
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, st, in, out, R, Cn);
     TDM_CHECK_LAUNCH("transpose");
+    return 0;
+}
+
+int tdm_launch_transpose_s16(const float* in, float* out, int R, int Cn, hipStream_t st) {
+    TDM_REQUIRE((R % 16) == 0, "transpose_s16: %d rows (the S16 row length) must be a multiple of 16", R);
+    dim3 grid((Cn + 31) / 32, (R + 31) / 32);
+    hipLaunchKernelGGL(transpose_s16_kernel, grid, dim3(256), 0, st, in, out, R, Cn);
+    TDM_CHECK_LAUNCH("transpose_s16");
+    return 0;
+}
+
+int tdm_launch_split_s16(const float* in, float* out, long n, hipStream_t st) {
+    TDM_REQUIRE((n % 16) == 0 && (((uintptr_t)in | (uintptr_t)out) & 63) == 0, "split_s16: %ld elements / alignment", n);
+    if (n == 0) return 0;
+    const long n4 = n / 4;
+    const int grid = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(split_s16_kernel, dim3(grid), dim3(256), 0, st, in, out, n4);
+    TDM_CHECK_LAUNCH("split_s16");
     return 0;
 }

@@ -27,6 +27,14 @@ struct GemmArgs {
     //    softmax - onehot is regenerated from the stored logits in the loader instead of being written back and re-read.
     float* ce_part; int ce_nblk; float* ce_tgt;
     const float* ce_lse; const int64_t* ce_ids; float ce_scale; int ce_V;
+    // Pre-split ("S16", tdm_s16.h) operands and outputs, bf16 kernels only.  An S16 tensor has the shape and byte size of
+    // its fp32 counterpart; every 64-byte group of 16 consecutive elements of a row holds hi[16] | lo[16] as bf16.
+    //  * s16_in: BOTH operands are S16 (row lengths multiples of 16): the loaders copy 16-byte pieces straight into the
+    //    hi / lo LDS planes — no conversion (the in-loader split was 28 % of the N = 2048 layer's time, repeated by every
+    //    column tile that re-reads a row panel);
+    //  * C16 != nullptr (NT): the epilogue also writes the result as S16 to C16[M][c_rs] (C may then be nullptr);
+    //  * gate_s16: `gate` is an S16 tensor (its elements are >= 0: the test is "nonzero").
+    int s16_in; float* C16; int gate_s16;
     int ablate;   // timing diagnostics (NT bf16 kernel; results are wrong when set): 1 no global loads after the first
                   // chunk, 2 no MFMA, 4 no epilogue stores, 8 no split / LDS stores after the first chunk
 };
@@ -36,11 +44,15 @@ int tdm_launch_gemm(const GemmArgs& g, hipStream_t st);
 int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st);
 int tdm_launch_gemm_tn_bf16(const GemmArgs& g, int nprod, hipStream_t st);
 int tdm_launch_transpose(const float* in, float* out, int R, int Cn, hipStream_t st);
+// out[c][r] = in[r][c] written as S16 (R % 16 == 0); out = S16 of in, elementwise over n (n % 16 == 0) floats
+int tdm_launch_transpose_s16(const float* in, float* out, int R, int Cn, hipStream_t st);
+int tdm_launch_split_s16(const float* in, float* out, long n, hipStream_t st);
 
 // fp32-MFMA attention (attn_mfma.hip). which: 0 forward (out = O, aux = lse), 1 dQ (out = dqkv, aux = D written),
 // 2 dK/dV (out = dqkv, aux = D read)
 int tdm_launch_attn_mfma(int which, int hd, const float* qkv, const float* o, const float* lse, const float* dO, float* out,
                          float* aux, long B, int L, int D, int H, DropArgs dr, hipStream_t st);
 // the same three kernels on the bf16 matrix cores with split operands (attn_bf16.hip, ~1e-5 relative): the default
+// out16 != nullptr: the S16 twin of `out` is written too (backward: `out` may then be nullptr)
 int tdm_launch_attn_bf16(int which, int hd, const float* qkv, const float* o, const float* lse, const float* dO, float* out,
-                         float* aux, long B, int L, int D, int H, DropArgs dr, hipStream_t st);
+                         float* out16, float* aux, long B, int L, int D, int H, DropArgs dr, hipStream_t st);

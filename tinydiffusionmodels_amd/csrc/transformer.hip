@@ -12,6 +12,7 @@
 #include "tdm_common.h"
 #include <cstdlib>
 #include "tdm_transformer.h"
+#include "tdm_s16.h"
 
 namespace {
 
@@ -86,12 +87,16 @@ TTLayout tt_layout(int D, int depth, int F) {
 }
 
 // --------------------------------- workspace -------------------------------------
-struct LayerWs { float *hin, *qkv, *o, *lse, *s1, *mean1, *rstd1, *h1, *f1, *s2, *mean2, *rstd2; };
+struct LayerWs {
+    float *hin, *qkv, *o, *lse, *s1, *mean1, *rstd1, *h1, *f1, *s2, *mean2, *rstd2;
+    float *hin16, *o16, *h1_16;   // S16 twins of the GEMM operands (bf16 GEMM modes; f1 itself is S16 there)
+};
 struct TTWs {
     float *that, *tb, *abuf, *wT;
     LayerWs L[8];
     // backward temporaries
     float *g_h, *g_s, *g_s1, *g_d, *g_f, *g_h1, *g_o, *g_qkv, *Dvec, *Sb, *part;
+    float *P16, *g16, *g_qkv16;   // S16: the parameter vector, the D-wide gradient operand of the current GEMM pair, d(qkv)
     long total;
 };
 TTWs tt_carve(float* base, long B, int Lq, int D, int H, int depth, int F, int training) {
@@ -110,7 +115,9 @@ TTWs tt_carve(float* base, long B, int Lq, int D, int H, int depth, int F, int t
         x.hin = take(M * D); x.qkv = take(M * 3 * D); x.o = take(M * D); x.lse = take(B * H * Lq);
         x.s1 = take(M * D); x.mean1 = take(M); x.rstd1 = take(M); x.h1 = take(M * D); x.f1 = take(M * F);
         x.s2 = take(M * D); x.mean2 = take(M); x.rstd2 = take(M);
+        x.hin16 = take(M * D); x.o16 = take(M * D); x.h1_16 = take(M * D);
     }
+    w.P16 = take(tt_layout(D, depth, F).total);
     if (training) {
         w.g_h = take(M * D); w.g_s = take(M * D); w.g_s1 = take(M * D); w.g_d = take(M * D); w.g_f = take(M * F); w.g_h1 = take(M * D);
         w.g_o = take(M * D); w.g_qkv = take(M * 3 * D); w.Dvec = take(B * H * Lq); w.Sb = take(B * D);
@@ -118,6 +125,7 @@ TTWs tt_carve(float* base, long B, int Lq, int D, int H, int depth, int F, int t
         const long c1 = (long)CS_SLABS * (F > 3 * D ? F : 3 * D);
         if (c1 > pmax) pmax = c1;
         w.part = take(pmax + (F > 3 * D ? F : 3 * D));
+        w.g16 = take(M * D); w.g_qkv16 = take(M * 3 * D);
     }
     w.total = off;
     return w;
@@ -129,23 +137,33 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// h0[m][d] = x[m][d] + (w[d]*t[b]/1000 + bias[d])      (src/shakespeare.py:116-118)
+// h0[m][d] = x[m][d] + (w[d]*t[b]/1000 + bias[d])      (src/shakespeare.py:116-118); h16 = S16 twin of h0 (or nullptr)
 __global__ __launch_bounds__(256) void add_timebias_kernel(const float* __restrict__ x, const int64_t* __restrict__ t,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
                                                            float* __restrict__ that, float* __restrict__ tb,
-                                                           float* __restrict__ h0, long B, int L, int D, DropArgs dr) {
-    const long total = B * L * D;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+                                                           float* __restrict__ h0, float* __restrict__ h16, long B, int L, int D,
+                                                           DropArgs dr) {
+    const long total4 = B * L * D / 4;
+    for (long i4 = (long)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * 256) {
+        const long i = i4 * 4;
         const int d = (int)(i % D);
         const long m = i / D;
         const long b = m / L;
         const float th = __fdiv_rn((float)t[b], 1000.f);
-        const float tv = fmaf(w[d], th, bias[d]);
-        float v = x[i] + tv;
-        if (dr.thr != 0u) v = tdm_keep(dr, (unsigned long long)i) ? v * dr.scale : 0.f;
-        h0[i] = v;
+        const float4 w4 = *reinterpret_cast<const float4*>(w + d), b4 = *reinterpret_cast<const float4*>(bias + d);
+        const float4 tv = make_float4(fmaf(w4.x, th, b4.x), fmaf(w4.y, th, b4.y), fmaf(w4.z, th, b4.z), fmaf(w4.w, th, b4.w));
+        const float4 xv = *reinterpret_cast<const float4*>(x + i);
+        float4 v = make_float4(xv.x + tv.x, xv.y + tv.y, xv.z + tv.z, xv.w + tv.w);
+        if (dr.thr != 0u) {
+            v.x = tdm_keep(dr, (unsigned long long)i) ? v.x * dr.scale : 0.f;
+            v.y = tdm_keep(dr, (unsigned long long)i + 1) ? v.y * dr.scale : 0.f;
+            v.z = tdm_keep(dr, (unsigned long long)i + 2) ? v.z * dr.scale : 0.f;
+            v.w = tdm_keep(dr, (unsigned long long)i + 3) ? v.w * dr.scale : 0.f;
+        }
+        *reinterpret_cast<float4*>(h0 + i) = v;
+        if (h16 != nullptr) tdm_store_s16_4(h16, m, D, d, v);
         if (m - b * L == 0) {
-            tb[b * D + d] = tv;
+            *reinterpret_cast<float4*>(tb + b * D + d) = tv;
             if (d == 0) that[b] = th;
         }
     }
@@ -367,9 +385,9 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(const float* __restri
 // y = LN(x + r) * gamma + beta, one wavefront per row, row cached in registers (D <= 1024)
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float* __restrict__ y, float* __restrict__ s_out,
-                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out, long M,
-                                                     int D, float eps) {
+                                                     float* __restrict__ y, float* __restrict__ y16,
+                                                     float* __restrict__ s_out, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, long M, int D, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long row = (long)blockIdx.x * 4 + wave;
     if (row >= M) return;
@@ -410,6 +428,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             o.z = (buf[q].z - mean) * rstd * g.z + be.z;
             o.w = (buf[q].w - mean) * rstd * g.w + be.w;
             reinterpret_cast<float4*>(y + row * D)[c4] = o;
+            if (y16 != nullptr) tdm_store_s16_4(y16, row, D, c4 * 4, o);
             if (s_out != nullptr) reinterpret_cast<float4*>(s_out + row * D)[c4] = buf[q];
         }
     }
@@ -428,7 +447,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ s, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      float* __restrict__ ds, float* __restrict__ ds_drop,
-                                                     float* __restrict__ part, long M, int D, DropArgs dr) {
+                                                     float* __restrict__ op16, float* __restrict__ part, long M, int D,
+                                                     DropArgs dr) {
     constexpr int R = 4 / NQ;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int D4 = D >> 2;
@@ -502,14 +522,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                     o.z = rs[rr] * (dd.z * gm[q].z - c1[rr] - x.z * c2[rr]);
                     o.w = rs[rr] * (dd.w * gm[q].w - c1[rr] - x.w * c2[rr]);
                     reinterpret_cast<float4*>(ds + row * D)[c4] = o;
-                    if (ds_drop != nullptr) {
+                    if (dr.thr != 0u) {
                         const unsigned long long e = (unsigned long long)row * D + c4 * 4;
                         o.x = tdm_keep(dr, e) ? o.x * dr.scale : 0.f;
                         o.y = tdm_keep(dr, e + 1) ? o.y * dr.scale : 0.f;
                         o.z = tdm_keep(dr, e + 2) ? o.z * dr.scale : 0.f;
                         o.w = tdm_keep(dr, e + 3) ? o.w * dr.scale : 0.f;
-                        reinterpret_cast<float4*>(ds_drop + row * D)[c4] = o;
+                        if (ds_drop != nullptr) reinterpret_cast<float4*>(ds_drop + row * D)[c4] = o;
                     }
+                    if (op16 != nullptr) tdm_store_s16_4(op16, row, D, c4 * 4, o);   // the linear layer's gradient operand
                     cacc[q].x += o.x; cacc[q].y += o.y; cacc[q].z += o.z; cacc[q].w += o.w;
                 }
             }
@@ -657,8 +678,15 @@ int attn_launch(int which, const float* qkv, const float* o, const float* lse, c
     return 0;
 }
 int attn_dispatch(int which, int hd, const float* qkv, const float* o, const float* lse, const float* dO, float* out,
-                  float* aux, long B, int L, int D, int H, DropArgs dr, hipStream_t st) {
-    if (g_attn_mode == 2) return tdm_launch_attn_bf16(which, hd, qkv, o, lse, dO, out, aux, B, L, D, H, dr, st);
+                  float* aux, long B, int L, int D, int H, DropArgs dr, hipStream_t st, float* out16 = nullptr) {
+    if (g_attn_mode == 2)   // writes the S16 twin itself (and skips the fp32 gradient nobody reads)
+        return tdm_launch_attn_bf16(which, hd, qkv, o, lse, dO, (which != 0 && out16 != nullptr) ? nullptr : out, out16, aux, B, L, D,
+                                    H, dr, st);
+    if (out16 != nullptr) {   // the fp32 cross-check kernels: fp32 result, then one split pass (after the dK/dV launch)
+        TDM_TRY(attn_dispatch(which, hd, qkv, o, lse, dO, out, aux, B, L, D, H, dr, st, nullptr));
+        if (which == 1) return 0;
+        return tdm_launch_split_s16(out, out16, B * L * (long)(which == 0 ? D : 3 * D), st);
+    }
     if (g_attn_mode == 1) return tdm_launch_attn_mfma(which, hd, qkv, o, lse, dO, out, aux, B, L, D, H, dr, st);
     switch (hd) {
         case 8: return attn_launch<8>(which, qkv, o, lse, dO, out, aux, B, L, D, H, dr, st);
@@ -670,27 +698,38 @@ int attn_dispatch(int which, int hd, const float* qkv, const float* o, const flo
     return 1;
 }
 
-// Y[M][N] = dropout(relu(X[M][K] W[N][K]^T + bias (+res)))
-int linear_fwd(const float* X, const float* W, const float* bias, const float* res, float* Y, long M, int N, int K,
-               int relu, DropArgs dr, hipStream_t st) {
+// Pre-split (S16) operands for the bf16 GEMMs: the producers of every GEMM operand (time-bias add, LayerNorm forward /
+// backward, attention, the FFN GEMM epilogues, the weight transposes) write an S16 twin — or, where nothing else reads the
+// fp32 tensor (the FFN hidden activation f1 and its gradient, d(qkv)), ONLY the S16 form — and the GEMM loaders copy 16-byte
+// pieces into LDS instead of converting: a row panel is re-read by N / 128 column tiles and by the weight-gradient GEMM, the
+// split happens once.  Needs D and the FFN width to be multiples of 16; otherwise (and in the fp32 GEMM mode) the fp32 path.
+inline bool tt_use16(int D, int F) { return g_gemm_mode != 0 && (D % 16) == 0 && (F % 16) == 0; }
+
+// Y[M][N] = dropout(relu(X[M][K] W[N][K]^T + bias (+res)));  s16: X and W are S16;  Y16: S16 twin of Y (Y may be nullptr)
+int linear_fwd(const float* X, const float* W, const float* bias, const float* res, float* Y, float* Y16, bool s16, long M,
+               int N, int K, int relu, DropArgs dr, hipStream_t st) {
     GemmArgs g{};
     g.A = X; g.a_rs = K; g.a_cs = 1;
     g.B = W; g.b_rs = 1; g.b_cs = K;
-    g.C = Y; g.c_rs = N; g.bias = bias; g.res = res; g.relu = relu; g.M = (int)M; g.N = N; g.K = K; g.splitk = 1;
+    g.C = Y; g.C16 = Y16; g.s16_in = s16 ? 1 : 0;
+    g.c_rs = N; g.bias = bias; g.res = res; g.relu = relu; g.M = (int)M; g.N = N; g.K = K; g.splitk = 1;
     g.drop = dr;
     if (g_gemm_mode != 0) return tdm_launch_gemm_nt_bf16(g, g_gemm_mode == 1 ? 3 : 1, st);
     return tdm_launch_gemm(g, st);
 }
 // dX[M][K] = dY[M][N] W[N][K] (+res), then dX = gate > 0 ? dX * gate_scale : 0 (ReLU / FFN-dropout backward)
+// s16: dY and the gate are S16, the transposed weight is built as S16;  dX16: S16 twin of dX (dX may be nullptr)
 int linear_dgrad(const float* dY, const float* W, float* wT, const float* res, const float* gate, float gate_scale,
-                 float* dX, long M, int N, int K, hipStream_t st) {
+                 float* dX, float* dX16, bool s16, long M, int N, int K, hipStream_t st) {
     GemmArgs g{};
     g.gate = gate; g.gate_scale = gate_scale;
     if (g_gemm_mode != 0) {   // dX = dY . (W^T)^T as a K-contiguous (NT) product on the transposed weight
-        TDM_TRY(tdm_launch_transpose(W, wT, N, K, st));
+        if (s16) TDM_TRY(tdm_launch_transpose_s16(W, wT, N, K, st));
+        else TDM_TRY(tdm_launch_transpose(W, wT, N, K, st));
         g.A = dY; g.a_rs = N; g.a_cs = 1;
         g.B = wT; g.b_rs = 1; g.b_cs = N;
-        g.C = dX; g.c_rs = K; g.res = res; g.M = (int)M; g.N = K; g.K = N; g.splitk = 1;
+        g.C = dX; g.C16 = dX16; g.s16_in = s16 ? 1 : 0; g.gate_s16 = (s16 && gate != nullptr) ? 1 : 0;
+        g.c_rs = K; g.res = res; g.M = (int)M; g.N = K; g.K = N; g.splitk = 1;
         return tdm_launch_gemm_nt_bf16(g, g_gemm_mode == 1 ? 3 : 1, st);
     }
     g.A = dY; g.a_rs = N; g.a_cs = 1;
@@ -699,8 +738,8 @@ int linear_dgrad(const float* dY, const float* W, float* wT, const float* res, c
     return tdm_launch_gemm(g, st);
 }
 // dW[N][K] partials = dY[M][N]^T X[M][K], split over M into SPLITK slabs at slab_region; bias_region != nullptr
-// (bf16 modes): the same kernel also writes db partials = per-split column sums of dY, [SPLITK][N]
-int linear_wgrad(const float* dY, const float* X, float* slab_region, float* bias_region, long M, int N, int K,
+// (bf16 modes): the same kernel also writes db partials = per-split column sums of dY, [SPLITK][N];  s16: dY and X are S16
+int linear_wgrad(const float* dY, const float* X, float* slab_region, float* bias_region, bool s16, long M, int N, int K,
                  hipStream_t st) {
     GemmArgs g{};
     g.A = dY; g.a_rs = 1; g.a_cs = N;
@@ -709,6 +748,7 @@ int linear_wgrad(const float* dY, const float* X, float* slab_region, float* bia
     g.c_split_stride = (long)N * K;
     if (g_gemm_mode != 0) {
         g.colsum = bias_region; g.colsum_stride = (N + 63) & ~63;
+        g.s16_in = s16 ? 1 : 0;
         return tdm_launch_gemm_tn_bf16(g, g_gemm_mode == 1 ? 3 : 1, st);
     }
     return tdm_launch_gemm(g, st);
@@ -727,19 +767,19 @@ int bias_grad(const float* dY, float* part, float* db, long M, int N, hipStream_
 // LayerNorm backward; G = gradient buffer base: dgamma/dbeta go to G[gamma_off .. +2D), the column sums of the
 // (dropped) input gradient to G[bias_off .. +D) (the bias gradient of the linear layer feeding the residual add)
 int ln_bwd(const float* dy, const float* dy2, const float* s, const float* mean, const float* rstd, const float* gamma,
-           float* ds, float* ds_drop, DropArgs dr, float* part, float* G, long gamma_off, long bias_off, long M, int D,
-           hipStream_t st) {
+           float* ds, float* ds_drop, float* op16, bool dropping, DropArgs dr, float* part, float* G, long gamma_off,
+           long bias_off, long M, int D, hipStream_t st) {
     const int NQ = D <= 256 ? 1 : (D <= 512 ? 2 : 4);
     const int R = 4 / NQ;
     long nb = (M + 4 * R - 1) / (4 * R);
     if (nb > LN_SLABS) nb = LN_SLABS;
-    if (ds_drop == nullptr) dr = DropArgs{};
+    if (!dropping) dr = DropArgs{};
     if (NQ == 1)
-        hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, dy, dy2, s, mean, rstd, gamma, ds, ds_drop, part, M, D, dr);
+        hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, dy, dy2, s, mean, rstd, gamma, ds, ds_drop, op16, part, M, D, dr);
     else if (NQ == 2)
-        hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3((unsigned)nb), dim3(256), 0, st, dy, dy2, s, mean, rstd, gamma, ds, ds_drop, part, M, D, dr);
+        hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3((unsigned)nb), dim3(256), 0, st, dy, dy2, s, mean, rstd, gamma, ds, ds_drop, op16, part, M, D, dr);
     else
-        hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3((unsigned)nb), dim3(256), 0, st, dy, dy2, s, mean, rstd, gamma, ds, ds_drop, part, M, D, dr);
+        hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3((unsigned)nb), dim3(256), 0, st, dy, dy2, s, mean, rstd, gamma, ds, ds_drop, op16, part, M, D, dr);
     TDM_CHECK_LAUNCH("ln_bwd");
     ReduceArgs ra{};
     ra.nsec = 2;
@@ -747,10 +787,10 @@ int ln_bwd(const float* dy, const float* dy2, const float* s, const float* mean,
     ra.sec[1].off = (int)bias_off; ra.sec[1].len = D; ra.sec[1].nslab = (int)nb; ra.sec[1].src_delta = 2L * D - bias_off;
     return tdm_launch_reduce(part, 3L * D, ra, G, st);
 }
-int ln_fwd(const float* x, const float* r, const float* gamma, const float* beta, float* y, float* s, float* mean,
+int ln_fwd(const float* x, const float* r, const float* gamma, const float* beta, float* y, float* y16, float* s, float* mean,
            float* rstd, long M, int D, hipStream_t st) {
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, r, gamma, beta, y, s, mean, rstd,
-                       M, D, 1e-5f);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, r, gamma, beta, y, y16, s, mean,
+                       rstd, M, D, 1e-5f);
     TDM_CHECK_LAUNCH("ln_fwd");
     return 0;
 }
@@ -770,24 +810,32 @@ int tt_forward(const float* P, const TTLayout& lay, const float* x, const int64_
                int L, int D, int H, int depth, int F, Drop drop, hipStream_t st) {
     const long M = B * L;
     const DropArgs none{};
+    const bool s16 = tt_use16(D, F);
+    if (s16) TDM_TRY(tdm_launch_split_s16(P, w.P16, lay.total & ~15L, st));   // (the tail past the last weight matrix is biases)
+    const float* PW = s16 ? w.P16 : P;   // weight matrices as GEMM operands
     {
-        long n = M * D;
+        long n = M * D / 4;
         int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
         hipLaunchKernelGGL(add_timebias_kernel, dim3(grid), dim3(256), 0, st, x, t, P + lay.te_w, P + lay.te_b, w.that,
-                           w.tb, w.L[0].hin, B, L, D, drop.site(0));
+                           w.tb, w.L[0].hin, s16 ? w.L[0].hin16 : nullptr, B, L, D, drop.site(0));
         TDM_CHECK_LAUNCH("add_timebias");
     }
     for (int l = 0; l < depth; ++l) {
         const LayerOff& o = lay.L[l];
         const LayerWs& a = w.L[l];
         float* hout = (l + 1 < depth) ? w.L[l + 1].hin : out;
-        TDM_TRY(linear_fwd(a.hin, P + o.in_w, P + o.in_b, nullptr, a.qkv, M, 3 * D, D, 0, none, st));
-        TDM_TRY(attn_dispatch(0, D / H, a.qkv, nullptr, nullptr, nullptr, a.o, a.lse, B, L, D, H, drop.site(1 + 4 * l), st));
-        TDM_TRY(linear_fwd(a.o, P + o.out_w, P + o.out_b, nullptr, w.abuf, M, D, D, 0, drop.site(2 + 4 * l), st));
-        TDM_TRY(ln_fwd(a.hin, w.abuf, P + o.n1_w, P + o.n1_b, a.h1, a.s1, a.mean1, a.rstd1, M, D, st));
-        TDM_TRY(linear_fwd(a.h1, P + o.l1_w, P + o.l1_b, nullptr, a.f1, M, F, D, 1, drop.site(3 + 4 * l), st));
-        TDM_TRY(linear_fwd(a.f1, P + o.l2_w, P + o.l2_b, nullptr, w.abuf, M, D, F, 0, drop.site(4 + 4 * l), st));
-        TDM_TRY(ln_fwd(a.h1, w.abuf, P + o.n2_w, P + o.n2_b, hout, a.s2, a.mean2, a.rstd2, M, D, st));
+        float* hout16 = (s16 && l + 1 < depth) ? w.L[l + 1].hin16 : nullptr;
+        TDM_TRY(linear_fwd(s16 ? a.hin16 : a.hin, PW + o.in_w, P + o.in_b, nullptr, a.qkv, nullptr, s16, M, 3 * D, D, 0, none, st));
+        TDM_TRY(attn_dispatch(0, D / H, a.qkv, nullptr, nullptr, nullptr, a.o, a.lse, B, L, D, H, drop.site(1 + 4 * l), st,
+                              s16 ? a.o16 : nullptr));
+        TDM_TRY(linear_fwd(s16 ? a.o16 : a.o, PW + o.out_w, P + o.out_b, nullptr, w.abuf, nullptr, s16, M, D, D, 0,
+                           drop.site(2 + 4 * l), st));
+        TDM_TRY(ln_fwd(a.hin, w.abuf, P + o.n1_w, P + o.n1_b, a.h1, s16 ? a.h1_16 : nullptr, a.s1, a.mean1, a.rstd1, M, D, st));
+        // the FFN hidden activation: S16 only in the bf16 GEMM modes (read by linear2, its weight gradient and the ReLU gate)
+        TDM_TRY(linear_fwd(s16 ? a.h1_16 : a.h1, PW + o.l1_w, P + o.l1_b, nullptr, s16 ? nullptr : a.f1, s16 ? a.f1 : nullptr, s16,
+                           M, F, D, 1, drop.site(3 + 4 * l), st));
+        TDM_TRY(linear_fwd(a.f1, PW + o.l2_w, P + o.l2_b, nullptr, w.abuf, nullptr, s16, M, D, F, 0, drop.site(4 + 4 * l), st));
+        TDM_TRY(ln_fwd(a.h1, w.abuf, P + o.n2_w, P + o.n2_b, hout, hout16, a.s2, a.mean2, a.rstd2, M, D, st));
     }
     return 0;
 }
@@ -798,41 +846,43 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
     const SlabPlan sp = slab_plan(D, depth, F);
     const bool dropping = drop.p > 0.f;
     const bool fused_bias = g_gemm_mode != 0;   // in_proj / linear1 bias gradients come out of the bf16 wgrad GEMM
+    const bool s16 = tt_use16(D, F);            // GEMM operands pre-split (see tt_use16): S16 twins / S16-only tensors
     const float* gh = dout;  // gradient w.r.t. the current layer's output
     float* gout = nullptr;
     for (int l = depth - 1; l >= 0; --l) {
         const LayerOff& o = lay.L[l];
         const LayerWs& a = w.L[l];
         // LayerNorm 2: hout = LN(h1 + dropout2(f2)); g_s = d(h1) residual part, g2 = d(f2); db2 = colsum(g2)
-        TDM_TRY(ln_bwd(gh, nullptr, a.s2, a.mean2, a.rstd2, P + o.n2_w, w.g_s, dropping ? w.g_d : nullptr,
-                       drop.site(4 + 4 * l), w.part, G, o.n2_w, o.l2_b, M, D, st));
-        const float* g2 = dropping ? w.g_d : w.g_s;
+        TDM_TRY(ln_bwd(gh, nullptr, a.s2, a.mean2, a.rstd2, P + o.n2_w, w.g_s, (dropping && !s16) ? w.g_d : nullptr,
+                       s16 ? w.g16 : nullptr, dropping, drop.site(4 + 4 * l), w.part, G, o.n2_w, o.l2_b, M, D, st));
+        const float* g2 = s16 ? w.g16 : (dropping ? w.g_d : w.g_s);
         // f2 = f1 W2^T + b2, f1 = dropout(relu(z1)): d(z1) = (g2 W2) * [f1 > 0] / (1 - p) in the GEMM epilogue
-        TDM_TRY(linear_wgrad(g2, a.f1, slabs + sp.base[l][3], nullptr, M, D, F, st));
-        TDM_TRY(linear_dgrad(g2, P + o.l2_w, w.wT, nullptr, a.f1, dropping ? drop.site(3 + 4 * l).scale : 1.f, w.g_f, M, D,
-                             F, st));
+        TDM_TRY(linear_wgrad(g2, a.f1, slabs + sp.base[l][3], nullptr, s16, M, D, F, st));
+        TDM_TRY(linear_dgrad(g2, P + o.l2_w, w.wT, nullptr, a.f1, dropping ? drop.site(3 + 4 * l).scale : 1.f, s16 ? nullptr : w.g_f,
+                             s16 ? w.g_f : nullptr, s16, M, D, F, st));
         // z1 = h1 W1^T + b1
         if (!fused_bias) TDM_TRY(bias_grad(w.g_f, w.part, G + o.l1_b, M, F, st));
-        TDM_TRY(linear_wgrad(w.g_f, a.h1, slabs + sp.base[l][2], fused_bias ? slabs + sp.bias_base[l][2] : nullptr, M, F, D,
-                             st));
-        TDM_TRY(linear_dgrad(w.g_f, P + o.l1_w, w.wT, nullptr, nullptr, 1.f, w.g_h1, M, F, D, st));
+        TDM_TRY(linear_wgrad(w.g_f, s16 ? a.h1_16 : a.h1, slabs + sp.base[l][2], fused_bias ? slabs + sp.bias_base[l][2] : nullptr,
+                             s16, M, F, D, st));
+        TDM_TRY(linear_dgrad(w.g_f, P + o.l1_w, w.wT, nullptr, nullptr, 1.f, w.g_h1, nullptr, s16, M, F, D, st));
         // LayerNorm 1: h1 = LN(hin + dropout1(a)); d(h1) = g_h1 (FFN path) + g_s (residual)
-        TDM_TRY(ln_bwd(w.g_h1, w.g_s, a.s1, a.mean1, a.rstd1, P + o.n1_w, w.g_s1, dropping ? w.g_d : nullptr,
-                       drop.site(2 + 4 * l), w.part, G, o.n1_w, o.out_b, M, D, st));
-        const float* g1 = dropping ? w.g_d : w.g_s1;
+        TDM_TRY(ln_bwd(w.g_h1, w.g_s, a.s1, a.mean1, a.rstd1, P + o.n1_w, w.g_s1, (dropping && !s16) ? w.g_d : nullptr,
+                       s16 ? w.g16 : nullptr, dropping, drop.site(2 + 4 * l), w.part, G, o.n1_w, o.out_b, M, D, st));
+        const float* g1 = s16 ? w.g16 : (dropping ? w.g_d : w.g_s1);
         // a = o Wout^T + bout
-        TDM_TRY(linear_wgrad(g1, a.o, slabs + sp.base[l][1], nullptr, M, D, D, st));
-        TDM_TRY(linear_dgrad(g1, P + o.out_w, w.wT, nullptr, nullptr, 1.f, w.g_o, M, D, D, st));
+        TDM_TRY(linear_wgrad(g1, s16 ? a.o16 : a.o, slabs + sp.base[l][1], nullptr, s16, M, D, D, st));
+        TDM_TRY(linear_dgrad(g1, P + o.out_w, w.wT, nullptr, nullptr, 1.f, w.g_o, nullptr, s16, M, D, D, st));
         // attention
         const DropArgs da = drop.site(1 + 4 * l);
-        TDM_TRY(attn_dispatch(1, D / H, a.qkv, a.o, a.lse, w.g_o, w.g_qkv, w.Dvec, B, L, D, H, da, st));
-        TDM_TRY(attn_dispatch(2, D / H, a.qkv, nullptr, a.lse, w.g_o, w.g_qkv, w.Dvec, B, L, D, H, da, st));
+        TDM_TRY(attn_dispatch(1, D / H, a.qkv, a.o, a.lse, w.g_o, w.g_qkv, w.Dvec, B, L, D, H, da, st, s16 ? w.g_qkv16 : nullptr));
+        TDM_TRY(attn_dispatch(2, D / H, a.qkv, nullptr, a.lse, w.g_o, w.g_qkv, w.Dvec, B, L, D, H, da, st, s16 ? w.g_qkv16 : nullptr));
         // qkv = hin Win^T + bin ; d(hin) = g_qkv Win + g_s1 (residual)
         if (!fused_bias) TDM_TRY(bias_grad(w.g_qkv, w.part, G + o.in_b, M, 3 * D, st));
-        TDM_TRY(linear_wgrad(w.g_qkv, a.hin, slabs + sp.base[l][0], fused_bias ? slabs + sp.bias_base[l][0] : nullptr, M,
-                             3 * D, D, st));
+        const float* gq = s16 ? w.g_qkv16 : w.g_qkv;
+        TDM_TRY(linear_wgrad(gq, s16 ? a.hin16 : a.hin, slabs + sp.base[l][0], fused_bias ? slabs + sp.bias_base[l][0] : nullptr, s16,
+                             M, 3 * D, D, st));
         gout = (l == 0 && dx != nullptr) ? dx : w.g_h;   // layer 0: this is d(loss)/d(dropout0(x + time bias))
-        TDM_TRY(linear_dgrad(w.g_qkv, P + o.in_w, w.wT, w.g_s1, nullptr, 1.f, gout, M, 3 * D, D, st));
+        TDM_TRY(linear_dgrad(gq, P + o.in_w, w.wT, w.g_s1, nullptr, 1.f, gout, nullptr, s16, M, 3 * D, D, st));
         gh = gout;
     }
     if (dropping) {   // input dropout: d(x + time bias) = mask * g / (1 - p)
@@ -1015,6 +1065,12 @@ int tdm_dropout_keep_u8(float p_drop, uint64_t seed, int site, int64_t idx0, int
     return 0;
 }
 
+// out (S16, tdm_s16.h) = split of in, n % 16 == 0 elements: every 16 consecutive floats become hi[16] | lo[16] bf16
+int tdm_split_s16_f32(const float* in, float* out, int64_t n, void* stream) {
+    TDM_REQUIRE(in != nullptr && out != nullptr && n >= 0, "split_s16: bad arguments");
+    return tdm_launch_split_s16(in, out, (long)n, (hipStream_t)stream);
+}
+
 int tdm_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float* C,
                  int64_t c_rs, const float* bias, const float* res, int M, int N, int K, int relu, int splitk,
                  int64_t c_split_stride, void* stream) {
@@ -1023,12 +1079,18 @@ int tdm_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int
     g.bias = bias; g.res = res; g.M = M; g.N = N; g.K = K; g.relu = relu & 1; g.splitk = splitk;
     g.ablate = (relu >> 8) & 15;   // timing diagnostics only
     g.c_split_stride = c_split_stride;
+    // relu & 2: both operands are S16 tensors (tdm_split_s16_f32); relu & 4: C is written as an S16 tensor (NT form).
+    // bf16 GEMM modes only.
+    g.s16_in = (relu >> 1) & 1;
+    if (relu & 4) { g.C16 = C; g.C = nullptr; }
+    TDM_REQUIRE((relu & 6) == 0 || g_gemm_mode != 0, "gemm: S16 operands / output exist in the bf16 GEMM modes only");
     if (g_gemm_mode != 0) {   // route the K-contiguous (NT) and token-major (TN) forms through the bf16 kernels
         const int nprod = g_gemm_mode == 1 ? 3 : 1;
         if (a_cs == 1 && b_rs == 1 && splitk <= 1 && (c_rs % 4) == 0 && (K % 4) == 0)
             return tdm_launch_gemm_nt_bf16(g, nprod, (hipStream_t)stream);
-        if (a_rs == 1 && b_cs == 1 && bias == nullptr && res == nullptr && !relu && (M % 4) == 0 && (N % 4) == 0)
+        if (a_rs == 1 && b_cs == 1 && bias == nullptr && res == nullptr && !(relu & 1) && (M % 4) == 0 && (N % 4) == 0)
             return tdm_launch_gemm_tn_bf16(g, nprod, (hipStream_t)stream);
+        TDM_REQUIRE((relu & 6) == 0, "gemm: S16 operands / output need the NT or TN form");
     }
     return tdm_launch_gemm(g, (hipStream_t)stream);
 }
