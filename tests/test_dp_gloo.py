@@ -176,3 +176,36 @@ def test_global_batch_count():
     from tinydiffusionmodels_amd import dp
     assert [dp.global_batch_count(20, it, 3, 3) for it in range(4)] == [9, 9, 2, 0]
     assert [dp.global_batch_count(60000, it, 128, 8) for it in (0, 57, 58, 59)] == [1024, 1024, 608, 0]
+
+
+def _rows_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from tinydiffusionmodels_amd import dp
+    dp.init_from_env("gloo")
+    V, D = 997, 16
+    g = torch.Generator().manual_seed(50 + rank)
+    ids = torch.randint(0, V, (3 + rank, 7), generator=g)            # ragged: the ranks hold different numbers of tokens
+    if rank == 2:
+        ids = ids[:0]                                                # a rank with an empty shard still joins the collectives
+    grad = torch.zeros(V, D)
+    grad.index_add_(0, ids.reshape(-1), torch.randn(ids.numel(), D, generator=g))   # an embedding gradient: token rows only
+    dense = grad.clone()
+    dist.all_reduce(dense, op=dist.ReduceOp.SUM)
+    u = dp.allreduce_rows_(grad, ids)
+    torch.save({"rows": grad, "dense": dense, "u": u, "ids": ids}, os.path.join(out_dir, f"rows{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_embedding_gradient_rowwise_allreduce_equals_dense(tmp_path):
+    """dp.allreduce_rows_ (the embedding-table gradient of the text train step): exchanging only the
+    union of the ranks' token rows gives bit-for-bit the dense all-reduce, with ragged and empty shards (world 3)."""
+    mp.spawn(_rows_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    r = [torch.load(tmp_path / f"rows{k}.pt") for k in range(3)]
+    union = torch.unique(torch.cat([x["ids"].reshape(-1) for x in r]))
+    for x in r:
+        assert torch.equal(x["rows"], x["dense"])
+        assert torch.equal(x["rows"], r[0]["rows"])
+        assert x["u"] == union.numel()

@@ -69,3 +69,43 @@ def test_two_rank_train_step_equals_global_batch_step(tmp_path):
     assert step > 5e-4                                              # the step really moved the weights (lr = 1e-3)
     close = ((r0["p1"] - ref).abs() < 0.05 * 1e-3).float().mean().item()
     assert close > 0.98, close                                      # sign flips of ~zero gradients aside
+
+
+def _text_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from tinydiffusionmodels_amd import dp
+    from tinydiffusionmodels_amd import shakespeare as S
+    dp.init_from_env("gloo")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7 + rank)                    # rank-dependent init and noise: train() must broadcast and average
+    V, D, L = 211, 32, 16
+    model = S.TinyTransformer(D, dropout=0.0).to(dev)
+    emb, rnd = S.LearnedEmbedding(V, D).to(dev), S.LearnedRounding(D, V).to(dev)
+    g = torch.Generator().manual_seed(100 + rank)
+    # each rank sees only token ids of its own residue class mod 2 (so the embedding rows a rank touches differ)
+    data = [(torch.randint(0, V // 2, (4, L), generator=g) * 2 + rank) for _ in range(3)]
+    e0 = emb.embeddings.weight.detach().clone()
+    S.train(model, rnd, emb, data, data[:1], dev, ckpt_path=os.path.join(out_dir, f"ckpt{rank}.pth"), epochs=1, lr=1e-3,
+            use_lr_scheduling=False)
+    torch.cuda.synchronize()
+    torch.save({"flat": model.flat.detach().cpu(), "emb": emb.embeddings.weight.detach().cpu(), "emb0": e0.cpu(),
+                "rw": rnd.decoder.weight.detach().cpu()},
+               os.path.join(out_dir, f"t{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_text_train_keeps_replicas_identical(tmp_path):
+    """shakespeare.train() under torch.distributed (2 ranks, real HIP kernels, gloo, one shared GPU): rank 0's weights are
+    broadcast, every step averages the gradients — dense for the denoiser / rounding head, row-wise for the embedding table
+    (dp.allreduce_rows_) — so both replicas end bit-identical although each saw different tokens and drew different noise,
+    and embedding rows that only the OTHER rank's tokens touch have moved on this rank too."""
+    mp.spawn(_text_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "t0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "t1.pt", weights_only=True)
+    for k in ("flat", "emb", "rw"):
+        assert torch.equal(r0[k], r1[k]), k
+    moved = (r0["emb"] - r0["emb0"]).abs().amax(dim=1) > 0
+    assert moved[0::2].any() and moved[1::2].any()       # even rows: rank 0's tokens; odd rows: rank 1's

@@ -169,6 +169,35 @@ def allreduce_grads_(flat_grads: torch.Tensor) -> float:
     return 1.0 / world
 
 
+def allreduce_rows_(grad: torch.Tensor, ids: torch.Tensor) -> int:
+    """Row-wise SUM over ranks of an embedding gradient grad[V][D] (row N1: nn.Embedding's gradient, src/shakespeare.py:60-86,
+    is zero outside the token rows of the batch): only the rows some rank touched travel — the ranks exchange their
+    unique token ids (two small all-gathers), reduce the union's rows as one dense [U][D] buffer, and scatter it back.
+    Exact: a row no rank touched is zero everywhere.  `ids`: this rank's token ids (any shape).  Returns U.
+    At V = 50,257, D = 256 the dense gradient is 51 MB per step; a 32 x 128-token batch touches at most 4,096 rows (4 MB)."""
+    _, world = world_info()
+    V = grad.shape[0]
+    if world == 1:
+        return int(torch.unique(ids).numel())
+    local = torch.unique(ids.reshape(-1).to(grad.device))
+    n = torch.tensor([local.numel()], dtype=torch.int64, device=grad.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    cap = int(max(int(s.item()) for s in sizes))
+    padded = torch.full((cap,), V, dtype=torch.int64, device=grad.device)     # V = "no row"
+    padded[:local.numel()] = local
+    gathered = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(gathered, padded)
+    union = torch.unique(torch.cat(gathered))                                 # sorted: the same order on every rank
+    union = union[union < V]
+    if union.numel() == 0:
+        return 0
+    buf = grad.index_select(0, union).contiguous()
+    allreduce_grads_(buf.view(-1))
+    grad.index_copy_(0, union, buf)
+    return int(union.numel())
+
+
 def broadcast_params_(flat_params: torch.Tensor, src: int = 0) -> None:
     _, world = world_info()
     if world > 1:

@@ -616,10 +616,28 @@ def train(model, rounding_fn, embedding_fn, data_loader, val_loader, device, ckp
     decaying rounding weight, validation pass, early stopping, `_best.pth`, final
     checkpoint dict).  Every per-step tensor op is native: embedding gather / scatter-add, q_sample and its
     x0-gradient, denoiser forward / backward, MSE, fused rounding cross-entropy, AdamW (NativeAdamW) — autograd only
-    chains the bridges."""
+    chains the bridges.  Under torch.distributed (one process per GPU, each with its own shard of the loader) the
+    replicas start from rank 0's weights and every step averages the gradients: dense all-reduces for the denoiser and
+    the rounding head, a ROW-WISE one for the embedding table (dp.allreduce_rows_: only the batch's token rows move)."""
     params = list(model.parameters()) + list(rounding_fn.parameters())
     if use_learned_embeddings:
         params += list(embedding_fn.parameters())
+    _, world = dp.world_info()
+    emb_w = embedding_fn.embeddings.weight if (use_learned_embeddings and hasattr(embedding_fn, "embeddings")) else None
+    if world > 1:
+        for p_ in params:
+            dp.broadcast_params_(p_.data, src=0)
+
+    def sync_grads(token_ids):
+        """Average the gradients over the ranks (world > 1)."""
+        for p_ in params:
+            if p_.grad is None:
+                continue
+            if p_ is emb_w:
+                dp.allreduce_rows_(p_.grad, token_ids)
+            else:
+                dp.allreduce_grads_(p_.grad.view(-1))
+            p_.grad.mul_(1.0 / world)
     optim = NativeAdamW(params, lr=lr, weight_decay=weight_decay)      # torch.optim.AdamW's update on tdm_adamw_flat_f32
     total_steps = len(data_loader) * epochs
     scheduler = get_cosine_schedule_with_warmup(optim, warmup_steps, total_steps) if use_lr_scheduling else None
@@ -644,7 +662,10 @@ def train(model, rounding_fn, embedding_fn, data_loader, val_loader, device, ckp
         for token_ids in data_loader:
             token_ids = token_ids.to(device)
             diff, rnd, total = losses(token_ids, rw)
-            optim.zero_grad(); total.backward(); optim.step()
+            optim.zero_grad(); total.backward()
+            if world > 1:
+                sync_grads(token_ids)
+            optim.step()
             if scheduler is not None:
                 scheduler.step()
             tr += torch.stack([diff.detach(), rnd.detach(), total.detach()])
