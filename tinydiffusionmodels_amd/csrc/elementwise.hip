@@ -360,7 +360,9 @@ __global__ __launch_bounds__(TG_BLOCK) void time_grad_kernel(TimeGradJobs jb, co
     const int job = blockIdx.x;
     const float* __restrict__ S = jb.S[job];
     const int C = jb.C[job];
-    const int c = threadIdx.x % C, g = threadIdx.x / C, ng = TG_BLOCK / C;
+    // (C need not divide the block: the threads past the last whole batch slice start beyond the batch and idle)
+    const int c = threadIdx.x % C, ng = TG_BLOCK / C;
+    const int g = (int)threadIdx.x / C < ng ? (int)threadIdx.x / C : B;
     float aw = 0.f, ab = 0.f;
     int b = g;
     for (; b + 7 * ng < B; b += 8 * ng) {
@@ -1034,7 +1036,7 @@ int tdm_launch_time_grad_multi2(const float* const* S, const float* const* S2, f
     TimeGradJobs jb{};
     TDM_REQUIRE(n >= 1 && n <= 4, "time_grad: %d jobs", n);
     for (int i = 0; i < n; ++i) {
-        TDM_REQUIRE(C[i] > 0 && EW_BLOCK % C[i] == 0, "time_grad: C=%d must divide %d", C[i], EW_BLOCK);
+        TDM_REQUIRE(C[i] > 0 && C[i] <= TG_BLOCK, "time_grad: C=%d must be in 1..%d", C[i], TG_BLOCK);
         jb.S[i] = S[i]; jb.d_tw[i] = d_tw[i]; jb.d_tb[i] = d_tb[i]; jb.C[i] = C[i];
         jb.S2[i] = (S2 != nullptr) ? S2[i] : nullptr;
         jb.d_b[i] = (d_b != nullptr) ? d_b[i] : nullptr;

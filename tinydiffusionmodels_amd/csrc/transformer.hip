@@ -894,12 +894,7 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
     // time embedding: hin0 = x + (w*that + b)
     hipLaunchKernelGGL(seqsum_kernel, dim3((unsigned)B), dim3(256), 0, st, gh, w.Sb, L, D);
     TDM_CHECK_LAUNCH("seqsum");
-    if (256 % D == 0) {
-        TDM_TRY(tdm_launch_time_grad(w.Sb, w.that, G + lay.te_w, G + lay.te_b, (int)B, D, st));
-    } else {
-        tdm_set_error("transformer backward: D=%d must divide 256 for the time-embedding gradient kernel", D);
-        return 1;
-    }
+    TDM_TRY(tdm_launch_time_grad(w.Sb, w.that, G + lay.te_w, G + lay.te_b, (int)B, D, st));
     // sum the split-K weight-gradient slabs
     ReduceArgs ra{};
     int n = 0;
