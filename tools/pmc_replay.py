@@ -48,15 +48,21 @@ def main():
                                                     _lib.ptr(st.deps), _lib.ptr(gs), _lib.ptr(st.ws.ws), _lib.ptr(slabs), B, lid,
                                                     _lib.stream()), "replay")
         torch.cuda.synchronize()
-    # text denoiser FFN1 shape on the NT bf16x3 GEMM (gemm_nt_bf16_kernel<3,...>)
+    # text denoiser FFN1 shape on the NT bf16x3 GEMM in its in-pipeline form (gemm_nt_bf16_kernel<3,...,true>): pre-split
+    # (S16) operands, ReLU, S16 output — linear1 of the encoder layer
     M, N, K = 32768, 2048, 256
     A = [torch.randn(M, K, device=dev) for _ in range(2)]
     Bm = torch.randn(N, K, device=dev) * 0.05
+    A16 = [torch.empty_like(a) for a in A]
+    B16 = torch.empty_like(Bm)
+    for a, a16 in zip(A, A16):
+        _lib.check(L.tdm_split_s16_f32(_lib.ptr(a), _lib.ptr(a16), a.numel(), _lib.stream()))
+    _lib.check(L.tdm_split_s16_f32(_lib.ptr(Bm), _lib.ptr(B16), Bm.numel(), _lib.stream()))
     bias = torch.zeros(N, device=dev)
     C = [torch.empty(M, N, device=dev) for _ in range(2)]
     for i in range(args.iters):
-        _lib.check(L.tdm_gemm_f32(_lib.ptr(A[i & 1]), K, 1, _lib.ptr(Bm), 1, K, _lib.ptr(C[i & 1]), N, _lib.ptr(bias), None, M, N, K, 1, 1, 0,
-                                  _lib.stream()))
+        _lib.check(L.tdm_gemm_f32(_lib.ptr(A16[i & 1]), K, 1, _lib.ptr(B16), 1, K, _lib.ptr(C[i & 1]), N, _lib.ptr(bias), None, M, N, K,
+                                  1 | 2 | 4, 1, 0, _lib.stream()))
     torch.cuda.synchronize()
 
 
