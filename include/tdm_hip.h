@@ -257,7 +257,9 @@ int tdm_conv_wgrad_nhwc_s16_f32(const float* in, const float* tb, const float* d
  * registers by forward and backward, so a backward call must receive the p_drop and
  * seed of its forward.  Parameters: ONE flat fp32 buffer in the reference's
  * state_dict order and native layouts (tdm_tt_param_offsets: 12 tensors per
- * layer, then time_emb.weight, time_emb.bias; last entry = total).          */
+ * layer, then time_emb.weight, time_emb.bias; last entry = total).  params, x, out and
+ * ws must be 64-byte aligned (the bf16 GEMM modes keep pre-split copies of the GEMM
+ * operands — "S16", see tdm_split_s16_f32 — in ws when D and ffn are multiples of 16). */
 int64_t tdm_tt_param_count(int D, int depth, int ffn);
 int tdm_tt_param_offsets(int D, int depth, int ffn, int64_t* offs);
 int64_t tdm_tt_workspace_floats(int64_t B, int L, int D, int H, int depth, int ffn, int training);
