@@ -710,7 +710,7 @@ __global__ __launch_bounds__(WS_THREADS) void conv_ws_kernel(ConvArgs ka, int nt
     int nstamp = 0;
     auto stamp = [&](int role, int tag) __attribute__((always_inline)) {
         if (a.ablate & 1024) {
-            if (lane == 0 && (wave == 0 || wave == 8 || wave == 12) && nstamp < 64)
+            if (lane == 0 && (wave == 0 || wave == 8) && nstamp < 64)
                 gstore<long long>(reinterpret_cast<long long*>(a.aux + (long)a.B * G::H * G::W * N) + ((long)blockIdx.x * 3 + role) * 64 + nstamp,
                                   ((long long)tag << 56) | ((long long)__builtin_readcyclecounter() & 0x00ffffffffffffffll));
             ++nstamp;
@@ -823,108 +823,70 @@ __global__ __launch_bounds__(WS_THREADS) void conv_ws_kernel(ConvArgs ka, int nt
         return;
     }
 
-    if (wave < 12) {
-    // ------------------------------- loaders (waves 8..11): global -> registers -> operand buffers -------------------------------
-    const int ptid = tid - 512, pw = wave - 8;
-    // TWO register sets (chunk s lives in set s & 1): a chunk is requested two steps before it is written to LDS — with one
-    // step of distance every step waited out the HBM latency (the same finding as in the one-role kernel at N = 32)
-    struct LSet { int goff[NPINv]; int plan_tile, plan_src; uint4 pin[NPINv]; };
-    LSet L0, L1;
-    L0.plan_tile = L0.plan_src = L1.plan_tile = L1.plan_src = -1;
-    int* const rowtab = reinterpret_cast<int*>(lds + 2 * OPB + Cf::TB) + pw * 32;
+    // ------------------------------- helpers (waves 8..15): loaders AND the epilogue of the previous tile -------------------------------
+    // Every helper wave moves 1/8 of each K chunk (global -> registers -> operand buffer, two register sets: a chunk is requested
+    // two steps before it is written to LDS) and walks ONE consumer block of the previous tile, half of it per step.  A single
+    // wave issues one vector instruction per ~4 cycles at best, and an epilogue walk is ~220 of them + ~70 scalar: with four
+    // dedicated walker waves the tile took as long as their two walks (tools/ws_probe.py), with eight waves sharing both jobs
+    // every role fits inside the consumers' two MFMA phases.  The walk's inputs (residual / mask / rank-1 input) are requested
+    // right after the half-walk that frees their registers, i.e. a whole tile ahead: on gfx9 loads and stores retire through one
+    // in-order counter, so a load requested just before its use would also wait for the acknowledgements of the stores in between.
     static_assert(!SKIP, "the fused skip conv (six K chunks of weights) stays on the one-role kernel");
-    struct TileGeo { int m0, tb0, ty0, nrows; };
-    auto geo = [&](int k) __attribute__((always_inline)) {
-        TileGeo t;
-        t.m0 = (slot + k * G_) * TILE_PX;
-        const int mlast = min(t.m0 + TILE_PX - 1, Mtot - 1);
-        t.tb0 = t.m0 / (G::H * G::W);
-        t.ty0 = (t.m0 - t.tb0 * (G::H * G::W)) / G::W;
-        t.nrows = padded_row<HW>(mlast) - (t.tb0 * G::HP + t.ty0) + 2;
-        return t;
-    };
-    auto prefetch = [&](LSet& Ls, int s_) __attribute__((always_inline)) {   // global -> registers: K chunk (s_ % nchunks) of tile (s_ / nchunks)
-        const int k = s_ / nchunks, c = s_ - k * nchunks;
-        const int si = (c >= nc0) ? 1 : 0;
-        const int ch = si ? c - nc0 : c;
-        const PinnedSrc s = a.src(si);
-        const int up = s.up, Hs = G::H >> up, Ws = G::W >> up;
-        if (Ls.plan_tile != k || Ls.plan_src != si) {
-            const TileGeo t = geo(k);
-            if (lane < 32) {
-                int py = t.ty0 + lane, b = t.tb0;
-                if (py >= G::HP) { py -= G::HP; ++b; }
-                if (HW == 14 && py >= G::HP) { py -= G::HP; ++b; }
-                const bool ok = lane < t.nrows && py >= 1 && py <= G::H && b < a.B;
-                rowtab[lane] = ok ? __mul24(__mul24(__mul24(b, Hs) + ((py - 1) >> up), Ws), s.C) * 4 : (int)0x80000000;
-            }
-            int pt = ptid;
-            asm volatile("" : "+v"(pt));   // opaque: keeps the tile-invariant (row, column) of every piece out of registers between plans
-            int lr = (pt >> 2) / G::WP;
-            int pc = (pt >> 2) - lr * G::WP;
-            const int cbase = (s.c0 + (pt & 3) * 4) * 4;
-#pragma unroll
-            for (int i = 0; i < NPINv; ++i) {
-                const int roff = rowtab[min(lr, 31)];
-                const bool ok = roff >= 0 && pc >= 1 && pc <= G::W && lr < t.nrows;
-                Ls.goff[i] = ok ? roff + __mul24((pc - 1) >> up, s.C) * 4 + cbase : (int)0x80000000;
-                pc += STEP % G::WP;
-                lr += STEP / G::WP;
-                if (pc >= G::WP) { pc -= G::WP; ++lr; }
-            }
-            Ls.plan_tile = k; Ls.plan_src = si;
+    const int hw_ = wave - 8, ptid = tid - 512;
+    constexpr int LTH2 = 512, NPH = (G::NR * G::WP * 4 + LTH2 - 1) / LTH2, STEP2 = LTH2 / 4;
+    int goff[NPH];
+    uint4 pin0[NPH], pin1[NPH];
+    int* const rowtab = reinterpret_cast<int*>(lds + 2 * OPB + Cf::TB) + hw_ * 32;
+    const PinnedSrc s0 = a.src(0);                       // (one K source: the launcher checks it)
+    const int up = s0.up, Hs = G::H >> up, Ws = G::W >> up;
+    const __amdgpu_buffer_rsrc_t rs_in =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s0.ptr), 0, a.B * Hs * Ws * s0.C * 4, 0x00020000);
+    auto plan = [&](int k) __attribute__((always_inline)) {      // byte offsets of this thread's pieces of tile k (both K chunks)
+        const int m0 = (slot + k * G_) * TILE_PX;
+        const int mlast = min(m0 + TILE_PX - 1, Mtot - 1);
+        const int tb0 = m0 / (G::H * G::W);
+        const int ty0 = (m0 - tb0 * (G::H * G::W)) / G::W;
+        const int nrows = padded_row<HW>(mlast) - (tb0 * G::HP + ty0) + 2;
+        if (lane < 32) {
+            int py = ty0 + lane, b = tb0;
+            if (py >= G::HP) { py -= G::HP; ++b; }
+            if (HW == 14 && py >= G::HP) { py -= G::HP; ++b; }
+            const bool ok = lane < nrows && py >= 1 && py <= G::H && b < a.B;
+            rowtab[lane] = ok ? __mul24(__mul24(__mul24(b, Hs) + ((py - 1) >> up), Ws), s0.C) * 4 : (int)0x80000000;
         }
-        const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.ptr), 0, a.B * Hs * Ws * s.C * 4, 0x00020000);
+        int pt = ptid;
+        asm volatile("" : "+v"(pt));   // opaque: keeps the tile-invariant (row, column) of every piece out of registers between plans
+        int lr = (pt >> 2) / G::WP;
+        int pc = (pt >> 2) - lr * G::WP;
+        const int cbase = (s0.c0 + (pt & 3) * 4) * 4;
 #pragma unroll
-        for (int i = 0; i < NPINv; ++i) {
-            const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, Ls.goff[i], ch << 6, 0));
-            Ls.pin[i] = make_uint4(v[0], v[1], v[2], v[3]);
+        for (int i = 0; i < NPH; ++i) {
+            const int roff = rowtab[min(lr, 31)];
+            const bool ok = roff >= 0 && pc >= 1 && pc <= G::W && lr < nrows;
+            goff[i] = ok ? roff + __mul24((pc - 1) >> up, s0.C) * 4 + cbase : (int)0x80000000;
+            pc += STEP2 % G::WP;
+            lr += STEP2 / G::WP;
+            if (pc >= G::WP) { pc -= G::WP; ++lr; }
         }
     };
-    auto stage = [&](const LSet& Ls, int s_) __attribute__((always_inline)) {   // registers -> operand buffer (s_ & 1); every piece of the image is rewritten
-        char* const tile = lds + (s_ & 1) * OPB;
-        char* const sdst = tile + (ptid >> 2) * PIXB + (ptid & 3) * 16;
+    auto issue = [&](uint4 (&pin)[NPH], int ch) __attribute__((always_inline)) {   // global -> registers: K chunk ch of the planned tile
 #pragma unroll
-        for (int i = 0; i < NPINv; ++i)
-            if (ptid + LTH * i < G::NR * G::WP * 4) *reinterpret_cast<uint4*>(sdst + i * (STEP * PIXB)) = Ls.pin[i];
+        for (int i = 0; i < NPH; ++i) {
+            const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, goff[i], ch << 6, 0));
+            pin[i] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    auto stage = [&](const uint4 (&pin)[NPH], int buf) __attribute__((always_inline)) {   // registers -> operand buffer; the whole image is rewritten
+        char* const sdst = lds + buf * OPB + (ptid >> 2) * PIXB + (ptid & 3) * 16;
+#pragma unroll
+        for (int i = 0; i < NPH; ++i)
+            if (ptid + LTH2 * i < G::NR * G::WP * 4) *reinterpret_cast<uint4*>(sdst + i * (STEP2 * PIXB)) = pin[i];
     };
 
-    if (S > 0) prefetch(L0, 0);
-    if (S > 1) prefetch(L1, 1);
-    if (S > 0) stage(L0, 0);
-    if (S > 2) prefetch(L0, 2);
-    WS_BARRIER(1);                                   // step 0 staged
-    // Exactly two steps per tile (chunk c of tile k is step g = 2 k + c), written out straight-line: step (k, 0) stages chunk
-    // 2k + 1 from set 1 and refills it with chunk 2k + 3, step (k, 1) does the same with set 0 and chunks 2k + 2 / 2k + 4 —
-    // the waits in front of a set's LDS writes can then leave the OTHER set's eight loads in flight (vmcnt(8)); as a
-    // loop over steps with a parity branch the compiler waited for everything, i.e. one step of distance.
-    {
-        const bool ld = !(a.ablate & 64), stg = !(a.ablate & 512);
-        for (int k = 0; k <= nk; ++k) {
-            const int g = 2 * k;
-            if (k >= 1) WS_BARRIER(1);                                          // the consumers' "T ready" barrier
-            if (g + 1 < S && stg) stage(L1, g + 1);
-            stamp(1, 3);
-            if (g + 3 < S && ld) prefetch(L1, g + 3);
-            WS_BARRIER(1);
-            if (g + 2 < S && stg) stage(L0, g + 2);
-            stamp(1, 3);
-            if (g + 4 < S && ld) prefetch(L0, g + 4);
-            WS_BARRIER(1);
-        }
-    }
-    return;
-    }
-
-    // ------------------------------- walkers (waves 12..15): the epilogue, two consumer blocks each -------------------------------
-    const int pw2 = wave - 12;
-    // ---- epilogue walk of one 32-pixel x 32-channel block (the code of conv_s16_kernel's epilogue) ----
-    int lane_e = lane, j_e = j, h_e = h;
-    asm volatile("" : "+v"(lane_e), "+v"(j_e), "+v"(h_e));
-    (void)j_e; (void)h_e;
-    constexpr int NIT = N / 8, GI = 4;
-    static_assert(NIT == GI, "one group of passes per block at N = 32");
+    // ---- epilogue walk of one 32-pixel x 32-channel block, two passes (16 pixels) at a time (the code of conv_s16_kernel's epilogue) ----
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    constexpr int NIT = N / 8, HP2 = 2;                  // 4 passes per block, 2 per half-walk
     const bool bwd = a.relu_mask_in != nullptr;
     const bool use_res = a.res != nullptr;
     const bool use_tb = !use_res && a.tb_out != nullptr && a.out_s16 != nullptr;
@@ -934,12 +896,16 @@ __global__ __launch_bounds__(WS_THREADS) void conv_ws_kernel(ConvArgs ka, int nt
         const_cast<unsigned char*>(a.relu_mask_in), 0, bwd ? Mtot * (N / 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(r1_x), 0, r1_x != nullptr ? Mtot * 4 : 0, 0x00020000);
-    struct Pre { float4 rt[GI]; unsigned mk[GI]; float rx[R1 ? GI : 1]; };
-    auto preload = [&](Pre& p, int mbase) __attribute__((always_inline)) {
+    struct Pre { float4 rt[NIT]; unsigned mk[NIT]; float rx[R1 ? NIT : 1]; };
+    Pre p;
+    float4 sacc[2][2];
+    const float* const Tw = Tall + hw_ * (32 * EPI);
+    auto preload_half = [&](int mbase, auto half_c) __attribute__((always_inline)) {
+        constexpr int H0 = decltype(half_c)::value * HP2;
         const int img0 = mbase / (G::H * G::W);
         const int mnext = (img0 + 1) * (G::H * G::W);
 #pragma unroll
-        for (int it = 0; it < GI; ++it) {
+        for (int it = H0; it < H0 + HP2; ++it) {
             const int e = it * 64 + lane_e;
             const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
             const int m = min(mbase + px, Mtot - 1);
@@ -951,39 +917,41 @@ __global__ __launch_bounds__(WS_THREADS) void conv_ws_kernel(ConvArgs ka, int nt
             if constexpr (R1) p.rx[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rx, m * 4, 0, 0));
         }
     };
-    auto walk = [&](const Pre& p, const float* T, int mbase, auto full_c) __attribute__((always_inline)) {
+    auto walk_half = [&](int mbase, auto half_c, auto full_c) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_c)::value;
+        constexpr int H0 = decltype(half_c)::value * HP2;
         const int img0 = mbase / (G::H * G::W);
         const int mnext = (img0 + 1) * (G::H * G::W);
-        float4 sacc[2][2];
+        if constexpr (H0 == 0) {
 #pragma unroll
-        for (int sl = 0; sl < 2; ++sl)
+            for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
-            for (int kd = 0; kd < 2; ++kd) sacc[sl][kd] = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 v[GI];
-        unsigned o[GI];
-        bool ok[GI];
+                for (int kd = 0; kd < 2; ++kd) sacc[sl][kd] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 v[HP2];
+        unsigned o[HP2];
+        bool ok[HP2];
 #pragma unroll
-        for (int k = 0; k < GI; ++k) {
-            const int e = k * 64 + lane_e;
+        for (int k = 0; k < HP2; ++k) {
+            const int e = (H0 + k) * 64 + lane_e;
             const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
-            v[k] = *reinterpret_cast<const float4*>(T + px * EPI + c);
+            v[k] = *reinterpret_cast<const float4*>(Tw + px * EPI + c);
             o[k] = (unsigned)(mbase + px) * N + c;
             ok[k] = FULL || mbase + px < Mtot;
         }
         if (a.relu) {
 #pragma unroll
-            for (int k = 0; k < GI; ++k) {
+            for (int k = 0; k < HP2; ++k) {
                 v[k].x = fmaxf(v[k].x, 0.f); v[k].y = fmaxf(v[k].y, 0.f); v[k].z = fmaxf(v[k].z, 0.f); v[k].w = fmaxf(v[k].w, 0.f);
             }
         }
-        if (a.aux != nullptr) {
+        if (a.aux != nullptr && !(a.ablate & 1024)) {
 #pragma unroll
-            for (int k = 0; k < GI; ++k) if (ok[k]) gstore4(a.aux + o[k], v[k]);
+            for (int k = 0; k < HP2; ++k) if (ok[k]) gstore4(a.aux + o[k], v[k]);
         }
         if (a.mask_out != nullptr) {
 #pragma unroll
-            for (int k = 0; k < GI; ++k)
+            for (int k = 0; k < HP2; ++k)
                 if (ok[k])
                     gstore<unsigned char>(a.mask_out + (o[k] >> 2),
                                           (unsigned char)((v[k].x > 0.f ? 1 : 0) | (v[k].y > 0.f ? 2 : 0) |
@@ -991,45 +959,46 @@ __global__ __launch_bounds__(WS_THREADS) void conv_ws_kernel(ConvArgs ka, int nt
         }
         if (a.res != nullptr) {
 #pragma unroll
-            for (int k = 0; k < GI; ++k) {
-                const float4 rz = p.rt[k];
+            for (int k = 0; k < HP2; ++k) {
+                const float4 rz = p.rt[H0 + k];
                 v[k].x += rz.x; v[k].y += rz.y; v[k].z += rz.z; v[k].w += rz.w;
             }
         }
         if constexpr (R1) if (r1_x != nullptr) {
 #pragma unroll
-            for (int k = 0; k < GI; ++k) {
-                const int c = ((k * 64 + lane_e) % (N / 4)) * 4;
+            for (int k = 0; k < HP2; ++k) {
+                const int c = (((H0 + k) * 64 + lane_e) % (N / 4)) * 4;
                 const float4 w4 = gload4(r1_w + c), b4 = gload4(r1_b + c);
-                v[k].x += fmaf(p.rx[k], w4.x, b4.x); v[k].y += fmaf(p.rx[k], w4.y, b4.y);
-                v[k].z += fmaf(p.rx[k], w4.z, b4.z); v[k].w += fmaf(p.rx[k], w4.w, b4.w);
+                const float rx = p.rx[H0 + k];
+                v[k].x += fmaf(rx, w4.x, b4.x); v[k].y += fmaf(rx, w4.y, b4.y);
+                v[k].z += fmaf(rx, w4.z, b4.z); v[k].w += fmaf(rx, w4.w, b4.w);
             }
         }
         if (bwd) {
 #pragma unroll
-            for (int k = 0; k < GI; ++k) {
-                const int m = mbase + (k * 64 + lane_e) / (N / 4);
-                const unsigned mk = p.mk[k];
+            for (int k = 0; k < HP2; ++k) {
+                const int m = mbase + ((H0 + k) * 64 + lane_e) / (N / 4);
+                const unsigned mk = p.mk[H0 + k];
                 const float4 u = v[k];
                 const float4 mv = make_float4((mk & 1u) ? u.x : 0.f, (mk & 2u) ? u.y : 0.f, (mk & 4u) ? u.z : 0.f,
                                               (mk & 8u) ? u.w : 0.f);
-                const bool s0 = ok[k] && m < mnext, s1 = ok[k] && m >= mnext;
-                sacc[0][0].x += s0 ? u.x : 0.f; sacc[0][0].y += s0 ? u.y : 0.f; sacc[0][0].z += s0 ? u.z : 0.f; sacc[0][0].w += s0 ? u.w : 0.f;
-                sacc[0][1].x += s0 ? mv.x : 0.f; sacc[0][1].y += s0 ? mv.y : 0.f; sacc[0][1].z += s0 ? mv.z : 0.f; sacc[0][1].w += s0 ? mv.w : 0.f;
-                sacc[1][0].x += s1 ? u.x : 0.f; sacc[1][0].y += s1 ? u.y : 0.f; sacc[1][0].z += s1 ? u.z : 0.f; sacc[1][0].w += s1 ? u.w : 0.f;
-                sacc[1][1].x += s1 ? mv.x : 0.f; sacc[1][1].y += s1 ? mv.y : 0.f; sacc[1][1].z += s1 ? mv.z : 0.f; sacc[1][1].w += s1 ? mv.w : 0.f;
+                const bool s0_ = ok[k] && m < mnext, s1_ = ok[k] && m >= mnext;
+                sacc[0][0].x += s0_ ? u.x : 0.f; sacc[0][0].y += s0_ ? u.y : 0.f; sacc[0][0].z += s0_ ? u.z : 0.f; sacc[0][0].w += s0_ ? u.w : 0.f;
+                sacc[0][1].x += s0_ ? mv.x : 0.f; sacc[0][1].y += s0_ ? mv.y : 0.f; sacc[0][1].z += s0_ ? mv.z : 0.f; sacc[0][1].w += s0_ ? mv.w : 0.f;
+                sacc[1][0].x += s1_ ? u.x : 0.f; sacc[1][0].y += s1_ ? u.y : 0.f; sacc[1][0].z += s1_ ? u.z : 0.f; sacc[1][0].w += s1_ ? u.w : 0.f;
+                sacc[1][1].x += s1_ ? mv.x : 0.f; sacc[1][1].y += s1_ ? mv.y : 0.f; sacc[1][1].z += s1_ ? mv.z : 0.f; sacc[1][1].w += s1_ ? mv.w : 0.f;
                 v[k] = mv;
             }
         }
         if (a.out != nullptr) {
 #pragma unroll
-            for (int k = 0; k < GI; ++k) if (ok[k]) gstore4(a.out + o[k], v[k]);
+            for (int k = 0; k < HP2; ++k) if (ok[k]) gstore4(a.out + o[k], v[k]);
         }
         if constexpr (R1) if (o1_out != nullptr) {
             const float4 w4 = gload4(o1_w + (lane_e & 7) * 4);
             const float ob = gload<float>(o1_b);
 #pragma unroll
-            for (int k = 0; k < GI; ++k) {
+            for (int k = 0; k < HP2; ++k) {
                 float d = ((v[k].x * w4.x + v[k].y * w4.y) + v[k].z * w4.z) + v[k].w * w4.w;
                 d += __shfl_xor(d, 1);
                 d += __shfl_xor(d, 2);
@@ -1040,10 +1009,10 @@ __global__ __launch_bounds__(WS_THREADS) void conv_ws_kernel(ConvArgs ka, int nt
         if (a.out_s16 != nullptr) {
             if (a.tb_out != nullptr) {
 #pragma unroll
-                for (int k = 0; k < GI; ++k) {
-                    float4 tz = p.rt[k];
+                for (int k = 0; k < HP2; ++k) {
+                    float4 tz = p.rt[H0 + k];
                     if (a.res != nullptr) {
-                        const int e = k * 64 + lane_e;
+                        const int e = (H0 + k) * 64 + lane_e;
                         const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
                         const int m = min(mbase + px, Mtot - 1);
                         tz = gload4(a.tb_out + (unsigned)((img0 + (m >= mnext ? 1 : 0)) * a.tb_out_stride + c));
@@ -1052,91 +1021,61 @@ __global__ __launch_bounds__(WS_THREADS) void conv_ws_kernel(ConvArgs ka, int nt
                 }
             }
 #pragma unroll
-            for (int k = 0; k < GI; ++k) {
-                const int c = ((k * 64 + lane_e) % (N / 4)) * 4;
+            for (int k = 0; k < HP2; ++k) {
+                const int c = (((H0 + k) * 64 + lane_e) % (N / 4)) * 4;
                 if (ok[k]) gstore_s16_o(a.out_s16, o[k], c, v[k]);
             }
         }
-        if (bwd && a.sums != nullptr) {
+        if constexpr (H0 != 0) {
+            if (bwd && a.sums != nullptr) {
 #pragma unroll
-            for (int sl = 0; sl < 2; ++sl)
+                for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
-                for (int kd = 0; kd < 2; ++kd) {
-                    float4 r = sacc[sl][kd];
+                    for (int kd = 0; kd < 2; ++kd) {
+                        float4 r = sacc[sl][kd];
 #pragma unroll
-                    for (int off = N / 4; off < 64; off <<= 1) {
-                        r.x += __shfl_xor(r.x, off); r.y += __shfl_xor(r.y, off);
-                        r.z += __shfl_xor(r.z, off); r.w += __shfl_xor(r.w, off);
+                        for (int off = N / 4; off < 64; off <<= 1) {
+                            r.x += __shfl_xor(r.x, off); r.y += __shfl_xor(r.y, off);
+                            r.z += __shfl_xor(r.z, off); r.w += __shfl_xor(r.w, off);
+                        }
+                        if (lane_e < N / 4 && mbase < Mtot) {
+                            const unsigned grp = (unsigned)mbase >> 5;
+                            gstore4(a.sums + (unsigned)(((grp * 2 + sl) * 2 + kd) * N + lane_e * 4), r);
+                        }
                     }
-                    if (lane_e < N / 4 && mbase < Mtot) {
-                        const unsigned grp = (unsigned)mbase >> 5;
-                        gstore4(a.sums + (unsigned)(((grp * 2 + sl) * 2 + kd) * N + lane_e * 4), r);
-                    }
-                }
+            }
         }
     };
-    auto walk_skip = [&](const float* T, int mbase) __attribute__((always_inline)) {     // skip_out = the second accumulator (+ its bias), plain stores
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int e = it * 64 + lane_e;
-            const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
-            const int m = mbase + px;
-            const float4 v = *reinterpret_cast<const float4*>(T + px * EPI + c);
-            if (m < Mtot) gstore4(a.skip_out + ((unsigned)m * N + c), v);
+    auto walk_step = [&](int k, auto half_c) __attribute__((always_inline)) {   // half a walk of tile k - 1, then the request for tile k's same half
+        asm volatile("" : "+v"(lane_e));   // opaque per step: keeps the per-lane offsets of the walk out of registers between steps
+        if (k >= 1 && !(a.ablate & 128)) {
+            const int mb = (slot + (k - 1) * G_) * TILE_PX + hw_ * 32;
+            if (mb + 32 <= Mtot) walk_half(mb, half_c, std::true_type{});
+            else walk_half(mb, half_c, std::false_type{});
         }
+        if (k < nk && !(a.ablate & 2048)) preload_half((slot + k * G_) * TILE_PX + hw_ * 32, half_c);
     };
 
-    // Schedule (step = K chunk c of tile k):
-    //   start of (k + 1, 0):  consumers: T <- accumulators of tile k, "T ready" barrier
-    //   (k + 1, 0), (k + 1, 1): walkers walk their first / second block of tile k       [needs >= 2 chunks per tile]
-    //   SKIP: start of (k + 1, 2): T <- skip accumulator of tile k, barrier; (k + 1, 2), (k + 1, 3): walkers store it
-    //   the inputs of a walk (residual / mask / rank-1 input) are requested one step ahead
-    WS_BARRIER(2);                                   // step 0 staged
-    Pre pa, pb;
+    const bool ld = !(a.ablate & 64), stg = !(a.ablate & 512);
+    if (nk > 0) { plan(0); issue(pin0, 0); issue(pin1, 1); }
+    if (nk > 0) stage(pin0, 0);
+    if (nk > 1) { plan(1); issue(pin0, 0); }
+    WS_BARRIER(1);                                     // step 0 staged
+    // One iteration = one tile = two steps, straight-line (see the loaders' note in the header of this kernel): step (k, 0)
+    // stages chunk (k, 1) from set 1 and refills it with chunk (k + 1, 1); step (k, 1) stages chunk (k + 1, 0) from set 0,
+    // plans tile k + 2 and refills set 0 with its chunk 0.  `goff` always belongs to the tile whose chunks are requested next.
     for (int k = 0; k <= nk; ++k) {
-        const int nch_k = (k < nk) ? nchunks : tail;
-        const int mb0 = (slot + (k - 1) * G_) * TILE_PX + (2 * pw2) * 32;      // first block of tile k - 1
-        for (int c = 0; c < nch_k; ++c) {
-            if (k >= 1 && c == 0) {
-                WS_BARRIER(2);                       // T ready
-                // opaque per tile: otherwise every per-lane offset of the walks is hoisted out of the tile loop, computed once
-                // (500 instructions) and parked in scratch (100 spilled registers)
-                asm volatile("" : "+v"(lane_e));
-                if (!(a.ablate & 2048)) {
-                preload(pb, mb0 + 32);
-                __builtin_amdgcn_s_waitcnt(0x0F70 | 0x0008);   // vmcnt(8): pa (requested a step ago) has arrived; pb's loads may fly
-                }
-                stamp(2, 3);
-                if (a.ablate & 128) {}
-                else if (mb0 + 32 <= Mtot) walk(pa, Tall + (2 * pw2) * (32 * EPI), mb0, std::true_type{});
-                else walk(pa, Tall + (2 * pw2) * (32 * EPI), mb0, std::false_type{});
-            }
-            if (k >= 1 && c == 1) {
-                asm volatile("" : "+v"(lane_e));
-                if (!(a.ablate & 2048)) __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0)
-                stamp(2, 3);
-                if (a.ablate & 128) {}
-                else if (mb0 + 64 <= Mtot) walk(pb, Tall + (2 * pw2 + 1) * (32 * EPI), mb0 + 32, std::true_type{});
-                else walk(pb, Tall + (2 * pw2 + 1) * (32 * EPI), mb0 + 32, std::false_type{});
-            }
-            if constexpr (SKIP) {
-                if (k >= 1 && c == 2) {
-                    WS_BARRIER(2);                   // T ready (skip accumulator)
-                    asm volatile("" : "+v"(lane_e));
-                    walk_skip(Tall + (2 * pw2) * (32 * EPI), mb0);
-                }
-                if (k >= 1 && c == 3) {
-                    asm volatile("" : "+v"(lane_e));
-                    walk_skip(Tall + (2 * pw2 + 1) * (32 * EPI), mb0 + 32);
-                }
-            }
-            if (k < nk && c == nch_k - 1) {            // next step starts tile k's epilogue: request its first block's inputs now
-                stamp(2, 4);
-                asm volatile("" : "+v"(lane_e));
-                if (!(a.ablate & 2048)) preload(pa, (slot + k * G_) * TILE_PX + (2 * pw2) * 32);
-            }
-            WS_BARRIER(2);
-        }
+        if (k >= 1) WS_BARRIER(1);                     // the consumers' "T ready" barrier
+        if (k < nk && stg) stage(pin1, 1);
+        stamp(1, 3);
+        if (k + 1 < nk && ld) issue(pin1, 1);
+        walk_step(k, std::integral_constant<int, 0>{});
+        WS_BARRIER(1);
+        if (k + 1 < nk && stg) stage(pin0, 0);
+        stamp(1, 3);
+        if (k + 2 < nk) { plan(k + 2); if (ld) issue(pin0, 0); }
+        walk_step(k, std::integral_constant<int, 1>{});
+        WS_BARRIER(1);
     }
 }
 
@@ -1221,8 +1160,8 @@ int launch_conv_ws(const ConvArgs& a, hipStream_t st) {
 }
 inline bool use_ws(const ConvArgs& a) {
     if (!g_conv_ws || (a.ablate & ~(64 | 128 | 256 | 512 | 1024 | 2048)) != 0 || g_conv_mt == 2 || a.skip_out != nullptr) return false;   // (64..512: role ablations, timing only)
-    const int nch = (a.src[0].nch >> 4) + (a.nsrc > 1 ? (a.src[1].nch >> 4) : 0);
-    return nch == 2;      // exactly two K chunks: their weights stay resident in LDS, and the hand-off schedule needs two steps per tile
+    return a.nsrc == 1 && (a.src[0].nch >> 4) == 2;   // ONE source of exactly two K chunks: the weights stay resident in LDS, the
+                                                      // helpers plan a tile once for both chunks, and the hand-off needs two steps per tile
 }
 
 

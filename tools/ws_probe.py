@@ -24,9 +24,9 @@ def run(hw, cin, cout, B, outs="s16", abl=0):
     raw = aux[y.numel():y.numel() + grid * 3 * 64 * 2].view(torch.int64).view(grid, 3, 64).cpu()
     tag = (raw >> 56)[0]; d = (raw & ((1 << 56) - 1)).double()
     print(f"hw={hw} {cin}->{cout} B={B} outs={outs} ablate={abl}: tag:median ticks since the previous stamp, stamps 24.. (steady state), {grid} workgroups")
-    for r, name in enumerate(("consumer", "loader", "walker")):
+    for r, name in enumerate(("consumer", "helper")):
         n = int((raw[0, r] != 0).sum().item())
         dt = d[:, r, 1:] - d[:, r, :-1]
         print(f"  {name:9s} " + " ".join(f"{int(tag[r, i])}:{dt[:, i - 1].median():.0f}" for i in range(24, min(n, 50))))
     _lib.check(L.tdm_set_conv_ws(0))
-run(28, 32, 32, 2048); run(28, 32, 32, 2048, abl=2048); run(28, 32, 32, 2048, abl=128)
+run(28, 32, 32, 2048); run(28, 32, 32, 2048, abl=128)
