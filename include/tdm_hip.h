@@ -339,6 +339,15 @@ int64_t tdm_round_workspace_floats(int64_t M, int V, int D);
 int tdm_round_ce_loss_grad_f32(const float* x, const float* W, const float* b, const int64_t* ids,
                                float grad_scale, float* loss_out, float* dx, float* dW, float* db,
                                float* ws, int64_t M, int V, int D, void* stream);
+/* The same loss and gradients WITHOUT ever holding the (M, V) logits (src/shakespeare.py:239-240 at vocabulary
+ * sizes where M x V floats do not fit): one statistics pass (the logits GEMM with its log-sum-exp epilogue and no
+ * store), then per chunk of Vc vocabulary entries (a multiple of 128) the chunk's logits are recomputed into a
+ * (M, Vc) scratch and consumed by the two gradient GEMMs.  One GEMM pass more, V / Vc times less workspace:
+ * ws = tdm_round_workspace_chunked_floats(M, V, D, Vc).                                                      */
+int64_t tdm_round_workspace_chunked_floats(int64_t M, int V, int D, int Vc);
+int tdm_round_ce_loss_grad_chunked_f32(const float* x, const float* W, const float* b, const int64_t* ids,
+                                       float grad_scale, float* loss_out, float* dx, float* dW, float* db,
+                                       float* ws, int64_t M, int V, int D, int Vc, void* stream);
 /* logits (M, ld >= V, ld % 4 == 0) = x W^T + b   (LearnedRounding.forward, src/shakespeare.py:101) */
 int tdm_round_logits_f32(const float* x, const float* W, const float* b, float* logits, int64_t ld,
                          int64_t M, int V, int D, void* stream);

@@ -664,6 +664,54 @@ def test_rounding_ce_c_abi_vs_oracle(dev, gemm_mode, M, V, D):
     assert torch.equal(dW2, dW) and torch.equal(db2, db)      # deterministic (fixed-order slab sums)
 
 
+@pytest.mark.parametrize("M,V,D,Vc", [(384, 5000, 256, 1024), (100, 777, 64, 256), (200, 1000, 32, 128), (64, 300, 64, 512)])
+def test_rounding_ce_without_stored_logits_vs_oracle(dev, gemm_mode, monkeypatch, M, V, D, Vc):
+    """tdm_round_ce_loss_grad_chunked_f32: the rounding loss and its three gradients with the (M, V) logits never held — a
+    statistics pass, then per vocabulary chunk of Vc entries the logits are recomputed into an (M, Vc) scratch.  Chunk counts
+    5 / 4 / 8 / 1 with ragged last chunks; against the oracle at the tolerance of the stored-logits form, the loss equal to it
+    bit for bit (same statistics pass), and through LearnedRounding.cross_entropy with TDM_ROUND_CHUNK set."""
+    if gemm_mode != 1:
+        pytest.skip("the rounding head has one arithmetic (bf16x3)")
+    from tinydiffusionmodels_amd import _lib
+    L = _lib.lib()
+    gen = torch.Generator().manual_seed(M + V)
+    x = torch.randn(M, D, generator=gen) * 0.8
+    W = torch.randn(V, D, generator=gen) * (2.0 / D ** 0.5)
+    b = torch.randn(V, generator=gen) * 0.1
+    ids = torch.randint(0, V, (M,), generator=gen)
+    ids[0], ids[-1] = V - 1, 0                                   # targets in the last (ragged) and the first chunk
+    loss_ref, dx_ref, dW_ref, db_ref = O.rounding_ce_and_grads(x, W, b, ids)
+    xd, Wd, bd, idd = x.to(dev), W.to(dev), b.to(dev), ids.to(dev)
+    n_full, n_chunk = L.tdm_round_workspace_floats(M, V, D), L.tdm_round_workspace_chunked_floats(M, V, D, Vc)
+    assert 0 < n_chunk and (Vc >= V or n_chunk < n_full)
+    ws = torch.full((n_chunk,), float("nan"), device=dev)
+    loss, dx, dW, db = torch.empty(1, device=dev), torch.empty(M, D, device=dev), torch.empty(V, D, device=dev), torch.empty(V, device=dev)
+    _lib.check(L.tdm_round_ce_loss_grad_chunked_f32(_lib.ptr(xd), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(idd), 0.25, _lib.ptr(loss),
+                                                    _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db), _lib.ptr(ws), M, V, D, Vc, _lib.stream()))
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_ref.item()) < 2e-5 * abs(loss_ref.item())
+    assert O.rel_err(dx.cpu(), 0.25 * dx_ref) < 1e-4
+    assert O.rel_err(dW.cpu(), 0.25 * dW_ref) < 1e-4
+    assert O.rel_err(db.cpu(), 0.25 * db_ref) < 1e-4
+    wsf = torch.empty(n_full, device=dev)
+    loss_f = torch.empty(1, device=dev); dW_f, db_f = torch.empty_like(dW), torch.empty_like(db)
+    _lib.check(L.tdm_round_ce_loss_grad_f32(_lib.ptr(xd), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(idd), 0.25, _lib.ptr(loss_f), None,
+                                            _lib.ptr(dW_f), _lib.ptr(db_f), _lib.ptr(wsf), M, V, D, _lib.stream()))
+    assert torch.equal(loss_f, loss)
+    assert O.rel_err(dW.cpu(), dW_f.cpu()) < 2e-5                 # chunk logits are recomputed by the same GEMM: only split-K differs
+    # the nn.Module surface
+    from tinydiffusionmodels_amd.shakespeare import LearnedRounding
+    monkeypatch.setenv("TDM_ROUND_CHUNK", str(Vc))
+    rnd = LearnedRounding(D, V).to(dev)
+    with torch.no_grad():
+        rnd.decoder.weight.copy_(Wd); rnd.decoder.bias.copy_(bd)
+    xg = xd.clone().requires_grad_(True)
+    ce = rnd.cross_entropy(xg.view(1, M, D), idd.view(1, M))
+    ce.backward()
+    assert abs(ce.item() - loss_ref.item()) < 2e-5 * abs(loss_ref.item())
+    assert O.rel_err(xg.grad.cpu(), dx_ref) < 1e-4 and O.rel_err(rnd.decoder.weight.grad.cpu(), dW_ref) < 1e-4
+
+
 @pytest.mark.parametrize("tag", ["cos1003", "cos2048"])
 def test_cosine_decode_golden(dev, golden_dir, gemm_mode, tag):
     """Native cosine-similarity decode (tdm_cosine_argmax_f32: row normalisation x2, MFMA similarity GEMM, row argmax) against

@@ -77,6 +77,8 @@ _SIGS = {
     "tdm_embed_scatter_add_f32": ([c_f, c_f, c_f, c_i64, c_int, c_int, c_float, c_f], c_int),
     "tdm_round_workspace_floats": ([c_i64, c_int, c_int], c_i64),
     "tdm_round_ce_loss_grad_f32": ([c_f, c_f, c_f, c_f, c_float, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_f], c_int),
+    "tdm_round_workspace_chunked_floats": ([c_i64, c_int, c_int, c_int], c_i64),
+    "tdm_round_ce_loss_grad_chunked_f32": ([c_f, c_f, c_f, c_f, c_float, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_f], c_int),
     "tdm_round_logits_f32": ([c_f, c_f, c_f, c_f, c_i64, c_i64, c_int, c_int, c_f], c_int),
     "tdm_round_argmax_f32": ([c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_f], c_int),
     "tdm_philox_normal_f32": ([c_u64, c_u64, c_f, c_i64, c_f], c_int),

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(NT_THREADS, (WM == 1 ? 4 : 2)) void gemm_nt_bf16_ke
             for (int p = 0; p < NPA; ++p) {
                 const int row = min(i0 + ((tid + NT_THREADS * p) >> 3), g.M - 1);
                 ce_l[p] = g.ce_lse[row];
-                ce_t[p] = (int)g.ce_ids[row];
+                ce_t[p] = (int)g.ce_ids[row] - g.ce_voff;
             }
         }
         f32x16 acc[WM][2];
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(NT_THREADS, (WM == 1 ? 4 : 2)) void gemm_nt_bf16_ke
                         if (g.gate != nullptr) u = g.gate[o + e] > 0.f ? u * g.gate_scale : 0.f;
                         if (g.drop.thr != 0u)
                             u = tdm_keep(g.drop, (unsigned long long)m * (unsigned)g.N + (unsigned)(n + e)) ? u * g.drop.scale : 0.f;
-                        g.C[o + e] = u;
+                        if (g.C != nullptr) g.C[o + e] = u;
                     }
                 } else if (m < g.M && nq >= 4 && !(g.ablate & 4)) {
                     const long o = (long)m * g.c_rs + n;
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
             const long gkc = kin ? gk : kbeg;
             pa[p] = *reinterpret_cast<const f32x4*>(g.A + gkc * g.a_cs + (oa ? ia : 0));
             pb[p] = *reinterpret_cast<const f32x4*>(g.B + gkc * g.b_rs + (ob ? ib : 0));
-            if constexpr (CE) { ce_l[p] = g.ce_lse[gkc]; ce_t[p] = (int)g.ce_ids[gkc]; }
+            if constexpr (CE) { ce_l[p] = g.ce_lse[gkc]; ce_t[p] = (int)g.ce_ids[gkc] - g.ce_voff; }
         }
     };
     if (kbeg < kend) gload(kbeg);
@@ -561,13 +561,13 @@ int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
     TDM_REQUIRE((g.a_rs % 4) == 0 && (g.b_cs % 4) == 0 && (g.c_rs % 4) == 0 && (g.K % 4) == 0,
                 "gemm_nt_bf16: leading dimensions and K must be multiples of 4");
     TDM_REQUIRE((((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.C | (uintptr_t)g.C16) & 15) == 0, "gemm_nt_bf16: 16-byte alignment");
-    TDM_REQUIRE(g.C != nullptr || g.C16 != nullptr, "gemm_nt_bf16: no output");
+    TDM_REQUIRE(g.C != nullptr || g.C16 != nullptr || g.ce_part != nullptr, "gemm_nt_bf16: no output");
     TDM_REQUIRE(g.splitk <= 1, "gemm_nt_bf16: no split-K");
     TDM_REQUIRE(!g.s16_in || ((g.K % 16) == 0 && (g.a_rs % 16) == 0 && (g.b_cs % 16) == 0 && g.ce_lse == nullptr),
                 "gemm_nt_bf16: S16 operands need K and the leading dimensions to be multiples of 16 (K=%d)", g.K);
     TDM_REQUIRE(g.C16 == nullptr || ((g.N % 16) == 0 && (g.c_rs % 16) == 0 && g.ce_part == nullptr),
                 "gemm_nt_bf16: an S16 output needs N and its leading dimension to be multiples of 16 (N=%d)", g.N);
-    TDM_REQUIRE(g.C != nullptr || (g.N % 4) == 0, "gemm_nt_bf16: an S16-only output needs N %% 4 == 0");
+
     TDM_REQUIRE(!g.gate_s16 || (g.c_rs % 16) == 0, "gemm_nt_bf16: an S16 gate needs a leading dimension that is a multiple of 16");
     TDM_REQUIRE(!(g.ce_lse != nullptr && g.ce_part != nullptr), "gemm_nt_bf16: one cross-entropy role per launch");
     static bool env_read = false;

@@ -275,6 +275,89 @@ int tdm_round_ce_loss_grad_f32(const float* x, const float* W, const float* b, c
     return 0;
 }
 
+// ---- the same loss and gradients WITHOUT ever holding the (M, V) logits: one statistics pass over the vocabulary (the logits
+// GEMM with its cross-entropy epilogue and no store), then per vocabulary chunk [v0, v0 + Vc): recompute the chunk's logits into
+// a (M, Vc) scratch and feed it to the two gradient GEMMs (softmax - onehot regenerated in their loaders, dx accumulated through
+// the residual input).  One GEMM pass more than the stored-logits form, 1 / (V / Vc) of its workspace.
+struct RoundChunkWs { float *clog, *lse, *rowloss, *tgt, *part, *wT, *wslab, *bslab; long total; int Vcp, sk, nblk; };
+RoundChunkWs round_chunk_carve(float* base, long M, int V, int D, int Vc) {
+    RoundChunkWs w{};
+    long off = 0;
+    auto take = [&](long n) { float* p = base ? base + off : nullptr; off += (n + 63) & ~63L; return p; };
+    w.Vcp = (int)pad4(Vc);
+    w.sk = round_splitk(w.Vcp, D);
+    w.nblk = ((V + 127) / 128) * 2;
+    w.clog = take(M * w.Vcp); w.lse = take(M); w.rowloss = take(M); w.tgt = take(M); w.part = take(M * w.nblk * 2);
+    w.wT = take((long)D * w.Vcp);
+    w.wslab = take((long)w.sk * w.Vcp * D);
+    w.bslab = take((long)w.sk * ((w.Vcp + 63) & ~63));
+    w.total = off;
+    return w;
+}
+
+int64_t tdm_round_workspace_chunked_floats(int64_t M, int V, int D, int Vc) {
+    if (M < 1 || V < 2 || D < 4 || Vc < 128 || (Vc % 128) != 0) return -1;
+    return round_chunk_carve(nullptr, M, V, D, Vc).total;
+}
+
+int tdm_round_ce_loss_grad_chunked_f32(const float* x, const float* W, const float* b, const int64_t* ids, float grad_scale,
+                                       float* loss_out, float* dx, float* dW, float* db, float* ws, int64_t M, int V, int D, int Vc,
+                                       void* stream) {
+    TDM_TRY(round_check(M, V, D));
+    TDM_REQUIRE(x && W && b && ids && loss_out && dW && db && ws, "round_ce_loss_grad_chunked: NULL pointer");
+    TDM_REQUIRE(Vc >= 128 && (Vc % 128) == 0, "round_ce_loss_grad_chunked: chunk of %d vocabulary entries (a multiple of 128)", Vc);
+    hipStream_t st = (hipStream_t)stream;
+    const RoundChunkWs w = round_chunk_carve(ws, M, V, D, Vc);
+    const float gscale = grad_scale / (float)M;
+    {   // statistics pass: (max, sum exp) per 64-column block and the target logit of every row; nothing else is stored
+        GemmArgs g{};
+        g.A = x; g.a_rs = D; g.a_cs = 1;
+        g.B = W; g.b_rs = 1; g.b_cs = D;
+        g.C = nullptr; g.c_rs = pad4(V); g.bias = b; g.M = (int)M; g.N = V; g.K = D; g.splitk = 1;
+        g.ce_part = w.part; g.ce_nblk = w.nblk; g.ce_tgt = w.tgt; g.ce_ids = ids;
+        TDM_TRY(tdm_launch_gemm_nt_bf16(g, 3, st));
+    }
+    hipLaunchKernelGGL(ce_lse_kernel, dim3((unsigned)((M + 3) / 4 < 4096 ? (M + 3) / 4 : 4096)), dim3(256), 0, st, w.part, w.tgt,
+                       w.lse, w.rowloss, (long)M, w.nblk);
+    TDM_CHECK_LAUNCH("ce_lse");
+    hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, st, w.rowloss, loss_out, (long)M);
+    TDM_CHECK_LAUNCH("ce_mean");
+    for (int v0 = 0, ci = 0; v0 < V; v0 += Vc, ++ci) {
+        const int vn = V - v0 < Vc ? V - v0 : Vc;     // vocabulary entries of this chunk
+        const int vp = (int)pad4(vn);                 // row length of its logits (zero-weight padding columns)
+        TDM_TRY(logits_gemm(x, W + (long)v0 * D, b + v0, w.clog, M, vn, vp, D, st));
+        if (dx != nullptr) {
+            dim3 tg((D + 31) / 32, (vp + 31) / 32);
+            hipLaunchKernelGGL(transpose_pad_kernel, tg, dim3(256), 0, st, W + (long)v0 * D, w.wT, vn, D, vp);
+            TDM_CHECK_LAUNCH("transpose_pad");
+            GemmArgs g{};
+            g.A = w.clog; g.a_rs = vp; g.a_cs = 1;
+            g.B = w.wT; g.b_rs = 1; g.b_cs = vp;
+            g.C = dx; g.c_rs = D; g.M = (int)M; g.N = D; g.K = vp; g.splitk = 1;
+            g.res = ci > 0 ? dx : nullptr;            // accumulate over the chunks
+            g.ce_lse = w.lse; g.ce_ids = ids; g.ce_scale = gscale; g.ce_V = vn; g.ce_voff = v0;
+            TDM_TRY(tdm_launch_gemm_nt_bf16(g, 3, st));
+        }
+        {
+            GemmArgs g{};
+            g.A = w.clog; g.a_rs = 1; g.a_cs = vp;
+            g.B = x; g.b_rs = D; g.b_cs = 1;
+            g.C = w.wslab; g.c_rs = D; g.M = vp; g.N = D; g.K = (int)M; g.splitk = w.sk;
+            g.c_split_stride = (long)w.Vcp * D;
+            g.colsum = w.bslab; g.colsum_stride = (w.Vcp + 63) & ~63;
+            g.ce_lse = w.lse; g.ce_ids = ids; g.ce_scale = gscale; g.ce_V = vn; g.ce_voff = v0;
+            TDM_TRY(tdm_launch_gemm_tn_bf16(g, 3, st));
+            ReduceArgs ra{};
+            ra.nsec = 1;
+            ra.sec[0].off = 0; ra.sec[0].len = (int)((long)vn * D); ra.sec[0].nslab = w.sk; ra.sec[0].stride_override = (long)w.Vcp * D;
+            TDM_TRY(tdm_launch_reduce(w.wslab, 0, ra, dW + (long)v0 * D, st));
+            ra.sec[0].len = vn; ra.sec[0].stride_override = (w.Vcp + 63) & ~63;
+            TDM_TRY(tdm_launch_reduce(w.bslab, 0, ra, db + v0, st));
+        }
+    }
+    return 0;
+}
+
 int tdm_round_logits_f32(const float* x, const float* W, const float* b, float* logits, int64_t ld, int64_t M, int V, int D,
                          void* stream) {
     TDM_TRY(round_check(M, V, D));

@@ -27,6 +27,7 @@ struct GemmArgs {
     //    softmax - onehot is regenerated from the stored logits in the loader instead of being written back and re-read.
     float* ce_part; int ce_nblk; float* ce_tgt;
     const float* ce_lse; const int64_t* ce_ids; float ce_scale; int ce_V;
+    int ce_voff;   // the stored logits are the vocabulary slice [ce_voff, ce_voff + ce_V): targets are compared as ce_ids - ce_voff
     // Pre-split ("S16", tdm_s16.h) operands and outputs, bf16 kernels only.  An S16 tensor has the shape and byte size of
     // its fp32 counterpart; every 64-byte group of 16 consecutive elements of a row holds hi[16] | lo[16] as bf16.
     //  * s16_in: BOTH operands are S16 (row lengths multiples of 16): the loaders copy 16-byte pieces straight into the
