@@ -102,9 +102,14 @@ __device__ __forceinline__ void put_s16(char* hi_plane, char* lo_plane, int row,
     *reinterpret_cast<f32x4*>((is_lo ? lo_plane : hi_plane) + row * PITCH + ((kq >> 2) * 16 + (kq & 1) * 8) * 2) = v;
 }
 
-template <int NPROD, bool CE, bool STATS, int WM, bool S16IN = false>
+// BUF (S16 operands, K % 32 == 0, operands < 2 GiB): the loads go through buffer descriptors — a per-tile 32-bit row offset
+// per piece (out-of-range rows get an offset beyond num_records: the hardware returns zeros) plus the chunk's scalar K
+// offset, i.e. NO vector instruction per load and per chunk; the generic path spends ~80 of them per chunk on 64-bit
+// address arithmetic, clamps and the zero selects (PMC: 8.2 vector instructions per MFMA after the split had gone).
+template <int NPROD, bool CE, bool STATS, int WM, bool S16IN = false, bool BUF = false>
 __global__ __launch_bounds__(NT_THREADS, (WM == 1 ? 4 : 2)) void gemm_nt_bf16_kernel(GemmArgs g, int ntx, int ntiles) {
     static_assert(!(S16IN && CE), "the cross-entropy loader regenerates its operand from fp32 logits");
+    static_assert(!BUF || S16IN, "descriptor loads serve the pre-split operands");
     using Cf = NtCfg<WM>;
     constexpr int TMv = Cf::TMv, NPA = Cf::NPA;
     // planes: A hi, A lo, B hi, B lo  (lo planes unused when NPROD == 1)
@@ -128,8 +133,35 @@ __global__ __launch_bounds__(NT_THREADS, (WM == 1 ? 4 : 2)) void gemm_nt_bf16_ke
     f32x4 pa[NPA], pb[2];
     unsigned ok = 0u;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    int voffA[BUF ? NPA : 1], voffB[BUF ? 2 : 1];
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, BUF ? (int)((long)g.M * g.a_rs * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, BUF ? (int)((long)g.N * g.b_cs * 4) : 0, 0x00020000);
     auto gload = [&](int tile, int k0) {
         const int i0 = (tile / ntx) * TMv, j0 = (tile % ntx) * TN_;
+        if constexpr (BUF) {
+            if (k0 == 0) {   // a new tile: this thread's row offsets (bytes); rows past the end -> out of range -> zeros
+#pragma unroll
+                for (int p = 0; p < NPA; ++p) {
+                    const int f = tid + NT_THREADS * p;
+                    const int row = i0 + (f >> 3);
+                    voffA[p] = row < g.M ? row * (int)g.a_rs * 4 + (f & 7) * 16 : (int)0x80000000;
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int f = tid + NT_THREADS * p;
+                    const int row = j0 + (f >> 3);
+                    voffB[p] = row < g.N ? row * (int)g.b_cs * 4 + (f & 7) * 16 : (int)0x80000000;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < NPA; ++p)
+                pa[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA[p], k0 * 4, 0));
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                pb[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[p], k0 * 4, 0));
+            ok = 0xffffffffu;
+            return;
+        }
         ok = 0u;
 #pragma unroll
         for (int p = 0; p < NPA; ++p) {   // TMv rows x 8 float4
@@ -339,9 +371,10 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
 
 constexpr int TPL = 4 * 32 * 64;   // one [4 col blocks][32 tokens][32 cols] bf16 image = 8 KB
 
-template <int NPROD, bool CE, bool S16IN = false>
+template <int NPROD, bool CE, bool S16IN = false, bool BUF = false>
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
     static_assert(!(S16IN && CE), "the cross-entropy loader regenerates its operand from fp32 logits");
+    static_assert(!BUF || S16IN, "descriptor loads serve the pre-split operands");
     // C[i][j] = sum_k A(i,k) B(k,j) with A(i,k) = A[k*a_cs + i], B(k,j) = B[k*b_rs + j]  (a_rs = b_cs = 1)
     __shared__ __attribute__((aligned(16))) char lds[4 * TPL];
     char* Ahi = lds; char* Alo = lds + TPL; char* Bhi = lds + 2 * TPL; char* Blo = lds + 3 * TPL;
@@ -371,7 +404,32 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
     int ce_t[CE ? 4 : 1];
     unsigned ok = 0u;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // BUF: descriptor loads as in the NT kernel — per-thread 32-bit offsets fixed for the whole workgroup (token row within
+    // the chunk, column piece; columns past the matrix -> out of range), the chunk's token offset as the scalar offset, and
+    // num_records = this split's last token: no vector instruction per load, zeros past either edge from the hardware
+    int voffA[BUF ? 4 : 1], voffB[BUF ? 4 : 1];
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, BUF ? (int)((long)kend * g.a_cs * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, BUF ? (int)((long)kend * g.b_rs * 4) : 0, 0x00020000);
+    if constexpr (BUF) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int f = tid + 256 * p;
+            const int mrow = f >> 5, c4 = f & 31;
+            const int ia = i0 + c4 * 4, ib = j0 + c4 * 4;
+            voffA[p] = ia < g.M ? (mrow * (int)g.a_cs + ia) * 4 : (int)0x80000000;
+            voffB[p] = ib < g.N ? (mrow * (int)g.b_rs + ib) * 4 : (int)0x80000000;
+        }
+    }
     auto gload = [&](int k0) {
+        if constexpr (BUF) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                pa[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA[p], k0 * (int)g.a_cs * 4, 0));
+                pb[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[p], k0 * (int)g.b_rs * 4, 0));
+            }
+            ok = 0xffffffffu;
+            return;
+        }
         ok = 0u;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {   // 32 token rows x 32 float4 columns
@@ -529,13 +587,13 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 namespace {
 int g_nt_wm = 0;   // 0: pick per problem; 1 / 2: force the 128- / 256-row tile (TDM_GEMM_WM, A/B timing)
 
-template <int NPROD, bool CE, bool STATS, int WM, bool S16IN = false>
+template <int NPROD, bool CE, bool STATS, int WM, bool S16IN = false, bool BUF = false>
 int launch_nt(const GemmArgs& g, hipStream_t st) {
     using Cf = NtCfg<WM>;
     static int resident = 0;   // workgroups the device holds at once (occupancy x CUs): the persistent grid
     if (resident == 0) {
         int dev = 0, cus = 0, per_cu = 0;
-        const void* fn = reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<NPROD, CE, STATS, WM, S16IN>);
+        const void* fn = reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<NPROD, CE, STATS, WM, S16IN, BUF>);
         hipError_t e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
@@ -548,7 +606,7 @@ int launch_nt(const GemmArgs& g, hipStream_t st) {
     }
     const int ntx = (g.N + TN_ - 1) / TN_, ntiles = ntx * ((g.M + Cf::TMv - 1) / Cf::TMv);
     dim3 grid(ntiles < resident ? ntiles : resident);
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<NPROD, CE, STATS, WM, S16IN>), grid, dim3(NT_THREADS), Cf::LDS, st, g, ntx, ntiles);
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<NPROD, CE, STATS, WM, S16IN, BUF>), grid, dim3(NT_THREADS), Cf::LDS, st, g, ntx, ntiles);
     TDM_CHECK_LAUNCH("gemm_nt_bf16");
     return 0;
 }
@@ -563,7 +621,7 @@ int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
     TDM_REQUIRE((((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.C | (uintptr_t)g.C16) & 15) == 0, "gemm_nt_bf16: 16-byte alignment");
     TDM_REQUIRE(g.C != nullptr || g.C16 != nullptr || g.ce_part != nullptr, "gemm_nt_bf16: no output");
     TDM_REQUIRE(g.splitk <= 1, "gemm_nt_bf16: no split-K");
-    TDM_REQUIRE(!g.s16_in || ((g.K % 16) == 0 && (g.a_rs % 16) == 0 && (g.b_cs % 16) == 0 && g.ce_lse == nullptr),
+    TDM_REQUIRE(!g.s16_in || ((g.K % 16) == 0 && (g.a_rs % 16) == 0 && (g.b_cs % 16) == 0 && g.ce_lse == nullptr && g.ce_part == nullptr),
                 "gemm_nt_bf16: S16 operands need K and the leading dimensions to be multiples of 16 (K=%d)", g.K);
     TDM_REQUIRE(g.C16 == nullptr || ((g.N % 16) == 0 && (g.c_rs % 16) == 0 && g.ce_part == nullptr),
                 "gemm_nt_bf16: an S16 output needs N and its leading dimension to be multiples of 16 (N=%d)", g.N);
@@ -589,7 +647,11 @@ int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
                     "gemm_nt_bf16: cross-entropy partials need a plain (bias-only) epilogue");
         return big ? launch_nt<3, false, true, 2>(g, st) : launch_nt<3, false, true, 1>(g, st);
     }
-    if (g.s16_in) return nprod == 3 ? launch_nt<3, false, false, 1, true>(g, st) : launch_nt<1, false, false, 1, true>(g, st);
+    if (g.s16_in) {
+        const bool buf = (g.K % 32) == 0 && (long)g.M * g.a_rs * 4 < 2147483647L && (long)g.N * g.b_cs * 4 < 2147483647L;
+        if (buf) return nprod == 3 ? launch_nt<3, false, false, 1, true, true>(g, st) : launch_nt<1, false, false, 1, true, true>(g, st);
+        return nprod == 3 ? launch_nt<3, false, false, 1, true>(g, st) : launch_nt<1, false, false, 1, true>(g, st);
+    }
     if (nprod == 3) return big ? launch_nt<3, false, false, 2>(g, st) : launch_nt<3, false, false, 1>(g, st);
     return big ? launch_nt<1, false, false, 2>(g, st) : launch_nt<1, false, false, 1>(g, st);
 }
@@ -611,7 +673,13 @@ int tdm_launch_gemm_tn_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
     } else if (g.s16_in) {
         TDM_REQUIRE((g.a_cs % 16) == 0 && (g.b_rs % 16) == 0 && (g.M % 16) == 0 && (g.N % 16) == 0,
                     "gemm_tn_bf16: S16 operands need M, N and the leading dimensions to be multiples of 16");
-        if (nprod == 3) hipLaunchKernelGGL((gemm_tn_bf16_kernel<3, false, true>), grid, dim3(256), 0, st, g);
+        // (whole 32-token chunks only: the zero fill of a ragged last chunk would have to come from the descriptor's range
+        //  check on voffset + soffset, which this code does not rely on)
+        const bool buf = (g.K % 32) == 0 && (long)g.K * g.a_cs * 4 < 2147483647L && (long)g.K * g.b_rs * 4 < 2147483647L;
+        if (buf) {
+            if (nprod == 3) hipLaunchKernelGGL((gemm_tn_bf16_kernel<3, false, true, true>), grid, dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, false, true, true>), grid, dim3(256), 0, st, g);
+        } else if (nprod == 3) hipLaunchKernelGGL((gemm_tn_bf16_kernel<3, false, true>), grid, dim3(256), 0, st, g);
         else hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, false, true>), grid, dim3(256), 0, st, g);
     } else if (nprod == 3) hipLaunchKernelGGL((gemm_tn_bf16_kernel<3, false>), grid, dim3(256), 0, st, g);
     else hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, false>), grid, dim3(256), 0, st, g);
