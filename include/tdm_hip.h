@@ -221,8 +221,8 @@ int tdm_conv_wgrad_nhwc_f32(const float* in, const float* tb, const float* dout,
  *      plain 16-byte copies — default                                          */
 int tdm_set_conv_mode(int mode);
 int tdm_get_conv_mode(void);
-/* N = 32 convolutions of mode 2: 1 = warp-specialised persistent kernel (8 producer + 8 consumer waves per CU;
- * default), 0 = the one-role kernel.  Same arithmetic, same bits out.                                           */
+/* 32 -> 32 28x28 convolutions of mode 2: 0 = the one-role kernel (default), 1 = warp-specialised persistent kernel
+ * (8 consumer + 8 helper waves per CU; measured slower, kept for A/B).  Same arithmetic, same bits out.        */
 int tdm_set_conv_ws(int on);
 int tdm_get_conv_ws(void);
 /* Pixel tile of the 28x28 N = 32 kernels of mode 2: 0 / 1 = 256 pixels per workgroup (default), 2 = 512 pixels (two
