@@ -202,3 +202,24 @@ def test_set_tables_retires_captured_samplers():
     gen = schedule.schedule_generation()
     schedule.set_tables(None)
     assert schedule.schedule_generation() == gen + 1
+
+
+def test_rounding_chunk_policy_and_rowwise_allreduce_world1(monkeypatch):
+    """Host policy of the rounding cross-entropy (row N1: at real vocabulary sizes the (B L, V) logits are never held) and the
+    single-process path of the embedding gradient's row-wise all-reduce."""
+    import torch
+    from tinydiffusionmodels_amd import dp
+    from tinydiffusionmodels_amd import shakespeare as S
+    monkeypatch.delenv("TDM_ROUND_CHUNK", raising=False)
+    assert S.round_ce_chunk(384, 5000) == 0                        # 7.7 MB of logits: stored once
+    assert S.round_ce_chunk(32768, 50257) == S.ROUND_CHUNK         # 6.6 GB: vocabulary chunks
+    assert S.ROUND_CHUNK % 128 == 0
+    monkeypatch.setenv("TDM_ROUND_CHUNK", "1000")
+    assert S.round_ce_chunk(8, 8) == 1024                          # rounded up to a multiple of 128
+    monkeypatch.setenv("TDM_ROUND_CHUNK", "0")
+    assert S.round_ce_chunk(32768, 50257) == 0
+    g = torch.zeros(50, 4)
+    ids = torch.tensor([[3, 7, 7], [49, 3, 0]])
+    g.index_add_(0, ids.reshape(-1), torch.ones(6, 4))
+    before = g.clone()
+    assert dp.allreduce_rows_(g, ids) == 4 and torch.equal(g, before)   # world 1: nothing moves, 4 distinct rows
