@@ -267,7 +267,8 @@ def _unsplit_s16(t):
     return (f[:, :16].double() + f[:, 16:].double()).float().view(t.shape)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 256, 64), (1000, 2048, 256), (130, 48, 2048), (257, 768, 256)])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 64), (1000, 2048, 256), (130, 48, 2048), (257, 768, 256), (17, 16, 32), (129, 272, 96),
+                                   (64, 144, 48), (515, 32, 80)])   # K % 32 != 0: the S16 path without descriptor loads
 def test_s16_operands_give_the_same_gemm_bitwise(dev, gemm_mode, M, N, K):
     """The pre-split ("S16") operand path of the bf16 GEMMs (tdm_split_s16_f32 + flag bits of tdm_gemm_f32): the loaders copy
     what the fp32-input loaders would have computed, so the K-contiguous (forward / data-gradient) and token-major (weight-
