@@ -450,6 +450,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     const int mbase = mbase0 + mt * 32;
     const int img0 = mbase / (G::H * G::W);         // image of the group's first pixel (scalar)
     const int mnext = (img0 + 1) * (G::H * G::W);   // a 32-pixel group touches at most two images
+    const bool has_epi_in = use_res || use_tb || bwd || (R1 && r1_x != nullptr);
     auto preload = [&](int g) {
 #pragma unroll
         for (int it = 0; it < GI; ++it) {
@@ -600,8 +601,12 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         static_for<0, NIT / GI>([&](auto g) {
             constexpr int gi = decltype(g)::value;
             if constexpr (gi > 0) {
-                preload(gi);
-                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): also retires the previous group's stores
+                // (a launch without epilogue inputs — rb4's data gradient — requests nothing and must not wait either: the
+                //  vmcnt(0) would sit behind the previous group's stores, ~2 k cycles per group: tools/ws_probe.py)
+                if (has_epi_in) {
+                    preload(gi);
+                    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): also retires the previous group's stores
+                }
             }
             walk(full_c, g);
             __builtin_amdgcn_sched_barrier(0);
