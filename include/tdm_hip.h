@@ -211,6 +211,17 @@ int tdm_conv_nhwc_f32(const float* in, const float* w, const float* bias, const 
 int tdm_conv_wgrad_nhwc_f32(const float* in, const float* tb, const float* dout, float* dw, float* db,
                             float* slabs, int64_t B, int HW, int Cin, int Cout, int ksize, void* stream);
 
+/* ---- a3: ResidualBlock(in_ch, out_ch).forward(x, t)  (src/mnist.py:45-61) as ONE call in the active conv arithmetic:
+ *   h = relu(conv1(x)); h = h + time_emb(that)[b][c]; h = relu(conv2(h)); out = h + (skip(x) if skw else x)
+ * x (B,HW,HW,Cin), out (B,HW,HW,Cout): NHWC fp32; c1w (3,3,Cin,Cout), c2w (3,3,Cout,Cout), skw (1,1,Cin,Cout): HWIO;
+ * tew, teb (Cout): time_emb.weight[:, 0] / .bias; that (B): the float `t` of the reference's (B,1,1,1) argument.
+ * skw == NULL: identity skip (Cin == Cout).  Geometries: HW in {14, 28}, Cin in {32, 64, 96}, Cout in {32, 64}, and the
+ * first block's HW 28, Cin 1, Cout 32.  scratch: tdm_resblock_scratch_floats(B, HW, Cin, Cout) floats.                 */
+int64_t tdm_resblock_scratch_floats(int64_t B, int HW, int Cin, int Cout);
+int tdm_resblock_fwd_f32(const float* x, const float* that, const float* c1w, const float* c1b, const float* c2w,
+                         const float* c2b, const float* tew, const float* teb, const float* skw, const float* skb,
+                         float* out, float* scratch, int64_t B, int HW, int Cin, int Cout, void* stream);
+
 /* Arithmetic of the UNet's MFMA convolutions (forward, data and weight gradient):
  *   0  exact fp32 (v_mfma_f32_32x32x2_f32, bitwise an fp32 fmaf chain)
  *   1  bf16x3 split operands on v_mfma_f32_32x32x16_bf16 (hi*hi + hi*lo + lo*hi,
@@ -313,6 +324,18 @@ int tdm_attention_fwd_f32(const float* qkv, float* o, float* lse, int64_t B, int
 int tdm_attention_bwd_f32(const float* qkv, const float* o, const float* lse, const float* dO, float* dqkv,
                           float* Dvec, int64_t B, int L, int D, int H, float p_drop, uint64_t seed, int site,
                           void* stream);
+/* Per-op residual LayerNorm of the post-LN encoder layer (norm1 / norm2 of nn.TransformerEncoderLayer,
+ * src/shakespeare.py:108-111): s = x + r (r may be NULL); y = (s - mean) * rstd * gamma + beta over the last dim
+ * (biased variance, eps 1e-5).  x, r, y, s: (M, D) fp32; mean, rstd: (M).  s / mean / rstd are optional (all or none):
+ * what the backward twin reads.  D % 4 == 0, D <= 1024.                                                            */
+int tdm_layernorm_residual_fwd_f32(const float* x, const float* r, const float* gamma, const float* beta, float* y,
+                                   float* s, float* mean, float* rstd, int64_t M, int D, void* stream);
+/* ds (M, D) = d(loss)/d(x) = d(loss)/d(r); dgamma_dbeta (2, D) = (dgamma, dbeta); deterministic (fixed-order partials).
+ * scratch: tdm_layernorm_scratch_floats(D) floats.                                                                 */
+int64_t tdm_layernorm_scratch_floats(int D);
+int tdm_layernorm_residual_bwd_f32(const float* dy, const float* s, const float* mean, const float* rstd,
+                                   const float* gamma, float* ds, float* dgamma_dbeta, float* scratch, int64_t M, int D,
+                                   void* stream);
 /* Host-side evaluation of the dropout mask (tests, oracle cross-check): keep_host[i] = 1 iff
  * flat element idx0 + i of dropout site `site` survives.  Sites in the order the reference's
  * forward reaches them: 0 input dropout (src/shakespeare.py:119); layer l: 1+4l attention

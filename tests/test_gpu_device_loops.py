@@ -238,16 +238,23 @@ def test_graph_sampler_device_noise_equals_eager_chain_with_same_draws(dev, L, g
     with torch.no_grad():
         got = reverse_diffusion(m, x, t_start=steps - 1, use_graph=True)
     sampler = next(iter(m._samplers.values()))
-    assert sampler.graph is not None and sampler.rng_state.cpu().tolist() == [steps, 0]
+    assert sampler.graph is not None and sampler.rng_state.cpu().tolist() == [sampler.offset0 + steps, 0]
     assert sampler.t_vec.cpu().tolist() == [0] * n
     zs = []
     for k in range(steps):
         z = torch.empty_like(x)
-        _lib.check(L.tdm_philox_normal_f32(sampler.seed, k, _lib.ptr(z), z.numel(), _lib.stream()))
+        _lib.check(L.tdm_philox_normal_f32(sampler.seed, sampler.offset0 + k, _lib.ptr(z), z.numel(), _lib.stream()))
         zs.append(z)
     with torch.no_grad():
         want = reverse_diffusion(m, x, noises=zs, t_start=steps - 1, use_graph=False)
     assert torch.equal(got, want)
+    # the cached sampler honours torch.manual_seed: reseeding reproduces the chain bit for bit, not reseeding
+    # draws a different one
+    with torch.no_grad():
+        torch.manual_seed(7)
+        again = reverse_diffusion(m, x, t_start=steps - 1, use_graph=True)
+        other = reverse_diffusion(m, x, t_start=steps - 1, use_graph=True)
+    assert next(iter(m._samplers.values())) is sampler and torch.equal(again, got) and not torch.equal(other, got)
 
 
 # ---------------------------------------------------------------- RCCL, world 1

@@ -343,6 +343,54 @@ def test_attention_per_op_vs_torch(dev, attn_mode, B, L, D, H, p_drop):
     assert e_o < tol and e_l < tol and e_g < tol
 
 
+@pytest.mark.parametrize("M,D,with_res", [(32768, 256, True), (301, 64, True), (5, 1024, False), (1, 32, True), (1000, 512, True),
+                                          (77, 300, True)])
+def test_layernorm_residual_per_op_vs_torch(dev, M, D, with_res):
+    """tdm_layernorm_residual_fwd_f32 / _bwd_f32 (norm1 / norm2 of nn.TransformerEncoderLayer, src/shakespeare.py:108-111:
+    y = LayerNorm(x + sublayer(x))) against fp32 F.layer_norm on the CPU: output, saved statistics, input gradient (the
+    gradient of both x and the residual), dgamma / dbeta; config 5's 32,768 x 256 rows, ragged row counts, every register
+    blocking of the backward kernel (D <= 256, <= 512, <= 1024), a width that is not a multiple of 64.  fp32 arithmetic
+    with wavefront reductions: 2e-5 (dgamma / dbeta sum M terms in a different order: 5e-5)."""
+    from tinydiffusionmodels_amd import _lib
+    L_ = _lib.lib()
+    g = torch.Generator().manual_seed(M + D)
+    x = (torch.randn(M, D, generator=g) * 1.3 + 0.2).requires_grad_(True)
+    r = (torch.randn(M, D, generator=g) * 0.5).requires_grad_(True) if with_res else None
+    gamma = (1 + 0.3 * torch.randn(D, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(D, generator=g)).requires_grad_(True)
+    dy = torch.randn(M, D, generator=g)
+    s_ref = x + r if with_res else x
+    y_ref = F.layer_norm(s_ref, (D,), gamma, beta, eps=1e-5)
+    y_ref.backward(dy)
+    mean_ref = s_ref.detach().mean(-1)
+    rstd_ref = 1.0 / torch.sqrt(s_ref.detach().var(-1, unbiased=False) + 1e-5)
+    xd, gd, bd, dyd = x.detach().to(dev), gamma.detach().to(dev), beta.detach().to(dev), dy.to(dev)
+    rd = r.detach().to(dev) if with_res else None
+    y = torch.empty(M, D, device=dev); s = torch.empty(M, D, device=dev)
+    mean = torch.empty(M, device=dev); rstd = torch.empty(M, device=dev)
+    _lib.check(L_.tdm_layernorm_residual_fwd_f32(_lib.ptr(xd), _lib.ptr(rd), _lib.ptr(gd), _lib.ptr(bd), _lib.ptr(y), _lib.ptr(s),
+                                                 _lib.ptr(mean), _lib.ptr(rstd), M, D, _lib.stream()), "ln_fwd")
+    y2 = torch.empty(M, D, device=dev)                      # statistics not requested: same output
+    _lib.check(L_.tdm_layernorm_residual_fwd_f32(_lib.ptr(xd), _lib.ptr(rd), _lib.ptr(gd), _lib.ptr(bd), _lib.ptr(y2), None, None,
+                                                 None, M, D, _lib.stream()), "ln_fwd")
+    ds = torch.full((M, D), float("nan"), device=dev); dgb = torch.full((2, D), float("nan"), device=dev)
+    scratch = torch.empty(L_.tdm_layernorm_scratch_floats(D), device=dev)
+    _lib.check(L_.tdm_layernorm_residual_bwd_f32(_lib.ptr(dyd), _lib.ptr(s), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gd), _lib.ptr(ds),
+                                                 _lib.ptr(dgb), _lib.ptr(scratch), M, D, _lib.stream()), "ln_bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    errs = {"y": O.rel_err(y.cpu(), y_ref.detach()), "s": O.rel_err(s.cpu(), s_ref.detach()), "mean": O.rel_err(mean.cpu(), mean_ref),
+            "rstd": O.rel_err(rstd.cpu(), rstd_ref), "dx": O.rel_err(ds.cpu(), x.grad),
+            "dgamma": O.rel_err(dgb[0].cpu(), gamma.grad), "dbeta": O.rel_err(dgb[1].cpu(), beta.grad)}
+    if with_res:
+        assert torch.equal(x.grad, r.grad)                  # (the reference's own autograd: one gradient for both addends)
+    print(f"[parity] layernorm per-op M={M} D={D}: " + " ".join(f"{k} {v:.1e}" for k, v in errs.items()))
+    assert all(v < (5e-5 if k in ("dgamma", "dbeta") else 2e-5) for k, v in errs.items()), errs
+    with pytest.raises(RuntimeError, match="saved together"):
+        _lib.check(L_.tdm_layernorm_residual_fwd_f32(_lib.ptr(xd), _lib.ptr(rd), _lib.ptr(gd), _lib.ptr(bd), _lib.ptr(y2), _lib.ptr(s),
+                                                     None, None, M, D, _lib.stream()), "ln_fwd")
+
+
 @pytest.mark.parametrize("B,L,dim", [(2, 37, 64), (1, 130, 128), (3, 128, 256)])
 def test_transformer_oracle_shapes_and_autograd_bridge(dev, golden_tables, gemm_mode, attn_mode, B, L, dim):
     """Ragged sequence lengths (not multiples of 128), other widths, and the
@@ -512,14 +560,16 @@ def test_text_graph_sampler_equals_eager_chain_with_same_draws(dev, gemm_mode):
     torch.manual_seed(5)
     got = reverse_diffusion(m, x, t_start=steps - 1, use_graph=True)
     sampler = next(iter(m._samplers.values()))
-    assert sampler.graph is not None and sampler.rng_state.cpu().tolist()[0] == steps and sampler.t_vec.cpu().tolist() == [0] * n
+    assert sampler.graph is not None and sampler.rng_state.cpu().tolist()[0] == sampler.offset0 + steps and sampler.t_vec.cpu().tolist() == [0] * n
     zs = []
     for k in range(steps):
         z = torch.empty_like(x)
-        _lib.check(_lib.lib().tdm_philox_normal_f32(sampler.seed, k, _lib.ptr(z), z.numel(), _lib.stream()))
+        _lib.check(_lib.lib().tdm_philox_normal_f32(sampler.seed, sampler.offset0 + k, _lib.ptr(z), z.numel(), _lib.stream()))
         zs.append(z)
     want = reverse_diffusion(m, x, noises=zs, t_start=steps - 1)
     assert torch.equal(got, want)
+    torch.manual_seed(5)                                               # the cached sampler honours torch.manual_seed
+    assert torch.equal(reverse_diffusion(m, x, t_start=steps - 1, use_graph=True), got)
     odd = reverse_diffusion(m, x, t_start=16, use_graph=True)          # odd chain: first step eager, then graph replays
     assert torch.isfinite(odd).all()
     m._samplers.clear()
@@ -711,6 +761,34 @@ def test_rounding_ce_without_stored_logits_vs_oracle(dev, gemm_mode, monkeypatch
     ce.backward()
     assert abs(ce.item() - loss_ref.item()) < 2e-5 * abs(loss_ref.item())
     assert O.rel_err(xg.grad.cpu(), dx_ref) < 1e-4 and O.rel_err(rnd.decoder.weight.grad.cpu(), dW_ref) < 1e-4
+
+
+def test_rounding_ce_out_of_range_id_poisons_the_loss(dev, gemm_mode):
+    """F.cross_entropy raises on a target id outside [0, V) (src/shakespeare.py:239-240).  The native call cannot raise
+    without a host sync; it must not return a plausible number either: the row's target slot stays NaN, so the loss is NaN
+    in both the stored-logits and the chunked form."""
+    from tinydiffusionmodels_amd import _lib
+    L_ = _lib.lib()
+    M, V, D = 96, 300, 32
+    g = torch.Generator().manual_seed(3)
+    x, W, b = torch.randn(M, D, generator=g).to(dev), (torch.randn(V, D, generator=g) * 0.2).to(dev), torch.zeros(V, device=dev)
+    ids = torch.randint(0, V, (M,), generator=g).to(dev)
+    loss, dW, db = torch.zeros(1, device=dev), torch.empty(V, D, device=dev), torch.empty(V, device=dev)
+    for chunk in (0, 128):
+        n = L_.tdm_round_workspace_chunked_floats(M, V, D, chunk) if chunk else L_.tdm_round_workspace_floats(M, V, D)
+        for bad in (None, V, -1):
+            idb = ids.clone()
+            if bad is not None:
+                idb[5] = bad
+            ws = torch.zeros(n, device=dev)                 # a clean workspace: the stale slot would read as logit 0.0
+            if chunk:
+                _lib.check(L_.tdm_round_ce_loss_grad_chunked_f32(_lib.ptr(x), _lib.ptr(W), _lib.ptr(b), _lib.ptr(idb), 1.0, _lib.ptr(loss),
+                                                                 None, _lib.ptr(dW), _lib.ptr(db), _lib.ptr(ws), M, V, D, chunk, _lib.stream()))
+            else:
+                _lib.check(L_.tdm_round_ce_loss_grad_f32(_lib.ptr(x), _lib.ptr(W), _lib.ptr(b), _lib.ptr(idb), 1.0, _lib.ptr(loss), None,
+                                                         _lib.ptr(dW), _lib.ptr(db), _lib.ptr(ws), M, V, D, _lib.stream()))
+            v = loss.item()
+            assert (v != v) == (bad is not None), (chunk, bad, v)
 
 
 @pytest.mark.parametrize("tag", ["cos1003", "cos2048"])

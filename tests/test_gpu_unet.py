@@ -244,6 +244,31 @@ def test_unet_forward_golden(dev, model, golden_dir):
         assert torch.equal(model(x, t), eps)      # module call == engine call
 
 
+def test_residual_block_module_golden(dev, lib, golden_dir):
+    """`from src.mnist import ResidualBlock` (src/mnist.py:45-61 of the reference): each of the four blocks, loaded with the
+    golden weights under the reference's own parameter names, maps the golden block input to the golden block output
+    (h1..h4 captured from the imported reference) through tdm_resblock_fwd_f32."""
+    from src.mnist import ResidualBlock
+    g = _load(golden_dir, "unet_forward.npz")
+    w = _weights(g)
+    that = (g["t"].float() / 1000).view(-1, 1, 1, 1)
+    h1, h2, h3 = g["h1"], g["h2"], g["h3"]
+    ins = {"rb1": g["x_noisy"], "rb2": F.avg_pool2d(h1, 2), "rb3": h2,
+           "rb4": torch.cat([F.interpolate(h3, scale_factor=2, mode="nearest"), h1], dim=1)}
+    outs = {"rb1": h1, "rb2": h2, "rb3": h3, "rb4": g["h4"]}
+    for name, ci, co in (("rb1", 1, 32), ("rb2", 32, 64), ("rb3", 64, 64), ("rb4", 96, 32)):
+        blk = ResidualBlock(ci, co)
+        missing = blk.load_state_dict({k[len(name) + 1:]: v for k, v in w.items() if k.startswith(name + ".")}, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+        blk = blk.to(dev)
+        with torch.no_grad():
+            y = blk(ins[name].to(dev), that.to(dev)).cpu()
+        assert y.shape == outs[name].shape
+        assert O.rel_err(y, outs[name]) < _tol(), name
+    with pytest.raises(RuntimeError, match="inference entry point"):
+        blk(ins["rb4"].to(dev), that.to(dev))          # autograd recording: refused loudly, no ATen fallback
+
+
 @pytest.mark.parametrize("B", [1, 9, 33])
 def test_unet_forward_oracle_ragged_batches(dev, model, golden_dir, B):
     p = _weights(_load(golden_dir, "unet_forward.npz"))

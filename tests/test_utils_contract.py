@@ -106,3 +106,64 @@ def test_simulated_training_workflow(tmp_path):
     fresh = torch.nn.Linear(4, 2)
     fresh.load_state_dict(U.load_checkpoint(tmp_path / "e2.pth", "cpu"))
     assert torch.equal(fresh.weight, model.weight)
+
+
+# ---- the drop-in module path: `src.utils` must be the module the functions resolve their globals in ------------
+# (the reference's tests/test_utils.py:94-222 patch by the STRING targets below; a star re-export made 5 of them miss)
+def test_src_utils_is_the_implementation_module():
+    import src.utils as S
+    assert S is U and S.load_checkpoint.__globals__ is vars(S)
+
+
+def _fake_tmp(name):
+    tmp = MagicMock()
+    tmp.name = name
+    ctx = MagicMock()
+    ctx.return_value.__enter__.return_value = tmp
+    return ctx, tmp
+
+
+def test_string_patch_targets_reach_load_checkpoint_gcs():
+    import src.utils as S
+    ctx, _ = _fake_tmp("/tmp/fake.pth")
+    with patch("src.utils.torch.load", return_value={"k": 1}) as tl, patch("src.utils.download_from_gcs") as dl, \
+            patch("src.utils.tempfile.NamedTemporaryFile", ctx), patch("src.utils.os.unlink") as ul:
+        assert S.load_checkpoint("gs://bkt/ck.pth", "cuda") == {"k": 1}
+    dl.assert_called_once_with("gs://bkt/ck.pth", "/tmp/fake.pth")
+    tl.assert_called_once_with("/tmp/fake.pth", map_location="cuda")
+    ul.assert_called_once_with("/tmp/fake.pth")
+
+
+def test_string_patch_targets_reach_save_checkpoint_gcs():
+    import src.utils as S
+    ctx, _ = _fake_tmp("/tmp/fake.pth")
+    state = {"w": 3}
+    with patch("src.utils.torch.save") as ts, patch("src.utils.upload_to_gcs") as up, \
+            patch("src.utils.tempfile.NamedTemporaryFile", ctx), patch("src.utils.os.unlink") as ul:
+        S.save_checkpoint(state, "gs://bkt/ck.pth")
+    ts.assert_called_once_with(state, "/tmp/fake.pth")
+    up.assert_called_once_with("/tmp/fake.pth", "gs://bkt/ck.pth")
+    ul.assert_called_once_with("/tmp/fake.pth")
+
+
+@pytest.mark.parametrize("content,writer", [("some text", "write_text"), (b"\x01\x02", "write_bytes")])
+def test_string_patch_target_path_reaches_save_samples_local(content, writer):
+    import src.utils as S
+    with patch("src.utils.Path") as P:
+        dest = P.return_value
+        S.save_samples(content, "/somewhere/s.out")
+    dest.parent.mkdir.assert_called_once_with(parents=True, exist_ok=True)
+    getattr(dest, writer).assert_called_once_with(content)
+
+
+def test_string_patch_targets_reach_save_samples_gcs_text():
+    import src.utils as S
+    ctx, tmp = _fake_tmp("/tmp/fake.txt")
+    with patch("src.utils.upload_to_gcs") as up, patch("src.utils.tempfile.NamedTemporaryFile", ctx), \
+            patch("src.utils.os.unlink") as ul:
+        S.save_samples("some text", "gs://bkt/s.txt")
+    tmp.write.assert_called_once_with("some text")
+    tmp.flush.assert_called_once()
+    tmp.close.assert_called_once()
+    up.assert_called_once_with("/tmp/fake.txt", "gs://bkt/s.txt")
+    ul.assert_called_once_with("/tmp/fake.txt")

@@ -54,6 +54,11 @@ _SIGS = {
                                  c_int),
     "tdm_conv_nhwc_s16_f32": ([c_f] * 10 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_f], c_int),
     "tdm_conv_wgrad_nhwc_s16_f32": ([c_f] * 5 + [c_i64, c_int, c_int, c_int, c_int, c_f], c_int),
+    "tdm_resblock_scratch_floats": ([c_i64, c_int, c_int, c_int], c_i64),
+    "tdm_resblock_fwd_f32": ([c_f] * 12 + [c_i64, c_int, c_int, c_int, c_f], c_int),
+    "tdm_layernorm_residual_fwd_f32": ([c_f] * 8 + [c_i64, c_int, c_f], c_int),
+    "tdm_layernorm_scratch_floats": ([c_int], c_i64),
+    "tdm_layernorm_residual_bwd_f32": ([c_f] * 8 + [c_i64, c_int, c_f], c_int),
     "tdm_set_gemm_mode": ([c_int], c_int),
     "tdm_get_gemm_mode": ([], c_int),
     "tdm_tt_param_count": ([c_int, c_int, c_int], c_i64),

@@ -153,6 +153,18 @@ __global__ __launch_bounds__(EW_BLOCK) void timebias_kernel(const int64_t* __res
     }
 }
 
+// tb[b][c] = fma(w[c], that[b], bias[c]) for ONE residual block whose caller already holds t-hat as floats
+// (ResidualBlock.forward(x, t), src/mnist.py:56-59: `self.time_emb(t)` on a (B,1,1,1) float tensor)
+__global__ __launch_bounds__(EW_BLOCK) void timebias_float_kernel(const float* __restrict__ that, const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, float* __restrict__ tb,
+                                                                  int B, int C) {
+    const int total = B * C;
+    for (int i = blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += gridDim.x * EW_BLOCK) {
+        const int b = i / C, c = i - b * C;
+        tb[i] = fmaf(w[c], that[b], bias[c]);
+    }
+}
+
 // ---- rb1.conv1 (Cin = 1) + rb1.skip ----------------------------------------
 // src/mnist.py:57 with in_ch=1 and :52: a1 = relu(conv3x3(x)+b1), s = x*ws+bs.
 // HBM-bound (4 B in, 256 B out per pixel): 8 lanes per pixel, float4 stores.
@@ -957,6 +969,12 @@ int tdm_launch_timebias(const int64_t* t, const float* params, const int* te_w_o
     TDM_CHECK_LAUNCH("timebias");
     return 0;
 }
+int tdm_launch_timebias_float(const float* that, const float* w, const float* bias, float* tb, int B, int C, hipStream_t st) {
+    hipLaunchKernelGGL(timebias_float_kernel, dim3(ew_grid((int64_t)B * C)), dim3(EW_BLOCK), 0, st, that, w, bias, tb, B, C);
+    TDM_CHECK_LAUNCH("timebias_float");
+    return 0;
+}
+
 int tdm_launch_conv_first(const float* x, const float* w1, const float* b1, const float* ws, const float* bs, float* a1,
                           float* s, int B, hipStream_t st) {
     hipLaunchKernelGGL(conv_first_kernel, dim3(ew_grid((int64_t)B * 784 * 8)), dim3(EW_BLOCK), 0, st, x, w1, b1, ws, bs,

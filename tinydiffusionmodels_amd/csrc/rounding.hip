@@ -161,6 +161,18 @@ inline int round_splitk(int Vp, int D) {
 // workspace carve (floats): logits [M][Vp] | lse [M] | rowloss [M] | target logit [M] | (max, sum exp) pairs [M][nblk][2] |
 // wT [D][Vp] | dW slabs [sk][Vp][D] | db slabs [sk][Vp] | xn [M][D] + [Vp]   (cosine decode: wT holds the normalised
 // table, xn the normalised rows and a zero bias)
+// The target logit of a row is written by the ONE tile that holds column ids[row]; an id outside [0, V) (F.cross_entropy
+// raises on it, src/shakespeare.py:240) would leave the slot as stale workspace and a plausible-looking loss.  Pre-filling
+// with NaN (all-ones bytes) makes such a batch show up as a NaN loss instead.
+static int ce_poison_targets(float* tgt, long M, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(tgt, 0xFF, (size_t)M * sizeof(float), st);
+    if (e != hipSuccess) {
+        tdm_set_error("round_ce: memset failed: %s", hipGetErrorString(e));
+        return 100 + (int)e;
+    }
+    return 0;
+}
+
 struct RoundWs { float *logits, *lse, *rowloss, *tgt, *part, *wT, *wslab, *bslab, *xn; long total; int Vp, sk, nblk; };
 RoundWs round_carve(float* base, long M, int V, int D) {
     RoundWs w{};
@@ -227,6 +239,7 @@ int tdm_round_ce_loss_grad_f32(const float* x, const float* W, const float* b, c
     const RoundWs w = round_carve(ws, M, V, D);
     const int Vp = w.Vp;
     const float gscale = grad_scale / (float)M;
+    TDM_TRY(ce_poison_targets(w.tgt, (long)M, st));
     // logits = x W^T + b, with the cross-entropy partials in the epilogue            (src/shakespeare.py:239)
     {
         GemmArgs g{};
@@ -309,6 +322,7 @@ int tdm_round_ce_loss_grad_chunked_f32(const float* x, const float* W, const flo
     hipStream_t st = (hipStream_t)stream;
     const RoundChunkWs w = round_chunk_carve(ws, M, V, D, Vc);
     const float gscale = grad_scale / (float)M;
+    TDM_TRY(ce_poison_targets(w.tgt, (long)M, st));
     {   // statistics pass: (max, sum exp) per 64-column block and the target logit of every row; nothing else is stored
         GemmArgs g{};
         g.A = x; g.a_rs = D; g.a_cs = 1;

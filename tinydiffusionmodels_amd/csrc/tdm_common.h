@@ -162,6 +162,7 @@ int tdm_launch_reduce(const float* slabs, long stride, const ReduceArgs& ra, flo
 // bump != nullptr: also bump[0] += 1 (the Philox offset of the fused train step, consumed by the preceding draw kernel)
 int tdm_launch_timebias(const int64_t* t, const float* params, const int* te_w_off, const int* te_b_off,
                         float* that, float* tb, int B, hipStream_t st, int64_t* bump = nullptr);
+int tdm_launch_timebias_float(const float* that, const float* w, const float* bias, float* tb, int B, int C, hipStream_t st);
 int tdm_launch_draw_q_sample(const float* x0, const float* sqrt_acp, const float* sqrt_1m_acp, uint64_t seed, int64_t* rng_state,
                              int64_t* t_out, float* noise_out, float* x_noisy_out, int64_t B, int64_t inner, bool bump,
                              hipStream_t st);

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         buf[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c4 < D4) {
             const float4 a = reinterpret_cast<const float4*>(x + row * D)[c4];
-            const float4 b = reinterpret_cast<const float4*>(r + row * D)[c4];
+            const float4 b = r != nullptr ? reinterpret_cast<const float4*>(r + row * D)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
             buf[q] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
             sum += (buf[q].x + buf[q].y) + (buf[q].z + buf[q].w);
         }
@@ -1050,6 +1050,39 @@ int tdm_attention_bwd_f32(const float* qkv, const float* o, const float* lse, co
     const DropArgs da = tdm_drop_site(p_drop, seed, site);
     TDM_TRY(attn_dispatch(1, D / H, qkv, o, lse, dO, dqkv, Dvec, B, L, D, H, da, (hipStream_t)stream));
     return attn_dispatch(2, D / H, qkv, nullptr, lse, dO, dqkv, Dvec, B, L, D, H, da, (hipStream_t)stream);
+}
+
+// Per-op post-LN residual LayerNorm of nn.TransformerEncoderLayer (norm1 / norm2, src/shakespeare.py:108-111):
+//   s = x + r (r may be NULL); y = (s - mean(s)) / sqrt(var(s) + 1e-5) * gamma + beta, statistics over the last dim (biased).
+// s / mean / rstd (optional, all or none) are what the backward twin reads.  Dropout-free: the train-mode mask of the
+// sub-layer output is applied by the producer of r.
+int tdm_layernorm_residual_fwd_f32(const float* x, const float* r, const float* gamma, const float* beta, float* y, float* s,
+                                   float* mean, float* rstd, int64_t M, int D, void* stream) {
+    TDM_REQUIRE(x && gamma && beta && y && M >= 0 && D > 0 && D % 4 == 0 && D <= 1024,
+                "layernorm_residual_fwd: bad arguments (M=%lld D=%d; D %% 4 == 0, D <= 1024)", (long long)M, D);
+    TDM_REQUIRE((s != nullptr) == (mean != nullptr) && (mean != nullptr) == (rstd != nullptr),
+                "layernorm_residual_fwd: s, mean and rstd are saved together or not at all");
+    if (M == 0) return 0;
+    return ln_fwd(x, r, gamma, beta, y, nullptr, s, mean, rstd, M, D, (hipStream_t)stream);
+}
+// Backward twin: given dy and the saved (s, mean, rstd): ds[M][D] = d(loss)/d(s) — the gradient of BOTH x and r — and
+// dgamma_dbeta[2][D] = (sum_m dy * xhat, sum_m dy).  scratch: tdm_layernorm_scratch_floats(D) floats (per-workgroup
+// partials, reduced in fixed order: deterministic).
+int64_t tdm_layernorm_scratch_floats(int D) { return (int64_t)LN_SLABS * 3 * D + 3 * (int64_t)D + 64; }
+int tdm_layernorm_residual_bwd_f32(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
+                                   float* ds, float* dgamma_dbeta, float* scratch, int64_t M, int D, void* stream) {
+    TDM_REQUIRE(dy && s && mean && rstd && gamma && ds && dgamma_dbeta && scratch && M >= 1 && D > 0 && D % 4 == 0 && D <= 1024,
+                "layernorm_residual_bwd: bad arguments (M=%lld D=%d; D %% 4 == 0, D <= 1024)", (long long)M, D);
+    // ln_bwd reduces into G[gamma_off .. + 2 D) and G[bias_off .. + D): lay them out behind the partials
+    float* G = scratch + (long)LN_SLABS * 3 * D;
+    TDM_TRY(ln_bwd(dy, nullptr, s, mean, rstd, gamma, ds, nullptr, nullptr, false, DropArgs{}, scratch, G, 0, 2L * D, M, D,
+                   (hipStream_t)stream));
+    hipError_t e = hipMemcpyAsync(dgamma_dbeta, G, (size_t)2 * D * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        tdm_set_error("layernorm_residual_bwd: copy failed: %s", hipGetErrorString(e));
+        return 100 + (int)e;
+    }
+    return 0;
 }
 
 // keep[i] = 1 if element idx0 + i of dropout site `site` survives (the mask the kernels regenerate in registers)

@@ -852,4 +852,56 @@ int tdm_conv_wgrad_nhwc_f32(const float* in, const float* tb, const float* dout,
     return 0;
 }
 
+// ---- a3: one ResidualBlock (src/mnist.py:45-61) as a stand-alone call, in the active conv arithmetic ---------------
+//   h = relu(conv1(x)); h = h + time_emb(that).view(B, C, 1, 1); h = relu(conv2(h)); out = h + (skip(x) | x)
+// x (B,HW,HW,Cin) and out (B,HW,HW,Cout) are NHWC fp32, conv weights HWIO, that (B) floats = the `t` the reference's
+// forward receives as (B,1,1,1).  skw == NULL: identity skip (Cin == Cout).  Geometries: the MFMA kernels' (HW in
+// {14, 28}, Cin a multiple of 32, Cout in {32, 64}) and the first block's (HW 28, Cin 1, Cout 32).
+int64_t tdm_resblock_scratch_floats(int64_t B, int HW, int Cin, int Cout) {
+    const int64_t M = B * HW * HW;
+    const int64_t cmax = Cin > Cout ? Cin : Cout;
+    // tb | a1 | s | per-conv scratch of the largest conv (packed weights + an S16 copy of its input)
+    return (B * Cout + 64) + 2 * (M * Cout + 64) + (9 * cmax * Cout + 64) + (M * cmax + 192);
+}
+
+int tdm_resblock_fwd_f32(const float* x, const float* that, const float* c1w, const float* c1b, const float* c2w,
+                         const float* c2b, const float* tew, const float* teb, const float* skw, const float* skb,
+                         float* out, float* scratch, int64_t B, int HW, int Cin, int Cout, void* stream) {
+    TDM_CHECK_B(B);
+    TDM_REQUIRE(x && that && c1w && c1b && c2w && c2b && tew && teb && out && scratch, "resblock_fwd: NULL pointer");
+    TDM_REQUIRE(HW == 28 || HW == 14, "resblock_fwd: HW %d (28 or 14)", HW);
+    TDM_REQUIRE(Cout == 32 || Cout == 64, "resblock_fwd: Cout %d (32 or 64)", Cout);
+    const bool first = (Cin == 1);
+    TDM_REQUIRE(first ? (HW == 28 && Cout == 32 && skw && skb) : (Cin % 32 == 0 && Cin <= 96),
+                "resblock_fwd: unsupported geometry Cin %d Cout %d HW %d", Cin, Cout, HW);
+    TDM_REQUIRE(skw != nullptr ? skb != nullptr : Cin == Cout, "resblock_fwd: identity skip needs Cin == Cout; a skip conv needs its bias");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t M = B * HW * HW;
+    auto al = [](int64_t n) { return (n + 63) & ~(int64_t)63; };
+    float* tb = scratch;
+    float* a1 = tb + al(B * Cout);
+    float* s = a1 + al(M * Cout);
+    float* cs = s + al(M * Cout);       // scratch of the per-layer conv entry points
+    auto conv = [&](const float* in, const float* w, const float* bias, const float* res, const float* tbi, float* o, int ci,
+                    int k, int relu) -> int {
+        if (g_conv_mode == 0) return tdm_conv_nhwc_f32(in, w, bias, res, tbi, o, nullptr, B, HW, ci, Cout, k, relu, stream);
+        if (g_conv_mode == 1) return tdm_conv_nhwc_bf16x3_f32(in, w, bias, res, tbi, o, nullptr, cs, B, HW, ci, Cout, k, relu, stream);
+        return tdm_conv_nhwc_s16_f32(in, w, bias, res, tbi, o, nullptr, nullptr, nullptr, cs, B, HW, ci, Cout, k, relu, stream);
+    };
+    TDM_TRY(tdm_launch_timebias_float(that, tew, teb, tb, (int)B, Cout, st));
+    const float* res = x;               // identity skip
+    if (first) {
+        TDM_TRY(tdm_launch_conv_first(x, c1w, c1b, skw, skb, a1, s, (int)B, st));
+        res = s;
+    } else {
+        TDM_TRY(conv(x, c1w, c1b, nullptr, nullptr, a1, Cin, 3, 1));
+        if (skw != nullptr) {
+            TDM_TRY(conv(x, skw, skb, nullptr, nullptr, s, Cin, 1, 0));
+            res = s;
+        }
+    }
+    return conv(a1, c2w, c2b, res, tb, out, Cout, 3, 1);
+}
+
+
 }  // extern "C"

@@ -85,44 +85,84 @@ class NativeComm:
 _native: Optional[NativeComm] = None
 _native_tried = False
 _native_error: Optional[str] = None
+_native_inits = 0          # communicators this process has bootstrapped: part of the store key (a re-init must not read a stale id)
+
+
+class CommInitError(RuntimeError):
+    """The native (libtdm_hip / RCCL) communicator could not be brought up; the job continues on torch.distributed."""
+
+
+def _all_ranks_ok(ok: bool) -> bool:
+    """MIN over ranks of a local success flag: every rank takes the same branch after every bootstrap stage, so a rank
+    that failed locally still joins exactly the collectives the others issue."""
+    flag = torch.tensor([1 if ok else 0], device="cuda", dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return int(flag.item()) == 1
 
 
 def native_comm() -> Optional[NativeComm]:
     """The process's native communicator, created on first use when the job runs one rank per GPU
     with the RCCL backend (TDM_COMM=torch keeps the collective in torch.distributed; gloo jobs
-    always do).  The unique id travels through torch.distributed's rendezvous store."""
-    global _native, _native_tried, _native_error
+    always do).  The unique id travels through torch.distributed's rendezvous store.
+
+    Bootstrap = three stages, each followed by a MIN agreement over the ranks: (1) local: library loads, RCCL binds,
+    rank 0 publishes a fresh unique id; (2) tdm_comm_init (collective); (3) a probe all-reduce cross-checked against
+    torch.distributed's.  Only comm-init failures (CommInitError, the library's RuntimeError, OSError from dlopen) fall
+    back — with the reason logged on rank 0 and reported by collective_name(); anything else propagates."""
+    global _native, _native_tried, _native_error, _native_inits
     if _native is not None or _native_tried:
         return _native
     _native_tried = True
     rank, world = world_info()
     if world == 1 or os.environ.get("TDM_COMM", "native") != "native" or dist.get_backend() != "nccl":
         return None
-    try:
-        store = dist.distributed_c10d._get_default_store()
+    _native_inits += 1
+    key = f"tdm_rccl_unique_id/{_native_inits}"
+    comm, err = None, None
+
+    def stage(fn):
+        nonlocal err
+        if err is None:
+            try:
+                fn()
+            except (CommInitError, RuntimeError, OSError) as e:
+                err = f"{type(e).__name__}: {e}"
+        if not _all_ranks_ok(err is None) and err is None:
+            err = "another rank could not initialise its native communicator"
+
+    def local_checks():
+        from . import _lib
+        if _lib.lib().tdm_comm_rccl_version() < 0:
+            raise CommInitError("librccl could not be loaded by libtdm_hip")
         if rank == 0:
-            store.set("tdm_rccl_unique_id", NativeComm.make_unique_id())
-        uid = bytes(store.get("tdm_rccl_unique_id"))
+            dist.distributed_c10d._get_default_store().set(key, NativeComm.make_unique_id())
+
+    def init():
+        nonlocal comm
+        uid = bytes(dist.distributed_c10d._get_default_store().get(key))
         comm = NativeComm(torch.cuda.current_device(), rank, world, uid)
-        # one-off cross-check against torch.distributed's own RCCL all-reduce
-        probe = torch.arange(1024, device="cuda", dtype=torch.float32) * (rank + 1)
-        want = probe.clone()
+
+    def probe():
+        buf = torch.arange(1024, device="cuda", dtype=torch.float32) * (rank + 1)
+        want = buf.clone()
         dist.all_reduce(want, op=dist.ReduceOp.SUM)
-        comm.allreduce_sum_(probe)
+        comm.allreduce_sum_(buf)
         torch.cuda.synchronize()
-        if not torch.equal(probe, want):
-            raise RuntimeError("native all-reduce disagrees with torch.distributed")
+        if not torch.equal(buf, want):
+            raise CommInitError("native all-reduce disagrees with torch.distributed")
+
+    stage(local_checks)
+    stage(init)
+    stage(probe)
+    if err is not None:
+        if comm is not None:
+            comm.close()
+        _native_error, _native = err, None
+        if rank == 0:
+            print(f"[tdm] native RCCL communicator unavailable ({err}); gradients go through torch.distributed.all_reduce",
+                  flush=True)
+    else:
         _native = comm
-    except Exception as e:   # keep training on the torch.distributed collective; bench.py reports which one ran
-        _native_error = f"{type(e).__name__}: {e}"
-        _native = None
-    # every rank must take the same path: agree (MIN) on whether the native communicator is usable
-    ok = torch.tensor([1 if _native is not None else 0], device="cuda", dtype=torch.int32)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok.item()) == 0 and _native is not None:
-        _native_error = "another rank could not initialise its native communicator"
-        _native.close()
-        _native = None
     return _native
 
 
@@ -208,3 +248,62 @@ def shard_chains(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     """[start, end) of the sampling chains owned by `rank` (no collectives)."""
     per = (n_total + world - 1) // world
     return min(rank * per, n_total), min((rank + 1) * per, n_total)
+
+
+def sampler_stream_key() -> int:
+    """Philox key of this rank's reverse-loop noise streams: a constant mixed with the rank, so identically seeded
+    ranks (same torch.manual_seed, hence the same drawn offsets) still sample different chains."""
+    rank, _ = world_info()
+    return (0x5EED5A3B1E0FD1FF ^ (rank * 0x9E3779B97F4A7C15)) & (2 ** 64 - 1)
+
+
+def draw_stream_offset() -> int:
+    """Base offset of one chain's Philox stream, from torch's CPU generator (so torch.manual_seed reproduces a chain).
+    2^40 steps of headroom below 2^62; two chains overlap only if their offsets fall within a chain length of each other."""
+    return int(torch.randint(0, 2 ** 62 - 2 ** 40, (1,)).item())
+
+
+def barrier() -> None:
+    _, world = world_info()
+    if world > 1:
+        dist.barrier()
+
+
+def allreduce_host_(values: torch.Tensor, op: str = "sum") -> torch.Tensor:
+    """In-place reduction over ranks of a small control tensor (validation sums, loader lengths): `torch.distributed`
+    on whatever device the tensor lives on — control plane, not the gradient path.  No-op at world 1."""
+    _, world = world_info()
+    if world > 1:
+        dist.all_reduce(values, op={"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}[op])
+    return values
+
+
+class ShardedBatches:
+    """Per-rank view of one epoch over a (N, ...) tensor of samples, the text loop's counterpart of mnist.train's
+    sharding: every rank walks the SAME permutation (seeded by `seed + epoch`, advanced by each __iter__), global
+    iteration `it` covers `world * batch_size` consecutive entries of it and rank r takes its consecutive slice
+    (shard_batch_indices).  All ranks therefore run the same number of iterations; in the ragged tail a rank's batch may
+    be short or EMPTY (shape (0, ...)) and `global_batch(it)` tells the train loop how many samples all ranks hold
+    together, so it can weight its gradient by B_local / B_global instead of exchanging counts.  drop_last is never
+    applied (the reference's DataLoader has none, src/shakespeare.py:589-590)."""
+
+    def __init__(self, data: torch.Tensor, batch_size: int, rank: int, world: int, shuffle: bool = True, seed: int = 0):
+        self.data, self.batch_size, self.rank, self.world, self.shuffle, self.seed = data, batch_size, rank, world, shuffle, seed
+        self.epoch = 0
+        self.n = int(data.shape[0])
+
+    def __len__(self) -> int:
+        per = self.world * self.batch_size
+        return (self.n + per - 1) // per
+
+    def global_batch(self, it: int) -> int:
+        return global_batch_count(self.n, it, self.batch_size, self.world)
+
+    def __iter__(self):
+        if self.shuffle:
+            perm = torch.randperm(self.n, generator=torch.Generator().manual_seed(self.seed + self.epoch))
+        else:
+            perm = torch.arange(self.n)
+        self.epoch += 1
+        for it in range(len(self)):
+            yield self.data[shard_batch_indices(perm, it, self.batch_size, self.rank, self.world)]

@@ -71,6 +71,51 @@ class _UNetFunction(torch.autograd.Function):
         return None, None, grads
 
 
+class ResidualBlock(nn.Module):
+    """src/mnist.py:45-61 as a stand-alone module: the reference's submodule names and parameter shapes
+    (`conv1`, `conv2`, `time_emb`, `skip`; drawn in the reference's order), forward(x, t) with x (B,in_ch,H,W)
+    and t the (B,1,1,1) float tensor SimpleUNet hands its blocks, computed by ONE C-ABI call
+    (tdm_resblock_fwd_f32: conv1+ReLU, time bias, conv2+ReLU, skip) in the active conv arithmetic.
+
+    Inference surface: SimpleUNet's own forward / backward run the fused whole-network pipeline over the flat
+    parameter, not four of these; a block called with autograd recording raises (no silent ATen fallback).
+    Geometries: H = W in {14, 28}; in_ch in {32, 64, 96} and out_ch in {32, 64}, or the first block's (1 -> 32 @ 28)."""
+
+    def __init__(self, in_ch: int, out_ch: int):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_ch, out_ch, 3, padding=1)
+        self.conv2 = nn.Conv2d(out_ch, out_ch, 3, padding=1)
+        self.time_emb = nn.Linear(1, out_ch)
+        if in_ch != out_ch:
+            self.skip = nn.Conv2d(in_ch, out_ch, 1)
+        else:
+            self.skip = nn.Identity()
+        self.in_ch, self.out_ch = in_ch, out_ch
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        E._need_cuda(x, t, self.conv1.weight)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise RuntimeError("ResidualBlock.forward is the inference entry point of the HIP path (call it under "
+                               "torch.no_grad()); training runs through SimpleUNet / DDPMTrainer")
+        B, C, H, W = x.shape
+        if C != self.in_ch or H != W or t.numel() != B:
+            raise RuntimeError(f"ResidualBlock({self.in_ch},{self.out_ch}): got x {tuple(x.shape)}, t {tuple(t.shape)}")
+        hwio = lambda w: w.detach().permute(2, 3, 1, 0).contiguous()                    # noqa: E731  (OIHW -> HWIO)
+        xn = x.detach().permute(0, 2, 3, 1).contiguous().float()                         # NHWC (identical when C == 1)
+        that = t.detach().reshape(B).contiguous().float()
+        has_skip = isinstance(self.skip, nn.Conv2d)
+        args = [xn, that, hwio(self.conv1.weight), self.conv1.bias.detach(), hwio(self.conv2.weight),
+                self.conv2.bias.detach(), self.time_emb.weight.detach().reshape(-1).contiguous(), self.time_emb.bias.detach(),
+                hwio(self.skip.weight) if has_skip else None, self.skip.bias.detach() if has_skip else None]
+        L = _lib.lib()
+        out = torch.empty(B, H, W, self.out_ch, device=x.device, dtype=torch.float32)
+        scratch = torch.empty(L.tdm_resblock_scratch_floats(B, H, self.in_ch, self.out_ch), device=x.device,
+                              dtype=torch.float32)
+        _lib.check(L.tdm_resblock_fwd_f32(*[_lib.ptr(a) for a in args], _lib.ptr(out), _lib.ptr(scratch), B, H, self.in_ch,
+                                          self.out_ch, _lib.stream()), "resblock_fwd")
+        return out.permute(0, 3, 1, 2).contiguous()
+
+
 class SimpleUNet(nn.Module):
     """The reference's noise predictor (src/mnist.py:64-87): four residual
     blocks (1→32 @28², 32→64 @14², 64→64 @14², 96→32 @28²), avg-pool down,
@@ -233,8 +278,10 @@ class _GraphSampler:
         self.z = torch.empty_like(self.xa)
         self.t_vec = torch.zeros(n, device=dev, dtype=torch.long)
         self.kidx = torch.zeros(1, device=dev, dtype=torch.long)
-        # device-drawn noise (Philox stream keyed by a seed taken from torch's generator, offset advanced on the device)
-        self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        # device-drawn noise: Philox key = a constant mixed with the rank (ranks draw distinct streams); the 64-bit stream
+        # OFFSET is what torch's generator governs — run() draws a fresh base offset per chain, the device advances it
+        self.seed = dp.sampler_stream_key()
+        self.offset0 = 0
         self.rng_state = torch.zeros(2, device=dev, dtype=torch.long)
         self.ws = E.UNetWorkspace(n, dev, training=False)  # owned here: the graph holds its address
         self.bank = None
@@ -285,6 +332,10 @@ class _GraphSampler:
         self.xa.copy_(x)
         self.t_vec.fill_(t_start)
         self.kidx.zero_()
+        # a fresh stream per chain, drawn from torch's (CPU) generator like the reference's randn_like draws are:
+        # `torch.manual_seed(s); reverse_diffusion(...)` twice gives the same samples although the sampler is cached
+        self.offset0 = dp.draw_stream_offset()
+        self.rng_state.copy_(torch.tensor([self.offset0, 0], dtype=torch.long))
         left = nsteps
         if left % 2 == 1:                                   # odd chain: first step eagerly (a -> b), then move b to a
             self._one(self.xa, self.xb)
@@ -514,7 +565,7 @@ class DDPMTrainer(DPStepper):
             if whole:
                 scale = dp.allreduce_grads_(self.grads)
                 self.optimizer_step(scale)
-        st.graph, st.graph_whole = g, whole
+        st.graph, st.graph_whole, st.graph_gen = g, whole, schedule_generation()
 
     def step(self, x0: Optional[torch.Tensor], t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
              global_batch: Optional[int] = None):
@@ -528,7 +579,7 @@ class DDPMTrainer(DPStepper):
             return super().step(x0)
         if x0.data_ptr() != st.x0.data_ptr():
             st.x0.copy_(x0)      # the graph reads a fixed address
-        if st.graph is None:
+        if st.graph is None or st.graph_gen != schedule_generation():   # (set_tables() retires the captured table addresses)
             self._capture(st)
         st.graph.replay()
         if not st.graph_whole:
@@ -627,7 +678,9 @@ def main(argv=None):
         data = synthetic_mnist(args.synthetic) if args.synthetic else None
         train(model, device, epochs=args.epochs, batch_size=args.batch_size, ckpt_path=args.ckpt, data=data)
     if args.sample:
-        sample(model, device, ckpt_path=args.ckpt)
+        dp.barrier()                                       # (rank 0 wrote the checkpoint)
+        if dp.world_info()[0] == 0:                        # the CLI's one 5x5 grid; bench.py shards large sampling batches
+            sample(model, device, ckpt_path=args.ckpt)
     if not args.train and not args.sample:
         print("Nothing to do. Pass --train or --sample.")
 

@@ -408,14 +408,15 @@ def load_text_dataset(path: Optional[str] = None) -> str:
     return Path(path).read_text(encoding="utf-8")
 
 
-def tokenize_corpus(text: str, tokenizer, seq_len: int, val_split=0.1):
+def tokenize_corpus(text: str, tokenizer, seq_len: int, val_split=0.1, generator=None):
     """Tokenize the full corpus once and slice it into fixed-length chunks with a random train / val split
-    (src/shakespeare.py:128-156): returns two `torch.utils.data.Subset`s of a (N_chunks, seq_len) long tensor."""
+    (src/shakespeare.py:128-156): returns two `torch.utils.data.Subset`s of a (N_chunks, seq_len) long tensor.
+    `generator`: the split's RNG (data-parallel runs pass one seeded alike on every rank)."""
     ids = tokenizer(text, add_special_tokens=False, return_attention_mask=False, return_tensors="pt").input_ids.squeeze(0)
     n_chunks = ids.size(0) // seq_len
     chunks = ids[: n_chunks * seq_len].view(n_chunks, seq_len)      # drop the remainder
     n_val = int(n_chunks * val_split)
-    return torch.utils.data.random_split(chunks, [n_chunks - n_val, n_val])
+    return torch.utils.data.random_split(chunks, [n_chunks - n_val, n_val], generator=generator)
 
 
 def get_cosine_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps, eta_min=0):
@@ -499,7 +500,8 @@ class _TextGraphSampler:
         self.xb = torch.empty_like(self.xa)
         self.eps = torch.empty_like(self.xa)
         self.t_vec = torch.zeros(n, device=dev, dtype=torch.long)
-        self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self.seed = dp.sampler_stream_key()                 # constant key mixed with the rank; run() draws the stream offset
+        self.offset0 = 0
         self.rng_state = torch.zeros(2, device=dev, dtype=torch.long)
         self.ws = TE.TTWorkspace(model.cfg, n, L, dev, training=False)
         self.graph = None
@@ -529,6 +531,8 @@ class _TextGraphSampler:
     def run(self, x, nsteps, t_start):
         self.xa.copy_(x)
         self.t_vec.fill_(t_start)
+        self.offset0 = dp.draw_stream_offset()             # torch.manual_seed governs the chain's noise (see mnist._GraphSampler)
+        self.rng_state.copy_(torch.tensor([self.offset0, 0], dtype=torch.long))
         left = nsteps
         if left % 2 == 1:
             self._one(self.xa, self.xb)
@@ -610,8 +614,9 @@ def cosine_argmax(x: torch.Tensor, embed_matrix: torch.Tensor) -> torch.Tensor:
 
 
 def sample(model, rounding_fn, embedding_fn, tokenizer, device, n_samples=4, seq_len=128,
-           use_learned_rounding=True, use_learned_embeddings=True, embed_dim=None):
-    """src/shakespeare.py:355-415."""
+           use_learned_rounding=True, use_learned_embeddings=True, embed_dim=None, index_offset=0):
+    """src/shakespeare.py:355-415.  index_offset: first sample number of this call (`sample_{i}.txt`): data-parallel
+    sampling shards the n chains over the ranks with no collective, each rank writing its own file numbers."""
     model.eval()
     rounding_fn.eval()
     if use_learned_embeddings:
@@ -624,7 +629,7 @@ def sample(model, rounding_fn, embedding_fn, tokenizer, device, n_samples=4, seq
         x = reverse_diffusion(model, x)
         tokens = decode_tokens(x, rounding_fn, embedding_fn, use_learned_rounding, use_learned_embeddings)
         texts = tokenizer.batch_decode(tokens, skip_special_tokens=True)
-        for i, text in enumerate(texts):
+        for i, text in enumerate(texts, start=index_offset):
             print(text)
             if isinstance(samples_dir, str) and samples_dir.startswith("gs://"):
                 sample_path = f"{samples_dir}/sample_{i}.txt"
@@ -637,37 +642,59 @@ def sample(model, rounding_fn, embedding_fn, tokenizer, device, n_samples=4, seq
 
 def train(model, rounding_fn, embedding_fn, data_loader, val_loader, device, ckpt_path="text_ckpt.pth", epochs=1,
           lr=1e-4, weight_decay=1e-4, rounding_weight=1.0, use_learned_embeddings=True, patience=5,
-          use_lr_scheduling=True, warmup_steps=100):
+          use_lr_scheduling=True, warmup_steps=100, losses_fn=None, optimizer_cls=None):
     """src/shakespeare.py:174-341 with the same control flow (cosine-warm-up LR,
     decaying rounding weight, validation pass, early stopping, `_best.pth`, final
     checkpoint dict).  Every per-step tensor op is native: embedding gather / scatter-add, q_sample and its
     x0-gradient, denoiser forward / backward, MSE, fused rounding cross-entropy, AdamW (NativeAdamW) — autograd only
-    chains the bridges.  Under torch.distributed (one process per GPU, each with its own shard of the loader) the
-    replicas start from rank 0's weights and every step averages the gradients: dense all-reduces for the denoiser and
-    the rounding head, a ROW-WISE one for the embedding table (dp.allreduce_rows_: only the batch's token rows move)."""
+    chains the bridges.
+
+    Under torch.distributed (one process per GPU, each with its own shard of the loader) the replicas start from rank 0's
+    weights and every step averages the gradients: dense all-reduces for the denoiser and the rounding head, a ROW-WISE
+    one for the embedding table (dp.allreduce_rows_: only the batch's token rows move).  The CONTROL flow is replicated
+    too: every rank must run the same number of iterations (checked up front), the validation sums are all-reduced so
+    `best_val_loss`, the patience counter and the early-stop `break` are the same decision everywhere, and only rank 0
+    writes checkpoints.  A loader with `global_batch(it)` (dp.ShardedBatches) may hand a rank a short or empty batch in
+    the ragged tail: the rank's gradient is weighted by B_local / B_global (zeros when empty) and it still joins the
+    step's collectives.
+
+    losses_fn / optimizer_cls (tests of the host control flow on CPU): replace the native `losses(token_ids, rw) ->
+    (diff, rnd, total)` closure and NativeAdamW."""
     params = list(model.parameters()) + list(rounding_fn.parameters())
     if use_learned_embeddings:
         params += list(embedding_fn.parameters())
-    _, world = dp.world_info()
+    rank, world = dp.world_info()
     emb_w = embedding_fn.embeddings.weight if (use_learned_embeddings and hasattr(embedding_fn, "embeddings")) else None
     if world > 1:
         for p_ in params:
             dp.broadcast_params_(p_.data, src=0)
+        lens = torch.tensor([len(data_loader), -len(data_loader), len(val_loader), -len(val_loader)], dtype=torch.int64,
+                            device=device)
+        dp.allreduce_host_(lens, "min")
+        if int(lens[0]) != -int(lens[1]) or int(lens[2]) != -int(lens[3]):
+            raise RuntimeError("text train(): the ranks' loaders differ in length (train "
+                               f"{int(lens[0])}..{-int(lens[1])}, val {int(lens[2])}..{-int(lens[3])} iterations): a rank "
+                               "that runs out of batches would leave the others blocked in the gradient all-reduce — shard "
+                               "with dp.ShardedBatches")
 
-    def sync_grads(token_ids):
-        """Average the gradients over the ranks (world > 1)."""
+    def sync_grads(token_ids, weight):
+        """Average the gradients over the ranks (world > 1); weight = this rank's share factor B_local * world / B_global
+        (1 for equal shards, 0 for a rank without samples)."""
         for p_ in params:
             if p_.grad is None:
-                continue
+                p_.grad = torch.zeros_like(p_)             # a rank whose batch was empty still joins every collective
+            if weight != 1.0:
+                p_.grad.mul_(weight)
             if p_ is emb_w:
                 dp.allreduce_rows_(p_.grad, token_ids)
             else:
                 dp.allreduce_grads_(p_.grad.view(-1))
             p_.grad.mul_(1.0 / world)
-    optim = NativeAdamW(params, lr=lr, weight_decay=weight_decay)      # torch.optim.AdamW's update on tdm_adamw_flat_f32
+    optim = (optimizer_cls or NativeAdamW)(params, lr=lr, weight_decay=weight_decay)   # torch.optim.AdamW's update on tdm_adamw_flat_f32
     total_steps = len(data_loader) * epochs
     scheduler = get_cosine_schedule_with_warmup(optim, warmup_steps, total_steps) if use_lr_scheduling else None
     best_val_loss, patience_counter = float("inf"), 0
+    global_batch = getattr(data_loader, "global_batch", None)
 
     def losses(token_ids, rw):
         x0 = embedding_fn(token_ids) if use_learned_embeddings else embedding_fn[token_ids]
@@ -678,51 +705,68 @@ def train(model, rounding_fn, embedding_fn, data_loader, val_loader, device, ckp
         diff = native_mse_loss(model(x_noisy, t), noise)
         rnd = rounding_fn.cross_entropy(x0, token_ids)     # logits + cross-entropy, fused native call (row N1)
         return diff, rnd, diff + rw * rnd
+    losses = losses_fn or losses
 
     for epoch in range(epochs):
         model.train(); rounding_fn.train()
         if use_learned_embeddings:
             embedding_fn.train()
         rw = dynamic_rounding_weight_schedule(epoch, epochs, rounding_weight)
-        tr = torch.zeros(3, device=device)
-        for token_ids in data_loader:
+        tr = torch.zeros(4, device=device)                 # sums of the per-batch (diff, rnd, total) and the batch count
+        for it, token_ids in enumerate(data_loader):
             token_ids = token_ids.to(device)
-            diff, rnd, total = losses(token_ids, rw)
-            optim.zero_grad(); total.backward()
+            b_local = int(token_ids.shape[0])
+            optim.zero_grad()
+            if b_local:
+                diff, rnd, total = losses(token_ids, rw)
+                total.backward()
+                tr += torch.stack([diff.detach(), rnd.detach(), total.detach(), torch.ones_like(diff.detach())])
             if world > 1:
-                sync_grads(token_ids)
+                gb = global_batch(it) if global_batch is not None else b_local * world
+                sync_grads(token_ids, b_local * world / float(gb))
+            elif not b_local:
+                continue
             optim.step()
             if scheduler is not None:
                 scheduler.step()
-            tr += torch.stack([diff.detach(), rnd.detach(), total.detach()])
         model.eval(); rounding_fn.eval()
         if use_learned_embeddings:
             embedding_fn.eval()
-        va = torch.zeros(3, device=device)
+        va = torch.zeros(4, device=device)
         with torch.no_grad():
             for token_ids in val_loader:
+                if token_ids.shape[0] == 0:
+                    continue
                 diff, rnd, total = losses(token_ids.to(device), rw)
-                va += torch.stack([diff, rnd, total])
-        tr = (tr / max(1, len(data_loader))).tolist()
-        va = (va / max(1, len(val_loader))).tolist()
-        print(f"Epoch {epoch + 1}/{epochs}:")
-        print(f"  Train: diff={tr[0]:.4f}, round={tr[1]:.4f}, total={tr[2]:.4f}")
-        print(f"  Val:   diff={va[0]:.4f}, round={va[1]:.4f}, total={va[2]:.4f}")
-        print(f"  Rounding weight: {rw:.3f}")
+                va += torch.stack([diff, rnd, total, torch.ones_like(diff)])
+        # the reference averages per-BATCH means over the batches (src/shakespeare.py:252-255, :291-298); across ranks the
+        # sums and the batch counts are reduced first, so every rank holds the same numbers and takes the same branch below
+        dp.allreduce_host_(tr); dp.allreduce_host_(va)
+        tr = (tr[:3] / tr[3].clamp_min(1.0)).tolist()
+        va = (va[:3] / va[3].clamp_min(1.0)).tolist()
+        if rank == 0:
+            print(f"Epoch {epoch + 1}/{epochs}:")
+            print(f"  Train: diff={tr[0]:.4f}, round={tr[1]:.4f}, total={tr[2]:.4f}")
+            print(f"  Val:   diff={va[0]:.4f}, round={va[1]:.4f}, total={va[2]:.4f}")
+            print(f"  Rounding weight: {rw:.3f}")
         if va[2] < best_val_loss:
             best_val_loss, patience_counter = va[2], 0
-            best_ckpt_path = ckpt_path.replace(".pth", "_best.pth")
-            checkpoint = {"diffusion_model": model.state_dict(), "rounding_fn": rounding_fn.state_dict(),
-                          "epoch": epoch, "val_loss": best_val_loss}
-            if use_learned_embeddings:
-                checkpoint["embedding_fn"] = embedding_fn.state_dict()
-            save_checkpoint(checkpoint, best_ckpt_path)
-            print(f"  New best validation loss! Saved to {best_ckpt_path}")
+            if rank == 0:
+                best_ckpt_path = ckpt_path.replace(".pth", "_best.pth")
+                checkpoint = {"diffusion_model": model.state_dict(), "rounding_fn": rounding_fn.state_dict(),
+                              "epoch": epoch, "val_loss": best_val_loss}
+                if use_learned_embeddings:
+                    checkpoint["embedding_fn"] = embedding_fn.state_dict()
+                save_checkpoint(checkpoint, best_ckpt_path)
+                print(f"  New best validation loss! Saved to {best_ckpt_path}")
         else:
             patience_counter += 1
             if patience_counter >= patience:
-                print(f"  Early stopping triggered after {patience} epochs without improvement")
+                if rank == 0:
+                    print(f"  Early stopping triggered after {patience} epochs without improvement")
                 break
+    if rank != 0:
+        return
     final_ckpt_path = get_vertex_checkpoint_path("text-model.pth") if "AIP_MODEL_DIR" in os.environ else ckpt_path
     print(f"✔ Saving final checkpoint to {final_ckpt_path}...")
     final_checkpoint = {"diffusion_model": model.state_dict(), "rounding_fn": rounding_fn.state_dict(),
@@ -784,10 +828,16 @@ def main(argv=None):
         raise SystemExit("--guided_sample needs the causal LM of --model_id (network / gated weights): out of scope here")
     if not torch.cuda.is_available():
         raise RuntimeError("src.shakespeare (HIP build) needs a GPU: there is no CPU fallback")
+    # one process per GPU under torchrun (RANK / WORLD_SIZE / LOCAL_RANK); a plain `python -m` run is world 1
+    rank, world, local_rank = dp.init_from_env(os.environ.get("TDM_DIST_BACKEND"))
+    if os.environ.get("TDM_SHARE_GPU") == "1":             # rehearsal: several ranks on one card (gloo collectives)
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
     if args.seed is not None:
         torch.manual_seed(args.seed)
-    device = torch.device("cuda")
-    print(f"Device: {device}")
+    device = torch.device("cuda", local_rank)
+    if rank == 0:
+        print(f"Device: {device}" + (f" (rank 0 of {world})" if world > 1 else ""))
 
     pretrained = None
     if args.byte_tokenizer:
@@ -814,15 +864,28 @@ def main(argv=None):
 
     if args.train:
         raw = load_text_dataset(args.corpus)
-        train_chunks, val_chunks = tokenize_corpus(raw, tokenizer, args.seq_len, args.val_split)
-        train_dl = DataLoader(train_chunks, batch_size=args.batch_size, shuffle=True)
-        val_dl = DataLoader(val_chunks, batch_size=args.batch_size, shuffle=False)
-        print(f"Training on {len(train_chunks)} chunks, validating on {len(val_chunks)} chunks")
+        if world > 1:
+            # the train / val split and the epoch shuffles must be the SAME on every rank: a generator of their own
+            split_gen = torch.Generator().manual_seed(0 if args.seed is None else args.seed)
+            train_chunks, val_chunks = tokenize_corpus(raw, tokenizer, args.seq_len, args.val_split, generator=split_gen)
+            as_tensor = lambda sub: sub.dataset[torch.as_tensor(sub.indices, dtype=torch.long)]   # noqa: E731
+            # disjoint per-rank slices of every global batch (batch_size per GPU, config 5); ragged tail weighted in train()
+            train_dl = dp.ShardedBatches(as_tensor(train_chunks), args.batch_size, rank, world, shuffle=True,
+                                         seed=int(split_gen.initial_seed()) + 1)
+            val_dl = dp.ShardedBatches(as_tensor(val_chunks), args.batch_size, rank, world, shuffle=False)
+        else:
+            train_chunks, val_chunks = tokenize_corpus(raw, tokenizer, args.seq_len, args.val_split)
+            train_dl = DataLoader(train_chunks, batch_size=args.batch_size, shuffle=True)
+            val_dl = DataLoader(val_chunks, batch_size=args.batch_size, shuffle=False)
+        if rank == 0:
+            print(f"Training on {len(train_chunks)} chunks, validating on {len(val_chunks)} chunks")
         train(diff_model, rounding_fn, embedding_fn, train_dl, val_dl, device, args.ckpt, epochs=args.epochs, lr=args.lr,
               weight_decay=args.weight_decay, rounding_weight=args.rounding_weight,
               use_learned_embeddings=args.use_learned_embeddings, patience=args.patience,
               use_lr_scheduling=args.use_lr_scheduling, warmup_steps=args.warmup_steps)
     texts = None
+    if args.sample and world > 1:
+        dp.barrier()                                       # rank 0 wrote the checkpoint the other ranks are about to read
     if args.sample:
         checkpoint = load_checkpoint(args.ckpt, device)
         if isinstance(checkpoint, dict) and "diffusion_model" in checkpoint:
@@ -838,9 +901,12 @@ def main(argv=None):
             if pretrained is None:
                 raise RuntimeError("an old-format checkpoint needs the pre-trained embedding matrix (--model_id)")
             args.use_cosine_fallback, args.use_learned_embeddings, embedding_fn = True, False, pretrained
-        texts = sample(diff_model, rounding_fn, embedding_fn, tokenizer, device, args.n, args.seq_len,
-                       use_learned_rounding=not args.use_cosine_fallback,
-                       use_learned_embeddings=args.use_learned_embeddings, embed_dim=embed_dim)
+        first, last = dp.shard_chains(args.n, rank, world)     # chains are independent: sharded, no collective
+        texts = []
+        if last > first:
+            texts = sample(diff_model, rounding_fn, embedding_fn, tokenizer, device, last - first, args.seq_len,
+                           use_learned_rounding=not args.use_cosine_fallback,
+                           use_learned_embeddings=args.use_learned_embeddings, embed_dim=embed_dim, index_offset=first)
     return texts
 
 

@@ -182,6 +182,7 @@ class TrainState:
         self.noise = torch.empty_like(self.x_noisy)
         self.graph = None
         self.graph_whole = False
+        self.graph_gen = -1          # schedule.schedule_generation() at capture time
         self.warm = 0
 
 
