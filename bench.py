@@ -55,13 +55,13 @@ LAUNCH_WORK = [
     (_C3(64, 64, 196), 3 * _T14(64) + _M14(64), 0),                          # rb3.conv2 (in, res, h3s)
     (_C3(96, 32, 784) + _C1(96, 32, 784), _T14(64) + 3 * _T28(32) + _M28(32), 0),   # rb4.conv1 + skip
     (_C3(32, 32, 784) + _C1(32, 1, 784), 3 * _T28(32) + _M28(32) + 3136, 0),  # rb4.conv2 + out
-    (2 * _C1(32, 1, 784), 3 * 3136 + 3 * _T28(32) + _M28(32), 0),            # MSE + out conv bwd
+    (2 * _C1(32, 1, 784) + _C1(96, 1, 784), 3 * 3136 + 3 * _T28(32) + _T14(64) + _M28(32), 0),   # MSE + out conv bwd + rb4.skip grads (factored): h4, h1s, h3s in; dc2s out
     (_C3(32, 32, 784), 2 * _T28(32), 0),                                     # rb4.conv2 wgrad
     (_C3(32, 32, 784), 2 * _T28(32) + _M28(32), 0),                          # rb4.conv2 dgrad
-    (_C3(64, 32, 784) + _C1(64, 32, 784), _T14(64) + 2 * _T28(32), 0),       # rb4.conv1 wgrad (up(h3) part)
-    (_C3(32, 32, 784) + _C1(32, 32, 784), 3 * _T28(32), 0),                  # rb4.conv1 wgrad (h1 part)
-    (_C3(32, 96, 784) + _C1(32, 96, 784), 2 * _T28(32) + _T28(96), 0),       # rb4.conv1 dgrad
-    (0, _T28(64) + _M14(64) + 2 * _T14(64), 0),                              # split_dcat_mask
+    (_C3(64, 32, 784), _T14(64) + _T28(32), 0),                              # rb4.conv1 wgrad (up(h3) part)
+    (_C3(32, 32, 784), 2 * _T28(32), 0),                                     # rb4.conv1 wgrad (h1 part)
+    (_C3(32, 96, 784) + _C1(1, 96, 784), 3 * _T28(32) + 3136, 0),            # rb4.conv1 dgrad: dh4s in; pair-summed (B,28,14,64) + (M,32) out; + rank-1 skip share
+    (0, _T28(32) + _M14(64) + 2 * _T14(64), 0),                              # split_dcat_mask (reads the pair-summed tensor)
     (_C3(64, 64, 196), 2 * _T14(64), 0),                                     # rb3.conv2 wgrad
     (_C3(64, 64, 196), 2 * _T14(64) + _M14(64), 0),                          # rb3.conv2 dgrad
     (_C3(64, 64, 196), 2 * _T14(64), 0),                                     # rb3.conv1 wgrad
@@ -76,7 +76,7 @@ LAUNCH_WORK = [
     (_C3(32, 32, 784), 2 * _T28(32) + _M28(32), 0),                          # rb1.conv2 dgrad
     (0, 2 * 12_544 + 2 * 6_272, 0),                                          # group_sums (time_emb / conv1 bias grads)
     (_C3(1, 32, 784), 3136 + _T28(32), 0),                                   # rb1.conv1 wgrad
-    (0, 0, 4 * (256 * (320 + 9248 + 64 + 64 + 64 + 64 + 27648 + 9248 + 3104 + 33 + 384 + 160 + 1) + 128 * (18432 + 2048) + 64 * 3 * 36864) + 725_892),  # reduce
+    (0, 0, 4 * (256 * (320 + 9248 + 64 + 64 + 64 + 64 + 27648 + 9248 + 32 + 33 + 384 + 160 + 1 + 4 * 96) + 128 * (18432 + 2048) + 64 * 3 * 36864) + 725_892),  # reduce
 ]
 MFMA_LAUNCH = "conv_s16<", "wgrad2_s16<"    # launches whose FLOPs run on the matrix cores (bf16x3: 3 MFMA FLOP per FLOP)
 

@@ -229,17 +229,12 @@ int tdm_resblock_fwd_f32(const float* x, const float* that, const float* c1w, co
  *      tensors are split while staging
  *   2  same arithmetic over pre-split "S16" tensors (bf16 hi/lo per 16-channel
  *      group, same 4 B/element) that the producing kernels write — loaders are
- *      plain 16-byte copies — default                                          */
+ *      plain 16-byte copies — default
+ * The three arithmetic selectors (conv / gemm / attention mode) are THREAD-LOCAL: they configure the calls the calling
+ * thread makes afterwards, every thread starts in the default arithmetic, and the library keeps no process-global mutable
+ * state (a process's only shared object is an explicit tdm_ctx).                                                  */
 int tdm_set_conv_mode(int mode);
 int tdm_get_conv_mode(void);
-/* 32 -> 32 28x28 convolutions of mode 2: 0 = the one-role kernel (default), 1 = warp-specialised persistent kernel
- * (8 consumer + 8 helper waves per CU; measured slower, kept for A/B).  Same arithmetic, same bits out.        */
-int tdm_set_conv_ws(int on);
-int tdm_get_conv_ws(void);
-/* Pixel tile of the 28x28 N = 32 kernels of mode 2: 0 / 1 = 256 pixels per workgroup (default), 2 = 512 pixels (two
- * 32-pixel M tiles per wave; measured no faster, kept for A/B).  Same arithmetic, same bits out.              */
-int tdm_set_conv_tile(int mt);
-int tdm_get_conv_tile(void);
 /* same contract as tdm_conv_nhwc_f32 through the bf16x3 kernel;
  * scratch >= ksize*ksize*Cin*Cout floats (pre-packed hi/lo weights)          */
 int tdm_conv_nhwc_bf16x3_f32(const float* in, const float* w, const float* bias, const float* res,

@@ -427,70 +427,6 @@ def test_unet_grads_teacher_forced_relu_masks(dev, model, conv_mode, golden_dir,
         assert worst_e2e < 2e-4
 
 
-@pytest.mark.parametrize("B", [2, 37, 700])
-def test_conv_tile_512_equals_tile_256_bitwise(dev, model, conv_mode, B):
-    """The 28x28 N = 32 kernels with two 32-pixel M tiles per wave (512-pixel workgroup tiles, tdm_set_conv_tile(2);
-    opt-in) against the default one-tile form: same per-pixel arithmetic, so the predicted noise, the loss
-    and every gradient of a train step are bit-identical — incl. ragged last tiles (B = 37) and more than one round
-    of 512-pixel tiles (B = 700)."""
-    if conv_mode != 2:
-        pytest.skip("the tile size is a property of the default (S16) kernels")
-    from tinydiffusionmodels_amd import _lib, unet_engine as E
-    L = _lib.lib()
-    g = torch.Generator().manual_seed(B)
-    x0 = (torch.rand(B, 1, 28, 28, generator=g) * 2 - 1).to(dev)
-    t = torch.randint(0, 1000, (B,), generator=g).to(dev)
-    noise = torch.randn(B, 1, 28, 28, generator=g).to(dev)
-    flat = model.flat.detach()
-    outs = []
-    try:
-        for mt in (1, 2):
-            _lib.check(L.tdm_set_conv_tile(mt))
-            st = E.TrainState(flat, B)
-            E.loss_and_grad(flat, st, x0, noise, t)
-            with torch.no_grad():
-                eps_inf = model(st.x_noisy, t)                      # inference path (no saved tensors, fused output conv only)
-            outs.append((st.eps.clone(), st.loss.clone(), st.grads.clone(), eps_inf.clone()))
-    finally:
-        _lib.check(L.tdm_set_conv_tile(0))
-    for a, b in zip(outs[0], outs[1]):
-        assert torch.equal(a, b)
-    assert torch.isfinite(outs[0][2]).all()
-
-
-@pytest.mark.parametrize("B", [1, 2, 37, 400, 700])
-def test_conv_warp_specialised_equals_one_role_kernel_bitwise(dev, model, conv_mode, B):
-    """The warp-specialised persistent N = 32 conv kernel (8 producer + 8 consumer waves, double-buffered operands,
-    epilogue walked by the producers; default) against the one-role kernel (tdm_set_conv_ws(0)): same arithmetic and
-    epilogue code, so a whole train step — predicted noise, loss, every gradient — and the inference forward are
-    bit-identical; B = 1 (fewer tiles than CUs), ragged last tiles, and more tiles than CUs (B >= 400: 2+ tiles per
-    workgroup, i.e. the cross-tile hand-off schedule)."""
-    if conv_mode != 2:
-        pytest.skip("a property of the default (S16) kernels")
-    from tinydiffusionmodels_amd import _lib, unet_engine as E
-    L = _lib.lib()
-    g = torch.Generator().manual_seed(B)
-    x0 = (torch.rand(B, 1, 28, 28, generator=g) * 2 - 1).to(dev)
-    t = torch.randint(0, 1000, (B,), generator=g).to(dev)
-    noise = torch.randn(B, 1, 28, 28, generator=g).to(dev)
-    flat = model.flat.detach()
-    outs = []
-    try:
-        for ws in (0, 1):
-            _lib.check(L.tdm_set_conv_ws(ws))
-            st = E.TrainState(flat, B)
-            E.loss_and_grad(flat, st, x0, noise, t)
-            with torch.no_grad():
-                eps_inf = model(st.x_noisy, t)
-            torch.cuda.synchronize()
-            outs.append((st.eps.clone(), st.loss.clone(), st.grads.clone(), eps_inf.clone()))
-    finally:
-        _lib.check(L.tdm_set_conv_ws(1))
-    names = ("eps", "loss", "grads", "eps (inference)")
-    for name, a, b in zip(names, outs[0], outs[1]):
-        assert torch.equal(a, b), (name, (a - b).abs().max().item())
-
-
 def test_schedule_tables_of_this_host(lib, golden_dir):
     """a1 on the box the tests run on, with the schedule NOT pinned: betas / alphas / alphas_cumprod are
     host-independent and must be bit-equal to the reference's (src/mnist.py:28-31; SURVEY.md §8 a1 sha256);

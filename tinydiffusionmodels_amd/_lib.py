@@ -46,10 +46,6 @@ _SIGS = {
     "tdm_conv_wgrad_nhwc_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int, c_f], c_int),
     "tdm_set_conv_mode": ([c_int], c_int),
     "tdm_get_conv_mode": ([], c_int),
-    "tdm_set_conv_ws": ([c_int], c_int),
-    "tdm_get_conv_ws": ([], c_int),
-    "tdm_set_conv_tile": ([c_int], c_int),
-    "tdm_get_conv_tile": ([], c_int),
     "tdm_conv_nhwc_bf16x3_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int, c_int, c_f],
                                  c_int),
     "tdm_conv_nhwc_s16_f32": ([c_f] * 10 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_f], c_int),
@@ -139,6 +135,32 @@ def lib() -> ctypes.CDLL:
                     fn.restype = restype
                 _lib = L
     return _lib
+
+
+def arithmetic():
+    """(conv, gemm, attention) arithmetic selectors of the CALLING thread (they are thread-local in the library)."""
+    L = lib()
+    return L.tdm_get_conv_mode(), L.tdm_get_gemm_mode(), L.tdm_get_attn_mode()
+
+
+class use_arithmetic:
+    """Run a block under the selectors another thread recorded: torch runs autograd backward functions on its own engine
+    thread, which starts in the library's default arithmetic — a backward pass must run in the arithmetic of ITS forward
+    (the saved workspace holds that arithmetic's tensors), so the bridges record `arithmetic()` in forward and re-apply it
+    here."""
+
+    def __init__(self, modes):
+        self.modes = modes
+
+    def __enter__(self):
+        L = lib()
+        self.saved = arithmetic()
+        check(L.tdm_set_conv_mode(self.modes[0])); check(L.tdm_set_gemm_mode(self.modes[1])); check(L.tdm_set_attn_mode(self.modes[2]))
+
+    def __exit__(self, *exc):
+        L = lib()
+        check(L.tdm_set_conv_mode(self.saved[0])); check(L.tdm_set_gemm_mode(self.saved[1])); check(L.tdm_set_attn_mode(self.saved[2]))
+        return False
 
 
 def check(rc: int, what: str = "") -> None:

@@ -395,8 +395,12 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
         __syncthreads();
         if (q == 0 && i < s.len) {
             const float r = ((sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e])) * (s.scale != 0.f ? s.scale : 1.f);
-            if (s.dst != nullptr) s.dst[i] = r;
-            else out[s.off + i] = r;
+            float* const d = s.dst != nullptr ? s.dst : out + s.off;
+            if (s.outer_w != nullptr) {
+                for (int jn = 0; jn < s.outer_n; ++jn) d[i * s.outer_n + jn] = r * s.outer_w[jn];
+            } else {
+                d[i] = r;
+            }
         }
     }
 }

@@ -70,6 +70,7 @@ __device__ __forceinline__ int src_offset(const ConvSrc& s, int PR0, int pos, in
 // would be dereferenced with flat_* instructions (both memory counters, slower issue): every access casts it back.
 #define TDM_GLOBAL __attribute__((address_space(1)))
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <typename T> __device__ __forceinline__ T gload(const void* p) { return *(const TDM_GLOBAL T*)p; }
 template <typename T> __device__ __forceinline__ void gstore(void* p, const T v) { *(TDM_GLOBAL T*)p = v; }
 __device__ __forceinline__ float4 gload4(const float* p) { const f32x4 v = gload<f32x4>(p); return make_float4(v[0], v[1], v[2], v[3]); }
@@ -174,6 +175,10 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     if constexpr (R1) { TDM_PIN(r1_x); TDM_PIN(r1_w); TDM_PIN(r1_b); }
     float* o1_out = R1 ? ka.o1_out : nullptr; const float* o1_w = ka.o1_w; const float* o1_b = ka.o1_b;   // fused 1x1 output conv (rb4.conv2)
     if constexpr (R1) { TDM_PIN(o1_out); TDM_PIN(o1_w); TDM_PIN(o1_b); }
+    // rb4.conv1's data gradient (ConvArgs::dc_pair): only the 28x28 N = 96 instantiation carries it
+    constexpr bool DCAT = HW == 28 && NT == 3 && !SKIP;
+    float* dc_pair = DCAT ? ka.dc_pair : nullptr; float* dc_h1 = ka.dc_h1; const float* rk1_d = ka.rk1_d; const float* rk1_u = ka.rk1_u;
+    if constexpr (DCAT) { TDM_PIN(dc_pair); TDM_PIN(dc_h1); TDM_PIN(rk1_d); TDM_PIN(rk1_u); }
     constexpr int N = NT * 32;
     constexpr int TILE_B = NRv * G::WP * PIXB;
     extern __shared__ float4 smem4[];
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
             if constexpr (R1) p.rx[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rx, m * 4, 0, 0));
         }
     };
-    preload(0);
+    if (!(DCAT && dc_pair != nullptr)) preload(0);   // (the d cat epilogue fetches its own two small inputs)
     stamp();                     // 6: tile inputs requested
     if constexpr (mt == 0) __syncthreads();   // every wave is done with the operand images
     stamp();                     // 7
@@ -479,6 +484,44 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     };
     to_lds(acc[mt]);
     stamp();                     // 8: transpose written
+    if constexpr (DCAT) if (dc_pair != nullptr) {
+        // d cat from rb4.conv1's data gradient (ConvArgs::dc_pair).  The wave's block holds 32 consecutive pixels x 96
+        // channels; tiles start at multiples of 32 and rows are 28 wide, so pixels 2k, 2k + 1 of the block are always a
+        // horizontal pair of one image row.  Part A: 16 pairs x 16 channel quads (channels 0..63) -> the pair's SUM goes to
+        // the half-width tensor; part B: 32 pixels x 8 quads (channels 64..95) -> dc_h1.  Both add the skip path's rank-one
+        // share d[m] * u[c].  8 passes of one LDS read (two in part A), at most 2 fma per value and one 16-byte store.
+        const int ca = (lane_e & 15) * 4, cb = 64 + (lane_e & 7) * 4;
+        const float4 ua = gload4(rk1_u + ca), ub = gload4(rk1_u + cb);
+        const bool whole = mbase + 32 <= Mtot;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int pp = it * 4 + (lane_e >> 4);                   // pair index inside the block
+            const int m0p = mbase + 2 * pp;
+            if (whole || m0p < Mtot) {                                // (Mtot is even: a pair is whole or absent)
+                const f32x2 d2 = gload<f32x2>(rk1_d + m0p);
+                const float ds = d2[0] + d2[1];
+                const float4 v0 = *reinterpret_cast<const float4*>(T + (2 * pp) * EPI + ca);
+                const float4 v1 = *reinterpret_cast<const float4*>(T + (2 * pp + 1) * EPI + ca);
+                float4 o;
+                o.x = fmaf(ds, ua.x, v0.x + v1.x); o.y = fmaf(ds, ua.y, v0.y + v1.y);
+                o.z = fmaf(ds, ua.z, v0.z + v1.z); o.w = fmaf(ds, ua.w, v0.w + v1.w);
+                gstore4(dc_pair + ((unsigned)(m0p >> 1) * 64 + ca), o);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int px = it * 8 + (lane_e >> 3);
+            const int m = mbase + px;
+            if (whole || m < Mtot) {
+                const float d = gload<float>(rk1_d + m);
+                const float4 v = *reinterpret_cast<const float4*>(T + px * EPI + cb);
+                float4 o;
+                o.x = fmaf(d, ub.x, v.x); o.y = fmaf(d, ub.y, v.y); o.z = fmaf(d, ub.z, v.z); o.w = fmaf(d, ub.w, v.w);
+                gstore4(dc_h1 + ((unsigned)m * 32 + (cb - 64)), o);
+            }
+        }
+        return;
+    }
     // Everything of p has been requested: wait for it HERE, once.  The requests sit under uniform branches, so without
     // this the compiler guards every pass's first use of p.rt / p.mk with s_waitcnt vmcnt(0) — which on gfx9
     // also waits for the previous pass's STORES (same counter).
@@ -651,439 +694,6 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     stamp();
 }
 
-// ---------------------------------------------------------------------------
-// Warp-specialised form of the N = 32 convolution (producer / consumer, persistent).  tools/phase_probe.py on the kernel
-// above: a workgroup lives 19.9 k cycles of which 8.0 k pass before its first MFMA (argument / plan prologue, then the
-// first chunk's HBM latency), 5.1 k in the epilogue and only 4.6 k in the two MFMA phases — and two co-resident
-// workgroups start together, so they wait together.  Here ONE workgroup of 16 waves owns a CU and walks tiles
-// slot, slot + G, ...: waves 0..7 CONSUME (fragment reads + MFMA out of LDS-resident weights and a double-buffered
-// pixel image; at the start of the next tile they dump their accumulators into per-wave transpose blocks and go on),
-// waves 8..15 HELP (each moves 1/8 of every K chunk, requested two steps before it is written to LDS, and runs the
-// epilogue walk of one consumer block of the PREVIOUS tile, half a walk per step).  One barrier per K chunk plus one
-// "transpose blocks ready" barrier per tile; no wave ever waits for HBM with accumulators in flight.
-// Same arithmetic, same operand layouts, same epilogue code as conv_s16_kernel<HW, 1, false>: bit-identical results.
-// Measured: 48 us against 39 us for the one-role kernel at B = 512 — opt-in, tdm_set_conv_ws(1).
-// ---------------------------------------------------------------------------
-constexpr int WS_THREADS = 1024;
-template <int HW, bool SKIP> struct WsCfg {
-    using G = Geo<HW>;
-    static constexpr int TILE_B = G::NR * G::WP * PIXB;
-    static constexpr int WB = 9 * 2048 + (SKIP ? 2048 : 0);        // packed weights of one K chunk
-    static constexpr int WCH = 2;                                  // K chunks whose weights stay RESIDENT in LDS for the whole launch
-    static constexpr int WALL = WCH * WB;
-    static constexpr int OPB = (TILE_B + 63) & ~63;                // one operand buffer: the staged pixel image of a K chunk
-    static constexpr int EPI = 32 + 4;
-    static constexpr int TB = 8 * 32 * EPI * 4;                    // 8 transpose blocks (one per consumer wave)
-    static constexpr int LDS = WALL + 2 * OPB + TB + 8 * 32 * 4;   // + the loaders' row tables
-};
-
-template <int HW, bool SKIP>
-__global__ __launch_bounds__(WS_THREADS) void conv_ws_kernel(ConvArgs ka, int ntiles) {
-    using G = Geo<HW>;
-    using Cf = WsCfg<HW, SKIP>;
-    constexpr int NT = 1, N = 32, EPI = Cf::EPI, OPB = Cf::OPB, TILE_B = Cf::TILE_B;
-    PinnedArgs a(ka);
-    constexpr bool R1 = HW == 28 && !SKIP;
-    const float* r1_x = R1 ? ka.r1_x : nullptr; const float* r1_w = ka.r1_w; const float* r1_b = ka.r1_b;
-    if constexpr (R1) { TDM_PIN(r1_x); TDM_PIN(r1_w); TDM_PIN(r1_b); }
-    float* o1_out = R1 ? ka.o1_out : nullptr; const float* o1_w = ka.o1_w; const float* o1_b = ka.o1_b;
-    if constexpr (R1) { TDM_PIN(o1_out); TDM_PIN(o1_w); TDM_PIN(o1_b); }
-    extern __shared__ float4 smem4[];
-    char* const wall = reinterpret_cast<char*>(smem4);          // resident packed weights, chunk c at wall + c * WB
-    char* const lds = wall + Cf::WALL;                         // the two pixel-image buffers
-    float* const Tall = reinterpret_cast<float*>(lds + 2 * OPB);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5, j = lane & 31;
-    const int Mtot = a.B * G::H * G::W;
-    const int G_ = gridDim.x;
-    const int slot = xcd_remap(blockIdx.x, G_);
-    const int nk = slot < ntiles ? (ntiles - slot + G_ - 1) / G_ : 0;      // tiles of this workgroup: slot + k * G_
-    const int nc0 = a.s0.nch >> 4;
-    constexpr int nchunks = 2;                                             // K chunks per tile (the launcher checks it)
-    const int S = nk * nchunks;                                            // K-chunk steps of this workgroup
-    // one extra (virtual) tile after the last: its first steps only carry the epilogue of tile nk - 1
-    const int tail = SKIP ? 4 : 2;
-    // Barriers: one at the end of every step, plus one "T ready" barrier at the START of step (k >= 1, c == 0) and, with the
-    // fused skip conv, of step (k >= 1, c == 2): the consumers dump accumulators into the transpose blocks first thing in
-    // those steps, the walkers read them from then until the next dump (two whole steps later at the earliest).
-    const int Stot = S + (nk > 0 ? tail : 0);
-    // role probe (ablate & 1024; tools/ws_probe.py): lane 0 of waves 0 / 8 / 12 stamps the shader clock before and after every
-    // barrier into the int64 table [workgroup][3 roles][64] the caller appended behind the B*H*W*N floats of aux
-    int nstamp = 0;
-    auto stamp = [&](int role, int tag) __attribute__((always_inline)) {
-        if (a.ablate & 1024) {
-            if (lane == 0 && (wave == 0 || wave == 8) && nstamp < 64)
-                gstore<long long>(reinterpret_cast<long long*>(a.aux + (long)a.B * G::H * G::W * N) + ((long)blockIdx.x * 3 + role) * 64 + nstamp,
-                                  ((long long)tag << 56) | ((long long)__builtin_readcyclecounter() & 0x00ffffffffffffffll));
-            ++nstamp;
-        }
-    };
-#define WS_BARRIER(role) do { stamp(role, 1); __syncthreads(); stamp(role, 2); } while (0)
-
-    // The packed weights of every K chunk (<= 36 KB: the 32-input-channel layers this kernel serves) are copied into LDS
-    // ONCE by all 16 waves — a per-chunk restaging like the one-role kernel's would be half of the loaders' work.
-    for (int c = 0; c < nchunks; ++c) {
-        const int si = (c >= nc0) ? 1 : 0;
-        const int ch = si ? c - nc0 : c;
-        const PinnedSrc s = a.src(si);
-        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<unsigned short*>(s.wp) + (long)(s.wchunk0 + ch) * (s.taps * 1024), 0, s.taps * 2048, 0x00020000);
-        for (int e = tid; e < 9 * 128; e += WS_THREADS) {
-            const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, e * 16, 0, 0));
-            reinterpret_cast<u32x4*>(wall + c * Cf::WB)[e] = v;
-        }
-    }
-
-    if (wave < 8) {
-        // ------------------------------- consumers -------------------------------
-        f32x16 bias_acc, acc;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 bz = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.bias != nullptr) bz = gload4(a.bias + 8 * g + 4 * h);
-            bias_acc[4 * g] = bz.x; bias_acc[4 * g + 1] = bz.y; bias_acc[4 * g + 2] = bz.z; bias_acc[4 * g + 3] = bz.w;
-        }
-        acc = bias_acc;
-        f32x16 sbias, acc2, hold2;      // fused 1x1 skip conv (SKIP): second accumulator and its parked copy
-        if constexpr (SKIP) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 bz = gload4(a.skip_bias + 8 * g + 4 * h);
-                sbias[4 * g] = bz.x; sbias[4 * g + 1] = bz.y; sbias[4 * g + 2] = bz.z; sbias[4 * g + 3] = bz.w;
-            }
-            acc2 = sbias; hold2 = sbias;
-        }
-        float* const T = Tall + wave * (32 * EPI);
-        auto to_lds = [&](const f32x16& ac) __attribute__((always_inline)) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(T + j * EPI + 8 * g + 4 * h) =
-                    make_float4(ac[4 * g], ac[4 * g + 1], ac[4 * g + 2], ac[4 * g + 3]);
-        };
-        WS_BARRIER(0);                                   // step 0 staged
-        int g = 0;
-        for (int k = 0; k <= nk; ++k) {
-            const int nch_k = (k < nk) ? nchunks : tail;
-            int aoff = 0;
-            if (k < nk) {
-                const int m0 = (slot + k * G_) * TILE_PX;
-                const int tb0 = m0 / (G::H * G::W);
-                const int ty0 = (m0 - tb0 * (G::H * G::W)) / G::W;
-                const int mb = min(m0 + wave * 32, Mtot - 1);
-                const int b0 = mb / (G::H * G::W);
-                const int rem0 = mb - b0 * (G::H * G::W);
-                const int y0 = rem0 / G::W, x0 = rem0 - y0 * G::W;
-                const int q = x0 + min(j, Mtot - 1 - mb);
-                const int dr = (q * (HW == 28 ? 2341 : 4682)) >> 16;
-                const int x = q - dr * G::W;
-                int y = y0 + dr, rowb = (b0 - tb0) * G::HP;
-                if (y >= G::H) { y -= G::H; rowb += G::HP; }
-                aoff = ((rowb + y + 1 - ty0) * G::WP + x + 1) * PIXB + h * 16;
-            }
-            for (int c = 0; c < nch_k; ++c, ++g) {
-                if (k >= 1 && c == 0) {                    // tile k - 1 is complete: hand its accumulators to the walkers
-                    to_lds(acc);
-                    acc = bias_acc;
-                    if constexpr (SKIP) { hold2 = acc2; acc2 = sbias; }
-                    WS_BARRIER(0);                       // T ready
-                }
-                if constexpr (SKIP) if (k >= 1 && c == 2) {
-                    to_lds(hold2);
-                    WS_BARRIER(0);                       // T ready (skip accumulator)
-                }
-                if (k < nk && !(a.ablate & 256)) {
-                    const char* tile = lds + (g & 1) * OPB;
-                    const char* wl = wall + c * Cf::WB;
-                    const int taps = (c >= nc0) ? a.s1.taps : a.s0.taps;
-#pragma unroll
-                    for (int tp = 0; tp < 9; ++tp) {
-                        if (taps == 9 || tp == 4) {
-                            const int toff = ((tp / 3 - 1) * G::WP + (tp % 3 - 1)) * PIXB;
-                            const int wt = (taps == 9) ? tp : 0;
-                            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(tile + aoff + toff);
-                            const bf16x8 al = *reinterpret_cast<const bf16x8*>(tile + aoff + toff + 32);
-                            const char* wb = wl + (wt * 2) * 1024 + lane * 16;
-                            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wb);
-                            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wb + 1024);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc, 0, 0, 0);
-                            if constexpr (SKIP) if (tp == 4) {
-                                const char* sb = wl + 9 * 2048 + lane * 16;
-                                const bf16x8 sh = *reinterpret_cast<const bf16x8*>(sb);
-                                const bf16x8 sl = *reinterpret_cast<const bf16x8*>(sb + 1024);
-                                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh, al, acc2, 0, 0, 0);
-                                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sl, ah, acc2, 0, 0, 0);
-                                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh, ah, acc2, 0, 0, 0);
-                            }
-                        }
-                    }
-                }
-                WS_BARRIER(0);
-            }
-        }
-        return;
-    }
-
-    // ------------------------------- helpers (waves 8..15): loaders AND the epilogue of the previous tile -------------------------------
-    // Every helper wave moves 1/8 of each K chunk (global -> registers -> operand buffer, two register sets: a chunk is requested
-    // two steps before it is written to LDS) and walks ONE consumer block of the previous tile, half of it per step.  A single
-    // wave issues one vector instruction per ~4 cycles at best, and an epilogue walk is ~220 of them + ~70 scalar: with four
-    // dedicated walker waves the tile took as long as their two walks (tools/ws_probe.py), with eight waves sharing both jobs
-    // every role fits inside the consumers' two MFMA phases.  The walk's inputs (residual / mask / rank-1 input) are requested
-    // right after the half-walk that frees their registers, i.e. a whole tile ahead: on gfx9 loads and stores retire through one
-    // in-order counter, so a load requested just before its use would also wait for the acknowledgements of the stores in between.
-    static_assert(!SKIP, "the fused skip conv (six K chunks of weights) stays on the one-role kernel");
-    const int hw_ = wave - 8, ptid = tid - 512;
-    constexpr int LTH2 = 512, NPH = (G::NR * G::WP * 4 + LTH2 - 1) / LTH2, STEP2 = LTH2 / 4;
-    int goff[NPH];
-    uint4 pin0[NPH], pin1[NPH];
-    int* const rowtab = reinterpret_cast<int*>(lds + 2 * OPB + Cf::TB) + hw_ * 32;
-    const PinnedSrc s0 = a.src(0);                       // (one K source: the launcher checks it)
-    const int up = s0.up, Hs = G::H >> up, Ws = G::W >> up;
-    const __amdgpu_buffer_rsrc_t rs_in =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s0.ptr), 0, a.B * Hs * Ws * s0.C * 4, 0x00020000);
-    auto plan = [&](int k) __attribute__((always_inline)) {      // byte offsets of this thread's pieces of tile k (both K chunks)
-        const int m0 = (slot + k * G_) * TILE_PX;
-        const int mlast = min(m0 + TILE_PX - 1, Mtot - 1);
-        const int tb0 = m0 / (G::H * G::W);
-        const int ty0 = (m0 - tb0 * (G::H * G::W)) / G::W;
-        const int nrows = padded_row<HW>(mlast) - (tb0 * G::HP + ty0) + 2;
-        if (lane < 32) {
-            int py = ty0 + lane, b = tb0;
-            if (py >= G::HP) { py -= G::HP; ++b; }
-            if (HW == 14 && py >= G::HP) { py -= G::HP; ++b; }
-            const bool ok = lane < nrows && py >= 1 && py <= G::H && b < a.B;
-            rowtab[lane] = ok ? __mul24(__mul24(__mul24(b, Hs) + ((py - 1) >> up), Ws), s0.C) * 4 : (int)0x80000000;
-        }
-        int pt = ptid;
-        asm volatile("" : "+v"(pt));   // opaque: keeps the tile-invariant (row, column) of every piece out of registers between plans
-        int lr = (pt >> 2) / G::WP;
-        int pc = (pt >> 2) - lr * G::WP;
-        const int cbase = (s0.c0 + (pt & 3) * 4) * 4;
-#pragma unroll
-        for (int i = 0; i < NPH; ++i) {
-            const int roff = rowtab[min(lr, 31)];
-            const bool ok = roff >= 0 && pc >= 1 && pc <= G::W && lr < nrows;
-            goff[i] = ok ? roff + __mul24((pc - 1) >> up, s0.C) * 4 + cbase : (int)0x80000000;
-            pc += STEP2 % G::WP;
-            lr += STEP2 / G::WP;
-            if (pc >= G::WP) { pc -= G::WP; ++lr; }
-        }
-    };
-    auto issue = [&](uint4 (&pin)[NPH], int ch) __attribute__((always_inline)) {   // global -> registers: K chunk ch of the planned tile
-#pragma unroll
-        for (int i = 0; i < NPH; ++i) {
-            const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, goff[i], ch << 6, 0));
-            pin[i] = make_uint4(v[0], v[1], v[2], v[3]);
-        }
-    };
-    auto stage = [&](const uint4 (&pin)[NPH], int buf) __attribute__((always_inline)) {   // registers -> operand buffer; the whole image is rewritten
-        char* const sdst = lds + buf * OPB + (ptid >> 2) * PIXB + (ptid & 3) * 16;
-#pragma unroll
-        for (int i = 0; i < NPH; ++i)
-            if (ptid + LTH2 * i < G::NR * G::WP * 4) *reinterpret_cast<uint4*>(sdst + i * (STEP2 * PIXB)) = pin[i];
-    };
-
-    // ---- epilogue walk of one 32-pixel x 32-channel block, two passes (16 pixels) at a time (the code of conv_s16_kernel's epilogue) ----
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    constexpr int NIT = N / 8, HP2 = 2;                  // 4 passes per block, 2 per half-walk
-    const bool bwd = a.relu_mask_in != nullptr;
-    const bool use_res = a.res != nullptr;
-    const bool use_tb = !use_res && a.tb_out != nullptr && a.out_s16 != nullptr;
-    const __amdgpu_buffer_rsrc_t rs_rt = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(use_res ? a.res : a.tb_out), 0, use_res ? Mtot * N * 4 : (use_tb ? a.B * a.tb_out_stride * 4 : 0), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_mk = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned char*>(a.relu_mask_in), 0, bwd ? Mtot * (N / 4) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(r1_x), 0, r1_x != nullptr ? Mtot * 4 : 0, 0x00020000);
-    struct Pre { float4 rt[NIT]; unsigned mk[NIT]; float rx[R1 ? NIT : 1]; };
-    Pre p;
-    float4 sacc[2][2];
-    const float* const Tw = Tall + hw_ * (32 * EPI);
-    auto preload_half = [&](int mbase, auto half_c) __attribute__((always_inline)) {
-        constexpr int H0 = decltype(half_c)::value * HP2;
-        const int img0 = mbase / (G::H * G::W);
-        const int mnext = (img0 + 1) * (G::H * G::W);
-#pragma unroll
-        for (int it = H0; it < H0 + HP2; ++it) {
-            const int e = it * 64 + lane_e;
-            const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
-            const int m = min(mbase + px, Mtot - 1);
-            const int o = m * N + c;
-            const int otb = (img0 + (m >= mnext ? 1 : 0)) * a.tb_out_stride + c;
-            const f32x4 r = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_rt, (use_res ? o : otb) * 4, 0, 0));
-            p.rt[it] = make_float4(r[0], r[1], r[2], r[3]);
-            p.mk[it] = __builtin_amdgcn_raw_buffer_load_b8(rs_mk, o >> 2, 0, 0);
-            if constexpr (R1) p.rx[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rx, m * 4, 0, 0));
-        }
-    };
-    auto walk_half = [&](int mbase, auto half_c, auto full_c) __attribute__((always_inline)) {
-        constexpr bool FULL = decltype(full_c)::value;
-        constexpr int H0 = decltype(half_c)::value * HP2;
-        const int img0 = mbase / (G::H * G::W);
-        const int mnext = (img0 + 1) * (G::H * G::W);
-        if constexpr (H0 == 0) {
-#pragma unroll
-            for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-                for (int kd = 0; kd < 2; ++kd) sacc[sl][kd] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        float4 v[HP2];
-        unsigned o[HP2];
-        bool ok[HP2];
-#pragma unroll
-        for (int k = 0; k < HP2; ++k) {
-            const int e = (H0 + k) * 64 + lane_e;
-            const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
-            v[k] = *reinterpret_cast<const float4*>(Tw + px * EPI + c);
-            o[k] = (unsigned)(mbase + px) * N + c;
-            ok[k] = FULL || mbase + px < Mtot;
-        }
-        if (a.relu) {
-#pragma unroll
-            for (int k = 0; k < HP2; ++k) {
-                v[k].x = fmaxf(v[k].x, 0.f); v[k].y = fmaxf(v[k].y, 0.f); v[k].z = fmaxf(v[k].z, 0.f); v[k].w = fmaxf(v[k].w, 0.f);
-            }
-        }
-        if (a.aux != nullptr && !(a.ablate & 1024)) {
-#pragma unroll
-            for (int k = 0; k < HP2; ++k) if (ok[k]) gstore4(a.aux + o[k], v[k]);
-        }
-        if (a.mask_out != nullptr) {
-#pragma unroll
-            for (int k = 0; k < HP2; ++k)
-                if (ok[k])
-                    gstore<unsigned char>(a.mask_out + (o[k] >> 2),
-                                          (unsigned char)((v[k].x > 0.f ? 1 : 0) | (v[k].y > 0.f ? 2 : 0) |
-                                                          (v[k].z > 0.f ? 4 : 0) | (v[k].w > 0.f ? 8 : 0)));
-        }
-        if (a.res != nullptr) {
-#pragma unroll
-            for (int k = 0; k < HP2; ++k) {
-                const float4 rz = p.rt[H0 + k];
-                v[k].x += rz.x; v[k].y += rz.y; v[k].z += rz.z; v[k].w += rz.w;
-            }
-        }
-        if constexpr (R1) if (r1_x != nullptr) {
-#pragma unroll
-            for (int k = 0; k < HP2; ++k) {
-                const int c = (((H0 + k) * 64 + lane_e) % (N / 4)) * 4;
-                const float4 w4 = gload4(r1_w + c), b4 = gload4(r1_b + c);
-                const float rx = p.rx[H0 + k];
-                v[k].x += fmaf(rx, w4.x, b4.x); v[k].y += fmaf(rx, w4.y, b4.y);
-                v[k].z += fmaf(rx, w4.z, b4.z); v[k].w += fmaf(rx, w4.w, b4.w);
-            }
-        }
-        if (bwd) {
-#pragma unroll
-            for (int k = 0; k < HP2; ++k) {
-                const int m = mbase + ((H0 + k) * 64 + lane_e) / (N / 4);
-                const unsigned mk = p.mk[H0 + k];
-                const float4 u = v[k];
-                const float4 mv = make_float4((mk & 1u) ? u.x : 0.f, (mk & 2u) ? u.y : 0.f, (mk & 4u) ? u.z : 0.f,
-                                              (mk & 8u) ? u.w : 0.f);
-                const bool s0_ = ok[k] && m < mnext, s1_ = ok[k] && m >= mnext;
-                sacc[0][0].x += s0_ ? u.x : 0.f; sacc[0][0].y += s0_ ? u.y : 0.f; sacc[0][0].z += s0_ ? u.z : 0.f; sacc[0][0].w += s0_ ? u.w : 0.f;
-                sacc[0][1].x += s0_ ? mv.x : 0.f; sacc[0][1].y += s0_ ? mv.y : 0.f; sacc[0][1].z += s0_ ? mv.z : 0.f; sacc[0][1].w += s0_ ? mv.w : 0.f;
-                sacc[1][0].x += s1_ ? u.x : 0.f; sacc[1][0].y += s1_ ? u.y : 0.f; sacc[1][0].z += s1_ ? u.z : 0.f; sacc[1][0].w += s1_ ? u.w : 0.f;
-                sacc[1][1].x += s1_ ? mv.x : 0.f; sacc[1][1].y += s1_ ? mv.y : 0.f; sacc[1][1].z += s1_ ? mv.z : 0.f; sacc[1][1].w += s1_ ? mv.w : 0.f;
-                v[k] = mv;
-            }
-        }
-        if (a.out != nullptr) {
-#pragma unroll
-            for (int k = 0; k < HP2; ++k) if (ok[k]) gstore4(a.out + o[k], v[k]);
-        }
-        if constexpr (R1) if (o1_out != nullptr) {
-            const float4 w4 = gload4(o1_w + (lane_e & 7) * 4);
-            const float ob = gload<float>(o1_b);
-#pragma unroll
-            for (int k = 0; k < HP2; ++k) {
-                float d = ((v[k].x * w4.x + v[k].y * w4.y) + v[k].z * w4.z) + v[k].w * w4.w;
-                d += __shfl_xor(d, 1);
-                d += __shfl_xor(d, 2);
-                d += __shfl_xor(d, 4);
-                if ((lane_e & 7) == 0 && ok[k]) gstore<float>(o1_out + (o[k] >> 5), d + ob);
-            }
-        }
-        if (a.out_s16 != nullptr) {
-            if (a.tb_out != nullptr) {
-#pragma unroll
-                for (int k = 0; k < HP2; ++k) {
-                    float4 tz = p.rt[H0 + k];
-                    if (a.res != nullptr) {
-                        const int e = (H0 + k) * 64 + lane_e;
-                        const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
-                        const int m = min(mbase + px, Mtot - 1);
-                        tz = gload4(a.tb_out + (unsigned)((img0 + (m >= mnext ? 1 : 0)) * a.tb_out_stride + c));
-                    }
-                    v[k].x += tz.x; v[k].y += tz.y; v[k].z += tz.z; v[k].w += tz.w;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < HP2; ++k) {
-                const int c = (((H0 + k) * 64 + lane_e) % (N / 4)) * 4;
-                if (ok[k]) gstore_s16_o(a.out_s16, o[k], c, v[k]);
-            }
-        }
-        if constexpr (H0 != 0) {
-            if (bwd && a.sums != nullptr) {
-#pragma unroll
-                for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-                    for (int kd = 0; kd < 2; ++kd) {
-                        float4 r = sacc[sl][kd];
-#pragma unroll
-                        for (int off = N / 4; off < 64; off <<= 1) {
-                            r.x += __shfl_xor(r.x, off); r.y += __shfl_xor(r.y, off);
-                            r.z += __shfl_xor(r.z, off); r.w += __shfl_xor(r.w, off);
-                        }
-                        if (lane_e < N / 4 && mbase < Mtot) {
-                            const unsigned grp = (unsigned)mbase >> 5;
-                            gstore4(a.sums + (unsigned)(((grp * 2 + sl) * 2 + kd) * N + lane_e * 4), r);
-                        }
-                    }
-            }
-        }
-    };
-    auto walk_step = [&](int k, auto half_c) __attribute__((always_inline)) {   // half a walk of tile k - 1, then the request for tile k's same half
-        asm volatile("" : "+v"(lane_e));   // opaque per step: keeps the per-lane offsets of the walk out of registers between steps
-        if (k >= 1 && !(a.ablate & 128)) {
-            const int mb = (slot + (k - 1) * G_) * TILE_PX + hw_ * 32;
-            if (mb + 32 <= Mtot) walk_half(mb, half_c, std::true_type{});
-            else walk_half(mb, half_c, std::false_type{});
-        }
-        if (k < nk && !(a.ablate & 2048)) preload_half((slot + k * G_) * TILE_PX + hw_ * 32, half_c);
-    };
-
-    const bool ld = !(a.ablate & 64), stg = !(a.ablate & 512);
-    if (nk > 0) { plan(0); issue(pin0, 0); issue(pin1, 1); }
-    if (nk > 0) stage(pin0, 0);
-    if (nk > 1) { plan(1); issue(pin0, 0); }
-    WS_BARRIER(1);                                     // step 0 staged
-    // One iteration = one tile = two steps, straight-line (see the loaders' note in the header of this kernel): step (k, 0)
-    // stages chunk (k, 1) from set 1 and refills it with chunk (k + 1, 1); step (k, 1) stages chunk (k + 1, 0) from set 0,
-    // plans tile k + 2 and refills set 0 with its chunk 0.  `goff` always belongs to the tile whose chunks are requested next.
-    for (int k = 0; k <= nk; ++k) {
-        if (k >= 1) WS_BARRIER(1);                     // the consumers' "T ready" barrier
-        if (k < nk && stg) stage(pin1, 1);
-        stamp(1, 3);
-        if (k + 1 < nk && ld) issue(pin1, 1);
-        walk_step(k, std::integral_constant<int, 0>{});
-        WS_BARRIER(1);
-        if (k + 1 < nk && stg) stage(pin0, 0);
-        stamp(1, 3);
-        if (k + 2 < nk) { plan(k + 2); if (ld) issue(pin0, 0); }
-        walk_step(k, std::integral_constant<int, 1>{});
-        WS_BARRIER(1);
-    }
-}
-
-#undef WS_BARRIER
 template <int HW, int NT, bool SKIP, int MT = 1>
 int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     using G = Geo<HW>;
@@ -1124,52 +734,6 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
-// 28x28, N = 32: 512-pixel tiles (two M tiles per wave) are built, bit-identical and selectable (tdm_set_conv_tile(2)),
-// but NOT the default: measured at B = 512 (tools/launch_times.py --tile 1|2) rb1.conv2 46.9 -> 51.6 us, rb4.conv2 49.8 ->
-// 50.7, the two data gradients 47.6 -> 47.9 / 43.2 -> 45.5 — a workgroup with twice the pixels lives twice as long, i.e. the
-// kernel's time is set by each wave's own instruction stream (time is linear in the tile count from 392 to 3136 tiles,
-// 26.5 ns per tile), not by a per-round fixed cost or the round quantisation, and the saved weight-fragment reads do not
-// show.  (The fused-skip form needs 64 accumulator registers per wave at MT = 2 and spills; it keeps 256-pixel tiles.)
-int g_conv_mt = 0;
-inline bool use_mt2(const ConvArgs& a) {
-    if ((a.ablate & 16) != 0) return false;                       // the phase probe instruments the one-tile form
-    return g_conv_mt == 2;
-}
-
-// warp-specialised N = 32 kernel: 1 = on (default), 0 = the one-role kernel (tdm_set_conv_ws; A/B and tests)
-int g_conv_ws = 0;   // opt-in (tdm_set_conv_ws): slower than the one-role kernel as of r2, see DESIGN.md section 5
-template <int HW, bool SKIP>
-int launch_conv_ws(const ConvArgs& a, hipStream_t st) {
-    using G = Geo<HW>;
-    using Cf = WsCfg<HW, SKIP>;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<HW, SKIP>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
-        if (e != hipSuccess || n <= 0) {
-            tdm_set_error("conv_ws: device query / LDS attribute (%d B) failed: %s", Cf::LDS, hipGetErrorString(e));
-            return 100 + (int)e;
-        }
-        cus = n;
-    }
-    const long Mtot = (long)a.B * G::H * G::W;
-    const int ntiles = (int)((Mtot + TILE_PX - 1) / TILE_PX);
-    const int grid = ntiles < cus ? ntiles : cus;
-    hipLaunchKernelGGL((conv_ws_kernel<HW, SKIP>), dim3(grid), dim3(WS_THREADS), Cf::LDS, st, a, ntiles);
-    TDM_CHECK_LAUNCH("conv_ws");
-    return 0;
-}
-inline bool use_ws(const ConvArgs& a) {
-    if (!g_conv_ws || (a.ablate & ~(64 | 128 | 256 | 512 | 1024 | 2048)) != 0 || g_conv_mt == 2 || a.skip_out != nullptr) return false;   // (64..512: role ablations, timing only)
-    return a.nsrc == 1 && (a.src[0].nch >> 4) == 2;   // ONE source of exactly two K chunks: the weights stay resident in LDS, the
-                                                      // helpers plan a tile once for both chunks, and the hand-off needs two steps per tile
-}
-
-
-
 // ---------------------------------------------------------------------------
 // weight gradient  dW[tap][ci][co] = sum_p A[p + tap][ci] * G[p][co]  (A, G are S16)
 // ---------------------------------------------------------------------------
@@ -1180,207 +744,6 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
     r[0] = lo4[0]; r[1] = lo4[1]; r[2] = lo4[2]; r[3] = lo4[3];
     r[4] = hi4[0]; r[5] = hi4[1]; r[6] = hi4[2]; r[7] = hi4[3];
     return __builtin_bit_cast(bf16x8, r);
-}
-
-// 8 waves = 2 tap groups (waves 0-3: taps 0..4, waves 4-7: taps 5..8) x 4 pixel quarters of the 256-pixel tile.
-// A wave keeps 5 tap accumulators (80 registers, not 144), which leaves room for TWO register sets of prefetched
-// tiles without spilling: the loads of tile t+2 are in flight while tile t is multiplied.  (With 9 accumulators per
-// wave the prefetch base pointer spilled; every prefetch load was then preceded by a scratch reload and an
-// s_waitcnt vmcnt(0), i.e. the loads of a tile were serialised and the kernel ran 5-6x off its MFMA time.)
-// A 1x1 source has one tap: the 8 waves split the tile's 16 K-steps instead.
-template <int HW>
-__global__ __launch_bounds__(512) void wgrad_s16_kernel(WgradArgs a) {
-    using G = Geo<HW>;
-    constexpr int NPX = G::NR * G::WP;
-    constexpr int APL = NPX * 64;
-    constexpr int GPL = TILE_PX * 64;
-    extern __shared__ float4 smem4[];
-    char* Ahi = reinterpret_cast<char*>(smem4);
-    char* Alo = Ahi + APL;
-    char* Ghi = Alo + APL;
-    char* Glo = Ghi + GPL;
-    int* pixoff = reinterpret_cast<int*>(Glo + GPL);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ci_tile = blockIdx.y % a.nci, co_tile = blockIdx.y / a.nci;
-    const int ci0 = ci_tile * 32, co0 = co_tile * 32;
-    const int Mtot = a.B * G::H * G::W;
-    const int taps = a.a.taps;
-    const ConvSrc& s = a.a;
-    const int g4 = lane >> 4, cb = g4 & 1, hh = g4 >> 1, q = (lane >> 2) & 3, pcq = lane & 3;
-    const int colb = (cb * 16 + pcq * 4) * 2;
-    const int tgrp = wave >> 2, wq = wave & 3;
-    const int tp0 = tgrp * 5, ntap = tgrp ? 4 : 5;
-    // staging role: piece8 = tid & 7 -> 16-channel group (piece8 >> 2), 16-byte piece of the group (piece8 & 3:
-    // 0,1 = hi halves, 2,3 = lo halves); destination plane / offset inside a 64-byte pixel row
-    const int piece8 = tid & 7, grp = piece8 >> 2, pq = piece8 & 3;
-    const int dcol = grp * 32 + (pq & 1) * 16;
-    const bool to_lo = pq >= 2;
-
-    f32x16 acc[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-
-    constexpr int NA = (NPX * 8 + 511) / 512;
-    constexpr int NG = TILE_PX * 8 / 512;
-    // Both operands come through buffer descriptors: a padding piece (or one past the end) gets an offset beyond
-    // num_records and reads as zeros — every prefetch is exactly NA + NG unconditional loads, so the compiler waits for
-    // the OLDER register set only (s_waitcnt vmcnt(NA + NG)).  The staging plan walks (row, column) of the padded-tall
-    // image incrementally, piece e = tid + 512 i sits at position (tid >> 3) + 64 i: no division per piece (three per
-    // piece before; per tile that index math was a longer dependent chain than the tile's 60 MFMAs).
-    const float* a_ptr = s.ptr; const float* g_ptr = a.g;
-    int a_C = s.C, a_c0 = s.c0, a_up = s.up, g_C = a.Cout, nB = a.B;
-    TDM_PIN(a_ptr); TDM_PIN(g_ptr); TDM_PIN(a_C); TDM_PIN(a_c0); TDM_PIN(a_up); TDM_PIN(g_C); TDM_PIN(nB);
-    const int Hs = G::H >> a_up, Ws = G::W >> a_up;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_ptr), 0, nB * Hs * Ws * a_C * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g_ptr), 0, Mtot * g_C * 4, 0x00020000);
-    const int a_col = a_c0 + ci0 + grp * 16 + pq * 4;   // float column of this thread's piece inside a pixel row of A
-    const int g_col = co0 + grp * 16 + pq * 4;
-    struct Stage { u32x4 pa[NA]; u32x4 pg[NG]; int pix; int nelem; };
-    Stage s0, s1;
-    auto prefetch = [&](Stage& st, int t) {
-        const int m0 = t * TILE_PX;
-        const int mlast = min(m0 + TILE_PX - 1, Mtot - 1);
-        const int tb0 = m0 / (G::H * G::W);
-        const int ty0 = (m0 - tb0 * (G::H * G::W)) / G::W;
-        const int PR0 = tb0 * G::HP + ty0;
-        const int nrows = padded_row<HW>(mlast) - PR0 + 2;
-        st.nelem = nrows * G::WP * 8;
-        st.pix = 0;
-        if (tid < TILE_PX) {   // staged-pixel index of tile pixel `tid`
-            const int m = min(m0 + tid, Mtot - 1);
-            const int b = m / (G::H * G::W);
-            const int rem = m - b * (G::H * G::W);
-            const int y = rem / G::W, x = rem - y * G::W;
-            st.pix = (b * G::HP + y + 1 - PR0) * G::WP + x + 1;
-        }
-        int pos = tid >> 3;
-        // opaque to the optimiser: otherwise the tile-invariant (row, column) of every piece is hoisted out of the tile
-        // loop, kept in registers across it and spilled
-        asm volatile("" : "+v"(pos));
-        int lr = pos / G::WP;
-        int pc = pos - lr * G::WP;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            int py = ty0 + lr, b = tb0;
-            if (py >= G::HP) { py -= G::HP; ++b; }
-            if (HW == 14 && py >= G::HP) { py -= G::HP; ++b; }
-            const bool ok = tid + 512 * i < st.nelem && py >= 1 && py <= G::H && pc >= 1 && pc <= G::W && b < nB;
-            const int off = __mul24(__mul24(__mul24(b, Hs) + ((py - 1) >> a_up), Ws) + ((pc - 1) >> a_up), a_C) + a_col;
-            st.pa[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? off * 4 : (int)0x80000000, 0, 0));
-            pc += 64 % G::WP;
-            lr += 64 / G::WP;
-            if (pc >= G::WP) { pc -= G::WP; ++lr; }
-        }
-#pragma unroll
-        for (int i = 0; i < NG; ++i) {   // pixels past the end are past num_records: zeros
-            const int m = m0 + ((tid + 512 * i) >> 3);
-            st.pg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, (__mul24(m, g_C) + g_col) * 4, 0, 0));
-        }
-    };
-    char* const ad = (to_lo ? Alo : Ahi) + dcol;
-    char* const gd = (to_lo ? Glo : Ghi) + dcol;
-    auto stage = [&](const Stage& st) {
-        __syncthreads();   // previous tile fully consumed
-        if (tid < TILE_PX) pixoff[tid] = st.pix;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int e = tid + 512 * i;
-            if (e < st.nelem) *reinterpret_cast<u32x4*>(ad + (e >> 3) * 64) = st.pa[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NG; ++i) *reinterpret_cast<u32x4*>(gd + ((tid + 512 * i) >> 3) * 64) = st.pg[i];
-        __syncthreads();
-    };
-    auto kstep = [&](int ks, int t0, int nt) {   // 16 pixels ks*16.., taps t0 .. t0+nt-1 -> acc[0..nt-1]
-        const int p0 = ks * 16 + hh * 8 + q;
-        const int gb0 = p0 * 64 + colb, gb1 = (p0 + 4) * 64 + colb;
-        const bf16x8 gh = tr_pair(Ghi + gb0, Ghi + gb1);
-        const bf16x8 gl = tr_pair(Glo + gb0, Glo + gb1);
-        const int ab0 = pixoff[p0] * 64 + colb, ab1 = pixoff[p0 + 4] * 64 + colb;
-#pragma unroll
-        for (int d = 0; d < 5; ++d) {
-            if (d < nt) {
-                const int tp = t0 + d;
-                const int to = ((tp / 3 - 1) * G::WP + (tp % 3 - 1)) * 64;
-                const bf16x8 ah = tr_pair(Ahi + ab0 + to, Ahi + ab1 + to);
-                const bf16x8 al = tr_pair(Alo + ab0 + to, Alo + ab1 + to);
-                acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh, acc[d], 0, 0, 0);
-                acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl, acc[d], 0, 0, 0);
-                acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh, acc[d], 0, 0, 0);
-            }
-        }
-    };
-    auto compute = [&]() {
-        if (taps == 9) {
-#pragma unroll 1
-            for (int k = 0; k < 4; ++k) kstep(wq * 4 + k, tp0, ntap);
-        } else {   // one tap, the centre of the padded-tall image: 2 K-steps per wave
-            kstep(wave * 2, 4, 1);
-            kstep(wave * 2 + 1, 4, 1);
-        }
-    };
-
-    // (prefetches past the last tile re-read tile ntiles-1: never staged, keeps the load count static)
-    const int step = gridDim.x, tlast = a.ntiles - 1;
-    int t = blockIdx.x;
-    prefetch(s0, min(t, tlast));
-    prefetch(s1, min(t + step, tlast));
-    for (; t < a.ntiles; t += 2 * step) {
-        stage(s0);
-        prefetch(s0, min(t + 2 * step, tlast));
-        compute();
-        if (t + step >= a.ntiles) break;
-        stage(s1);
-        prefetch(s1, min(t + 3 * step, tlast));
-        compute();
-    }
-
-    // partial sums of the waves that share a tap -> LDS -> fixed-order sum -> this workgroup's slab
-    float* red = reinterpret_cast<float*>(smem4);   // 8 waves x 1024 floats
-    float* slab = a.slab + (long)blockIdx.x * a.slab_stride;
-    if (taps == 9) {
-#pragma unroll
-        for (int d = 0; d < 5; ++d) {
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[d][r];
-            __syncthreads();
-            // tap d of group 0 (waves 0-3) and tap 5 + d of group 1 (waves 4-7; d < 4): 2 x 1024 outputs
-#pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) {
-                const int o = tid + 512 * k2;
-                const int grp2 = o >> 10, idx = o & 1023;
-                if (grp2 == 0 || d < 4) {
-                    const float* rb = red + grp2 * 4096 + idx;
-                    const float sum = (rb[0] + rb[1024]) + (rb[2048] + rb[3072]);
-                    const int r = idx >> 6, ln = idx & 63;
-                    const int ci = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
-                    const int co = ln & 31;
-                    const int wt = grp2 * 5 + d;
-                    slab[a.w_off + (long)(wt * a.a.w_rows + a.a.w_r0 + ci0 + ci) * a.Cout + co0 + co] = sum;
-                }
-            }
-        }
-    } else {
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[0][r];
-        __syncthreads();
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-            const int idx = tid + 512 * k2;
-            float sum = 0.f;
-#pragma unroll
-            for (int w8 = 0; w8 < 8; ++w8) sum += red[w8 * 1024 + idx];
-            const int r = idx >> 6, ln = idx & 63;
-            const int ci = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
-            const int co = ln & 31;
-            slab[a.w_off + (long)(a.a.w_r0 + ci0 + ci) * a.Cout + co0 + co] = sum;
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1656,7 +1019,6 @@ __global__ __launch_bounds__(1024) void wgrad2_s16_kernel(WgradArgs a) {
     }
 }
 
-int g_wgrad_form = 2;   // 2 = producer / consumer kernel (default), 1 = the phase-serial kernel above (kept for A/B timing)
 
 template <int HW, bool SK2>
 int launch_wgrad2_t(const WgradArgs& a, int nslab, hipStream_t st) {
@@ -1676,26 +1038,6 @@ int launch_wgrad2_t(const WgradArgs& a, int nslab, hipStream_t st) {
     const int nco = a.Cout / 32;
     hipLaunchKernelGGL((wgrad2_s16_kernel<HW, SK2>), dim3(nslab, a.nci * nco), dim3(1024), lds, st, a);
     TDM_CHECK_LAUNCH("wgrad2_s16");
-    return 0;
-}
-
-template <int HW>
-int launch_wgrad_t(const WgradArgs& a, int nslab, hipStream_t st) {
-    using G = Geo<HW>;
-    constexpr size_t lds = (size_t)2 * G::NR * G::WP * 64 + (size_t)2 * TILE_PX * 64 + TILE_PX * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_s16_kernel<HW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            tdm_set_error("wgrad_s16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return 100 + (int)e;
-        }
-        attr_set = true;
-    }
-    const int nco = a.Cout / 32;
-    hipLaunchKernelGGL((wgrad_s16_kernel<HW>), dim3(nslab, a.nci * nco), dim3(512), lds, st, a);
-    TDM_CHECK_LAUNCH("wgrad_s16");
     return 0;
 }
 
@@ -1726,7 +1068,11 @@ int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st) {
         TDM_REQUIRE(a.src[i].tb == nullptr, "conv_s16: the time bias is pre-added by the producer of an S16 tensor");
         TDM_REQUIRE(a.src[i].wp != nullptr && (((uintptr_t)a.src[i].wp) & 15) == 0, "conv_s16: packed weights missing");
     }
-    TDM_REQUIRE(a.out != nullptr || a.out_s16 != nullptr || a.o1_out != nullptr, "conv_s16: no output");
+    TDM_REQUIRE(a.out != nullptr || a.out_s16 != nullptr || a.o1_out != nullptr || a.dc_pair != nullptr, "conv_s16: no output");
+    TDM_REQUIRE(a.dc_pair == nullptr || (hw == 28 && N == 96 && a.dc_h1 != nullptr && a.rk1_d != nullptr && a.rk1_u != nullptr &&
+                                         a.out == nullptr && a.out_s16 == nullptr && a.res == nullptr && a.relu_mask_in == nullptr &&
+                                         ((long)a.B * 784) % 2 == 0),
+                "conv_s16: the paired d cat epilogue is built for the 28x28 N = 96 data gradient alone");
     TDM_REQUIRE(a.o1_out == nullptr || (hw == 28 && N == 32 && a.skip_out == nullptr && a.o1_w != nullptr && a.o1_b != nullptr),
                 "conv_s16: the fused output conv is built for the 28x28 N = 32 kernel");
     TDM_REQUIRE(a.r1_x == nullptr || (hw == 28 && N == 32 && a.skip_out == nullptr && a.res == nullptr && a.r1_w != nullptr && a.r1_b != nullptr),
@@ -1744,9 +1090,7 @@ int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st) {
         for (int i = 0; i < a.nsrc; ++i) TDM_REQUIRE(a.src[i].taps == 9, "conv_s16: fused skip rides on 3x3 sources");
         return launch_conv_t<28, 1, true>(a, st);
     }
-    if (hw == 28 && N == 32 && use_ws(a)) return launch_conv_ws<28, false>(a, st);
-    if (hw == 14 && N == 32 && use_ws(a)) return launch_conv_ws<14, false>(a, st);
-    if (hw == 28 && N == 32) return use_mt2(a) ? launch_conv_t<28, 1, false, 2>(a, st) : launch_conv_t<28, 1, false>(a, st);
+    if (hw == 28 && N == 32) return launch_conv_t<28, 1, false>(a, st);
     if (hw == 28 && N == 64) return launch_conv_t<28, 2, false>(a, st);
     if (hw == 28 && N == 96) return launch_conv_t<28, 3, false>(a, st);
     if (hw == 14 && N == 32) return launch_conv_t<14, 1, false>(a, st);
@@ -1754,20 +1098,6 @@ int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st) {
     tdm_set_error("conv_s16: unsupported geometry hw=%d N=%d", hw, N);
     return 1;
 }
-
-extern "C" int tdm_set_conv_ws(int on) {
-    TDM_REQUIRE(on == 0 || on == 1, "conv_ws %d (0 = one-role N = 32 kernel, 1 = warp-specialised)", on);
-    g_conv_ws = on;
-    return 0;
-}
-extern "C" int tdm_get_conv_ws(void) { return g_conv_ws; }
-
-extern "C" int tdm_set_conv_tile(int mt) {
-    TDM_REQUIRE(mt >= 0 && mt <= 2, "conv tile %d (0 = automatic, 1 = 256-pixel tiles, 2 = 512-pixel tiles for the 28x28 N = 32 kernels)", mt);
-    g_conv_mt = mt;
-    return 0;
-}
-extern "C" int tdm_get_conv_tile(void) { return g_conv_mt; }
 
 int tdm_launch_wgrad_s16(const WgradArgs& a, int hw, int nslab, hipStream_t st) {
     TDM_REQUIRE(a.Cout % 32 == 0 && a.nci >= 1, "wgrad_s16: Cout %d / nci %d", a.Cout, a.nci);
@@ -1778,14 +1108,9 @@ int tdm_launch_wgrad_s16(const WgradArgs& a, int hw, int nslab, hipStream_t st) 
                 "wgrad_s16: batch %d out of range (B * %d * %d must stay below 2^23 pixels: 32-bit S16 addressing)", a.B, hw, hw);
     TDM_REQUIRE((long)a.B * (hw >> a.a.up) * (hw >> a.a.up) * a.a.C * 4 < 2147483647L && (long)a.B * hw * hw * a.Cout * 4 < 2147483647L,
                 "wgrad_s16: a tensor of batch %d exceeds 2^31 bytes", a.B);
-    TDM_REQUIRE(a.g2 == nullptr || (g_wgrad_form == 2 && a.a.taps == 9), "wgrad_s16: the fused 1x1 gradient rides on the 3x3 producer/consumer kernel");
-    if (g_wgrad_form == 2) {
-        if (hw == 28) return a.g2 ? launch_wgrad2_t<28, true>(a, nslab, st) : launch_wgrad2_t<28, false>(a, nslab, st);
-        if (hw == 14) return a.g2 ? launch_wgrad2_t<14, true>(a, nslab, st) : launch_wgrad2_t<14, false>(a, nslab, st);
-    } else {
-        if (hw == 28) return launch_wgrad_t<28>(a, nslab, st);
-        if (hw == 14) return launch_wgrad_t<14>(a, nslab, st);
-    }
+    TDM_REQUIRE(a.g2 == nullptr || a.a.taps == 9, "wgrad_s16: the fused 1x1 gradient rides on a 3x3 launch");
+    if (hw == 28) return a.g2 ? launch_wgrad2_t<28, true>(a, nslab, st) : launch_wgrad2_t<28, false>(a, nslab, st);
+    if (hw == 14) return a.g2 ? launch_wgrad2_t<14, true>(a, nslab, st) : launch_wgrad2_t<14, false>(a, nslab, st);
     tdm_set_error("wgrad_s16: unsupported hw=%d", hw);
     return 1;
 }

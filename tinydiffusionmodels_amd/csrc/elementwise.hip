@@ -133,12 +133,19 @@ __global__ __launch_bounds__(EW_BLOCK) void to_unit_u8_kernel(const float* __res
 // ---- timestep bias ----------------------------------------------------------
 // src/mnist.py:77 and :58: that = t.float()/1000; tb[b][c] = w[c]*that + bias[c]
 // for the four blocks (32+64+64+32 = 192 channels per sample).
-struct TeOffs { int w[4]; int b[4]; };
+struct TeOffs { int w[4]; int b[4]; int skw4, outw; };
 __global__ __launch_bounds__(EW_BLOCK) void timebias_kernel(const int64_t* __restrict__ t,
                                                             const float* __restrict__ params, TeOffs o,
                                                             float* __restrict__ that, float* __restrict__ tb, int B,
-                                                            int64_t* __restrict__ bump) {
+                                                            int64_t* __restrict__ bump, float* __restrict__ u96) {
     if (bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0) bump[0] += 1;
+    // u[ci] = sum_co W_skip(rb4)[ci][co] * w_out[co]: the vector that turns d(loss)/d(eps) into the skip path's share of
+    // d(loss)/d(cat) (out_bwd_s16_kernel's header), 96 x 32 products by the launch's first workgroup
+    if (u96 != nullptr && blockIdx.x == 0 && threadIdx.x < 96) {
+        float acc = 0.f;
+        for (int co = 0; co < 32; ++co) acc = fmaf(params[o.skw4 + threadIdx.x * 32 + co], params[o.outw + co], acc);
+        u96[threadIdx.x] = acc;
+    }
     const int total = B * 192;
     for (int i = blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += gridDim.x * EW_BLOCK) {
         const int b = i / 192, c = i - b * 192;
@@ -731,20 +738,30 @@ __device__ __forceinline__ float4 mask4(const float4 d, unsigned mk) {
     return make_float4((mk & 1u) ? d.x : 0.f, (mk & 2u) ? d.y : 0.f, (mk & 4u) ? d.z : 0.f, (mk & 8u) ? d.w : 0.f);
 }
 
-// out_bwd_kernel + S16 copies of dout / dc2 + bias gradients of rb4.conv2 (sum dc2) and rb4.skip (sum dout)
+// Backward of the model's 1x1 output conv (src/mnist.py:87) and everything that follows from dout4 = d(loss)/d(h4) being
+// RANK ONE: dout4[m][c] = d[m] * w_out[c] with d = d(loss)/d(eps).  rb4's skip conv (a 1x1 conv over the 96-channel concat,
+// src/mnist.py:52,61) receives exactly dout4 as its output gradient, so
+//   dW_skip[ci][co] = (sum_m cat[m][ci] d[m]) * w_out[co]     -> this kernel emits the 96-vector v = sum_m cat[m] d[m]
+//   db_skip[co]     = (sum_m d[m]) * w_out[co]
+//   d cat[m][ci]   += d[m] * u[ci],  u = W_skip w_out          -> added in the epilogue of rb4.conv1's data gradient
+// and dout4 itself is never written (it was a 51 MB S16 tensor read by three launches, and a second K source with its own
+// staged images in the data gradient).  What stays a tensor: dc2 = dout4 * (a2 > 0) (S16), the input of rb4.conv2's
+// gradients.  Also: dW_out = sum d h4, db_out = sum d, db(rb4.conv2) = sum dc2, and — fused — F.mse_loss forward/backward.
+// cat = [up2(h3) | h1] exists only as the S16 tensors h3s (B,14,14,64) and h1s (B,28,28,32).
 __global__ __launch_bounds__(EW_BLOCK) void out_bwd_s16_kernel(const float* __restrict__ deps,
                                                                const float* __restrict__ h4, const float* __restrict__ w,
-                                                               const unsigned char* __restrict__ a2m, float* __restrict__ dout,
-                                                               float* __restrict__ dout_s16, float* __restrict__ dc2_s16,
+                                                               const unsigned char* __restrict__ a2m,
+                                                               const float* __restrict__ h1s, const float* __restrict__ h3s,
+                                                               float* __restrict__ dc2_s16,
                                                                float* __restrict__ slab, long slab_stride, int w_off,
-                                                               int b_off, int c2b_off, int skb_off, int64_t M,
+                                                               int b_off, int c2b_off, int skb_off, int vsk_off, int64_t M,
                                                                const float* __restrict__ eps, const float* __restrict__ noise,
                                                                float* __restrict__ deps_out, float dscale, int loss_off) {
     __shared__ float4 shw[EW_BLOCK];
     __shared__ float shb[4];
     const int c4 = threadIdx.x & 7;
     const float4 wv = *reinterpret_cast<const float4*>(w + c4 * 4);
-    float4 gw = make_float4(0.f, 0.f, 0.f, 0.f), g_c2 = gw, g_sk = gw;
+    float4 gw = make_float4(0.f, 0.f, 0.f, 0.f), g_c2 = gw, g_v1 = gw, g_v3 = gw;
     float gb = 0.f, gl = 0.f;
     const int64_t total = M * 8;
     const int64_t S = (int64_t)gridDim.x * EW_BLOCK;
@@ -758,32 +775,47 @@ __global__ __launch_bounds__(EW_BLOCK) void out_bwd_s16_kernel(const float* __re
         }
         return df * dscale;
     };
-    auto finish = [&](int64_t i, float d, const float4& hv, unsigned am) {
+    auto dpure = [&](int64_t m) { return fused ? (eps[m] - noise[m]) * dscale : deps[m]; };   // (no side effects: second pass)
+    auto finish = [&](int64_t i, float d, const float4& hv, unsigned am, const float4& h1v) {
         const int64_t m = i >> 3;
         float4 o;
         o.x = d * wv.x; o.y = d * wv.y; o.z = d * wv.z; o.w = d * wv.w;
-        if (dout != nullptr) reinterpret_cast<float4*>(dout)[i] = o;
-        tdm_store_s16_4(dout_s16, m, 32, c4 * 4, o);
         const float4 mk = mask4(o, am);
         tdm_store_s16_4(dc2_s16, m, 32, c4 * 4, mk);
         gw.x += d * hv.x; gw.y += d * hv.y; gw.z += d * hv.z; gw.w += d * hv.w;
         g_c2.x += mk.x; g_c2.y += mk.y; g_c2.z += mk.z; g_c2.w += mk.w;
-        g_sk.x += o.x; g_sk.y += o.y; g_sk.z += o.z; g_sk.w += o.w;
+        g_v1.x += d * h1v.x; g_v1.y += d * h1v.y; g_v1.z += d * h1v.z; g_v1.w += d * h1v.w;
         if (c4 == 0) gb += d;
     };
     int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x;
     // four independent items in flight per thread (one workgroup per slab = one wave per SIMD: latency-bound otherwise)
     for (; i + 3 * S < total; i += 4 * S) {
-        float d[4]; float4 hv[4]; unsigned am[4];
+        float d[4]; float4 hv[4], h1v[4]; unsigned am[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t k = i + u * S;
             d[u] = dval(k >> 3); hv[u] = reinterpret_cast<const float4*>(h4)[k]; am[u] = a2m[k];
+            h1v[u] = tdm_load_s16_4(h1s, k >> 3, 32, c4 * 4);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) finish(i + u * S, d[u], hv[u], am[u]);
+        for (int u = 0; u < 4; ++u) finish(i + u * S, d[u], hv[u], am[u], h1v[u]);
     }
-    for (; i < total; i += S) finish(i, dval(i >> 3), reinterpret_cast<const float4*>(h4)[i], a2m[i]);
+    for (; i < total; i += S)
+        finish(i, dval(i >> 3), reinterpret_cast<const float4*>(h4)[i], a2m[i], tdm_load_s16_4(h1s, i >> 3, 32, c4 * 4));
+    // v over the up-sampled channels: sum over the half-resolution pixels of h3 * (sum of d over its 2x2 fine pixels)
+    {
+        const int q4 = threadIdx.x & 15;                 // channel quad of the 64 (the grid stride is a multiple of 16)
+        const int64_t total3 = (M >> 2) * 16;
+        for (int64_t k = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; k < total3; k += S) {
+            const int p = (int)(k >> 4);
+            const int q = p / 14, xo = p - q * 14;
+            const int b = q / 14, yo = q - b * 14;
+            const int64_t m00 = (int64_t)(b * 28 + 2 * yo) * 28 + 2 * xo;
+            const float ds = (dpure(m00) + dpure(m00 + 1)) + (dpure(m00 + 28) + dpure(m00 + 29));
+            const float4 hv = tdm_load_s16_4(h3s, p, 64, q4 * 4);
+            g_v3.x += ds * hv.x; g_v3.y += ds * hv.y; g_v3.z += ds * hv.z; g_v3.w += ds * hv.w;
+        }
+    }
     float* dst = slab + (long)blockIdx.x * slab_stride;
     if (fused && loss_off >= 0) {
         const float sl = block_sum(gl, shb);
@@ -792,8 +824,11 @@ __global__ __launch_bounds__(EW_BLOCK) void out_bwd_s16_kernel(const float* __re
     const float sb = block_sum(gb, shb);
     quad_reduce_store(gw, shw, 8, dst + w_off);
     quad_reduce_store(g_c2, shw, 8, dst + c2b_off);
-    quad_reduce_store(g_sk, shw, 8, dst + skb_off);
+    quad_reduce_store(g_v3, shw, 16, dst + vsk_off);
+    quad_reduce_store(g_v1, shw, 8, dst + vsk_off + 64);
     if (threadIdx.x == 0) dst[b_off] = sb;
+    __syncthreads();
+    if (threadIdx.x < 32) dst[skb_off + threadIdx.x] = w[threadIdx.x] * ((shb[0] + shb[1]) + (shb[2] + shb[3]));   // db_skip partial = w_out * sum d
 }
 
 // dc_s16 = split(dout * (a > 0)); per-channel slab partials of the masked (and unmasked) gradient
@@ -833,10 +868,12 @@ __global__ __launch_bounds__(EW_BLOCK) void relu_mask_s16_kernel(const float* __
     quad_reduce_store(gu, sh, C4, b_unmasked_off >= 0 ? dst + b_unmasked_off : nullptr);
 }
 
-// split_dcat_kernel + relu_mask_s16_kernel in one pass (rb3): dout3 = 2x2 sum of dcat[.., 0:64] (upsample backward),
+// Upsample backward + ReLU mask of rb3.conv2's output in one pass (rb3): dout3 = 2x2 sum of d cat[.., 0:64].  The data
+// gradient of rb4.conv1 has already added horizontally adjacent pixels in its epilogue (the pair sits in one wave's transpose
+// block): `dch` is (B, 28, 14, 64), and this kernel adds the two rows — 2 loads per output instead of 4, half the bytes.
 // dc2_s16 = split(dout3 * (a2 > 0)), slab partials of the masked gradient (rb3.conv2 bias gradient).
 // One workgroup per slab; c4 = tid & 15 is fixed per thread (the grid stride is a multiple of 16).
-__global__ __launch_bounds__(EW_BLOCK) void split_dcat_mask_s16_kernel(const float* __restrict__ dcat,
+__global__ __launch_bounds__(EW_BLOCK) void split_dcat_mask_s16_kernel(const float* __restrict__ dch,
                                                                        const unsigned char* __restrict__ a2m,
                                                                        float* __restrict__ dout3, float* __restrict__ dc_s16,
                                                                        float* __restrict__ slab, long slab_stride,
@@ -846,35 +883,35 @@ __global__ __launch_bounds__(EW_BLOCK) void split_dcat_mask_s16_kernel(const flo
     const int64_t total = (int64_t)B * 196 * 16;
     const int64_t S = (int64_t)gridDim.x * EW_BLOCK;
     const int c4 = threadIdx.x & 15;   // (the grid stride is a multiple of 16)
-    struct Item { float4 v00, v01, v10, v11; unsigned am; };
+    struct Item { float4 v0, v1; unsigned am; };
     auto fetch = [&](int64_t i, Item& it) {   // (32-bit index math)
         const int p = (int)(i >> 4);
-        const int q = p / 14, xo = p - q * 14;
-        const int b = q / 14, yo = q - b * 14;
-        const float4* src = reinterpret_cast<const float4*>(dcat) + (unsigned)(((b * 28 + 2 * yo) * 28 + 2 * xo) * 24 + c4);
-        it.v00 = src[0]; it.v01 = src[24]; it.v10 = src[28 * 24]; it.v11 = src[28 * 24 + 24];
+        const int q = p / 14, xo = p - q * 14;      // q = b * 14 + yo: rows 2q and 2q + 1 of the (B * 28)-row half-width image
+        const float4* src = reinterpret_cast<const float4*>(dch) + (unsigned)((2 * q * 14 + xo) * 16 + c4);
+        it.v0 = src[0]; it.v1 = src[14 * 16];
         it.am = a2m[i];
     };
     auto finish = [&](int64_t i, const Item& it) {
         float4 d;
-        d.x = ((it.v00.x + it.v01.x) + it.v10.x) + it.v11.x; d.y = ((it.v00.y + it.v01.y) + it.v10.y) + it.v11.y;
-        d.z = ((it.v00.z + it.v01.z) + it.v10.z) + it.v11.z; d.w = ((it.v00.w + it.v01.w) + it.v10.w) + it.v11.w;
+        d.x = it.v0.x + it.v1.x; d.y = it.v0.y + it.v1.y; d.z = it.v0.z + it.v1.z; d.w = it.v0.w + it.v1.w;
         reinterpret_cast<float4*>(dout3)[i] = d;
         const float4 o = mask4(d, it.am);
         tdm_store_s16_4(dc_s16, i >> 4, 64, c4 * 4, o);
         gm.x += o.x; gm.y += o.y; gm.z += o.z; gm.w += o.w;
     };
     int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x;
-    for (; i + S < total; i += 2 * S) {   // two items (eight 16-byte loads) in flight per thread
-        Item a, b2;
-        fetch(i, a); fetch(i + S, b2);
-        finish(i, a); finish(i + S, b2);
+    for (; i + 3 * S < total; i += 4 * S) {   // four items (eight 16-byte loads) in flight per thread
+        Item a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fetch(i + u * S, a[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) finish(i + u * S, a[u]);
     }
     for (; i < total; i += S) { Item a; fetch(i, a); finish(i, a); }
     quad_reduce_store(gm, sh, 16, slab + (long)blockIdx.x * slab_stride + b_masked_off);
 }
 
-// combine_dh1_kernel + relu_mask_s16_kernel in one pass (rb1): dout1 = dcat[.., 64:96] + 0.25 * dp1 (concat skip +
+// combine_dh1_kernel + relu_mask_s16_kernel in one pass (rb1): dout1 = dcat_h1 (= d cat[.., 64:96], (M, 32)) + 0.25 * dp1 (concat skip +
 // avg-pool backward), dc2_s16 = split(dout1 * (a2 > 0)), slab partials of the masked gradient (rb1.conv2 bias).
 __global__ __launch_bounds__(EW_BLOCK) void combine_dh1_mask_s16_kernel(const float* __restrict__ dcat,
                                                                         const float* __restrict__ dp1,
@@ -892,7 +929,7 @@ __global__ __launch_bounds__(EW_BLOCK) void combine_dh1_mask_s16_kernel(const fl
         const int p = (int)(i >> 3);
         const int q = p / 28, x = p - q * 28;
         const int b = q / 28, y = q - b * 28;
-        dc = reinterpret_cast<const float4*>(dcat)[(unsigned)(p * 24 + 16 + c4)];
+        dc = reinterpret_cast<const float4*>(dcat)[(unsigned)(p * 8 + c4)];           // d cat[.., 64:96] as its own (M, 32) tensor
         dp = reinterpret_cast<const float4*>(dp1)[(unsigned)(((b * 14 + (y >> 1)) * 14 + (x >> 1)) * 8 + c4)];
         am = a2m[(unsigned)i];
         xv = xin != nullptr ? xin[p] : 0.f;
@@ -962,10 +999,11 @@ __global__ __launch_bounds__(EW_BLOCK) void group_sums_kernel(GroupSumJobs jb, c
 
 // ------------------------------- launchers -----------------------------------
 int tdm_launch_timebias(const int64_t* t, const float* params, const int* te_w_off, const int* te_b_off, float* that,
-                        float* tb, int B, hipStream_t st, int64_t* bump) {
+                        float* tb, int B, hipStream_t st, int64_t* bump, float* u96, int skw4_off, int outw_off) {
     TeOffs o;
     for (int i = 0; i < 4; ++i) { o.w[i] = te_w_off[i]; o.b[i] = te_b_off[i]; }
-    hipLaunchKernelGGL(timebias_kernel, dim3(ew_grid((int64_t)B * 192)), dim3(EW_BLOCK), 0, st, t, params, o, that, tb, B, bump);
+    o.skw4 = skw4_off; o.outw = outw_off;
+    hipLaunchKernelGGL(timebias_kernel, dim3(ew_grid((int64_t)B * 192)), dim3(EW_BLOCK), 0, st, t, params, o, that, tb, B, bump, u96);
     TDM_CHECK_LAUNCH("timebias");
     return 0;
 }
@@ -1132,13 +1170,14 @@ int tdm_launch_avgpool_s16(const float* in, float* out, float* out_s16, int B, i
     TDM_CHECK_LAUNCH("avgpool_s16");
     return 0;
 }
-int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, const unsigned char* a2, float* dout,
-                           float* dout_s16, float* dc2_s16, float* slab, long slab_stride, int w_off, int b_off,
-                           int c2b_off, int skb_off, int64_t M, int nslab, hipStream_t st, const float* eps,
+int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, const unsigned char* a2, const float* h1s,
+                           const float* h3s, float* dc2_s16, float* slab, long slab_stride, int w_off, int b_off,
+                           int c2b_off, int skb_off, int vsk_off, int64_t M, int nslab, hipStream_t st, const float* eps,
                            const float* noise, float* deps_out, int loss_off) {
     TDM_REQUIRE(deps != nullptr || (eps != nullptr && noise != nullptr), "out_bwd_s16: needs deps, or eps and noise");
-    hipLaunchKernelGGL(out_bwd_s16_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, deps, h4, w, a2, dout, dout_s16, dc2_s16,
-                       slab, slab_stride, w_off, b_off, c2b_off, skb_off, M, eps, noise, deps_out, 2.0f / (float)M, loss_off);
+    TDM_REQUIRE(h1s != nullptr && h3s != nullptr && (M % 784) == 0, "out_bwd_s16: needs the S16 concat sources of whole 28x28 images");
+    hipLaunchKernelGGL(out_bwd_s16_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, deps, h4, w, a2, h1s, h3s, dc2_s16,
+                       slab, slab_stride, w_off, b_off, c2b_off, skb_off, vsk_off, M, eps, noise, deps_out, 2.0f / (float)M, loss_off);
     TDM_CHECK_LAUNCH("out_bwd_s16");
     return 0;
 }

@@ -585,8 +585,6 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 }  // namespace
 
 namespace {
-int g_nt_wm = 0;   // 0: pick per problem; 1 / 2: force the 128- / 256-row tile (TDM_GEMM_WM, A/B timing)
-
 template <int NPROD, bool CE, bool STATS, int WM, bool S16IN = false, bool BUF = false>
 int launch_nt(const GemmArgs& g, hipStream_t st) {
     using Cf = NtCfg<WM>;
@@ -628,32 +626,22 @@ int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
 
     TDM_REQUIRE(!g.gate_s16 || (g.c_rs % 16) == 0, "gemm_nt_bf16: an S16 gate needs a leading dimension that is a multiple of 16");
     TDM_REQUIRE(!(g.ce_lse != nullptr && g.ce_part != nullptr), "gemm_nt_bf16: one cross-entropy role per launch");
-    static bool env_read = false;
-    if (!env_read) {
-        if (const char* e = getenv("TDM_GEMM_WM")) g_nt_wm = atoi(e);
-        env_read = true;
-    }
-    // 256-row tiles (64 x 64 per wave) when they still make at least one round of workgroups over the chip
-    const long tiles256 = (long)((g.N + TN_ - 1) / TN_) * ((g.M + 255) / 256);
-    // Measured (tools/time_gemm.py, M = 32768): the 256-row tile is NOT faster — N = 2048, K = 256: 185 us (128-row, four
-    // waves per SIMD) vs 201 us (256-row, two waves per SIMD); bf16 operands 135 vs 150 us; equal on the other layer shapes.
-    // Halving the waves per SIMD costs what the halved LDS fragment traffic buys.  It stays selectable (TDM_GEMM_WM=2).
-    (void)tiles256;
-    const bool big = g_nt_wm == 2;
+    // (A 256-row tile — 64 x 64 per wave, one workgroup per CU, same loop — was built and measured in round 2: N = 2048,
+    //  K = 256: 185 us at 128 rows / four waves per SIMD vs 201 us; DESIGN.md section 5.  It is no longer compiled in.)
     if (g.ce_lse != nullptr || g.ce_part != nullptr) {
         TDM_REQUIRE(nprod == 3 && g.ce_ids != nullptr, "gemm_nt_bf16: the cross-entropy forms run in the bf16x3 arithmetic and need the target ids");
-        if (g.ce_lse != nullptr) return big ? launch_nt<3, true, false, 2>(g, st) : launch_nt<3, true, false, 1>(g, st);
+        if (g.ce_lse != nullptr) return launch_nt<3, true, false, 1>(g, st);
         TDM_REQUIRE(g.ce_tgt != nullptr && g.ce_nblk >= (g.N + 63) / 64 && g.res == nullptr && !g.relu && g.gate == nullptr && g.drop.thr == 0u,
                     "gemm_nt_bf16: cross-entropy partials need a plain (bias-only) epilogue");
-        return big ? launch_nt<3, false, true, 2>(g, st) : launch_nt<3, false, true, 1>(g, st);
+        return launch_nt<3, false, true, 1>(g, st);
     }
     if (g.s16_in) {
         const bool buf = (g.K % 32) == 0 && (long)g.M * g.a_rs * 4 < 2147483647L && (long)g.N * g.b_cs * 4 < 2147483647L;
         if (buf) return nprod == 3 ? launch_nt<3, false, false, 1, true, true>(g, st) : launch_nt<1, false, false, 1, true, true>(g, st);
         return nprod == 3 ? launch_nt<3, false, false, 1, true>(g, st) : launch_nt<1, false, false, 1, true>(g, st);
     }
-    if (nprod == 3) return big ? launch_nt<3, false, false, 2>(g, st) : launch_nt<3, false, false, 1>(g, st);
-    return big ? launch_nt<1, false, false, 2>(g, st) : launch_nt<1, false, false, 1>(g, st);
+    if (nprod == 3) return launch_nt<3, false, false, 1>(g, st);
+    return launch_nt<1, false, false, 1>(g, st);
 }
 
 // C[M][N] = sum_k A[k][M]^T B[k][N]: A(i,k) = A[k*a_cs + i], B(k,j) = B[k*b_rs + j]; raw split-K output

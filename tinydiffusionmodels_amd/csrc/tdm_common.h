@@ -92,6 +92,15 @@ struct ConvArgs {
     const float* r1_x;
     const float* r1_w;
     const float* r1_b;
+    // rb4.conv1's data gradient (S16 kernel, 28x28, N = 96 = the concat's channels): when dc_pair != nullptr the epilogue
+    //  * adds the skip path's share rk1_d[m] * rk1_u[c] (rank one: out_bwd_s16_kernel's header; rk1_d: [M], rk1_u: [96]),
+    //  * writes channels 0..63 (the up-sampled h3 part) with horizontally adjacent pixels already ADDED — dc_pair is
+    //    (B, 28, 14, 64): half of the 2x2 sum of the upsample backward, taken where the pair sits in one transpose block —
+    //  * and channels 64..95 (the h1 part) to dc_h1, a (M, 32) tensor.  `out` is not written.
+    const float* rk1_d;
+    const float* rk1_u;
+    float* dc_pair;
+    float* dc_h1;
     // Fused 1x1 output conv N -> 1 (src/mnist.py:87, same kernel instantiation): o1_out[m] = sum_c value[m][c] * o1_w[c]
     // + o1_b[0] over the value that goes to `out` (after ReLU and residual), with conv_out_kernel's association, so the
     // [M][32] tensor need not be written when nothing else reads it (sampling).  o1_out: [M] or nullptr.
@@ -147,6 +156,10 @@ struct ReduceSec {
     long stride_override;  // distance between this section's slabs; 0 = the launch's common stride
     float* dst;            // where the section's sums go; nullptr = out + off
     float scale;           // factor applied to the sums; 0 = 1
+    // outer_w != nullptr: the section's sums r[i] are one factor of a rank-one gradient: element i writes the outer_n
+    // values r[i] * outer_w[j] to (dst ? dst : out + off)[i * outer_n + j] (rb4.skip's weight gradient, out_bwd_s16_kernel)
+    const float* outer_w;
+    int outer_n;
 };
 #define TDM_MAX_SECS 40
 struct ReduceArgs {
@@ -160,8 +173,10 @@ int tdm_launch_reduce(const float* slabs, long stride, const ReduceArgs& ra, flo
 // elementwise / small kernels (elementwise.hip)
 // ---------------------------------------------------------------------------
 // bump != nullptr: also bump[0] += 1 (the Philox offset of the fused train step, consumed by the preceding draw kernel)
+// u96 != nullptr: also u96[ci] = sum_co params[skw4_off + ci * 32 + co] * params[outw_off + co] (96 values; ConvArgs::rk1_u)
 int tdm_launch_timebias(const int64_t* t, const float* params, const int* te_w_off, const int* te_b_off,
-                        float* that, float* tb, int B, hipStream_t st, int64_t* bump = nullptr);
+                        float* that, float* tb, int B, hipStream_t st, int64_t* bump = nullptr, float* u96 = nullptr,
+                        int skw4_off = 0, int outw_off = 0);
 int tdm_launch_timebias_float(const float* that, const float* w, const float* bias, float* tb, int B, int C, hipStream_t st);
 int tdm_launch_draw_q_sample(const float* x0, const float* sqrt_acp, const float* sqrt_1m_acp, uint64_t seed, int64_t* rng_state,
                              int64_t* t_out, float* noise_out, float* x_noisy_out, int64_t B, int64_t inner, bool bump,
@@ -194,11 +209,14 @@ int tdm_launch_pool_skip_s16(const float* h1, const float* wsk, const float* bsk
 int tdm_launch_s16_to_nchw(const float* in_s16, float* out, int B, int HWpix, int C, hipStream_t st);   // accessor: hi + lo -> fp32 NCHW
 int tdm_launch_avgpool_s16(const float* in, float* out, float* out_s16, int B, int Hout, int C, hipStream_t st);
 // deps == nullptr: the MSE backward is fused — d = (eps - noise) * 2/M is computed here (and written to deps_out when
-// given), and the slab partial of sum (eps - noise)^2 goes to slab offset loss_off (F.mse_loss, src/mnist.py:158)
-int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, const unsigned char* a2m, float* dout,
-                           float* dout_s16, float* dc2_s16, float* slab, long slab_stride, int w_off, int b_off,
-                           int c2b_off, int skb_off, int64_t M, int nslab, hipStream_t st, const float* eps = nullptr,
-                           const float* noise = nullptr, float* deps_out = nullptr, int loss_off = -1);
+// given), and the slab partial of sum (eps - noise)^2 goes to slab offset loss_off (F.mse_loss, src/mnist.py:158).
+// dout4 = d x w_out is rank one and never written: the kernel emits rb4.skip's gradients in factored form (partial rows:
+// vsk_off: the 96-vector sum_m cat[m] d[m] over cat = [up2(h3s) | h1s]; skb_off: w_out * sum d) — elementwise.hip
+int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, const unsigned char* a2m, const float* h1s,
+                           const float* h3s, float* dc2_s16, float* slab, long slab_stride, int w_off, int b_off,
+                           int c2b_off, int skb_off, int vsk_off, int64_t M, int nslab, hipStream_t st,
+                           const float* eps = nullptr, const float* noise = nullptr, float* deps_out = nullptr,
+                           int loss_off = -1);
 // time_emb weight / bias gradients of the four blocks and the conv1 bias gradients of rb2..rb4 as slab partials, straight
 // from the per-32-pixel-group sums the data-gradient launches wrote (ConvArgs::sums; one buffer per block)
 struct GroupSumJobs { const float* gs[4]; int C[4]; int HWpix[4]; int tew[4]; int c1b[4]; };

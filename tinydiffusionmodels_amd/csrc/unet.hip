@@ -90,11 +90,11 @@ const PackTab kPack = make_pack();
 
 // 0: exact fp32 MFMA (conv_mfma.hip); 1: bf16x3, fp32 tensors split while staging (conv_bf16.hip);
 // 2: bf16x3 over pre-split "S16" tensors written by the producers (conv_s16.hip) — same arithmetic as 1
-int g_conv_mode = 2;
+thread_local int g_conv_mode = 2;   // per calling thread (tdm_set_conv_mode): no process-global mutable state
 
 // ------------------------------ workspace --------------------------------------
 struct Ws {
-    float *that, *tb, *S[4], *scratch;
+    float *that, *tb, *S[4], *scratch, *u96;
     unsigned short* wpack;
     float *a1_1, *s1, *a2_1, *h1, *p1;
     float *a1_2, *s2, *a2_2, *h2;
@@ -121,7 +121,7 @@ Ws carve(float* base, int64_t B, int training) {
         return p;
     };
     const int64_t M28 = B * 784, M14 = B * 196;
-    w.that = take(B); w.tb = take(B * 192); w.scratch = take(2048);
+    w.that = take(B); w.tb = take(B * 192); w.scratch = take(2048); w.u96 = take(128);
     for (int i = 0; i < 4; ++i) w.S[i] = take(B * 64);
     w.wpack = reinterpret_cast<unsigned short*>(take((kPack.total_u16 + 1) / 2));
     w.a1_1 = take(M28 * 32); w.s1 = take(M28 * 32); w.a2_1 = take(M28 * 32); w.h1 = take(M28 * 32);
@@ -289,11 +289,11 @@ int wgrad_s16(hipStream_t st, int hw, int B, const float* act_s16, int C, int c_
     X(F_RB3C1, "rb3.conv1 fwd 64->64 @14 (conv_s16<14,2>)") X(F_RB3C2, "rb3.conv2 fwd 64->64 @14 (conv_s16<14,2>)")     \
     X(F_RB4C1, "rb4.conv1 + rb4.skip fwd 96->32 @28 (conv_s16<28,1,skip>)")                                             \
     X(F_RB4C2, "rb4.conv2 + out fwd 32->32 @28 (conv_s16<28,1>)")                                                       \
-    X(B_OUT_BWD, "out conv bwd + relu mask (out_bwd_s16)") X(B_WG_RB4C2, "rb4.conv2 wgrad (wgrad2_s16<28>)")            \
+    X(B_OUT_BWD, "out conv bwd + relu mask + rb4.skip grads in factored form (out_bwd_s16)") X(B_WG_RB4C2, "rb4.conv2 wgrad (wgrad2_s16<28>)")            \
     X(B_DG_RB4C2, "rb4.conv2 dgrad 32->32 @28 (conv_s16<28,1>)")                                                        \
-    X(B_WG_RB4C1A, "rb4.conv1+skip wgrad, up(h3) part (wgrad2_s16<28,sk>)")                                             \
-    X(B_WG_RB4C1B, "rb4.conv1+skip wgrad, h1 part (wgrad2_s16<28,sk>)")                                                 \
-    X(B_DG_RB4C1, "rb4.conv1+skip dgrad 32->96 @28 (conv_s16<28,3>)") X(B_SPLIT_DCAT, "upsample bwd + relu mask (split_dcat_mask_s16)") \
+    X(B_WG_RB4C1A, "rb4.conv1 wgrad, up(h3) part (wgrad2_s16<28>)")                                             \
+    X(B_WG_RB4C1B, "rb4.conv1 wgrad, h1 part (wgrad2_s16<28>)")                                                 \
+    X(B_DG_RB4C1, "rb4.conv1 dgrad 32->96 @28 + rank-1 skip share, paired (conv_s16<28,3>)") X(B_SPLIT_DCAT, "upsample bwd + relu mask (split_dcat_mask_s16)") \
     X(B_WG_RB3C2, "rb3.conv2 wgrad (wgrad2_s16<14>)") X(B_DG_RB3C2, "rb3.conv2 dgrad 64->64 @14 (conv_s16<14,2>)")      \
     X(B_WG_RB3C1, "rb3.conv1 wgrad (wgrad2_s16<14>)")                                                                   \
     X(B_DG_RB3C1, "rb3.conv1 dgrad 64->64 @14 (conv_s16<14,2>)") X(B_RELU_MASK2, "relu mask rb2 (relu_mask_s16)")       \
@@ -324,7 +324,7 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
                      hipStream_t st) {
     const int tew[4] = {kL.rb[0].tew, kL.rb[1].tew, kL.rb[2].tew, kL.rb[3].tew};
     const int teb[4] = {kL.rb[0].teb, kL.rb[1].teb, kL.rb[2].teb, kL.rb[3].teb};
-    RUN(F_TIMEBIAS, tdm_launch_timebias(t, P, tew, teb, w.that, w.tb, B, st, w.rng_bump));
+    RUN(F_TIMEBIAS, tdm_launch_timebias(t, P, tew, teb, w.that, w.tb, B, st, w.rng_bump, w.u96, kL.rb[3].skw, kL.outw));
     RUN(F_PACK, tdm_launch_pack(P, kPack.pa, w.wpack, st));
     const BlockOff &r1 = kL.rb[0], &r2 = kL.rb[1], &r3 = kL.rb[2], &r4 = kL.rb[3];
     // rb1: conv1 (Cin = 1) writes a1 (mask) and split(a1 + tb) for conv2
@@ -380,9 +380,10 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
 // emit (bias / 1-channel-conv / time-embedding gradients, the loss): those kernels are bandwidth-bound only with ~4
 // workgroups per CU, i.e. up to 1024 partial rows, which would be 740 MB of full-width slabs for ~1 KB of payload each.
 constexpr int NSLAB = 256;
-constexpr int EROWS = 1024, ESTRIDE = 960;
+constexpr int EROWS = 1024, ESTRIDE = 1056;
 enum { E_OUT = 0, E_LOSS = 33, E_C2B4 = 64, E_SKB4 = 96, E_C2B3 = 128, E_C2B2 = 192, E_SKB2 = 256, E_C2B1 = 320, E_SKW1 = 352,
-       E_SKB1 = 384, E_TE1 = 416, E_TE2 = 480, E_TE3 = 608, E_TE4 = 736, E_C1B2 = 800, E_C1B3 = 864, E_C1B4 = 928 };
+       E_SKB1 = 384, E_TE1 = 416, E_TE2 = 480, E_TE3 = 608, E_TE4 = 736, E_C1B2 = 800, E_C1B3 = 864, E_C1B4 = 928,
+       E_VSK = 960 /* 96: sum_m cat[m][ci] d[m], the left factor of rb4.skip's rank-one weight gradient */ };
 constexpr long ESLAB_BASE = (long)NSLAB * SLAB_STRIDE;   // float offset of the compact rows inside the slab buffer
 
 int unet_backward_s16(const float* P, const float* x, const float* deps, float* G, const Ws& w, float* slabs, int B,
@@ -397,26 +398,29 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     const long NP = SLAB_STRIDE;
     float* const es = slabs + ESLAB_BASE;
     TDM_REQUIRE(deps != nullptr || mse != nullptr, "unet_backward: no output gradient");
-    // ---- out conv + rb4 ----
-    RUN(B_OUT_BWD, tdm_launch_out_bwd_s16(deps, w.h4, P + kL.outw, w.m2[3], nullptr, w.dout4s, w.dc2s_4, es, ESTRIDE, E_OUT,
-                                          E_OUT + 32, E_C2B4, E_SKB4, M28, ER28, st, deps ? nullptr : mse->eps,
+    // ---- out conv + rb4 ----  (dout4 = d x w_out is rank one and never written: out_bwd_s16_kernel's header)
+    const float* const dvec = deps ? deps : mse->deps_out;   // d(loss)/d(eps), [M]
+    TDM_REQUIRE(dvec != nullptr, "unet_backward: the fused MSE form needs a deps buffer");
+    float* const dc_pair = w.dcat;                  // (B, 28, 14, 64): d cat[.., 0:64], horizontal pairs added
+    float* const dc_h1 = w.dcat + M28 * 32;         // (M, 32):         d cat[.., 64:96]
+    RUN(B_OUT_BWD, tdm_launch_out_bwd_s16(deps, w.h4, P + kL.outw, w.m2[3], w.h1s, w.h3s, w.dc2s_4, es, ESTRIDE, E_OUT,
+                                          E_OUT + 32, E_C2B4, E_SKB4, E_VSK, M28, ER28, st, deps ? nullptr : mse->eps,
                                           deps ? nullptr : mse->noise, deps ? nullptr : mse->deps_out, deps ? -1 : E_LOSS));
     RUN(B_WG_RB4C2, wgrad_s16(st, 28, B, w.a1s_4, 32, 32, 0, 9, w.dc2s_4, 32, slabs, r4.c2w, 32, 0, NS));
     RUN(B_DG_RB4C2, conv_s16_1(st, w, 28, B, w.dc2s_4, 32, 9, kPack.dg[W_RB4C2], 32, nullptr, 0,
                                S16Out{nullptr, nullptr, nullptr, w.dh4s, nullptr, w.m1[3], w.gs[3]}));   // + ReLU backward of a1
-    // rb4.conv1 and rb4.skip read the same concat: the 1x1 gradients ride on the 3x3 launches (fifth accumulator of tap group 1)
-    RUN(B_WG_RB4C1A, wgrad_s16(st, 28, B, w.h3s, 64, 64, 1, 9, w.dh4s, 32, slabs, r4.c1w, 96, 0, NS, w.dout4s, r4.skw));
-    RUN(B_WG_RB4C1B, wgrad_s16(st, 28, B, w.h1s, 32, 32, 0, 9, w.dh4s, 32, slabs, r4.c1w, 96, 64, NS, w.dout4s, r4.skw));
-    {
+    RUN(B_WG_RB4C1A, wgrad_s16(st, 28, B, w.h3s, 64, 64, 1, 9, w.dh4s, 32, slabs, r4.c1w, 96, 0, NS));
+    RUN(B_WG_RB4C1B, wgrad_s16(st, 28, B, w.h1s, 32, 32, 0, 9, w.dh4s, 32, slabs, r4.c1w, 96, 64, NS));
+    {   // d cat = conv1's transposed conv of dh4 (+ the skip path's rank-one share, added in the epilogue)
         ConvArgs a{};
-        a.nsrc = 2;
+        a.nsrc = 1;
         a.src[0] = s16_src(w.dh4s, 32, 32, 0, 9, w.wpack + kPack.dg[W_RB4C1], 0);
-        a.src[1] = s16_src(w.dout4s, 32, 32, 0, 1, w.wpack + kPack.dg[W_RB4SK], 0);
-        a.out = w.dcat; a.B = B;
+        a.B = B;
+        a.dc_pair = dc_pair; a.dc_h1 = dc_h1; a.rk1_d = dvec; a.rk1_u = w.u96;
         RUN(B_DG_RB4C1, tdm_launch_conv_s16(a, 28, 96, st));
     }
     // ---- rb3 ---- (upsample backward and the ReLU mask of rb3.conv2's output in one pass)
-    RUN(B_SPLIT_DCAT, tdm_launch_split_dcat_mask_s16(w.dcat, w.m2[2], w.dout3, w.dc2s_3, es, ESTRIDE, E_C2B3, B, ER14, st));
+    RUN(B_SPLIT_DCAT, tdm_launch_split_dcat_mask_s16(dc_pair, w.m2[2], w.dout3, w.dc2s_3, es, ESTRIDE, E_C2B3, B, ER14, st));
     RUN(B_WG_RB3C2, wgrad_s16(st, 14, B, w.a1s_3, 64, 64, 0, 9, w.dc2s_3, 64, slabs, r3.c2w, 64, 0, NS4));
     RUN(B_DG_RB3C2, conv_s16_1(st, w, 14, B, w.dc2s_3, 64, 9, kPack.dg[W_RB3C2], 64, nullptr, 0,
                                S16Out{nullptr, nullptr, nullptr, w.dh3s, nullptr, w.m1[2], w.gs[2]}));
@@ -440,7 +444,7 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     // ---- rb1 ---- (concat skip + avg-pool backward and the ReLU mask of rb1.conv2's output in one pass)
     // (rb1.skip has one input channel: its weight / bias gradients are sums over x * dout1 and dout1, taken here while
     //  dout1 is in registers — the fp32 tensor itself is never written)
-    RUN(B_COMBINE_DH1, tdm_launch_combine_dh1_mask_s16(w.dcat, w.dp1, w.m2[0], nullptr, w.dc2s_1, es, ESTRIDE, E_C2B1, B, ER28, st,
+    RUN(B_COMBINE_DH1, tdm_launch_combine_dh1_mask_s16(dc_h1, w.dp1, w.m2[0], nullptr, w.dc2s_1, es, ESTRIDE, E_C2B1, B, ER28, st,
                                                        x, E_SKW1, E_SKB1));
     RUN(B_WG_RB1C2, wgrad_s16(st, 28, B, w.a1s_1, 32, 32, 0, 9, w.dc2s_1, 32, slabs, r1.c2w, 32, 0, NS));
     RUN(B_DG_RB1C2, conv_s16_1(st, w, 28, B, w.dc2s_1, 32, 9, kPack.dg[W_RB1C2], 32, nullptr, 0,
@@ -464,13 +468,16 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     sec(r1.c1w, 288 + 32, NS); sec(r1.c2w, 9216, NS);
     sec(r2.c1w, 18432, NS2); sec(r2.c2w, 36864, NS4); sec(r2.skw, 2048, NS2);
     sec(r3.c1w, 36864, NS4); sec(r3.c2w, 36864, NS4);
-    sec(r4.c1w, 27648, NS); sec(r4.c2w, 9216, NS); sec(r4.skw, 3072, NS);
+    sec(r4.c1w, 27648, NS); sec(r4.c2w, 9216, NS);
     // partial rows of the elementwise producers
     esec(kL.outw, 33, E_OUT, ER28); esec(r4.c2b, 32, E_C2B4, ER28); esec(r4.skb, 32, E_SKB4, ER28);
     esec(r3.c2b, 64, E_C2B3, ER14); esec(r2.c2b, 64, E_C2B2, ER14); esec(r2.skb, 64, E_SKB2, ER14);
     esec(r1.c2b, 32, E_C2B1, ER28); esec(r1.skw, 32, E_SKW1, ER28); esec(r1.skb, 32, E_SKB1, ER28);
     esec(r1.tew, 64, E_TE1, ERG); esec(r2.tew, 128, E_TE2, ERG); esec(r3.tew, 128, E_TE3, ERG); esec(r4.tew, 64, E_TE4, ERG);
     esec(r2.c1b, 64, E_C1B2, ERG); esec(r3.c1b, 64, E_C1B3, ERG); esec(r4.c1b, 32, E_C1B4, ERG);
+    // rb4.skip's weight gradient = v (x) w_out (out_bwd_s16_kernel): the section sums the 96 partials of v and writes 96 x 32
+    esec(r4.skw, 96, E_VSK, ER28);
+    ra.sec[n - 1].outer_w = P + kL.outw; ra.sec[n - 1].outer_n = 32;
     if (deps == nullptr) {   // loss = mean (eps - noise)^2
         esec(0, 1, E_LOSS, ER28);
         ra.sec[n - 1].dst = mse->loss_out; ra.sec[n - 1].scale = 1.0f / (float)M28;

@@ -60,13 +60,15 @@ class _UNetFunction(torch.autograd.Function):
         eps = E.unet_forward(flat.detach(), x, t, ws, save=need_grad)
         if need_grad:
             ctx.ws = ws
+            ctx.arith = _lib.arithmetic()          # (backward runs on the autograd thread: _lib.use_arithmetic)
             ctx.save_for_backward(x, flat)
         return eps
 
     @staticmethod
     def backward(ctx, deps):
         x, flat = ctx.saved_tensors
-        grads = E.unet_backward(flat.detach(), x, deps.contiguous(), ctx.ws)
+        with _lib.use_arithmetic(ctx.arith):
+            grads = E.unet_backward(flat.detach(), x, deps.contiguous(), ctx.ws)
         ctx.ws = None
         return None, None, grads
 

@@ -231,6 +231,7 @@ class _TTFunction(torch.autograd.Function):
         y = TE.tt_forward(cfg, flat.detach(), x.detach(), t, ws, save=save, p_drop=p_drop, seed=seed)
         if save:
             ctx.ws, ctx.cfg, ctx.need_x, ctx.drop = ws, cfg, need_x, (p_drop, seed)
+            ctx.arith = _lib.arithmetic()          # (backward runs on the autograd thread: _lib.use_arithmetic)
             ctx.save_for_backward(flat)
         return y
 
@@ -238,8 +239,9 @@ class _TTFunction(torch.autograd.Function):
     def backward(ctx, dout):
         (flat,) = ctx.saved_tensors
         dx = torch.empty_like(dout, memory_format=torch.contiguous_format) if ctx.need_x else None
-        grads = TE.tt_backward(ctx.cfg, flat.detach(), dout.contiguous(), ctx.ws, dx=dx, p_drop=ctx.drop[0],
-                               seed=ctx.drop[1])
+        with _lib.use_arithmetic(ctx.arith):
+            grads = TE.tt_backward(ctx.cfg, flat.detach(), dout.contiguous(), ctx.ws, dx=dx, p_drop=ctx.drop[0],
+                                   seed=ctx.drop[1])
         ctx.ws = None
         return dx, None, grads, None, None, None
 

@@ -18,16 +18,10 @@ def main():
     ap.add_argument("--B", type=int, action="append")
     ap.add_argument("--ids", type=str, default="")
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--tile", type=int, default=0, help="tdm_set_conv_tile")
-    ap.add_argument("--ws", type=int, default=-1, help="tdm_set_conv_ws")
     args = ap.parse_args()
     from tinydiffusionmodels_amd import _lib, unet_engine as E
     from tinydiffusionmodels_amd.mnist import SimpleUNet
     L = _lib.lib()
-    if args.tile:
-        _lib.check(L.tdm_set_conv_tile(args.tile))
-    if args.ws >= 0:
-        _lib.check(L.tdm_set_conv_ws(args.ws))
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     model = SimpleUNet().to(dev)
