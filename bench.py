@@ -265,6 +265,31 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * args.steps / elapsed
 
+    # ---- steady state: the same replayed step until >= 1 s has passed.  The driver's window (--steps 20 --warmup 5) is
+    #      ~20 ms of GPU time, inside the clock / power ramp of a cold device; this block shows what the step sustains ----
+    ss_steps, ss_t0 = 0, time.perf_counter()
+    sync()
+    ss_t0 = time.perf_counter()
+    while True:
+        for _ in range(100):
+            trainer.step(x0)
+        ss_steps += 100
+        torch.cuda.synchronize()
+        stop = torch.tensor([1.0 if time.perf_counter() - ss_t0 >= 1.0 else 0.0], device=dev)
+        if world > 1:
+            dist.all_reduce(stop, op=dist.ReduceOp.MAX)      # every rank leaves the loop after the same number of steps
+        if stop.item() > 0 or ss_steps >= 20000:
+            break
+    sync()
+    ss_el = time.perf_counter() - ss_t0
+    if world > 1:
+        tt = torch.tensor([ss_el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ss_el = tt.item()
+    steady = {"steps": ss_steps, "seconds": round(ss_el, 3), "steps_per_s": round(world * ss_steps / ss_el, 2),
+              "ms_per_step": round(1e3 * ss_el / ss_steps, 4),
+              "note": "same hipGraph replay as `value`, run for >= 1 s after it (clock ramp of the short driver window excluded)"}
+
     # the step's one collective, timed alone (725,892 B per rank per step; ring-equivalent bandwidth)
     allreduce = None
     if world > 1:
@@ -301,6 +326,7 @@ def main():
                    else "eager launches from one C-ABI call", "collective": dp.collective_name()},
         "images_per_s": round(value * B_TRAIN, 1),
         "final_loss": loss_val,
+        "steady_state": steady,
     }
     if allreduce is not None:
         out["allreduce"] = allreduce
@@ -311,8 +337,8 @@ def main():
         flops = TRAIN_FLOP_PER_SAMPLE * B_TRAIN
         byts = TRAIN_BYTES_PER_SAMPLE * B_TRAIN + OPT_BYTES_PER_STEP
         out["step_roofline"] = {"tflops": round(flops / step_s / 1e12, 2),
-                                "frac_f32_mfma": round(flops / step_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                                "frac_bf16_mfma_issue": round(3 * flops / step_s / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                                **({"frac_f32_mfma": round(flops / step_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)} if args.conv_mode == 0 else
+                                   {"frac_bf16_mfma_issue": round(3 * flops / step_s / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}),
                                 "gbs": round(byts / step_s / 1e9, 1), "algorithmic_bytes": byts,
                                 "frac_hbm": round(byts / step_s / 1e9 / PEAK_HBM_GBS, 4)}
 
@@ -356,27 +382,36 @@ def main():
                                "all_us": {str(r["id"]): r["us"] for r in rows}}
         cb = out["launch_table"]["conv_blocks"]
         cb["hbm_frac"] = round(cb["bytes"] / (cb["us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)
-        # ---- roofline: the dominant launch = rb4.conv1 with its fused skip conv, exactly as it runs in the step.
-        # Algorithmic bytes (SURVEY.md §8d convention, fp32 in + out elements of the conv): 96 in + 32 out channels of
-        # rb4.conv1 plus the 32 output channels of rb4.skip — the skip's input is the same concat and is not counted
-        # a second time (the per-conv sum of §8d would count it twice: 411 MB) — x 784 pixels x B.
-        r9 = next(r for r in rows if r["launch"].startswith("rb4.conv1 + rb4.skip fwd"))
-        kbytes = (96 + 32 + 32) * 4 * 784 * B_TRAIN
-        ms9 = r9["us"] * 1e-3
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_conv_traffic.json")     # PMC FETCH_SIZE/WRITE_SIZE of this kernel, see file
+        # ---- roofline: the DOMINANT launch of the step = the longest one, exactly as it runs in the step (in-pipeline
+        # arguments).  Algorithmic bytes follow SURVEY.md section 8d (fp32 in + out elements of the convolution the launch
+        # computes; an input shared by a fused second conv is counted once): rb4.conv1 + rb4.skip forward reads the 96-channel
+        # concat and writes 32 + 32 channels; their data gradient reads 32 + 32 gradient channels and writes 96 — both
+        # 160 channels x 4 B x 784 pixels x B.  `tensor_bytes_per_launch` is what the launch AS BUILT reads + writes
+        # (the rank-one skip gradient and the pair-summed output make the data gradient touch less than the algorithm names);
+        # `traffic` = HBM bytes from the PMC passes of the round-end profile (profiles/r03_conv_traffic.json, per launch id).
+        ALGO_CH = {9: 96 + 32 + 32, 16: 32 + 32 + 96, 3: 32 + 32 + 1, 10: 32 + 32 + 32 + 1, 13: 64, 29: 64}
+        traffic_by_id = {}
+        tpath = os.path.join(ROOT, "profiles", "r03_conv_traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        ach = kbytes / (ms9 * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                           "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
-                           "kernel": "conv_s16_kernel<28,1,true,false>: rb4.conv1 3x3 96->32 + fused rb4.skip 1x1 96->32 @28x28, B=512, "
-                                     "in-pipeline arguments (two K sources: up2(h3) S16 + h1 S16; outputs: S16 twin + time bias, ReLU byte mask, skip fp32)",
-                           "ms_per_launch": round(ms9, 4), "flop_per_launch": r9["flop"], "algorithmic_bytes_per_launch": kbytes,
-                           "tensor_bytes_per_launch": r9["bytes"],
-                           "mfma_tflops_bf16": round(3 * r9["flop"] / (ms9 * 1e-3) / 1e12, 1), "mfma_peak_bf16": PEAK_BF16_MFMA_TFLOPS,
-                           "timing": "HIP events on the launch stream, 20 launches alternating two workspaces; profiles/ holds the rocprofv3 "
-                                     "kernel-trace average of the same kernel from the same command"}
+            traffic_by_id = {int(k): v for k, v in json.load(open(tpath)).get("by_launch_id", {}).items()}
+
+        def roof(r):
+            kb = ALGO_CH.get(r["id"], 0) * 4 * 784 * B_TRAIN or r["bytes"]
+            ms_ = r["us"] * 1e-3
+            ach = kb / (ms_ * 1e-3) / 1e9
+            tr = traffic_by_id.get(r["id"], {})
+            return {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+                    "traffic": tr.get("hbm_bytes_per_launch"), "kernel": r["launch"] + f", B={B_TRAIN}, in-pipeline arguments (launch id {r['id']})",
+                    "ms_per_launch": round(ms_, 4), "flop_per_launch": r["flop"], "algorithmic_bytes_per_launch": kb,
+                    "tensor_bytes_per_launch": r["bytes"], "tensor_frac": r["hbm_frac"],
+                    "mfma_tflops_bf16": round(3 * r["flop"] / (ms_ * 1e-3) / 1e12, 1), "mfma_peak_bf16": PEAK_BF16_MFMA_TFLOPS,
+                    "timing": "HIP events on the launch stream, 20 launches alternating two workspaces; profiles/r03_* hold the rocprofv3 "
+                              "kernel-trace average and the PMC passes of the same launch"}
+        dom = max((r for r in rows if any(k in r["launch"] for k in MFMA_LAUNCH)), key=lambda r: r["us"])
+        out["roofline"] = roof(dom)
+        r9 = next(r for r in rows if r["id"] == 9)
+        if dom["id"] != 9:
+            out["roofline"]["second"] = roof(r9)      # the forward twin (round 2's roofline launch), for continuity
         del sts, gscratch
 
     # ---- the same step in the exact-fp32 arithmetic (--conv-mode 0), for the record ----

@@ -636,6 +636,9 @@ int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
         return launch_nt<3, false, true, 1>(g, st);
     }
     if (g.s16_in) {
+        // large problems: persistent one-workgroup-per-CU kernel with an LDS-DMA operand ring (gemm_ring.hip), same bits out
+        static const bool ring_on = [] { const char* e = getenv("TDM_GEMM_RING"); return e == nullptr || atoi(e) != 0; }();   // (A/B timing)
+        if (ring_on && tdm_gemm_nt_ring_ok(g)) return tdm_launch_gemm_nt_ring(g, nprod, st);
         const bool buf = (g.K % 32) == 0 && (long)g.M * g.a_rs * 4 < 2147483647L && (long)g.N * g.b_cs * 4 < 2147483647L;
         if (buf) return nprod == 3 ? launch_nt<3, false, false, 1, true, true>(g, st) : launch_nt<1, false, false, 1, true, true>(g, st);
         return nprod == 3 ? launch_nt<3, false, false, 1, true>(g, st) : launch_nt<1, false, false, 1, true>(g, st);

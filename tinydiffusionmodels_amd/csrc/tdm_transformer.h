@@ -44,6 +44,10 @@ int tdm_launch_gemm(const GemmArgs& g, hipStream_t st);
 // bf16 MFMA GEMMs (gemm_bf16.hip); nprod = 3 (hi/lo split operands, ~1e-5) or 1 (plain bf16 operands)
 int tdm_launch_gemm_nt_bf16(const GemmArgs& g, int nprod, hipStream_t st);
 int tdm_launch_gemm_tn_bf16(const GemmArgs& g, int nprod, hipStream_t st);
+// S16-operand NT GEMM on the LDS-DMA ring kernel (gemm_ring.hip): bit-identical to tdm_launch_gemm_nt_bf16's kernels;
+// serves K % 32 == 0, N % 8 == 0, operands < 2 GiB, problems of at least 32 tiles of 256 x 128
+bool tdm_gemm_nt_ring_ok(const GemmArgs& g);
+int tdm_launch_gemm_nt_ring(const GemmArgs& g, int nprod, hipStream_t st);
 int tdm_launch_transpose(const float* in, float* out, int R, int Cn, hipStream_t st);
 // out[c][r] = in[r][c] written as S16 (R % 16 == 0); out = S16 of in, elementwise over n (n % 16 == 0) floats
 int tdm_launch_transpose_s16(const float* in, float* out, int R, int Cn, hipStream_t st);
