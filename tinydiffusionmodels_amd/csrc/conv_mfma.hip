@@ -362,21 +362,26 @@ int launch_wgrad_t(const WgradArgs& a, int nslab, hipStream_t st) {
     return 0;
 }
 
-// out[off + i] = sum over the section's slabs, in a fixed order (deterministic).  A workgroup covers 64 elements x 4
-// slab quarters: thread (e, q) adds slabs q, q + 4, ... with 8 independent loads in flight, the quarters meet in LDS —
-// 4x the threads and 2x the loads in flight of the one-thread-per-element form, which was latency-bound at 2.3 TB/s.
+// out[off + i] = sum over the section's slabs, in a fixed order (deterministic).  A workgroup covers EPB elements x
+// 256 / EPB slab groups: thread (e, q) adds slabs q, q + NQ, ... with 8 independent loads in flight, the groups meet in LDS.
+// Wide, shallow sections (the MFMA weight-gradient slabs: thousands of elements x 64-256 slabs) use 64 x 4; the narrow, DEEP
+// ones (bias / time-embedding partial rows of the elementwise producers: 32-128 elements x up to 1024 rows) use 16 x 16 —
+// with 64 x 4 their one or two workgroups walked 256 dependent rounds of loads each and set the launch's time (32 us for
+// 90 MB; the deep sections hold 4 MB of it).
+__device__ __forceinline__ int reduce_epb(int nslab) { return nslab > 256 ? 16 : 64; }
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, long stride,
                                                            ReduceArgs ra, float* __restrict__ out) {
-    __shared__ float sh[4][64];
+    __shared__ float sh[256];
     // 1-D grid of exactly the workgroups the sections need (a (max length, sections) grid launched 15,000 workgroups of
     // which 2,800 had work: the empty ones cost a third of the kernel's time)
     int si = 0;
     while (si + 1 < ra.nsec && (int)blockIdx.x >= ra.blk0[si + 1]) ++si;
     const ReduceSec s = ra.sec[si];
     if (s.stride_override != 0) stride = s.stride_override;
-    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int epb = reduce_epb(s.nslab), nq = 256 / epb;
+    const int e = threadIdx.x % epb, q = threadIdx.x / epb;
     {
-        const int i0 = ((int)blockIdx.x - ra.blk0[si]) * 64;
+        const int i0 = ((int)blockIdx.x - ra.blk0[si]) * epb;
         const int i = i0 + e;
         float acc[8];
 #pragma unroll
@@ -384,17 +389,19 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
         if (i < s.len) {
             const float* p = slabs + s.off + s.src_delta + i;
             int k = q;
-            for (; k + 28 < s.nslab; k += 32) {
+            for (; k + 7 * nq < s.nslab; k += 8 * nq) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc[u] += p[(long)(k + 4 * u) * stride];
+                for (int u = 0; u < 8; ++u) acc[u] += p[(long)(k + nq * u) * stride];
             }
-            for (; k < s.nslab; k += 4) acc[0] += p[(long)k * stride];
+            for (; k < s.nslab; k += nq) acc[0] += p[(long)k * stride];
         }
         __syncthreads();
-        sh[q][e] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        sh[q * epb + e] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
         __syncthreads();
         if (q == 0 && i < s.len) {
-            const float r = ((sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e])) * (s.scale != 0.f ? s.scale : 1.f);
+            float r = 0.f;
+            for (int qq = 0; qq < nq; ++qq) r += sh[qq * epb + e];      // fixed order
+            r *= (s.scale != 0.f ? s.scale : 1.f);
             float* const d = s.dst != nullptr ? s.dst : out + s.off;
             if (s.outer_w != nullptr) {
                 for (int jn = 0; jn < s.outer_n; ++jn) d[i * s.outer_n + jn] = r * s.outer_w[jn];
@@ -446,7 +453,7 @@ int tdm_launch_reduce(const float* slabs, long stride, const ReduceArgs& ra, flo
     (void)maxlen;
     ReduceArgs rb = ra;
     int nb = 0;
-    for (int i = 0; i < ra.nsec; ++i) { rb.blk0[i] = nb; nb += (ra.sec[i].len + 63) / 64; }
+    for (int i = 0; i < ra.nsec; ++i) { const int epb = ra.sec[i].nslab > 256 ? 16 : 64; rb.blk0[i] = nb; nb += (ra.sec[i].len + epb - 1) / epb; }
     rb.blk0[ra.nsec] = nb;
     TDM_REQUIRE(nb >= 1, "reduce: empty sections");
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(nb), dim3(256), 0, st, slabs, stride, rb, out);

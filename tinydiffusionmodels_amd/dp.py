@@ -166,17 +166,67 @@ def native_comm() -> Optional[NativeComm]:
     return _native
 
 
+_graph_ok: Optional[bool] = None
+_graph_why: str = ""
+
+
+def graph_collective_ok() -> bool:
+    """May the train step's all-reduce be CAPTURED into the step's hipGraph (one host call per step at world > 1)?
+    TDM_GRAPH_COLLECTIVE=0 / 1 forces the answer; the default ("auto") is a self-check, run once per process and agreed on by
+    all ranks (MIN): the native RCCL all-reduce of a probe buffer is captured on a side graph, replayed twice and compared with
+    torch.distributed's result.  Anything short of a clean pass on EVERY rank keeps the three-call form (graph replay,
+    all-reduce, AdamW), with the reason reported by collective_name()."""
+    global _graph_ok, _graph_why
+    if _graph_ok is not None:
+        return _graph_ok
+    rank, world = world_info()
+    env = os.environ.get("TDM_GRAPH_COLLECTIVE", "auto")
+    comm = native_comm() if world > 1 else None
+    if world == 1 or comm is None:
+        _graph_ok, _graph_why = False, "no native communicator"
+        return False
+    if env in ("0", "1"):
+        _graph_ok, _graph_why = env == "1", f"TDM_GRAPH_COLLECTIVE={env}"
+        return _graph_ok
+    ok, why = True, "capture / replay / compare self-check passed"
+    try:
+        base = torch.arange(4096, device="cuda", dtype=torch.float32) * (rank + 1) + 0.5
+        want = base.clone()
+        dist.all_reduce(want, op=dist.ReduceOp.SUM)
+        buf = base.clone()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            comm.allreduce_sum_(buf)
+        for _ in range(2):
+            buf.copy_(base)
+            g.replay()
+            torch.cuda.synchronize()
+            if not torch.equal(buf, want):
+                ok, why = False, "captured all-reduce disagrees with torch.distributed"
+        del g
+    except RuntimeError as e:
+        ok, why = False, f"capture failed: {e}"
+    if not _all_ranks_ok(ok) and ok:
+        ok, why = False, "another rank's captured all-reduce failed its self-check"
+    _graph_ok, _graph_why = ok, why
+    if rank == 0:
+        print(f"[tdm] train-step hipGraph {'includes' if ok else 'stops before'} the RCCL all-reduce ({why})", flush=True)
+    return ok
+
+
 def collective_name() -> str:
     _, world = world_info()
     if world == 1:
         return "none (1 rank)"
     if _native is not None:
-        return "libtdm_hip tdm_allreduce_sum_f32 (RCCL)"
+        return "libtdm_hip tdm_allreduce_sum_f32 (RCCL)" + (f"; in-graph: {_graph_ok} ({_graph_why})" if _graph_ok is not None else "")
     return f"torch.distributed all_reduce ({dist.get_backend()})" + (f"; native comm unavailable: {_native_error}" if _native_error else "")
 
 
 def shutdown() -> None:
-    global _native, _native_tried
+    global _native, _native_tried, _graph_ok
+    _graph_ok = None
     if _native is not None:
         _native.close()
     _native, _native_tried = None, False

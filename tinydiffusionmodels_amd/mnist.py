@@ -491,8 +491,9 @@ class DDPMTrainer(DPStepper):
     With t / noise left to the trainer the whole step is ONE hipGraph replay: the draws come from a
     device-side Philox stream, AdamW's step count lives in device memory, nothing is written by the host
     (`graph=False` or TDM_TRAIN_GRAPH=0 runs the same launches eagerly).  At world > 1 the graph ends before
-    the collective (replay, all-reduce, AdamW = three host calls per step); TDM_GRAPH_COLLECTIVE=1 captures
-    the RCCL all-reduce and AdamW too.  Explicit t / noise (teacher forcing, parity tests) run eagerly.
+    the collective (replay, all-reduce, AdamW = three host calls per step) unless dp.graph_collective_ok(): by default a
+    capture / replay / compare self-check of the native RCCL all-reduce that every rank must pass — then the all-reduce and
+    AdamW are captured too and a step is ONE host call at any world size (TDM_GRAPH_COLLECTIVE=0 / 1 forces it).  Explicit t / noise (teacher forcing, parity tests) run eagerly.
     One trainer serves every batch size (workspaces per size, optimiser state shared), and its constructor
     issues no collective unless `broadcast` (default: rank 0's weights to every replica, once)."""
 
@@ -513,7 +514,6 @@ class DDPMTrainer(DPStepper):
         # rank-distinct draw streams: a seed from torch's generator (so torch.manual_seed governs it) mixed with the rank
         self.seed = (int(torch.randint(0, 2 ** 62, (1,)).item()) ^ (self.rank * 0x9E3779B97F4A7C15)) & (2 ** 64 - 1)
         self.use_graph = (os.environ.get("TDM_TRAIN_GRAPH", "1") != "0") if graph is None else bool(graph)
-        self.graph_collective = os.environ.get("TDM_GRAPH_COLLECTIVE", "0") == "1"
         self._states = {}
         self._cur = self._state(batch_size)
         if broadcast:
@@ -560,7 +560,7 @@ class DDPMTrainer(DPStepper):
 
     # ---- the hipGraph form of step() ----
     def _capture(self, st: "E.TrainState") -> None:
-        whole = self.world == 1 or (self.graph_collective and dp.native_comm() is not None)
+        whole = self.world == 1 or dp.graph_collective_ok()      # (collective: every rank reaches this at its second step)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             E.loss_and_grad_philox(self.flat, st, st.x0, self.seed, self.rng_state)
