@@ -550,6 +550,32 @@ def test_full_size_properties_config5(dev, gemm_mode):
     del st, st64
 
 
+def test_train_step_on_ring_kernels_vs_oracle(dev, golden_tables, gemm_mode):
+    """A denoiser train step large enough for every K-contiguous linear layer product to run on the LDS-DMA ring kernel
+    (gemm_ring.hip; 8,192 tokens) against the CPU oracle: loss and every gradient."""
+    if gemm_mode == 0:
+        pytest.skip("the ring kernels serve the bf16 GEMM modes")
+    from tinydiffusionmodels_amd import transformer_engine as TE
+    dim, B, L = 256, 64, 128
+    m = _model(dim, dev)
+    m.eval()
+    p = O.transformer_init_params(dim, seed=7)
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(B, L, dim, generator=g) * 0.5
+    noise = torch.randn(B, L, dim, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    loss_ref, grads_ref = O.transformer_loss_and_grads(p, x0, t, noise, golden_tables)
+    st = TE.TTTrainState(m.cfg, m.flat.detach(), B, L)
+    loss = TE.tt_loss_and_grad(m.flat.detach(), st, x0.to(dev), noise.to(dev), t.to(dev))
+    got = TE.state_dict_from_flat(st.grads, dim, m.cfg.depth, m.cfg.ffn)
+    tol = _ftol(gemm_mode)
+    assert abs(loss.item() - loss_ref.item()) < tol * abs(loss_ref.item())
+    errs = {k: O.rel_err(got[k].cpu(), v) for k, v in grads_ref.items()}
+    worst = max(errs, key=errs.get)
+    print(f"[parity] ring-kernel train step: worst gradient {worst} {errs[worst]:.1e}")
+    assert errs[worst] < tol, (worst, errs[worst])
+
+
 def test_text_graph_sampler_equals_eager_chain_with_same_draws(dev, gemm_mode):
     """The hipGraph text reverse loop (device-resident step index, Philox noise drawn inside the update kernel, one
     C-ABI call per step) against the eager teacher-forced loop fed the SAME draws: bitwise equal

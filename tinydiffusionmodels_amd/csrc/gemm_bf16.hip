@@ -664,6 +664,7 @@ int tdm_launch_gemm_tn_bf16(const GemmArgs& g, int nprod, hipStream_t st) {
     } else if (g.s16_in) {
         TDM_REQUIRE((g.a_cs % 16) == 0 && (g.b_rs % 16) == 0 && (g.M % 16) == 0 && (g.N % 16) == 0,
                     "gemm_tn_bf16: S16 operands need M, N and the leading dimensions to be multiples of 16");
+
         // (whole 32-token chunks only: the zero fill of a ragged last chunk would have to come from the descriptor's range
         //  check on voffset + soffset, which this code does not rely on)
         const bool buf = (g.K % 32) == 0 && (long)g.K * g.a_cs * 4 < 2147483647L && (long)g.K * g.b_rs * 4 < 2147483647L;

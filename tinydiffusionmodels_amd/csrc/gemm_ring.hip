@@ -341,6 +341,13 @@ int launch_ring(const GemmArgs& g, hipStream_t st) {
     return 0;
 }
 
+
+// (A token-major / weight-gradient twin of this kernel — 256 x 128 output tile per (tile, split) workgroup, token rows copied
+//  by LDS-DMA as they lie in memory with a token XOR swizzle for ds_read_b64_tr_b16, XCD-contiguous splits — was built in
+//  round 3 and was bit-identical to gemm_tn_bf16_kernel but NOT faster: 132 vs 124 us on the 2048 x 256 gradient, 128 vs 118
+//  on 256 x 2048.  Those products move 0.8-1.1 GB of operand re-reads per launch through L2 and are bound there, not by
+//  staging instructions; DESIGN.md section 5.  It is not compiled in.)
+
 }  // namespace tdm_ring
 using namespace tdm_ring;
 
@@ -362,3 +369,4 @@ int tdm_launch_gemm_nt_ring(const GemmArgs& g, int nprod, hipStream_t st) {
     if (twin) return nprod == 3 ? launch_ring<3, RingTwin>(g, st) : launch_ring<1, RingTwin>(g, st);
     return nprod == 3 ? launch_ring<3, RingBig>(g, st) : launch_ring<1, RingBig>(g, st);
 }
+
