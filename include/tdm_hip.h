@@ -287,6 +287,15 @@ int tdm_tt_loss_grad_f32(const float* params, const float* x0, const float* nois
                          float* dpred, float* loss_out, float* grads, float* ws, float* slabs,
                          int64_t B, int L, int D, int H, int depth, int ffn, float p_drop, uint64_t seed,
                          void* stream);
+/* tdm_tt_loss_grad_f32 with its randomness on the device: t ~ U{0..999} and noise ~ N(0,1) from the Philox stream (seed,
+ * rng_state[0]) into t_buf (B) / noise (B,L,D) — the draws of src/shakespeare.py:228-229 — and this step's dropout masks =
+ * masks(drop_seed) with every site key XORed with the low 32 bits of the advanced stream offset (rng_state[0] after the call
+ * = before + 1): fresh draws and fresh masks on every hipGraph replay, no host-written scalar.  L * D % 4 == 0.            */
+int tdm_tt_loss_grad_philox_f32(const float* params, const float* x0, const float* sqrt_acp, const float* sqrt_1m_acp,
+                                uint64_t seed, int64_t* rng_state, int64_t* t_buf, float* noise, float* x_noisy,
+                                float* pred, float* dpred, float* loss_out, float* grads, float* ws, float* slabs,
+                                int64_t B, int L, int D, int H, int depth, int ffn, float p_drop, uint64_t drop_seed,
+                                void* stream);
 /* one reverse step of src/shakespeare.py:382-385 / :343-352 for a uniform t_index */
 int tdm_tt_p_sample_step_f32(const float* params, const float* x, const int64_t* t, const float* noise,
                              const float* tab_recip, const float* tab_eps, const float* tab_sigma,
@@ -336,6 +345,10 @@ int tdm_layernorm_residual_bwd_f32(const float* dy, const float* s, const float*
  * forward reaches them: 0 input dropout (src/shakespeare.py:119); layer l: 1+4l attention
  * probabilities (B,H,L,L), 2+4l dropout1 (B,L,D), 3+4l FFN dropout (B,L,ffn), 4+4l dropout2. */
 int tdm_dropout_keep_u8(float p_drop, uint64_t seed, int site, int64_t idx0, int64_t n, uint8_t* keep_host);
+/* the same with the site key XORed with `salt` (what tdm_tt_loss_grad_philox_f32's kernels apply: salt = low word of the
+ * advanced Philox offset)                                                                                            */
+int tdm_dropout_keep_salted_u8(float p_drop, uint64_t seed, uint32_t salt, int site, int64_t idx0, int64_t n,
+                               uint8_t* keep_host);
 /* ---- N1: learned embedding table and rounding head of the text train step
  *      (src/shakespeare.py:46-102 modules, :225-243 train step, :387-390 decode) ----
  * table (V,D) fp32, ids (M,) int64 token ids in [0,V), W (V,D) / b (V,) = LearnedRounding.decoder.  */

@@ -336,7 +336,7 @@ def _hash32(x):
     return x
 
 
-def dropout_keep(p: float, seed: int, site: int, shape) -> torch.Tensor:
+def dropout_keep(p: float, seed: int, site: int, shape, salt: int = 0) -> torch.Tensor:
     """Boolean keep-mask of one dropout site (all True for p = 0)."""
     import numpy as np
     n = int(np.prod(shape))
@@ -348,6 +348,7 @@ def dropout_keep(p: float, seed: int, site: int, shape) -> torch.Tensor:
         seed_lo = np.array([seed & 0xFFFFFFFF], dtype=np.uint32)
         seed_hi = np.array([(seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
         key = _hash32(seed_lo ^ _hash32(seed_hi + np.uint32((0x9E3779B9 * (site + 1)) & 0xFFFFFFFF)))
+        key = key ^ np.uint32(salt & 0xFFFFFFFF)       # (DropArgs::salt: the device-drawn train step salts with its Philox offset)
         idx = np.arange(n, dtype=np.uint64)
         lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
         hi = (idx >> np.uint64(32)).astype(np.uint32)
@@ -355,17 +356,17 @@ def dropout_keep(p: float, seed: int, site: int, shape) -> torch.Tensor:
     return torch.from_numpy(u >= np.uint32(thr)).view(*shape)
 
 
-def _dropout(x: torch.Tensor, p: float, seed: int, site: int) -> torch.Tensor:
+def _dropout(x: torch.Tensor, p: float, seed: int, site: int, salt: int = 0) -> torch.Tensor:
     if not p > 0.0:
         return x
     import numpy as np
     scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
-    return x * (dropout_keep(p, seed, site, tuple(x.shape)).to(x.dtype) * scale)
+    return x * (dropout_keep(p, seed, site, tuple(x.shape), salt).to(x.dtype) * scale)
 
 
 def transformer_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor,
                         n_heads: int = 4, depth: int = 3, eps: float = 1e-5,
-                        p_drop: float = 0.0, seed: int = 0) -> torch.Tensor:
+                        p_drop: float = 0.0, seed: int = 0, salt: int = 0) -> torch.Tensor:
     """src/shakespeare.py:115-120 with nn.TransformerEncoderLayer's defaults written out:
     post-LN, ReLU FFN, LayerNorm eps 1e-5, no mask, no positional encoding, no final
     norm.  p_drop = 0: eval mode; p_drop > 0: train mode with the hash-defined masks above.
@@ -374,7 +375,7 @@ def transformer_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.Te
     hd = D // n_heads
     ts = (t.float() / TIMESTEPS).unsqueeze(-1)                               # (B,1)
     tb = F.linear(ts, p["time_emb.weight"], p["time_emb.bias"]).unsqueeze(1)  # (B,1,D)
-    x = _dropout(x + tb, p_drop, seed, 0)
+    x = _dropout(x + tb, p_drop, seed, 0, salt)
     for l in range(depth):
         pre = f"encoder.layers.{l}."
         qkv = F.linear(x, p[pre + "self_attn.in_proj_weight"], p[pre + "self_attn.in_proj_bias"])
@@ -383,24 +384,24 @@ def transformer_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.Te
         k = k.view(B, L, n_heads, hd).transpose(1, 2)
         v = v.view(B, L, n_heads, hd).transpose(1, 2)
         att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd), dim=-1)
-        att = _dropout(att, p_drop, seed, 1 + 4 * l)
+        att = _dropout(att, p_drop, seed, 1 + 4 * l, salt)
         o = (att @ v).transpose(1, 2).reshape(B, L, D)
         o = F.linear(o, p[pre + "self_attn.out_proj.weight"], p[pre + "self_attn.out_proj.bias"])
-        x = F.layer_norm(x + _dropout(o, p_drop, seed, 2 + 4 * l), (D,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], eps)
+        x = F.layer_norm(x + _dropout(o, p_drop, seed, 2 + 4 * l, salt), (D,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], eps)
         f = F.relu(F.linear(x, p[pre + "linear1.weight"], p[pre + "linear1.bias"]))
-        f = F.linear(_dropout(f, p_drop, seed, 3 + 4 * l), p[pre + "linear2.weight"], p[pre + "linear2.bias"])
-        x = F.layer_norm(x + _dropout(f, p_drop, seed, 4 + 4 * l), (D,), p[pre + "norm2.weight"], p[pre + "norm2.bias"], eps)
+        f = F.linear(_dropout(f, p_drop, seed, 3 + 4 * l, salt), p[pre + "linear2.weight"], p[pre + "linear2.bias"])
+        x = F.layer_norm(x + _dropout(f, p_drop, seed, 4 + 4 * l, salt), (D,), p[pre + "norm2.weight"], p[pre + "norm2.bias"], eps)
     return x
 
 
 def transformer_loss_and_grads(p, x0, t, noise, tables, n_heads: int = 4, depth: int = 3,
-                               p_drop: float = 0.0, seed: int = 0, want_dx: bool = False):
+                               p_drop: float = 0.0, seed: int = 0, want_dx: bool = False, salt: int = 0):
     """Denoiser part of src/shakespeare.py:230-236 (p_drop = 0: the eval-mode network)."""
     leaf = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
     x_noisy = q_sample(x0, t, noise, tables)
     if want_dx:
         x_noisy = x_noisy.detach().requires_grad_(True)
-    pred = transformer_forward(leaf, x_noisy, t, n_heads, depth, p_drop=p_drop, seed=seed)
+    pred = transformer_forward(leaf, x_noisy, t, n_heads, depth, p_drop=p_drop, seed=seed, salt=salt)
     loss = F.mse_loss(pred, noise)
     loss.backward()
     grads = {k: v.grad.detach() for k, v in leaf.items()}

@@ -69,6 +69,8 @@ _SIGS = {
     "tdm_attention_fwd_f32": ([c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_float, c_u64, c_int, c_f], c_int),
     "tdm_attention_bwd_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_float, c_u64, c_int, c_f], c_int),
     "tdm_dropout_keep_u8": ([c_float, c_u64, c_int, c_i64, c_i64, c_f], c_int),
+    "tdm_dropout_keep_salted_u8": ([c_float, c_u64, ctypes.c_uint32, c_int, c_i64, c_i64, c_f], c_int),
+    "tdm_tt_loss_grad_philox_f32": ([c_f, c_f, c_f, c_f, c_u64] + [c_f] * 10 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_float, c_u64, c_f], c_int),
     "tdm_tt_p_sample_step_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_i64, c_int, c_int, c_int,
                                   c_int, c_int, c_f], c_int),
     "tdm_tt_p_sample_step_philox_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_u64, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int,

@@ -20,6 +20,10 @@ struct DropArgs {
     uint32_t thr;   // 0 = dropout off
     uint32_t key;
     float scale;    // 1 / (1 - p)
+    // Optional per-step salt in DEVICE memory, XORed into the site key by the kernels: a hipGraph-captured train step bakes
+    // `key` into its kernel arguments, so what changes from replay to replay has to be read from memory (the low word of the
+    // step's Philox offset, tdm_tt_loss_grad_philox_f32).  nullptr (and always on the host) = unsalted.
+    const uint32_t* salt;
 };
 
 __host__ __device__ __forceinline__ uint32_t tdm_hash32(uint32_t x) {
@@ -30,7 +34,11 @@ __host__ __device__ __forceinline__ uint32_t tdm_hash32(uint32_t x) {
 }
 
 __host__ __device__ __forceinline__ bool tdm_keep(const DropArgs& d, unsigned long long idx) {
-    const uint32_t u = tdm_hash32(tdm_hash32((uint32_t)idx ^ d.key) + (uint32_t)(idx >> 32));
+    uint32_t key = d.key;
+#ifdef __HIP_DEVICE_COMPILE__
+    if (d.salt != nullptr) key ^= *d.salt;     // (uniform address: one scalar load, hoisted out of the element loops)
+#endif
+    const uint32_t u = tdm_hash32(tdm_hash32((uint32_t)idx ^ key) + (uint32_t)(idx >> 32));
     return u >= d.thr;
 }
 
@@ -43,5 +51,6 @@ inline DropArgs tdm_drop_site(float p, uint64_t seed, int site) {
     if (d.thr == 0) d.thr = 1;
     d.key = tdm_hash32((uint32_t)seed ^ tdm_hash32((uint32_t)(seed >> 32) + 0x9E3779B9U * (uint32_t)(site + 1)));
     d.scale = 1.0f / (1.0f - p);
+    d.salt = nullptr;
     return d;
 }

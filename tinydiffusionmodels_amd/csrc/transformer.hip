@@ -25,7 +25,8 @@ thread_local int g_attn_mode = 2;
 // train-mode dropout of one call: p = 0 -> off
 struct Drop {
     float p; uint64_t seed;
-    DropArgs site(int s) const { return tdm_drop_site(p, seed, s); }
+    const uint32_t* salt = nullptr;   // device word XORed into every site key (DropArgs::salt), or nullptr
+    DropArgs site(int s) const { DropArgs d = tdm_drop_site(p, seed, s); if (d.thr != 0u) d.salt = salt; return d; }
 };
 
 constexpr int LN_SLABS = 256;  // workgroup partials of the LayerNorm affine / bias gradients (one workgroup per CU)
@@ -986,6 +987,30 @@ int tdm_tt_loss_grad_f32(const float* params, const float* x0, const float* nois
     return tt_backward(params, lay, dpred, grads, nullptr, w, slabs, B, L, D, H, depth, ffn, drop, st);
 }
 
+// The same step with its randomness on the device (src/shakespeare.py:221-236 incl. the draws of :228-229): t and noise from
+// the Philox stream (seed, rng_state[0]) into t_buf / noise, and the dropout masks of this step = masks(drop_seed) salted with
+// the low word of the (already advanced) stream offset — nothing the host writes per step, so the call is hipGraph-replayable
+// with fresh draws and fresh masks on every replay.
+int tdm_tt_loss_grad_philox_f32(const float* params, const float* x0, const float* sqrt_acp, const float* sqrt_1m_acp,
+                                uint64_t seed, int64_t* rng_state, int64_t* t_buf, float* noise, float* x_noisy, float* pred,
+                                float* dpred, float* loss_out, float* grads, float* ws, float* slabs, int64_t B, int L, int D,
+                                int H, int depth, int ffn, float p_drop, uint64_t drop_seed, void* stream) {
+    TDM_TRY(tt_check(B, L, D, H, depth, ffn));
+    TDM_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "tt_loss_grad_philox: dropout probability %g outside [0, 1)", (double)p_drop);
+    TDM_REQUIRE(params && x0 && sqrt_acp && sqrt_1m_acp && rng_state && t_buf && noise && x_noisy && pred && dpred && loss_out &&
+                    grads && ws && slabs, "tt_loss_grad_philox: NULL pointer");
+    TDM_REQUIRE(((long)L * D) % 4 == 0, "tt_loss_grad_philox: L * D must be a multiple of 4");
+    Drop drop{p_drop, drop_seed};
+    drop.salt = reinterpret_cast<const uint32_t*>(rng_state);    // low word of the offset (little endian), read AFTER the bump below
+    const TTLayout lay = tt_layout(D, depth, ffn);
+    const TTWs w = tt_carve(ws, B, L, D, H, depth, ffn, 1);
+    hipStream_t st = (hipStream_t)stream;
+    TDM_TRY(tdm_launch_draw_q_sample(x0, sqrt_acp, sqrt_1m_acp, seed, rng_state, t_buf, noise, x_noisy, B, (int64_t)L * D, true, st));
+    TDM_TRY(tt_forward(params, lay, x_noisy, t_buf, pred, w, B, L, D, H, depth, ffn, drop, st));
+    TDM_TRY(tdm_mse_fwd_bwd_f32(pred, noise, loss_out, dpred, w.part, B * L * D, stream));
+    return tt_backward(params, lay, dpred, grads, nullptr, w, slabs, B, L, D, H, depth, ffn, drop, st);
+}
+
 int tdm_tt_p_sample_step_f32(const float* params, const float* x, const int64_t* t, const float* noise,
                              const float* tab_recip, const float* tab_eps, const float* tab_sigma, int t_index,
                              float* eps, float* x_out, float* ws, int64_t B, int L, int D, int H, int depth, int ffn,
@@ -1087,8 +1112,13 @@ int tdm_layernorm_residual_bwd_f32(const float* dy, const float* s, const float*
 
 // keep[i] = 1 if element idx0 + i of dropout site `site` survives (the mask the kernels regenerate in registers)
 int tdm_dropout_keep_u8(float p_drop, uint64_t seed, int site, int64_t idx0, int64_t n, uint8_t* keep_host) {
+    return tdm_dropout_keep_salted_u8(p_drop, seed, 0u, site, idx0, n, keep_host);
+}
+// ... with the site key salted (DropArgs::salt: the device-drawn train step salts with the low word of its Philox offset)
+int tdm_dropout_keep_salted_u8(float p_drop, uint64_t seed, uint32_t salt, int site, int64_t idx0, int64_t n, uint8_t* keep_host) {
     TDM_REQUIRE(p_drop >= 0.f && p_drop < 1.f && keep_host != nullptr && n >= 0, "dropout_keep: bad arguments");
-    const DropArgs d = tdm_drop_site(p_drop, seed, site);
+    DropArgs d = tdm_drop_site(p_drop, seed, site);
+    d.key ^= salt;
     for (int64_t i = 0; i < n; ++i) keep_host[i] = (d.thr == 0u || tdm_keep(d, (unsigned long long)(idx0 + i))) ? 1 : 0;
     return 0;
 }

@@ -440,31 +440,77 @@ def dynamic_rounding_weight_schedule(epoch, total_epochs, initial_weight=1.0, fi
 class DenoiserTrainer:
     """Denoiser part of the text train step (src/shakespeare.py:230-236 + AdamW :197)
     as one fused device-side step on given embeddings x0 (B,L,D): t, noise,
-    q_sample, TinyTransformer forward, MSE, backward, (RCCL all-reduce), AdamW."""
+    q_sample, TinyTransformer forward, MSE, backward, (RCCL all-reduce), AdamW.
+
+    With t / noise left to the trainer the step is ONE hipGraph replay, like DDPMTrainer's: the draws come from a device-side
+    Philox stream, the dropout masks of a step are the trainer's mask family (one 64-bit seed drawn from torch's generator at
+    construction) salted with that step's stream offset, and AdamW's step count lives in device memory — nothing is written
+    by the host per step (`graph=False` or TDM_TRAIN_GRAPH=0 issues the same launches eagerly; a changed lr, dropout rate or
+    schedule recaptures).  At world > 1 the graph includes the all-reduce when dp.graph_collective_ok().  Explicit t / noise
+    (teacher forcing, parity tests) run eagerly through tdm_tt_loss_grad_f32 with host-drawn dropout seeds, as before."""
 
     def __init__(self, model: TinyTransformer, batch_size: int, seq_len: int, lr: float = 1e-4,
-                 weight_decay: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8):
+                 weight_decay: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, graph: Optional[bool] = None):
         self.model, self.lr, self.wd, self.betas, self.eps = model, lr, weight_decay, betas, eps
         self.flat = model.flat.detach()
         E._need_cuda(self.flat)
+        dev = self.flat.device
         self.state = TE.TTTrainState(model.cfg, self.flat, batch_size, seq_len)
         self.rank, self.world = dp.world_info()
+        self.use_graph = (os.environ.get("TDM_TRAIN_GRAPH", "1") != "0") if graph is None else bool(graph)
+        self.step_state = torch.zeros(4, dtype=torch.long, device=dev)     # {AdamW steps taken, scratch, beta1^t, beta2^t}
+        self.rng_state = torch.zeros(2, dtype=torch.long, device=dev)      # {Philox stream offset, scratch}
+        # rank-distinct streams, governed by torch.manual_seed: the draw key and the dropout mask family of this trainer
+        self.seed = (int(torch.randint(0, 2 ** 62, (1,)).item()) ^ (self.rank * 0x9E3779B97F4A7C15)) & (2 ** 64 - 1)
+        self.drop_seed = (int(torch.randint(0, 2 ** 62, (1,)).item()) ^ (self.rank * 0xC2B2AE3D27D4EB4F)) & (2 ** 64 - 1)
         dp.broadcast_params_(self.flat, src=0)
+
+    @property
+    def steps_taken(self) -> int:
+        return int(self.step_state[0].item()) + self.state.step      # (host sync: checkpoints / tests only)
+
+    def _p_drop(self) -> float:
+        return self.model.p_drop if self.model.training else 0.0   # model.train() -> the reference's dropout
+
+    def _device_step(self, st, x0, lr: float, whole: bool):
+        TE.tt_loss_and_grad_philox(self.flat, st, x0, self.seed, self.rng_state, p_drop=self._p_drop(), drop_seed=self.drop_seed)
+        if whole:
+            scale = dp.allreduce_grads_(st.grads)
+            E.adamw_step_dev(self.flat, st.grads, st.m, st.v, self.step_state, lr, self.betas, self.eps, self.wd, grad_scale=scale)
 
     def step(self, x0, t=None, noise=None, lr: Optional[float] = None):
         st = self.state
-        if t is None:
-            t = torch.randint(0, T, (x0.shape[0],), device=x0.device)
-        if noise is None:
-            noise = torch.randn_like(x0)
-        p_drop = self.model.p_drop if self.model.training else 0.0   # model.train() -> the reference's dropout
-        seed = self.model.next_dropout_seed() if p_drop > 0.0 else 0
-        loss = TE.tt_loss_and_grad(self.flat, st, x0, noise, t, p_drop=p_drop, seed=seed)
-        scale = dp.allreduce_grads_(st.grads)
-        st.step += 1
-        E.adamw_step(self.flat, st.grads, st.m, st.v, st.step, self.lr if lr is None else lr, self.betas, self.eps,
-                     self.wd, grad_scale=scale)
-        return loss
+        lr = self.lr if lr is None else lr
+        if t is not None or noise is not None:        # teacher-forced form (parity tests): host-side step count
+            if t is None:
+                t = torch.randint(0, T, (x0.shape[0],), device=x0.device)
+            if noise is None:
+                noise = torch.randn_like(x0)
+            p_drop = self._p_drop()
+            seed = self.model.next_dropout_seed() if p_drop > 0.0 else 0
+            loss = TE.tt_loss_and_grad(self.flat, st, x0, noise, t, p_drop=p_drop, seed=seed)
+            scale = dp.allreduce_grads_(st.grads)
+            st.step += 1
+            E.adamw_step(self.flat, st.grads, st.m, st.v, self.steps_taken, lr, self.betas, self.eps, self.wd, grad_scale=scale)
+            return loss
+        if not self.use_graph or st.warm < 1:          # first step eagerly (lazy kernel attributes, allocator warm-up)
+            st.warm += 1
+            self._device_step(st, x0, lr, True)
+            return st.loss
+        if x0.data_ptr() != st.x0.data_ptr():
+            st.x0.copy_(x0)                            # the graph reads a fixed address
+        key = (schedule_generation(), float(lr), self._p_drop(), self.drop_seed)
+        if st.graph is None or st.graph_key != key:
+            whole = self.world == 1 or dp.graph_collective_ok()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._device_step(st, st.x0, lr, whole)
+            st.graph, st.graph_whole, st.graph_key = g, whole, key
+        st.graph.replay()
+        if not st.graph_whole:
+            scale = dp.allreduce_grads_(st.grads)
+            E.adamw_step_dev(self.flat, st.grads, st.m, st.v, self.step_state, lr, self.betas, self.eps, self.wd, grad_scale=scale)
+        return st.loss
 
 
 def p_sample(model, x, t, noise=None):

@@ -160,6 +160,33 @@ class TTTrainState:
         self.dpred = torch.empty_like(self.x_noisy)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step = 0
+        # device-drawn step (tdm_tt_loss_grad_philox_f32): fixed-address batch, drawn t / noise; the hipGraph of the step
+        self.x0 = torch.empty_like(self.x_noisy)
+        self.t = torch.zeros(B, dtype=torch.long, device=dev)
+        self.noise = torch.empty_like(self.x_noisy)
+        self.graph = None
+        self.graph_whole = False
+        self.graph_key = None          # (schedule generation, lr, p_drop, dropout seed) the capture was made under
+        self.warm = 0
+
+
+def tt_loss_and_grad_philox(flat, st: TTTrainState, x0, seed: int, rng_state: torch.Tensor, p_drop: float = 0.0, drop_seed: int = 0):
+    """tt_loss_and_grad with t ~ U{0..999} and noise ~ N(0,1) drawn on the device (src/shakespeare.py:228-229) from the Philox
+    stream (seed, rng_state[0]) into st.t / st.noise, and the step's dropout masks salted with the advanced offset: nothing the
+    host writes per step (hipGraph-replayable)."""
+    _need_cuda(flat, x0, rng_state)
+    cfg = st.cfg
+    tabs = device_tables(x0.device)
+    B, L, D = x0.shape
+    if (B, L) != (st.B, st.L):
+        raise RuntimeError("TTTrainState batch mismatch")
+    x0 = x0.contiguous()
+    _lib.check(_lib.lib().tdm_tt_loss_grad_philox_f32(
+        _lib.ptr(flat), _lib.ptr(x0), _lib.ptr(tabs["sqrt_alphas_cumprod"]), _lib.ptr(tabs["sqrt_one_minus_alphas_cumprod"]),
+        int(seed) & _U64, _lib.ptr(rng_state), _lib.ptr(st.t), _lib.ptr(st.noise), _lib.ptr(st.x_noisy), _lib.ptr(st.pred),
+        _lib.ptr(st.dpred), _lib.ptr(st.loss), _lib.ptr(st.grads), _lib.ptr(st.ws.ws), _lib.ptr(slabs_for(cfg, x0.device)),
+        B, L, D, cfg.n_heads, cfg.depth, cfg.ffn, float(p_drop), int(drop_seed) & _U64, _lib.stream()), "tt_loss_grad_philox")
+    return st.loss
 
 
 def tt_loss_and_grad(flat, st: TTTrainState, x0, noise, t, p_drop: float = 0.0, seed: int = 0):
