@@ -109,3 +109,39 @@ def test_two_rank_text_train_keeps_replicas_identical(tmp_path):
         assert torch.equal(r0[k], r1[k]), k
     moved = (r0["emb"] - r0["emb0"]).abs().amax(dim=1) > 0
     assert moved[0::2].any() and moved[1::2].any()       # even rows: rank 0's tokens; odd rows: rank 1's
+
+
+def _main_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0", TDM_DIST_BACKEND="gloo", TDM_SHARE_GPU="1")
+    import io
+    import contextlib
+    import torch.distributed as dist
+    from tinydiffusionmodels_amd import shakespeare as S
+    os.chdir(out_dir)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        S.main(["--train", "--byte_tokenizer", "--embed_dim", "32", "--epochs", "2", "--batch_size", "8", "--seq_len", "16",
+                "--corpus", os.path.join(out_dir, "corpus.txt"), "--ckpt", os.path.join(out_dir, "ck.pth"), "--seed", "0",
+                "--warmup_steps", "2", "--lr", "1e-3"])
+    torch.cuda.synchronize()
+    with open(os.path.join(out_dir, f"out{rank}.txt"), "w") as f:
+        f.write(buf.getvalue())
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_text_cli_main(tmp_path):
+    """`torchrun -m src.shakespeare --train --byte_tokenizer` at world 2 (src/shakespeare.py:473-600 with the build's DP init):
+    main() reads RANK / WORLD_SIZE / LOCAL_RANK, shards the chunk list across the ranks (same permutation, disjoint slices),
+    trains with averaged gradients, and only rank 0 prints the epoch lines and writes the checkpoints."""
+    (tmp_path / "corpus.txt").write_text("Now is the winter of our discontent made glorious summer by this sun of York.\n" * 40,
+                                         encoding="utf-8")
+    mp.spawn(_main_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    out0, out1 = (tmp_path / "out0.txt").read_text(), (tmp_path / "out1.txt").read_text()
+    assert "Epoch 2/2" in out0 and "rank 0 of 2" in out0
+    assert "Epoch" not in out1
+    assert (tmp_path / "ck.pth").exists() and (tmp_path / "ck_best.pth").exists()
+    ck = torch.load(tmp_path / "ck.pth", map_location="cpu", weights_only=True)
+    assert ck["final_training"] and all(torch.isfinite(v).all() for v in ck["diffusion_model"].values())
