@@ -380,13 +380,27 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
     char* Ahi = lds; char* Alo = lds + TPL; char* Bhi = lds + 2 * TPL; char* Blo = lds + 3 * TPL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int i0 = blockIdx.y * TM, j0 = blockIdx.x * TN_;
+    // Workgroup -> (column tile, row tile, split).  All tiles of one split read the same token range of both operands;
+    // workgroups are dealt to the 8 XCDs (one L2 each) round-robin by linear id, so in grid order a split's tiles sit on
+    // every XCD and its token range is fetched from HBM up to 8 times.  With a split count that is a multiple of 8 the ids
+    // are re-dealt so that XCD x runs splits x * gz/8 .. (x + 1) * gz/8 - 1 whole, tile after tile: one HBM fetch per token
+    // range, the other tiles hit in that XCD's L2.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (gridDim.z >= 8 && (gridDim.z & 7) == 0) {
+        const int gxy = gridDim.x * gridDim.y;
+        const int lin = bx + gridDim.x * (by + gridDim.y * bz);
+        const int xcd = lin & 7, k = lin >> 3;
+        bz = xcd * (gridDim.z >> 3) + k / gxy;
+        const int rem = k % gxy;
+        by = rem / gridDim.x; bx = rem - by * gridDim.x;
+    }
+    const int i0 = by * TM, j0 = bx * TN_;
     const int g4 = lane >> 4, cb = g4 & 1, hh = g4 >> 1, q = (lane >> 2) & 3, pcq = lane & 3;
     const int colb = (cb * 16 + pcq * 4) * 2;
     int kbeg = 0, kend = g.K;
     if (g.splitk > 1) {
         const int chunk = ((g.K + g.splitk - 1) / g.splitk + BK - 1) / BK * BK;
-        kbeg = blockIdx.z * chunk;
+        kbeg = bz * chunk;
         kend = min(g.K, kbeg + chunk);
     }
     f32x16 acc[2][2];
@@ -448,7 +462,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
         }
     };
     if (kbeg < kend) gload(kbeg);
-    const bool do_cs = g.colsum != nullptr && blockIdx.x == 0;
+    const bool do_cs = g.colsum != nullptr && bx == 0;
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);   // this thread's 4 A columns (c4 = tid & 31), rows tid>>5 (+8p)
     float csum8[S16IN ? 8 : 1] = {};                  // S16 operands: the 8 columns of this thread's hi or lo piece
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
@@ -523,7 +537,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
             float a = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) a += red[(k * 32 + ph) * 8 + e] + red[(k * 32 + ph + 2) * 8 + e];
-            float* dst = g.colsum + (long)blockIdx.z * g.colsum_stride;
+            float* dst = g.colsum + (long)bz * g.colsum_stride;
             if (i0 + tid < g.M) dst[i0 + tid] = a;
         }
     } else if (do_cs) {   // 8 row groups -> one sum per column, fixed order
@@ -538,7 +552,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
                 const float4 b = red[tid + 32 * k];
                 a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
             }
-            float* dst = g.colsum + (long)blockIdx.z * g.colsum_stride;
+            float* dst = g.colsum + (long)bz * g.colsum_stride;
             const int i = i0 + tid * 4;
             if (i + 0 < g.M) dst[i + 0] = a.x;
             if (i + 1 < g.M) dst[i + 1] = a.y;
@@ -546,7 +560,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
             if (i + 3 < g.M) dst[i + 3] = a.w;
         }
     }
-    float* C = g.C + (g.splitk > 1 ? (long)blockIdx.z * g.c_split_stride : 0L);
+    float* C = g.C + (g.splitk > 1 ? (long)bz * g.c_split_stride : 0L);
     const int h = lane >> 5, jl = lane & 31;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)

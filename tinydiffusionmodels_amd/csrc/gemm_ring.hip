@@ -56,11 +56,6 @@ using RingTwin = RingCfg<2, 2>;   // 256 threads, 128 x 128, 64 KB
 
 #define TDM_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 
-__device__ __forceinline__ int ring_xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-}
-
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // (int template parameters, not the config type: a kernel instantiated over a type of the anonymous namespace gets a host
@@ -76,10 +71,19 @@ __global__ __launch_bounds__(WMS * 128, 2) void gemm_nt_ring_kernel(GemmArgs g, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;     // rows wm * 64 .. +63 of the tile, columns wn * 64 .. +63
-    const int slot = ring_xcd_remap(blockIdx.x, gridDim.x);
-    const int per = ntiles / gridDim.x, rem = ntiles % gridDim.x;
-    const int t_beg = slot * per + min(slot, rem);
-    const int ntw = per + (slot < rem ? 1 : 0);   // tiles of this workgroup: t_beg .. t_beg + ntw - 1
+    // Tile -> workgroup map.  Tiles are numbered token-block-major (the ntx column tiles of a 256-token block are consecutive).
+    // Workgroups are dealt to the 8 XCDs round-robin by blockIdx, each XCD with its own L2: XCD x owns the contiguous tile
+    // range [ntiles x / 8, ntiles (x + 1) / 8) and its q workgroups walk it INTERLEAVED (workgroup k: tiles k, k + q, ...),
+    // so the q tiles in flight on an XCD at any time are q / ntx token blocks with all their column tiles — a token block's
+    // rows are fetched from HBM once and the other column tiles hit in that L2.  (Contiguous per-workgroup ranges had 16
+    // different token blocks per XCD in flight, each re-read 8 times: 552 MB of HBM traffic for the 304 MB of the N = 2048
+    // layer's tensors, profiles/r03_conv_traffic.json text_ffn1_gemm of the first round-3 run.)
+    const int ngrp = gridDim.x < 8 ? (int)gridDim.x : 8;
+    const int grp = blockIdx.x % ngrp, kx = blockIdx.x / ngrp;
+    const int qx = ((int)gridDim.x + ngrp - 1 - grp) / ngrp;                       // workgroups of this group
+    const int t_lo = (int)((long)ntiles * grp / ngrp), t_hi = (int)((long)ntiles * (grp + 1) / ngrp);
+    const int t_beg = t_lo + kx;
+    const int ntw = t_hi - t_lo > kx ? (t_hi - t_lo - kx + qx - 1) / qx : 0;      // tiles t_beg, t_beg + qx, ...
     const int nchunk = g.K / RK;
     const int total = ntw * nchunk;               // the workgroup's stream of (tile, chunk) pairs
     if (total == 0) return;
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(WMS * 128, 2) void gemm_nt_ring_kernel(GemmArgs g, 
 #pragma unroll
         for (int i = 0; i < DMA_B; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, TDM_LDS(ist + STAGE_A + (wave * DMA_B + i) * 1024), 16, voffB[i], ikoff, 0, 0);
-        if (++it_chunk == nchunk) { it_chunk = 0; ++it_tile; }
+        if (++it_chunk == nchunk) { it_chunk = 0; it_tile += qx; }
     };
     auto issue = [&](int s) { issue_a(s); issue_b(); };
 
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(WMS * 128, 2) void gemm_nt_ring_kernel(GemmArgs g, 
             const bool interior = i0 + RM <= g.M && j0 + RN <= g.N;
             if (!(g.ablate & 8)) epilogue(cur_tile, st);
             zero_acc();
-            cur_chunk = 0; ++cur_tile;
+            cur_chunk = 0; cur_tile += qx;
             if (loads_free && interior && estores > 0 && !(g.ablate & 12)) behind = D;
             else wait_vm<0>();                    // (ragged tile or loads in the epilogue: drain, keep the counts exact)
         }

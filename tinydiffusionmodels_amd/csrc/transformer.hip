@@ -29,7 +29,7 @@ struct Drop {
     DropArgs site(int s) const { DropArgs d = tdm_drop_site(p, seed, s); if (d.thr != 0u) d.salt = salt; return d; }
 };
 
-constexpr int LN_SLABS = 256;  // workgroup partials of the LayerNorm affine / bias gradients (one workgroup per CU)
+constexpr int LN_SLABS = 1024;  // workgroup partials of the LayerNorm affine / bias gradients (four 4-wave workgroups per CU: the row loop has no prefetch, occupancy hides its latency)
 constexpr int CS_SLABS = 256;  // row-block partials of the bias gradients
 
 // Weight-gradient GEMMs contract over tokens (K = B*L, tens of thousands) into small [N][K] outputs:
@@ -41,6 +41,7 @@ inline int wgrad_splitk(int N, int K) {
     int sk = (target + tiles - 1) / tiles;
     if (sk < 1) sk = 1;
     if (sk > 128) sk = 128;
+    if (sk >= 8) sk = (sk + 4) / 8 * 8;   // whole splits per XCD (gemm_tn_bf16_kernel's workgroup map)
     return sk;
 }
 // slab regions (floats) of the 4 weight matrices of one layer, in order in_w, out_w, l1_w, l2_w

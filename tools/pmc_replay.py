@@ -4,7 +4,7 @@ workspaces, replays the chosen launches (tdm_unet_replay_launch_f32, in-pipeline
 workspaces so the 256 MB Infinity Cache cannot serve one launch's inputs to the next) and one NT GEMM of the text
 denoiser's FFN shape.
 
-    python tools/pmc_replay.py [--iters 5] [--ids 9,7,16,18,14] [--B 512]
+    python tools/pmc_replay.py [--iters 5] [--ids 16,9,3,...] [--B 512] [--names-out names.json]
 """
 import argparse
 import os
@@ -19,7 +19,8 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--ids", type=str, default="9,7,16,18,14,3")
+    ap.add_argument("--ids", type=str, default="16,9,3,13,7,14,12,18,11,17")
+    ap.add_argument("--names-out", type=str, default=None)
     ap.add_argument("--B", type=int, default=512)
     args = ap.parse_args()
     from tinydiffusionmodels_amd import _lib, unet_engine as E
@@ -40,6 +41,9 @@ def main():
     slabs = E.slabs_for(dev)
     gs = torch.empty_like(sts[0].grads)
     torch.cuda.synchronize()
+    if args.names_out:
+        import json
+        json.dump({v: L.tdm_unet_launch_name(int(v)).decode() for v in args.ids.split(",")}, open(args.names_out, "w"))
     for lid in [int(v) for v in args.ids.split(",")]:
         print("replaying", lid, L.tdm_unet_launch_name(lid).decode(), flush=True)
         for i in range(args.iters):
