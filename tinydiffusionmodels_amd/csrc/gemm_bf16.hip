@@ -376,8 +376,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
     static_assert(!(S16IN && CE), "the cross-entropy loader regenerates its operand from fp32 logits");
     static_assert(!BUF || S16IN, "descriptor loads serve the pre-split operands");
     // C[i][j] = sum_k A(i,k) B(k,j) with A(i,k) = A[k*a_cs + i], B(k,j) = B[k*b_rs + j]  (a_rs = b_cs = 1)
-    __shared__ __attribute__((aligned(16))) char lds[4 * TPL];
-    char* Ahi = lds; char* Alo = lds + TPL; char* Bhi = lds + 2 * TPL; char* Blo = lds + 3 * TPL;
+    __shared__ __attribute__((aligned(16))) char lds[2 * 4 * TPL];   // two buffers of [A hi | A lo | B hi | B lo] images
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     // Workgroup -> (column tile, row tile, split).  All tiles of one split read the same token range of both operands;
@@ -461,12 +460,12 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
             if constexpr (CE) { ce_l[p] = g.ce_lse[gkc]; ce_t[p] = (int)g.ce_ids[gkc] - g.ce_voff; }
         }
     };
-    if (kbeg < kend) gload(kbeg);
     const bool do_cs = g.colsum != nullptr && bx == 0;
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);   // this thread's 4 A columns (c4 = tid & 31), rows tid>>5 (+8p)
     float csum8[S16IN ? 8 : 1] = {};                  // S16 operands: the 8 columns of this thread's hi or lo piece
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        __syncthreads();
+    // the prefetched chunk (registers) -> operand images of buffer `buf`
+    auto stage = [&](int buf) {
+        char* const Ahi = lds + buf * (4 * TPL); char* const Alo = Ahi + TPL; char* const Bhi = Ahi + 2 * TPL; char* const Blo = Ahi + 3 * TPL;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int f = tid + 256 * p;
@@ -496,33 +495,52 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs g) {
                 if (do_cs) { csum.x += va[0]; csum.y += va[1]; csum.z += va[2]; csum.w += va[3]; }
             }
         }
-        __syncthreads();
-        if (k0 + BK < kend) gload(k0 + BK);
+    };
+    auto kstep = [&](int buf, int ks) {
+        const char* const Ahi = lds + buf * (4 * TPL); const char* const Alo = Ahi + TPL; const char* const Bhi = Ahi + 2 * TPL; const char* const Blo = Ahi + 3 * TPL;
+        const int m0r = ks * 16 + hh * 8 + q;   // token row of this lane's first transposed read
+        bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int m0r = ks * 16 + hh * 8 + q;   // token row of this lane's first transposed read
-            bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int ao = ((wm * 2 + t) * 32 + m0r) * 64 + colb;
-                const int bo = ((wn * 2 + t) * 32 + m0r) * 64 + colb;
-                ah[t] = tr_pair(Ahi + ao, Ahi + ao + 4 * 64);
-                bh[t] = tr_pair(Bhi + bo, Bhi + bo + 4 * 64);
-                if (NPROD == 3) {
-                    al[t] = tr_pair(Alo + ao, Alo + ao + 4 * 64);
-                    bl[t] = tr_pair(Blo + bo, Blo + bo + 4 * 64);
-                }
+        for (int t = 0; t < 2; ++t) {
+            const int ao = ((wm * 2 + t) * 32 + m0r) * 64 + colb;
+            const int bo = ((wn * 2 + t) * 32 + m0r) * 64 + colb;
+            ah[t] = tr_pair(Ahi + ao, Ahi + ao + 4 * 64);
+            bh[t] = tr_pair(Bhi + bo, Bhi + bo + 4 * 64);
+            if (NPROD == 3) {
+                al[t] = tr_pair(Alo + ao, Alo + ao + 4 * 64);
+                bl[t] = tr_pair(Blo + bo, Blo + bo + 4 * 64);
             }
+        }
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    if (NPROD == 3) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-                    }
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < 2; ++nt) {
+                if (NPROD == 3) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
                 }
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+            }
+    };
+    // Two operand buffers, ONE barrier per 32-token chunk: chunk c + 1 (in registers since the middle of the previous
+    // iteration) is written into the other buffer between the two K steps of chunk c — every wave left that buffer at the
+    // barrier that ended iteration c - 1 — and chunk c + 2's loads are requested right behind it.  (The single-buffer loop
+    // had two barriers around 24 MFMAs per wave: the matrix pipe ran at about a third of its rate.)
+    if (kbeg < kend) {
+        gload(kbeg);
+        stage(0);
+        if (kbeg + BK < kend) gload(kbeg + BK);
+        __syncthreads();
+        int buf = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            kstep(buf, 0);
+            if (k0 + BK < kend) {
+                stage(buf ^ 1);
+                if (k0 + 2 * BK < kend) gload(k0 + 2 * BK);
+            }
+            kstep(buf, 1);
+            __syncthreads();
+            buf ^= 1;
         }
     }
     if (S16IN && do_cs) {   // column c of the tile = hi piece + lo piece of its 16-column group, 8 row groups each, fixed order
