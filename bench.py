@@ -54,8 +54,8 @@ LAUNCH_WORK = [
     (_C3(64, 64, 196), 2 * _T14(64) + _M14(64), 0),                          # rb3.conv1
     (_C3(64, 64, 196), 3 * _T14(64) + _M14(64), 0),                          # rb3.conv2 (in, res, h3s)
     (_C3(96, 32, 784) + _C1(96, 32, 784), _T14(64) + 3 * _T28(32) + _M28(32), 0),   # rb4.conv1 + skip
-    (_C3(32, 32, 784) + _C1(32, 1, 784), 3 * _T28(32) + _M28(32) + 3136, 0),  # rb4.conv2 + out
-    (2 * _C1(32, 1, 784) + _C1(96, 1, 784), 3 * 3136 + 3 * _T28(32) + _T14(64) + _M28(32), 0),   # MSE + out conv bwd + rb4.skip grads (factored): h4, h1s, h3s in; dc2s out
+    (_C3(32, 32, 784) + 2 * _C1(32, 1, 784), 2 * _T28(32) + _M28(32) + 3 * 3136 + 784 * 5, 0),  # rb4.conv2 + out conv + MSE fwd/bwd + out conv grads (a1s, s4 in; mask, eps, deps, 40-float rows per 32 pixels out; noise in)
+    (_C1(32, 1, 784) + _C1(96, 1, 784), 3136 + 784 * 5 + 2 * _T28(32) + _T14(64) + _M28(32), 0),   # relu mask of d x w_out + rb4.skip grads (factored): deps, rows, h1s, h3s, mask in; dc2s out
     (_C3(32, 32, 784), 2 * _T28(32), 0),                                     # rb4.conv2 wgrad
     (_C3(32, 32, 784), 2 * _T28(32) + _M28(32), 0),                          # rb4.conv2 dgrad
     (_C3(64, 32, 784), _T14(64) + _T28(32), 0),                              # rb4.conv1 wgrad (up(h3) part)
@@ -361,7 +361,7 @@ def main():
             def call(i, lid=lid):
                 st = sts[i & 1]
                 _lib.check(L.tdm_unet_replay_launch_f32(_lib.ptr(trainer.flat), _lib.ptr(st.x_noisy), _lib.ptr(tt_), _lib.ptr(st.eps),
-                                                        _lib.ptr(st.deps), _lib.ptr(gscratch), _lib.ptr(st.ws.ws), _lib.ptr(slabs),
+                                                        _lib.ptr(st.deps), _lib.ptr(nz), _lib.ptr(gscratch), _lib.ptr(st.ws.ws), _lib.ptr(slabs),
                                                         B_TRAIN, lid, _lib.stream()), "replay")
             ms = time_events(call, 20)
             name = L.tdm_unet_launch_name(lid).decode()

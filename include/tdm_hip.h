@@ -193,9 +193,11 @@ int tdm_broadcast_f32(tdm_ctx* ctx, float* buf, int64_t n, int root, void* strea
  * arguments it had inside the step (bench.py times every launch with events; PMC per kernel).   */
 int tdm_unet_launch_count(void);
 const char* tdm_unet_launch_name(int id);
+/* noise != NULL: the train step's launches (the MSE backward sits in the epilogue of the forward's last
+ * launch and WRITES deps); NULL: those of tdm_unet_fwd_f32(save) + tdm_unet_bwd_f32 over the given deps. */
 int tdm_unet_replay_launch_f32(const float* params, const float* x_noisy, const int64_t* t, float* eps,
-                               const float* deps, float* grads, float* ws, float* slabs, int64_t B, int id,
-                               void* stream);
+                               float* deps, const float* noise, float* grads, float* ws, float* slabs,
+                               int64_t B, int id, void* stream);
 
 /* ---- per-layer entry points (tests / profiling) --------------------------- */
 /* generic NHWC 3x3 (pad 1) or 1x1 convolution as implicit GEMM on fp32 MFMA.

@@ -156,7 +156,9 @@ __device__ __forceinline__ void gstore_s16_o(float* s16, unsigned o, int c, cons
 // epilogue) and b set by the LDS fragment traffic — a wave reading ONE weight fragment pair for TWO pixel fragments halves
 // the rounds (and the fixed cost paid per round) and cuts the fragment bytes per MFMA by a quarter, at the same 4 waves
 // per SIMD (32 accumulator registers instead of 16; single prefetch set).
-template <int HW, int NT, bool SKIP, bool PROBE, int MT = 1>
+// MSE: the instantiation of rb4.conv2's forward launch in a train step (ConvArgs::o1_tgt): fused output conv + MSE backward;
+// it carries neither the rank-1 residual nor the ReLU-backward sums (their registers would push the walk over the 128 budget).
+template <int HW, int NT, bool SKIP, bool PROBE, int MT = 1, bool MSE = false>
 __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kernel(ConvArgs ka) {
     using G = Geo<HW>;
     constexpr int TPX = TILE_PX * MT;                                  // pixels of the workgroup's tile
@@ -171,10 +173,15 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     PinnedArgs a(ka);
     // rank-1 residual (ConvArgs::r1_*): only the 28x28 N = 32 instantiation (rb1.conv2) carries its registers
     constexpr bool R1 = HW == 28 && NT == 1 && !SKIP;
-    const float* r1_x = R1 ? ka.r1_x : nullptr; const float* r1_w = ka.r1_w; const float* r1_b = ka.r1_b;
-    if constexpr (R1) { TDM_PIN(r1_x); TDM_PIN(r1_w); TDM_PIN(r1_b); }
+    static_assert(!MSE || R1, "the fused MSE backward rides on the 28x28 N = 32 kernel's fused output conv");
+    constexpr bool R1X = R1 && !MSE;
+    const float* r1_x = R1X ? ka.r1_x : nullptr; const float* r1_w = ka.r1_w; const float* r1_b = ka.r1_b;
+    if constexpr (R1X) { TDM_PIN(r1_x); TDM_PIN(r1_w); TDM_PIN(r1_b); }
     float* o1_out = R1 ? ka.o1_out : nullptr; const float* o1_w = ka.o1_w; const float* o1_b = ka.o1_b;   // fused 1x1 output conv (rb4.conv2)
     if constexpr (R1) { TDM_PIN(o1_out); TDM_PIN(o1_w); TDM_PIN(o1_b); }
+    const float* o1_tgt = MSE ? ka.o1_tgt : nullptr; float* o1_deps = ka.o1_deps; float* o1_sums = ka.o1_sums;   // MSE at the source (training)
+    int o1_dscale_bits = __float_as_int(ka.o1_dscale);
+    if constexpr (MSE) { TDM_PIN(o1_tgt); TDM_PIN(o1_deps); TDM_PIN(o1_sums); TDM_PIN(o1_dscale_bits); }
     // rb4.conv1's data gradient (ConvArgs::dc_pair): only the 28x28 N = 96 instantiation carries it
     constexpr bool DCAT = HW == 28 && NT == 3 && !SKIP;
     float* dc_pair = DCAT ? ka.dc_pair : nullptr; float* dc_h1 = ka.dc_h1; const float* rk1_d = ka.rk1_d; const float* rk1_u = ka.rk1_u;
@@ -435,9 +442,9 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     asm volatile("" : "+v"(lane_e), "+v"(j_e), "+v"(h_e));
     constexpr int EPI = N + 4;   // floats per staged pixel row: (N/4 + 1) x 16 B, an odd slot count
     constexpr int NIT = N / 8;   // passes per M tile: 32 * N/4 float4, 64 per instruction
-    const bool bwd = NT != 3 && a.relu_mask_in != nullptr;   // (N = 32 / 64 outputs only)
+    const bool bwd = !MSE && NT != 3 && a.relu_mask_in != nullptr;   // (N = 32 / 64 outputs only)
     constexpr int GI = 4;   // passes per group: 4 independent chains, 16 value registers
-    struct Pre { float4 rt[GI]; unsigned mk[GI]; float rx[R1 ? GI : 1]; } p;   // inputs of ONE group of passes; rt: residual, else the time-bias row
+    struct Pre { float4 rt[GI]; unsigned mk[GI]; float rx[R1X ? GI : 1]; float tg[MSE ? GI : 1]; } p;   // inputs of ONE group of passes; rt: residual, else the time-bias row
     // branch-free: absent inputs get an empty descriptor (num_records 0 -> zeros), so the requests are one straight run
     // of loads (under uniform branches each request became a load + s_waitcnt vmcnt(0) + spill at N = 64)
     const bool use_res = a.res != nullptr;
@@ -448,6 +455,8 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         const_cast<unsigned char*>(a.relu_mask_in), 0, bwd ? Mtot * (N / 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(r1_x), 0, r1_x != nullptr ? Mtot * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_tg = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(o1_tgt), 0, o1_tgt != nullptr ? Mtot * 4 : 0, 0x00020000);
     float* T = reinterpret_cast<float*>(smem4) + wave * (32 * EPI);
     // The wave's MT M tiles go through the epilogue one after the other (same wave-private LDS block, same registers).
     static_for<0, MT>([&](auto mtc) {
@@ -455,7 +464,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     const int mbase = mbase0 + mt * 32;
     const int img0 = mbase / (G::H * G::W);         // image of the group's first pixel (scalar)
     const int mnext = (img0 + 1) * (G::H * G::W);   // a 32-pixel group touches at most two images
-    const bool has_epi_in = use_res || use_tb || bwd || (R1 && r1_x != nullptr);
+    const bool has_epi_in = use_res || use_tb || bwd || (R1X && r1_x != nullptr) || MSE;
     auto preload = [&](int g) {
 #pragma unroll
         for (int it = 0; it < GI; ++it) {
@@ -467,7 +476,8 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
             const f32x4 r = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_rt, (use_res ? o : otb) * 4, 0, 0));
             p.rt[it] = make_float4(r[0], r[1], r[2], r[3]);
             p.mk[it] = __builtin_amdgcn_raw_buffer_load_b8(rs_mk, o >> 2, 0, 0);
-            if constexpr (R1) p.rx[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rx, m * 4, 0, 0));
+            if constexpr (R1X) p.rx[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rx, m * 4, 0, 0));
+            if constexpr (MSE) p.tg[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_tg, m * 4, 0, 0));
         }
     };
     if (!(DCAT && dc_pair != nullptr)) preload(0);   // (the d cat epilogue fetches its own two small inputs)
@@ -535,6 +545,8 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
         for (int kd = 0; kd < 2; ++kd) sacc[sl][kd] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 o1_gw = make_float4(0.f, 0.f, 0.f, 0.f);   // fused MSE backward (o1_tgt): sum d * value of this lane's channel quad ...
+    float o1_gb = 0.f, o1_gl = 0.f;                    // ... sum d, sum (eps - tgt)^2 (lanes with lane % 8 == 0 only)
     auto walk = [&](auto full_c, auto group_c) {
         constexpr bool FULL = decltype(full_c)::value;
         constexpr int I0 = decltype(group_c)::value * GI;
@@ -574,7 +586,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
                 v[k].x += rz.x; v[k].y += rz.y; v[k].z += rz.z; v[k].w += rz.w;
             }
         }
-        if constexpr (R1) if (r1_x != nullptr) {   // rank-1 residual: the one-input-channel skip conv, recomputed (same fma as conv_first)
+        if constexpr (R1X) if (r1_x != nullptr) {   // rank-1 residual: the one-input-channel skip conv, recomputed (same fma as conv_first)
 #pragma unroll
             for (int k = 0; k < GI; ++k) {
                 const int c = (((I0 + k) * 64 + lane_e) % (N / 4)) * 4;
@@ -613,6 +625,15 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
                 d += __shfl_xor(d, 2);
                 d += __shfl_xor(d, 4);
                 if ((lane_e & 7) == 0 && ok[k]) gstore<float>(o1_out + (o[k] >> 5), d + ob);
+                if constexpr (MSE) if (ok[k]) {   // every lane of the pixel holds d after the butterfly
+                    const float df = (d + ob) - p.tg[k];
+                    const float dl = df * __int_as_float(o1_dscale_bits);
+                    o1_gw.x += dl * v[k].x; o1_gw.y += dl * v[k].y; o1_gw.z += dl * v[k].z; o1_gw.w += dl * v[k].w;
+                    if ((lane_e & 7) == 0) {
+                        o1_gb += dl; o1_gl += df * df;
+                        gstore<float>(o1_deps + (o[k] >> 5), dl);
+                    }
+                }
             }
         }
         if (a.out_s16 != nullptr) {
@@ -657,6 +678,20 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     };
     if (mbase + 32 <= Mtot) groups(std::true_type{});
     else groups(std::false_type{});
+    if constexpr (MSE) {   // lanes with equal lane % 8 hold the same channel quad: butterfly over bits 3..5
+        float4 r = o1_gw;
+        float rb = o1_gb, rl = o1_gl;
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+            r.x += __shfl_xor(r.x, off); r.y += __shfl_xor(r.y, off); r.z += __shfl_xor(r.z, off); r.w += __shfl_xor(r.w, off);
+            rb += __shfl_xor(rb, off); rl += __shfl_xor(rl, off);
+        }
+        if (lane_e < 8 && mbase < Mtot) {
+            float* const row = o1_sums + ((unsigned)mbase >> 5) * 40u;
+            gstore4(row + lane_e * 4, r);
+            if (lane_e == 0) { gstore<float>(row + 32, rb); gstore<float>(row + 33, rl); }
+        }
+    }
     if (bwd && a.sums != nullptr) {
         // lanes with equal lane_e % (N/4) hold the same channel quad of different pixels: butterfly over the rest
 #pragma unroll
@@ -726,6 +761,23 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st) {
             }
             hipLaunchKernelGGL((conv_s16_kernel<HW, NT, SKIP, true>), dim3(ntiles), dim3(CONV_THREADS), lds_req, st, a);
             TDM_CHECK_LAUNCH("conv_s16(probe)");
+            return 0;
+        }
+    }
+    if constexpr (HW == 28 && NT == 1 && !SKIP && MT == 1) {
+        if (a.o1_tgt != nullptr) {   // rb4.conv2 of a train step: output conv + MSE backward in the epilogue
+            static bool mse_attr = false;
+            if (!mse_attr) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<HW, NT, SKIP, false, 1, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 110000);
+                if (e != hipSuccess) {
+                    tdm_set_error("conv_s16: hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+                    return 100 + (int)e;
+                }
+                mse_attr = true;
+            }
+            hipLaunchKernelGGL((conv_s16_kernel<HW, NT, SKIP, false, 1, true>), dim3(ntiles), dim3(CONV_THREADS), lds_req, st, a);
+            TDM_CHECK_LAUNCH("conv_s16(mse)");
             return 0;
         }
     }
@@ -1073,6 +1125,10 @@ int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st) {
                                          a.out == nullptr && a.out_s16 == nullptr && a.res == nullptr && a.relu_mask_in == nullptr &&
                                          ((long)a.B * 784) % 2 == 0),
                 "conv_s16: the paired d cat epilogue is built for the 28x28 N = 96 data gradient alone");
+    TDM_REQUIRE(a.o1_tgt == nullptr || (a.o1_out != nullptr && a.o1_deps != nullptr && a.o1_sums != nullptr &&
+                                        a.r1_x == nullptr && a.relu_mask_in == nullptr && (a.ablate & 16) == 0),
+                "conv_s16: the fused MSE backward needs the fused output conv, a deps buffer and the partial rows (and neither "
+                "the rank-1 residual nor a ReLU backward)");
     TDM_REQUIRE(a.o1_out == nullptr || (hw == 28 && N == 32 && a.skip_out == nullptr && a.o1_w != nullptr && a.o1_b != nullptr),
                 "conv_s16: the fused output conv is built for the 28x28 N = 32 kernel");
     TDM_REQUIRE(a.r1_x == nullptr || (hw == 28 && N == 32 && a.skip_out == nullptr && a.res == nullptr && a.r1_w != nullptr && a.r1_b != nullptr),

@@ -756,7 +756,8 @@ __global__ __launch_bounds__(EW_BLOCK) void out_bwd_s16_kernel(const float* __re
                                                                float* __restrict__ slab, long slab_stride, int w_off,
                                                                int b_off, int c2b_off, int skb_off, int vsk_off, int64_t M,
                                                                const float* __restrict__ eps, const float* __restrict__ noise,
-                                                               float* __restrict__ deps_out, float dscale, int loss_off) {
+                                                               float* __restrict__ deps_out, float dscale, int loss_off,
+                                                               const float* __restrict__ o1_sums, int o1_rows) {
     __shared__ float4 shw[EW_BLOCK];
     __shared__ float shb[4];
     const int c4 = threadIdx.x & 7;
@@ -776,6 +777,11 @@ __global__ __launch_bounds__(EW_BLOCK) void out_bwd_s16_kernel(const float* __re
         return df * dscale;
     };
     auto dpure = [&](int64_t m) { return fused ? (eps[m] - noise[m]) * dscale : deps[m]; };   // (no side effects: second pass)
+    // o1_sums != nullptr: rb4.conv2's forward epilogue has already taken the MSE backward (deps holds d) and the output
+    // conv's gradients as per-32-pixel-group rows (ConvArgs::o1_sums) — h4 was never written; this kernel only condenses
+    // the rows of its slice into its partial row.
+    const bool has_h4 = h4 != nullptr;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     auto finish = [&](int64_t i, float d, const float4& hv, unsigned am, const float4& h1v) {
         const int64_t m = i >> 3;
         float4 o;
@@ -794,14 +800,14 @@ __global__ __launch_bounds__(EW_BLOCK) void out_bwd_s16_kernel(const float* __re
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t k = i + u * S;
-            d[u] = dval(k >> 3); hv[u] = reinterpret_cast<const float4*>(h4)[k]; am[u] = a2m[k];
+            d[u] = dval(k >> 3); hv[u] = has_h4 ? reinterpret_cast<const float4*>(h4)[k] : zero; am[u] = a2m[k];
             h1v[u] = tdm_load_s16_4(h1s, k >> 3, 32, c4 * 4);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) finish(i + u * S, d[u], hv[u], am[u], h1v[u]);
     }
     for (; i < total; i += S)
-        finish(i, dval(i >> 3), reinterpret_cast<const float4*>(h4)[i], a2m[i], tdm_load_s16_4(h1s, i >> 3, 32, c4 * 4));
+        finish(i, dval(i >> 3), has_h4 ? reinterpret_cast<const float4*>(h4)[i] : zero, a2m[i], tdm_load_s16_4(h1s, i >> 3, 32, c4 * 4));
     // v over the up-sampled channels: sum over the half-resolution pixels of h3 * (sum of d over its 2x2 fine pixels)
     {
         const int q4 = threadIdx.x & 15;                 // channel quad of the 64 (the grid stride is a multiple of 16)
@@ -822,11 +828,18 @@ __global__ __launch_bounds__(EW_BLOCK) void out_bwd_s16_kernel(const float* __re
         if (threadIdx.x == 0) dst[loss_off] = sl;
     }
     const float sb = block_sum(gb, shb);
-    quad_reduce_store(gw, shw, 8, dst + w_off);
+    if (o1_sums == nullptr) quad_reduce_store(gw, shw, 8, dst + w_off);
     quad_reduce_store(g_c2, shw, 8, dst + c2b_off);
     quad_reduce_store(g_v3, shw, 16, dst + vsk_off);
     quad_reduce_store(g_v1, shw, 8, dst + vsk_off + 64);
-    if (threadIdx.x == 0) dst[b_off] = sb;
+    if (threadIdx.x == 0 && o1_sums == nullptr) dst[b_off] = sb;
+    if (o1_sums != nullptr && threadIdx.x < 34) {   // [0..31] d W_out, [32] d b_out, [33] sum of squared errors: fixed row order
+        float acc = 0.f;
+        for (int r = blockIdx.x; r < o1_rows; r += gridDim.x) acc += o1_sums[(long)r * 40 + threadIdx.x];
+        if (threadIdx.x < 32) dst[w_off + threadIdx.x] = acc;
+        else if (threadIdx.x == 32) dst[b_off] = acc;
+        else if (loss_off >= 0) dst[loss_off] = acc;
+    }
     __syncthreads();
     if (threadIdx.x < 32) dst[skb_off + threadIdx.x] = w[threadIdx.x] * ((shb[0] + shb[1]) + (shb[2] + shb[3]));   // db_skip partial = w_out * sum d
 }
@@ -1173,11 +1186,14 @@ int tdm_launch_avgpool_s16(const float* in, float* out, float* out_s16, int B, i
 int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, const unsigned char* a2, const float* h1s,
                            const float* h3s, float* dc2_s16, float* slab, long slab_stride, int w_off, int b_off,
                            int c2b_off, int skb_off, int vsk_off, int64_t M, int nslab, hipStream_t st, const float* eps,
-                           const float* noise, float* deps_out, int loss_off) {
+                           const float* noise, float* deps_out, int loss_off, const float* o1_sums) {
     TDM_REQUIRE(deps != nullptr || (eps != nullptr && noise != nullptr), "out_bwd_s16: needs deps, or eps and noise");
+    TDM_REQUIRE((h4 != nullptr) != (o1_sums != nullptr) && (o1_sums == nullptr || deps != nullptr),
+                "out_bwd_s16: either h4 (output conv gradients taken here) or the forward epilogue's partial rows + deps");
     TDM_REQUIRE(h1s != nullptr && h3s != nullptr && (M % 784) == 0, "out_bwd_s16: needs the S16 concat sources of whole 28x28 images");
     hipLaunchKernelGGL(out_bwd_s16_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, deps, h4, w, a2, h1s, h3s, dc2_s16,
-                       slab, slab_stride, w_off, b_off, c2b_off, skb_off, vsk_off, M, eps, noise, deps_out, 2.0f / (float)M, loss_off);
+                       slab, slab_stride, w_off, b_off, c2b_off, skb_off, vsk_off, M, eps, noise, deps_out, 2.0f / (float)M, loss_off,
+                       o1_sums, (int)((M + 31) / 32));
     TDM_CHECK_LAUNCH("out_bwd_s16");
     return 0;
 }

@@ -107,6 +107,15 @@ struct ConvArgs {
     const float* o1_w;
     const float* o1_b;
     float* o1_out;
+    // F.mse_loss forward / backward at the source (training, src/mnist.py:158-159 on the output of :87): with o1_tgt != nullptr
+    // (the noise target, [M]) the same epilogue also writes o1_deps[m] = (o1_out[m] - o1_tgt[m]) * o1_dscale = d loss / d eps
+    // and, per 32-pixel group g, the partial row o1_sums[g * 40 + ...]: [0..31] = sum_m d[m] * value[m][c] (the output conv's
+    // weight gradient), [32] = sum_m d[m] (its bias gradient), [33] = sum_m (eps - tgt)^2 — so the [M][32] tensor is not
+    // written for the backward pass either (`out` may be nullptr).
+    const float* o1_tgt;
+    float* o1_deps;
+    float* o1_sums;
+    float o1_dscale;
 };
 
 // hw in {28,14}; N in {32,64,96}; dgrad: transposed convolution with the forward weights
@@ -216,7 +225,7 @@ int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, c
                            const float* h3s, float* dc2_s16, float* slab, long slab_stride, int w_off, int b_off,
                            int c2b_off, int skb_off, int vsk_off, int64_t M, int nslab, hipStream_t st,
                            const float* eps = nullptr, const float* noise = nullptr, float* deps_out = nullptr,
-                           int loss_off = -1);
+                           int loss_off = -1, const float* o1_sums = nullptr);
 // time_emb weight / bias gradients of the four blocks and the conv1 bias gradients of rb2..rb4 as slab partials, straight
 // from the per-32-pixel-group sums the data-gradient launches wrote (ConvArgs::sums; one buffer per block)
 struct GroupSumJobs { const float* gs[4]; int C[4]; int HWpix[4]; int tew[4]; int c1b[4]; };

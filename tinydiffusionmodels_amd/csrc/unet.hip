@@ -199,11 +199,13 @@ int wgrad(hipStream_t st, int hw, int B, const float* act, int C, int c_used, in
     return tdm_launch_wgrad(a, hw, nslab, st);
 }
 
+// deps == nullptr: the train step's form — F.mse_loss forward + backward (src/mnist.py:158; d = 2 (eps - noise) / n, loss
+// partials travel through the slabs to loss_out) is fused into the pipeline: at_source = in the epilogue of the forward's
+// last launch (rb4.conv2 + output conv: ConvArgs::o1_tgt — the forward is then called with the same MseIn and h4 is never
+// written); otherwise in the first backward kernel, which reads eps, noise and h4.
+struct MseIn { const float* eps; const float* noise; float* deps_out; float* loss_out; bool at_source; };
 int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* eps, const Ws& w, int B, int save,
-                     hipStream_t st);
-// deps == nullptr: the train step's form — F.mse_loss forward + backward (src/mnist.py:158) is fused into the first
-// backward kernel (d = 2 (eps - noise) / n; loss partials travel through the slabs to loss_out)
-struct MseIn { const float* eps; const float* noise; float* deps_out; float* loss_out; };
+                     hipStream_t st, const MseIn* mse = nullptr);
 constexpr long SLAB_STRIDE = TDM_UNET_NPARAM + 64;   // S16 pipeline: [parameters | loss partial | pad]
 int unet_backward_s16(const float* P, const float* x, const float* deps, float* G, const Ws& w, float* slabs, int B,
                       hipStream_t st, const MseIn* mse = nullptr);
@@ -288,8 +290,8 @@ int wgrad_s16(hipStream_t st, int hw, int B, const float* act_s16, int C, int c_
     X(F_RB2C1, "rb2.conv1 fwd 32->64 @14 (conv_s16<14,2>)") X(F_RB2C2, "rb2.conv2 fwd 64->64 @14 (conv_s16<14,2>)")     \
     X(F_RB3C1, "rb3.conv1 fwd 64->64 @14 (conv_s16<14,2>)") X(F_RB3C2, "rb3.conv2 fwd 64->64 @14 (conv_s16<14,2>)")     \
     X(F_RB4C1, "rb4.conv1 + rb4.skip fwd 96->32 @28 (conv_s16<28,1,skip>)")                                             \
-    X(F_RB4C2, "rb4.conv2 + out fwd 32->32 @28 (conv_s16<28,1>)")                                                       \
-    X(B_OUT_BWD, "out conv bwd + relu mask + rb4.skip grads in factored form (out_bwd_s16)") X(B_WG_RB4C2, "rb4.conv2 wgrad (wgrad2_s16<28>)")            \
+    X(F_RB4C2, "rb4.conv2 + out conv fwd + MSE fwd/bwd 32->32 @28 (conv_s16<28,1>)")                                                       \
+    X(B_OUT_BWD, "relu mask of d x w_out + rb4.skip grads in factored form (out_bwd_s16)") X(B_WG_RB4C2, "rb4.conv2 wgrad (wgrad2_s16<28>)")            \
     X(B_DG_RB4C2, "rb4.conv2 dgrad 32->32 @28 (conv_s16<28,1>)")                                                        \
     X(B_WG_RB4C1A, "rb4.conv1 wgrad, up(h3) part (wgrad2_s16<28>)")                                             \
     X(B_WG_RB4C1B, "rb4.conv1 wgrad, h1 part (wgrad2_s16<28>)")                                                 \
@@ -321,7 +323,7 @@ thread_local int g_only_launch = -1;   // >= 0: the S16 forward / backward issue
     } while (0)
 
 int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* eps, const Ws& w, int B, int save,
-                     hipStream_t st) {
+                     hipStream_t st, const MseIn* mse) {
     const int tew[4] = {kL.rb[0].tew, kL.rb[1].tew, kL.rb[2].tew, kL.rb[3].tew};
     const int teb[4] = {kL.rb[0].teb, kL.rb[1].teb, kL.rb[2].teb, kL.rb[3].teb};
     RUN(F_TIMEBIAS, tdm_launch_timebias(t, P, tew, teb, w.that, w.tb, B, st, w.rng_bump, w.u96, kL.rb[3].skw, kL.outw));
@@ -370,6 +372,10 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
         a.bias = P + r4.c2b; a.relu = 1; a.B = B;
         a.out = save ? w.h4 : nullptr; a.mask_out = save ? w.m2[3] : nullptr; a.res = w.s4; a.tb_out_stride = 192;
         a.o1_w = P + kL.outw; a.o1_b = P + kL.outb; a.o1_out = eps;
+        if (mse != nullptr && mse->at_source) {   // MSE backward + the output conv's gradients here; h4's buffer holds the partial rows
+            a.out = nullptr;
+            a.o1_tgt = mse->noise; a.o1_deps = mse->deps_out; a.o1_sums = w.h4; a.o1_dscale = 2.0f / (float)((int64_t)B * 784);
+        }
         RUN(F_RB4C2, tdm_launch_conv_s16(a, 28, 32, st));
     }
     return 0;
@@ -403,9 +409,13 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     TDM_REQUIRE(dvec != nullptr, "unet_backward: the fused MSE form needs a deps buffer");
     float* const dc_pair = w.dcat;                  // (B, 28, 14, 64): d cat[.., 0:64], horizontal pairs added
     float* const dc_h1 = w.dcat + M28 * 32;         // (M, 32):         d cat[.., 64:96]
-    RUN(B_OUT_BWD, tdm_launch_out_bwd_s16(deps, w.h4, P + kL.outw, w.m2[3], w.h1s, w.h3s, w.dc2s_4, es, ESTRIDE, E_OUT,
-                                          E_OUT + 32, E_C2B4, E_SKB4, E_VSK, M28, ER28, st, deps ? nullptr : mse->eps,
-                                          deps ? nullptr : mse->noise, deps ? nullptr : mse->deps_out, deps ? -1 : E_LOSS));
+    if (deps == nullptr && mse->at_source)
+        RUN(B_OUT_BWD, tdm_launch_out_bwd_s16(mse->deps_out, nullptr, P + kL.outw, w.m2[3], w.h1s, w.h3s, w.dc2s_4, es, ESTRIDE, E_OUT,
+                                              E_OUT + 32, E_C2B4, E_SKB4, E_VSK, M28, ER28, st, nullptr, nullptr, nullptr, E_LOSS, w.h4));
+    else
+        RUN(B_OUT_BWD, tdm_launch_out_bwd_s16(deps, w.h4, P + kL.outw, w.m2[3], w.h1s, w.h3s, w.dc2s_4, es, ESTRIDE, E_OUT,
+                                              E_OUT + 32, E_C2B4, E_SKB4, E_VSK, M28, ER28, st, deps ? nullptr : mse->eps,
+                                              deps ? nullptr : mse->noise, deps ? nullptr : mse->deps_out, deps ? -1 : E_LOSS));
     RUN(B_WG_RB4C2, wgrad_s16(st, 28, B, w.a1s_4, 32, 32, 0, 9, w.dc2s_4, 32, slabs, r4.c2w, 32, 0, NS));
     RUN(B_DG_RB4C2, conv_s16_1(st, w, 28, B, w.dc2s_4, 32, 9, kPack.dg[W_RB4C2], 32, nullptr, 0,
                                S16Out{nullptr, nullptr, nullptr, w.dh4s, nullptr, w.m1[3], w.gs[3]}));   // + ReLU backward of a1
@@ -567,12 +577,14 @@ int unet_backward(const float* P, const float* x, const float* deps, float* G, c
 
 // F.mse_loss + backward of the whole network (src/mnist.py:158-159).  Default pipeline: the MSE rides in the first backward
 // kernel (no separate pass over eps / noise, no deps round trip); the other arithmetics keep the stand-alone kernels.
-int loss_and_backward(const float* P, const float* x_noisy, const float* noise, const float* eps, float* deps, float* loss_out,
-                      float* G, const Ws& w, float* slabs, int B, hipStream_t st) {
+int forward_loss_backward(const float* P, const float* x_noisy, const int64_t* t, const float* noise, float* eps, float* deps,
+                          float* loss_out, float* G, const Ws& w, float* slabs, int B, hipStream_t st) {
     if (g_conv_mode == 2) {
-        const MseIn mi{eps, noise, deps, loss_out};
+        const MseIn mi{eps, noise, deps, loss_out, true};
+        TDM_TRY(unet_forward_s16(P, x_noisy, t, eps, w, B, 1, st, &mi));
         return unet_backward_s16(P, x_noisy, nullptr, G, w, slabs, B, st, &mi);
     }
+    TDM_TRY(unet_forward(P, x_noisy, t, eps, w, B, 1, st));
     TDM_TRY(tdm_mse_fwd_bwd_f32(eps, noise, loss_out, deps, w.scratch, (int64_t)B * 784, (void*)st));
     return unet_backward(P, x_noisy, deps, G, w, slabs, B, st);
 }
@@ -651,8 +663,7 @@ int tdm_unet_loss_grad_f32(const float* params, const float* x0, const float* no
     const Ws w = carve(ws, B, 1);
     hipStream_t st = (hipStream_t)stream;
     TDM_TRY(tdm_q_sample_f32(x0, noise, t, sqrt_acp, sqrt_1m_acp, x_noisy, B, 784, stream));
-    TDM_TRY(unet_forward(params, x_noisy, t, eps, w, (int)B, 1, st));
-    return loss_and_backward(params, x_noisy, noise, eps, deps, loss_out, grads, w, slabs, (int)B, st);
+    return forward_loss_backward(params, x_noisy, t, noise, eps, deps, loss_out, grads, w, slabs, (int)B, st);
 }
 
 int tdm_unet_p_sample_step_f32(const float* params, const float* x, const int64_t* t, const float* noise,
@@ -681,8 +692,7 @@ int tdm_unet_loss_grad_philox_f32(const float* params, const float* x0, const fl
     TDM_REQUIRE(sqrt_acp && sqrt_1m_acp, "unet_loss_grad_philox: NULL schedule table");
     TDM_TRY(tdm_launch_draw_q_sample(x0, sqrt_acp, sqrt_1m_acp, seed, rng_state, t_buf, noise, x_noisy, B, 784, !fold, st));
     if (fold) w.rng_bump = rng_state;
-    TDM_TRY(unet_forward(params, x_noisy, t_buf, eps, w, (int)B, 1, st));
-    return loss_and_backward(params, x_noisy, noise, eps, deps, loss_out, grads, w, slabs, (int)B, st);
+    return forward_loss_backward(params, x_noisy, t_buf, noise, eps, deps, loss_out, grads, w, slabs, (int)B, st);
 }
 
 // One reverse step with device-resident step index and device-drawn noise (src/mnist.py:191-193, :167-180):
@@ -701,16 +711,19 @@ int tdm_unet_p_sample_step_philox_f32(const float* params, const float* x, int64
 // full tdm_unet_loss_grad_f32 call with the same arguments has filled.  Results are those of the full step's launch.
 int tdm_unet_launch_count(void) { return (int)L_COUNT; }
 const char* tdm_unet_launch_name(int id) { return (id >= 0 && id < (int)L_COUNT) ? kLaunchNames[id] : ""; }
-int tdm_unet_replay_launch_f32(const float* params, const float* x_noisy, const int64_t* t, float* eps, const float* deps,
-                               float* grads, float* ws, float* slabs, int64_t B, int id, void* stream) {
+int tdm_unet_replay_launch_f32(const float* params, const float* x_noisy, const int64_t* t, float* eps, float* deps,
+                               const float* noise, float* grads, float* ws, float* slabs, int64_t B, int id, void* stream) {
     TDM_CHECK_B(B);
     TDM_REQUIRE(g_conv_mode == 2, "replay_launch: the launch ids describe the default (S16) pipeline");
     TDM_REQUIRE(id >= 0 && id < (int)L_COUNT, "replay_launch: id %d out of range", id);
     TDM_REQUIRE(params && x_noisy && t && eps && deps && grads && ws && slabs, "replay_launch: NULL pointer");
     const Ws w = carve(ws, B, 1);
+    // noise != nullptr: the train step's form (MSE backward in the forward's last epilogue, deps is its output);
+    // nullptr: the stand-alone backward over a given deps (tdm_unet_bwd_f32's launches)
+    const MseIn mi{eps, noise, deps, slabs + ESLAB_BASE - 1 /* a pad float of the last slab */, true};
     g_only_launch = id;
-    int rc = unet_forward_s16(params, x_noisy, t, eps, w, (int)B, 1, (hipStream_t)stream);
-    if (rc == 0) rc = unet_backward_s16(params, x_noisy, deps, grads, w, slabs, (int)B, (hipStream_t)stream);
+    int rc = unet_forward_s16(params, x_noisy, t, eps, w, (int)B, 1, (hipStream_t)stream, noise ? &mi : nullptr);
+    if (rc == 0) rc = unet_backward_s16(params, x_noisy, noise ? nullptr : deps, grads, w, slabs, (int)B, (hipStream_t)stream, noise ? &mi : nullptr);
     g_only_launch = -1;
     return rc;
 }

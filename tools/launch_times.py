@@ -43,7 +43,7 @@ def main():
             def call(i, lid=lid):
                 st = sts[i & 1]
                 _lib.check(L.tdm_unet_replay_launch_f32(_lib.ptr(flat), _lib.ptr(st.x_noisy), _lib.ptr(t), _lib.ptr(st.eps),
-                                                        _lib.ptr(st.deps), _lib.ptr(gs), _lib.ptr(st.ws.ws), _lib.ptr(slabs), B, lid,
+                                                        _lib.ptr(st.deps), _lib.ptr(nz), _lib.ptr(gs), _lib.ptr(st.ws.ws), _lib.ptr(slabs), B, lid,
                                                         _lib.stream()), "replay")
             res[(B, lid)] = bench.time_events(call, args.iters) * 1e3
         del sts

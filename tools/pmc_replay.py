@@ -49,7 +49,7 @@ def main():
         for i in range(args.iters):
             st = sts[i & 1]
             _lib.check(L.tdm_unet_replay_launch_f32(_lib.ptr(flat), _lib.ptr(st.x_noisy), _lib.ptr(t), _lib.ptr(st.eps),
-                                                    _lib.ptr(st.deps), _lib.ptr(gs), _lib.ptr(st.ws.ws), _lib.ptr(slabs), B, lid,
+                                                    _lib.ptr(st.deps), _lib.ptr(nz), _lib.ptr(gs), _lib.ptr(st.ws.ws), _lib.ptr(slabs), B, lid,
                                                     _lib.stream()), "replay")
         torch.cuda.synchronize()
     # text denoiser FFN1 shape on the NT bf16x3 GEMM in its in-pipeline form (gemm_nt_bf16_kernel<3,...,true>): pre-split
