@@ -824,7 +824,19 @@ __global__ __launch_bounds__(1024) void wgrad2_s16_kernel(WgradArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ci_tile = blockIdx.y % a.nci, co_tile = blockIdx.y / a.nci;
+    // Workgroup -> (slab slot, channel-tile combination).  The gridDim.y combinations of one slot walk the SAME pixel tiles
+    // (same gradient tiles for the ci tiles, same activation tiles for the co tiles); in grid order they are gridDim.x
+    // workgroups apart, i.e. — one 1024-thread workgroup per CU — in different rounds when the grid exceeds the chip
+    // (rb4.conv1's up(h3) part: 256 x 2: the 51 MB gradient tensor came from HBM twice).  Dispatch order L is therefore
+    // re-dealt: XCD L % 8 runs its slots' combinations back to back, so they are co-resident and share through that L2.
+    int comb = blockIdx.y, bxs = blockIdx.x;
+    if ((gridDim.x & 7) == 0) {
+        const int L = blockIdx.x + gridDim.x * blockIdx.y;
+        const int k = L >> 3;
+        comb = k % (int)gridDim.y;
+        bxs = (L & 7) + 8 * (k / (int)gridDim.y);        // (xcd_remap below turns this into the XCD's contiguous slot range)
+    }
+    const int ci_tile = comb % a.nci, co_tile = comb / a.nci;
     const int ci0 = ci_tile * 32, co0 = co_tile * 32;
     const int Mtot = a.B * G::H * G::W;
     const int ntiles = (Mtot + W2_TP - 1) / W2_TP;
@@ -833,7 +845,7 @@ __global__ __launch_bounds__(1024) void wgrad2_s16_kernel(WgradArgs a) {
     // Workgroups of one XCD take NEIGHBOURING tiles at the same time (slot = contiguous range per XCD): a 128-pixel tile
     // stages 10 rows for 4.6 rows of payload, and with blockIdx-ordered tiles the 2.2x halo re-reads went to eight
     // different L2s, i.e. to HBM — the kernel was bandwidth-bound on its own halo.
-    const int slot = xcd_remap(blockIdx.x, gridDim.x);
+    const int slot = xcd_remap(bxs, gridDim.x);
     const int nk = (ntiles - slot + step - 1) / step;   // tiles of this workgroup: slot + k * step
     float* const slab = a.slab + (long)slot * a.slab_stride;
 

@@ -306,6 +306,8 @@ __global__ __launch_bounds__(WMS * 128, 2) void gemm_nt_ring_kernel(GemmArgs g, 
         __builtin_amdgcn_s_barrier();             // ... and every wave has finished reading stage (s - 1) % NSTAGE
         char* const st = lds + (s % NSTAGE) * STAGE;
         const bool more = s + D < total && !(g.ablate & 1);   // pair s + D goes into the stage pair s - 1 occupied (free since the barrier)
+        // (requesting both K steps' fragments before the first MFMA was measured: K loop unchanged (81 -> 80 us), whole kernel
+        //  153 -> 173 us on the N = 2048 layer — the longer live ranges cost the epilogue more than the loop gains)
         if (!(g.ablate & 2)) kstep(st, 0);
         if (more) issue_a(s + D);
         if (!(g.ablate & 2)) kstep(st, 1);
