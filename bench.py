@@ -382,6 +382,13 @@ def main():
                                "all_us": {str(r["id"]): r["us"] for r in rows}}
         cb = out["launch_table"]["conv_blocks"]
         cb["hbm_frac"] = round(cb["bytes"] / (cb["us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)
+        # `bytes` above are the tensors the launches AS BUILT touch — a tensor that is no longer written (h4, dout4, the
+        # full-width d cat) LOWERS that fraction although the step got faster.  SURVEY.md section 8d's ALGORITHMIC bytes of
+        # the convolutions these 14 launches compute do not move with the implementation: fp32 input + output elements of
+        # rb1.conv2, rb2.conv1/2, rb3.conv1/2, rb4.conv1 + rb4.skip, rb4.conv2 + out, forward and data gradient.
+        algo_fwd = 4 * (784 * (64 + 128 + 128 + 64 + 33) + 196 * (96 + 128 + 128 + 128))
+        cb["algorithmic_bytes"] = 2 * algo_fwd * B_TRAIN
+        cb["hbm_frac_algorithmic"] = round(cb["algorithmic_bytes"] / (cb["us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)
         # ---- roofline: the DOMINANT launch of the step = the longest one, exactly as it runs in the step (in-pipeline
         # arguments).  Algorithmic bytes follow SURVEY.md section 8d (fp32 in + out elements of the convolution the launch
         # computes; an input shared by a fused second conv is counted once): rb4.conv1 + rb4.skip forward reads the 96-channel
