@@ -271,7 +271,10 @@ def _unsplit_s16(t):
                                    (64, 144, 48), (515, 32, 80),   # K % 32 != 0: the S16 path without descriptor loads
                                    # >= 32 tiles of 256 x 128: the persistent LDS-DMA ring kernel (gemm_ring.hip) — ragged rows and
                                    # columns (zero-filled by the descriptor), deep K, one chunk, more tiles than CUs, an uneven tile split
-                                   (4100, 272, 2048), (2048, 528, 32), (8192, 2048, 64), (33000, 144, 96), (16384, 768, 256)])
+                                   (4100, 272, 2048), (2048, 528, 32), (8192, 2048, 64), (33000, 144, 96),
+                                   # whole tiles and >= 8 K chunks: the tile-pipelined form (epilogue slices under the next tile's MFMAs),
+                                   # uneven tiles per workgroup / several tiles each / deep K
+                                   (16384, 768, 256), (32768, 1024, 256), (8192, 512, 2048)])
 def test_s16_operands_give_the_same_gemm_bitwise(dev, gemm_mode, M, N, K):
     """The pre-split ("S16") operand path of the bf16 GEMMs (tdm_split_s16_f32 + flag bits of tdm_gemm_f32): the loaders copy
     what the fp32-input loaders would have computed, so the K-contiguous (forward / data-gradient) and token-major (weight-
