@@ -366,6 +366,36 @@ def test_unet_grads_oracle_and_autograd_bridge(dev, model, golden_dir, golden_ta
     model.zero_grad()
 
 
+@pytest.mark.parametrize("B", [5, 37])
+def test_train_step_form_equals_forward_plus_backward(dev, model, conv_mode, B):
+    """The train step takes F.mse_loss's backward and the output conv's gradients in the epilogue of the forward's last
+    launch and never writes h4 (default arithmetic; ConvArgs::o1_tgt); tdm_unet_fwd_f32(save) + tdm_unet_bwd_f32 over a given
+    d(loss)/d(eps) is the stand-alone form that reads h4.  Same d, same kernels otherwise: every gradient except the output
+    conv's is BIT-identical, the output conv's and the loss agree to summation order (src/mnist.py:156-159)."""
+    from tinydiffusionmodels_amd import unet_engine as E
+    flat = model.flat.detach()
+    g = torch.Generator().manual_seed(900 + B)
+    x0 = (torch.rand(B, 1, 28, 28, generator=g) * 2 - 1).to(dev)
+    t = torch.randint(0, 1000, (B,), generator=g).to(dev)
+    noise = torch.randn(B, 1, 28, 28, generator=g).to(dev)
+    st = E.TrainState(flat, B)
+    loss = E.loss_and_grad(flat, st, x0, noise, t).clone()
+    ws = E.UNetWorkspace(B, dev, training=True)
+    eps = E.unet_forward(flat, st.x_noisy, t, ws, save=True)
+    assert torch.equal(eps, st.eps)
+    deps = (eps - noise) * (2.0 / (B * 784))
+    assert torch.equal(deps, st.deps)                                    # the epilogue's d is F.mse_loss's backward, bit for bit
+    grads = E.unet_backward(flat, st.x_noisy, deps, ws)
+    a, b = E.state_dict_from_flat(st.grads), E.state_dict_from_flat(grads)
+    for k in a:
+        if k.startswith("out."):
+            assert O.rel_err(a[k], b[k]) < 2e-6, k
+        else:
+            assert torch.equal(a[k], b[k]), k
+    ref_loss = ((eps - noise).double() ** 2).mean().item()
+    assert abs(loss.item() - ref_loss) < 2e-6 * ref_loss
+
+
 def _mask_io(ws, B, block, which, mask=None):
     """Read (mask=None) or install the ReLU sign mask of block / conv `which` as a (B,C,H,W) uint8 tensor."""
     from tinydiffusionmodels_amd import _lib
