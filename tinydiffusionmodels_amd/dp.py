@@ -189,6 +189,9 @@ def graph_collective_ok() -> bool:
         _graph_ok, _graph_why = env == "1", f"TDM_GRAPH_COLLECTIVE={env}"
         return _graph_ok
     ok, why = True, "capture / replay / compare self-check passed"
+    g = None
+    # stage 1: capture.  Agreed on by all ranks BEFORE anyone replays: a rank whose capture failed would leave the others
+    # waiting inside the replayed collective.
     try:
         base = torch.arange(4096, device="cuda", dtype=torch.float32) * (rank + 1) + 0.5
         want = base.clone()
@@ -198,17 +201,25 @@ def graph_collective_ok() -> bool:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             comm.allreduce_sum_(buf)
-        for _ in range(2):
-            buf.copy_(base)
-            g.replay()
-            torch.cuda.synchronize()
-            if not torch.equal(buf, want):
-                ok, why = False, "captured all-reduce disagrees with torch.distributed"
-        del g
     except RuntimeError as e:
         ok, why = False, f"capture failed: {e}"
-    if not _all_ranks_ok(ok) and ok:
-        ok, why = False, "another rank's captured all-reduce failed its self-check"
+    if not _all_ranks_ok(ok):
+        if ok:
+            ok, why = False, "another rank could not capture the all-reduce"
+    else:
+        # stage 2: every rank replays the same number of times, then compares
+        try:
+            for _ in range(2):
+                buf.copy_(base)
+                g.replay()
+                torch.cuda.synchronize()
+                if not torch.equal(buf, want):
+                    ok, why = False, "captured all-reduce disagrees with torch.distributed"
+        except RuntimeError as e:
+            ok, why = False, f"replay failed: {e}"
+        if not _all_ranks_ok(ok) and ok:
+            ok, why = False, "another rank's captured all-reduce failed its self-check"
+    del g
     _graph_ok, _graph_why = ok, why
     if rank == 0:
         print(f"[tdm] train-step hipGraph {'includes' if ok else 'stops before'} the RCCL all-reduce ({why})", flush=True)
