@@ -188,7 +188,7 @@ int tdm_allreduce_sum_f32(tdm_ctx* ctx, float* buf, int64_t n, void* stream);
 int tdm_broadcast_f32(tdm_ctx* ctx, float* buf, int64_t n, int root, void* stream);
 
 /* ---- profiling: one launch of the train step at a time ------------------------
- * The default train step is ~45 launches; each has an id and a name.  After a full
+ * The default train step's forward + backward are 33 launches; each has an id and a name.  After a full
  * tdm_unet_loss_grad_f32 call, tdm_unet_replay_launch_f32 re-issues launch `id` alone with the
  * arguments it had inside the step (bench.py times every launch with events; PMC per kernel).   */
 int tdm_unet_launch_count(void);
