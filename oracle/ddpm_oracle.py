@@ -322,7 +322,7 @@ def transformer_init_params(dim: int, depth: int = 3, ffn: int = 2048, seed: int
 # generator; the product replaces that stream by a counter-based hash so that forward and
 # backward (and this oracle) can regenerate a mask from (seed, site, element index) alone:
 #   key  = hash32(seed_lo ^ hash32(seed_hi + 0x9E3779B9 * (site + 1)))
-#   u    = hash32(hash32(idx_lo ^ key) + idx_hi);  keep = u >= round(p * 2^32)
+#   u    = hash32((idx_lo ^ key) + 0x9E3779B9 * idx_hi);  keep = u >= round(p * 2^32)
 #   y    = x * (keep * (1 / (1 - p)))            -- torch's x * (mask / (1 - p))
 # with hash32 = the "lowbias32" finaliser.  Sites, in the order the reference's forward reaches
 # them: 0 input dropout; layer l: 1+4l attention probabilities (B,H,L,L), 2+4l dropout1 (B,L,D),
@@ -352,7 +352,7 @@ def dropout_keep(p: float, seed: int, site: int, shape, salt: int = 0) -> torch.
         idx = np.arange(n, dtype=np.uint64)
         lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
         hi = (idx >> np.uint64(32)).astype(np.uint32)
-        u = _hash32(_hash32(lo ^ key) + hi)
+        u = _hash32((lo ^ key) + hi * np.uint32(0x9E3779B9))
     return torch.from_numpy(u >= np.uint32(thr)).view(*shape)
 
 

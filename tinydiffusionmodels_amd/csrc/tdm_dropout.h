@@ -6,7 +6,7 @@
 // so forward and backward regenerate it in registers (nothing is stored) and the
 // CPU oracle recomputes the identical mask with integer arithmetic:
 //   key  = hash32(seed_lo ^ hash32(seed_hi + 0x9E3779B9 * (site + 1)))
-//   u    = hash32(hash32(idx_lo ^ key) + idx_hi)
+//   u    = hash32((idx_lo ^ key) + 0x9E3779B9 * idx_hi)      (one hash per element; idx_hi = 0 below 2^32 elements)
 //   keep = u >= thr,  thr = round(p * 2^32)  =>  P(keep) = 1 - p
 //   y    = keep ? x * (1 / (1 - p)) : 0                (torch: x * (mask / (1 - p)))
 // hash32 is the "lowbias32" integer finaliser.  Sites are numbered in the order the
@@ -38,7 +38,7 @@ __host__ __device__ __forceinline__ bool tdm_keep(const DropArgs& d, unsigned lo
 #ifdef __HIP_DEVICE_COMPILE__
     if (d.salt != nullptr) key ^= *d.salt;     // (uniform address: one scalar load, hoisted out of the element loops)
 #endif
-    const uint32_t u = tdm_hash32(tdm_hash32((uint32_t)idx ^ key) + (uint32_t)(idx >> 32));
+    const uint32_t u = tdm_hash32(((uint32_t)idx ^ key) + 0x9E3779B9U * (uint32_t)(idx >> 32));
     return u >= d.thr;
 }
 
