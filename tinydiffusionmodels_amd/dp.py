@@ -273,7 +273,7 @@ def allreduce_grads_(flat_grads: torch.Tensor) -> float:
 def allreduce_rows_(grad: torch.Tensor, ids: torch.Tensor) -> int:
     """Row-wise SUM over ranks of an embedding gradient grad[V][D] (row N1: nn.Embedding's gradient, src/shakespeare.py:60-86,
     is zero outside the token rows of the batch): only the rows some rank touched travel — the ranks exchange their
-    unique token ids (two small all-gathers), reduce the union's rows as one dense [U][D] buffer, and scatter it back.
+    unique token ids (a MAX all-reduce of their count + one all-gather), reduce the union's rows as one dense [U][D] buffer, and scatter it back.
     Exact: a row no rank touched is zero everywhere.  `ids`: this rank's token ids (any shape).  Returns U.
     At V = 50,257, D = 256 the dense gradient is 51 MB per step; a 32 x 128-token batch touches at most 4,096 rows (4 MB)."""
     _, world = world_info()
@@ -282,9 +282,8 @@ def allreduce_rows_(grad: torch.Tensor, ids: torch.Tensor) -> int:
         return int(torch.unique(ids).numel())
     local = torch.unique(ids.reshape(-1).to(grad.device))
     n = torch.tensor([local.numel()], dtype=torch.int64, device=grad.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    cap = int(max(int(s.item()) for s in sizes))
+    dist.all_reduce(n, op=dist.ReduceOp.MAX)                                   # one collective + ONE host read for the pad length
+    cap = int(n.item())
     padded = torch.full((cap,), V, dtype=torch.int64, device=grad.device)     # V = "no row"
     padded[:local.numel()] = local
     gathered = [torch.empty_like(padded) for _ in range(world)]
