@@ -467,7 +467,7 @@ class DenoiserTrainer:
 
     @property
     def steps_taken(self) -> int:
-        return int(self.step_state[0].item()) + self.state.step      # (host sync: checkpoints / tests only)
+        return int(self.step_state[0].item())      # (host sync: checkpoints / tests only)
 
     def _p_drop(self) -> float:
         return self.model.p_drop if self.model.training else 0.0   # model.train() -> the reference's dropout
@@ -481,7 +481,7 @@ class DenoiserTrainer:
     def step(self, x0, t=None, noise=None, lr: Optional[float] = None):
         st = self.state
         lr = self.lr if lr is None else lr
-        if t is not None or noise is not None:        # teacher-forced form (parity tests): host-side step count
+        if t is not None or noise is not None:        # teacher-forced form (parity tests)
             if t is None:
                 t = torch.randint(0, T, (x0.shape[0],), device=x0.device)
             if noise is None:
@@ -490,8 +490,8 @@ class DenoiserTrainer:
             seed = self.model.next_dropout_seed() if p_drop > 0.0 else 0
             loss = TE.tt_loss_and_grad(self.flat, st, x0, noise, t, p_drop=p_drop, seed=seed)
             scale = dp.allreduce_grads_(st.grads)
-            st.step += 1
-            E.adamw_step(self.flat, st.grads, st.m, st.v, self.steps_taken, lr, self.betas, self.eps, self.wd, grad_scale=scale)
+            # (the same device-side step count as the graph form: a trainer may mix teacher-forced and device-drawn steps)
+            E.adamw_step_dev(self.flat, st.grads, st.m, st.v, self.step_state, lr, self.betas, self.eps, self.wd, grad_scale=scale)
             return loss
         if not self.use_graph or st.warm < 1:          # first step eagerly (lazy kernel attributes, allocator warm-up)
             st.warm += 1
