@@ -567,7 +567,7 @@ class DDPMTrainer(DPStepper):
             if whole:
                 scale = dp.allreduce_grads_(self.grads)
                 self.optimizer_step(scale)
-        st.graph, st.graph_whole, st.graph_gen = g, whole, schedule_generation()
+        st.graph, st.graph_whole, st.graph_gen = g, whole, (schedule_generation(), float(self.lr), float(self.weight_decay))
 
     def step(self, x0: Optional[torch.Tensor], t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
              global_batch: Optional[int] = None):
@@ -581,7 +581,8 @@ class DDPMTrainer(DPStepper):
             return super().step(x0)
         if x0.data_ptr() != st.x0.data_ptr():
             st.x0.copy_(x0)      # the graph reads a fixed address
-        if st.graph is None or st.graph_gen != schedule_generation():   # (set_tables() retires the captured table addresses)
+        # (set_tables() retires the captured table addresses; lr / weight decay are kernel arguments baked into the graph)
+        if st.graph is None or st.graph_gen != (schedule_generation(), float(self.lr), float(self.weight_decay)):
             self._capture(st)
         st.graph.replay()
         if not st.graph_whole:
