@@ -632,12 +632,49 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
 }
 
 // Sb[b][d] = sum_l g[b][l][d]
+// (one workgroup per sequence; D / 4 column quads x 256 / (D / 4) row groups, four independent row chains per thread, row groups
+//  added in fixed order through LDS — one thread per column walking L dependent loads ran at 1 TB/s: 32 us for 34 MB)
 __global__ __launch_bounds__(256) void seqsum_kernel(const float* __restrict__ g, float* __restrict__ Sb, int L, int D) {
+    __shared__ float4 sh[256];
     const long b = blockIdx.x;
-    for (int d = threadIdx.x; d < D; d += 256) {
-        float acc = 0.f;
-        for (int l = 0; l < L; ++l) acc += g[(b * L + l) * D + d];
-        Sb[b * D + d] = acc;
+    const int D4 = D >> 2;
+    if ((D & 3) != 0 || D4 > 256 || (256 % D4) != 0) {   // odd widths: the plain form
+        for (int d = threadIdx.x; d < D; d += 256) {
+            float acc = 0.f;
+            for (int l = 0; l < L; ++l) acc += g[(b * L + l) * D + d];
+            Sb[b * D + d] = acc;
+        }
+        return;
+    }
+    const int R = 256 / D4, c4 = threadIdx.x % D4, rg = threadIdx.x / D4;
+    const float4* base = reinterpret_cast<const float4*>(g + b * L * D) + c4;
+    float4 a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int l = rg;
+    for (; l + 3 * R < L; l += 4 * R) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 v = base[(long)(l + u * R) * D4];
+            a[u].x += v.x; a[u].y += v.y; a[u].z += v.z; a[u].w += v.w;
+        }
+    }
+    for (; l < L; l += R) {
+        const float4 v = base[(long)l * D4];
+        a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w;
+    }
+    float4 t;
+    t.x = (a[0].x + a[1].x) + (a[2].x + a[3].x); t.y = (a[0].y + a[1].y) + (a[2].y + a[3].y);
+    t.z = (a[0].z + a[1].z) + (a[2].z + a[3].z); t.w = (a[0].w + a[1].w) + (a[2].w + a[3].w);
+    sh[threadIdx.x] = t;
+    __syncthreads();
+    if (rg == 0) {
+        float4 r = sh[c4];
+        for (int k = 1; k < R; ++k) {
+            const float4 o = sh[k * D4 + c4];
+            r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+        }
+        reinterpret_cast<float4*>(Sb + b * D)[c4] = r;
     }
 }
 
