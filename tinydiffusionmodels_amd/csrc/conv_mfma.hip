@@ -18,6 +18,8 @@
 // consecutive MFMAs.  The LDS pixel stride is 20 floats = 5 x 16 B (an odd
 // number of 16-B slots), which makes those reads bank-conflict free.
 #include "tdm_common.h"
+#include <cstdlib>
+#include <cstdint>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -378,6 +380,44 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     while (si + 1 < ra.nsec && (int)blockIdx.x >= ra.blk0[si + 1]) ++si;
     const ReduceSec s = ra.sec[si];
     if (s.stride_override != 0) stride = s.stride_override;
+    if (s.vec4) {   // wide shallow sections with aligned geometry: 64 element QUADS x 4 slab quarters, 16-byte loads
+        __shared__ float4 sh4[256];
+        const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+        const int i4 = ((int)blockIdx.x - ra.blk0[si]) * 64 + e;
+        float4 acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool in = i4 * 4 < s.len;
+        if (in) {
+            const float* p = slabs + s.off + s.src_delta + (long)i4 * 4;
+            int k = q;
+            for (; k + 12 < s.nslab; k += 16) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 v = *reinterpret_cast<const float4*>(p + (long)(k + 4 * u) * stride);
+                    acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+                }
+            }
+            for (; k < s.nslab; k += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(p + (long)k * stride);
+                acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+            }
+        }
+        float4 t;
+        t.x = (acc[0].x + acc[1].x) + (acc[2].x + acc[3].x); t.y = (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y);
+        t.z = (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z); t.w = (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w);
+        sh4[threadIdx.x] = t;
+        __syncthreads();
+        if (q == 0 && in) {
+            float4 r = sh4[e];
+            for (int qq = 1; qq < 4; ++qq) { const float4 o = sh4[qq * 64 + e]; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }   // fixed order
+            const float sc = s.scale != 0.f ? s.scale : 1.f;
+            r.x *= sc; r.y *= sc; r.z *= sc; r.w *= sc;
+            float* const d = s.dst != nullptr ? s.dst : out + s.off;
+            *reinterpret_cast<float4*>(d + (long)i4 * 4) = r;
+        }
+        return;
+    }
     const int epb = reduce_epb(s.nslab), nq = 256 / epb;
     const int e = threadIdx.x % epb, q = threadIdx.x / epb;
     {
@@ -453,7 +493,17 @@ int tdm_launch_reduce(const float* slabs, long stride, const ReduceArgs& ra, flo
     (void)maxlen;
     ReduceArgs rb = ra;
     int nb = 0;
-    for (int i = 0; i < ra.nsec; ++i) { const int epb = ra.sec[i].nslab > 256 ? 16 : 64; rb.blk0[i] = nb; nb += (ra.sec[i].len + epb - 1) / epb; }
+    static const bool allow_vec4 = [] { const char* e = getenv("TDM_REDUCE_VEC4"); return e == nullptr || atoi(e) != 0; }();
+    for (int i = 0; i < ra.nsec; ++i) {
+        ReduceSec& s = rb.sec[i];
+        const long sstride = s.stride_override != 0 ? s.stride_override : stride;
+        const float* dstp = s.dst != nullptr ? s.dst : out + s.off;
+        s.vec4 = allow_vec4 && s.nslab <= 256 && s.nslab >= 4 && s.len >= 4096 && (s.len & 3) == 0 && (sstride & 3) == 0 && s.outer_w == nullptr &&
+                 (((uintptr_t)(slabs + s.off + s.src_delta)) & 15) == 0 && (((uintptr_t)dstp) & 15) == 0;
+        const int epb = s.vec4 ? 256 : (s.nslab > 256 ? 16 : 64);
+        rb.blk0[i] = nb;
+        nb += (s.len + epb - 1) / epb;
+    }
     rb.blk0[ra.nsec] = nb;
     TDM_REQUIRE(nb >= 1, "reduce: empty sections");
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(nb), dim3(256), 0, st, slabs, stride, rb, out);

@@ -169,6 +169,7 @@ struct ReduceSec {
     // values r[i] * outer_w[j] to (dst ? dst : out + off)[i * outer_n + j] (rb4.skip's weight gradient, out_bwd_s16_kernel)
     const float* outer_w;
     int outer_n;
+    int vec4;              // set by tdm_launch_reduce: the section is walked with 16-byte loads (lengths / offsets / stride multiples of 4)
 };
 #define TDM_MAX_SECS 40
 struct ReduceArgs {
