@@ -14,6 +14,7 @@ store, barriers) and the collective backend of the CPU / shared-GPU rehearsals
 ("gloo")."""
 import ctypes
 import os
+import sys
 from typing import Optional, Tuple
 
 import torch
@@ -160,7 +161,7 @@ def native_comm() -> Optional[NativeComm]:
         _native_error, _native = err, None
         if rank == 0:
             print(f"[tdm] native RCCL communicator unavailable ({err}); gradients go through torch.distributed.all_reduce",
-                  flush=True)
+                  file=sys.stderr, flush=True)
     else:
         _native = comm
     return _native
@@ -222,7 +223,7 @@ def graph_collective_ok() -> bool:
     del g
     _graph_ok, _graph_why = ok, why
     if rank == 0:
-        print(f"[tdm] train-step hipGraph {'includes' if ok else 'stops before'} the RCCL all-reduce ({why})", flush=True)
+        print(f"[tdm] train-step hipGraph {'includes' if ok else 'stops before'} the RCCL all-reduce ({why})", file=sys.stderr, flush=True)
     return ok
 
 
