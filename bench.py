@@ -191,12 +191,62 @@ def time_events(fn, iters, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start N fresh worker processes of this script,
+    one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torchrun would), let rank 0's JSON line through to this
+    process's stdout and return the workers' worst exit code.  Runs BEFORE anything initialises HIP in this process
+    (torch.cuda.device_count() does not): the children are spawned, never exec'ed over a process that holds the GPU."""
+    import socket
+    import subprocess
+    share = os.environ.get("TDM_SHARE_GPU") == "1"       # rehearsal: all ranks on cuda:0 (collectives over gloo)
+    visible = torch.cuda.device_count()
+    if visible < 1:
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    if not share and visible < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {visible} GPU(s) visible on this host — refusing to report a "
+                         f"{n}-GPU number from fewer devices (TDM_SHARE_GPU=1 TDM_DIST_BACKEND=gloo rehearses the "
+                         f"multi-rank path on one GPU)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   TDM_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    limit = float(os.environ.get("TDM_BENCH_TIMEOUT", "1500"))
+    t0, rc = time.time(), 0
+    try:
+        while any(p.poll() is None for p in procs):
+            failed = [p for p in procs if p.poll() not in (None, 0)]
+            if failed or time.time() - t0 > limit:
+                rc = failed[0].returncode if failed else 124
+                print(f"[bench] {'a rank exited with ' + str(rc) if failed else 'timeout'}; stopping the other ranks",
+                      file=sys.stderr, flush=True)
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    return rc or max((abs(p.returncode or 0) for p in procs), default=0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--sample-steps", type=int, default=100, help="reverse steps timed at B=4096 (0 = skip)")
+    ap.add_argument("--sample-steps", type=int, default=100, help="reverse steps of the short (`quick`) chain timed at B=4096 (0 = skip)")
+    ap.add_argument("--sample-chains", type=int, default=3, help="complete 1000-step reverse chains timed at B=4096, median reported (0 = skip)")
     ap.add_argument("--text-steps", type=int, default=20, help="text-denoiser train steps timed (0 = skip)")
     ap.add_argument("--gemm-mode", type=int, default=1, choices=[0, 1, 2],
                     help="transformer linear layers of the headline text figure: 1 = bf16x3 split MFMA (parity path, default), "
@@ -208,10 +258,27 @@ def main():
                     help="UNet conv arithmetic: 2 = bf16x3 split MFMA over pre-split tensors (default), "
                          "1 = bf16x3 splitting while staging, 0 = exact fp32 MFMA")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
+    # ---- N ranks: either torchrun (the driver's N > 1 form) set WORLD_SIZE, or this process starts the ranks itself ----
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={os.environ['WORLD_SIZE']}: the flag and the "
+                         f"launcher disagree (torchrun --nproc-per-node N needs --gpus N)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # stdout carries exactly ONE line, the JSON of rank 0: whatever libraries print on fd 1 meanwhile (gloo's "[Gloo] Rank 0 is
+    # connected to ..." banner, RCCL debug output) is sent to stderr; the saved descriptor is used for the final print only
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    if os.environ.get("TDM_SHARE_GPU") != "1" and torch.cuda.device_count() < max(world, local_rank + 1):
+        raise SystemExit(f"bench.py: rank {rank} of {world} needs GPU {local_rank}, but only {torch.cuda.device_count()} "
+                         f"device(s) are visible")
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X; there is no CPU path")
     # TDM_DIST_BACKEND=gloo + TDM_SHARE_GPU=1: rehearsal of the multi-rank path on a one-GPU box
@@ -313,7 +380,7 @@ def main():
         "metric": "DDPM train steps/sec, MNIST UNet b=512/GPU (512-image steps summed over GPUs)",
         "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.conv_mode == 0 else "f32 (bf16x3 operands)",
         "arithmetic": "fp32 everywhere (fp32-input MFMA convs)" if args.conv_mode == 0 else
                       "fp32 tensors and accumulation; conv operands split into bf16 hi+lo, hi*hi + hi*lo + lo*hi on bf16 MFMA "
                       "(16 mantissa bits per operand, predicted noise within 2e-5 of the fp32 reference (1.3e-5 on the golden batch; bound 1e-3))",
@@ -397,10 +464,13 @@ def main():
         # (the rank-one skip gradient and the pair-summed output make the data gradient touch less than the algorithm names);
         # `traffic` = HBM bytes from the PMC passes of the round-end profile (profiles/r03_conv_traffic.json, per launch id).
         ALGO_CH = {9: 96 + 32 + 32, 16: 32 + 32 + 96, 3: 32 + 32 + 1, 10: 32 + 32 + 32 + 1, 13: 64, 29: 64}
-        traffic_by_id = {}
-        tpath = os.path.join(ROOT, "profiles", "r03_conv_traffic.json")
-        if os.path.exists(tpath):
-            traffic_by_id = {int(k): v for k, v in json.load(open(tpath)).get("by_launch_id", {}).items()}
+        traffic_by_id, traffic_src = {}, None
+        for tname in ("r04_conv_traffic.json", "r03_conv_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath):
+                traffic_by_id = {int(k): v for k, v in json.load(open(tpath)).get("by_launch_id", {}).items()}
+                traffic_src = f"profiles/{tname}: FETCH_SIZE x2 + WRITE_SIZE PMC passes of the round-end profile (NOT collected in this run)"
+                break
 
         def roof(r):
             kb = ALGO_CH.get(r["id"], 0) * 4 * 784 * B_TRAIN or r["bytes"]
@@ -408,11 +478,11 @@ def main():
             ach = kb / (ms_ * 1e-3) / 1e9
             tr = traffic_by_id.get(r["id"], {})
             return {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
-                    "traffic": tr.get("hbm_bytes_per_launch"), "kernel": r["launch"] + f", B={B_TRAIN}, in-pipeline arguments (launch id {r['id']})",
+                    "traffic": tr.get("hbm_bytes_per_launch"), "traffic_source": traffic_src if tr else None, "kernel": r["launch"] + f", B={B_TRAIN}, in-pipeline arguments (launch id {r['id']})",
                     "ms_per_launch": round(ms_, 4), "flop_per_launch": r["flop"], "algorithmic_bytes_per_launch": kb,
                     "tensor_bytes_per_launch": r["bytes"], "tensor_frac": r["hbm_frac"],
                     "mfma_tflops_bf16": round(3 * r["flop"] / (ms_ * 1e-3) / 1e12, 1), "mfma_peak_bf16": PEAK_BF16_MFMA_TFLOPS,
-                    "timing": "HIP events on the launch stream, 20 launches alternating two workspaces; profiles/r03_* hold the rocprofv3 "
+                    "timing": "HIP events on the launch stream, 20 launches alternating two workspaces; profiles/r04_* hold the rocprofv3 "
                               "kernel-trace average and the PMC passes of the same launch"}
         dom = max((r for r in rows if any(k in r["launch"] for k in MFMA_LAUNCH)), key=lambda r: r["us"])
         out["roofline"] = roof(dom)
@@ -439,28 +509,50 @@ def main():
         del tr0
         _lib.check(L.tdm_set_conv_mode(2))
 
-    # ---- 1000-step sampling rate at B=4096 (configs[3]); sharded over ranks, no collectives ----
-    if args.sample_steps > 0:
+    # ---- 1000-step sampling rate at B=4096 (configs[3]); chains sharded over ranks, no collectives.  SURVEY.md section 8d:
+    #      three COMPLETE 1000-step chains, median (`--sample-chains`); the short chain of `--sample-steps` reverse steps
+    #      is kept as `quick` (what rounds 1-3 reported, extrapolated) ----
+    if args.sample_steps > 0 or args.sample_chains > 0:
         xs = torch.randn(B_SAMPLE, 1, 28, 28, device=dev, generator=torch.Generator(device=dev).manual_seed(99 + rank))
-        with torch.no_grad():
-            reverse_diffusion(model, xs, t_start=args.sample_steps - 1)   # warm-up: captures the two-step hipGraph
-            sync()
-            t0 = time.perf_counter()
-            reverse_diffusion(model, xs, t_start=args.sample_steps - 1)
-            sync()
-            el = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = tt.item()
-        ms_rev = 1e3 * el / args.sample_steps
+
+        def chain(nsteps):
+            with torch.no_grad():
+                sync()
+                t0 = time.perf_counter()
+                reverse_diffusion(model, xs, t_start=nsteps - 1)
+                sync()
+                el = time.perf_counter() - t0
+            if world > 1:
+                tt = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = tt.item()
+            return el
+
         sbytes = 1_967_056 * B_SAMPLE + 725_892 + 4 * 784 * 4 * B_SAMPLE
-        out["sampling"] = {"batch_per_gpu": B_SAMPLE, "ms_per_reverse_step": round(ms_rev, 3),
-                           "reverse_steps_timed": args.sample_steps, "hipgraph": args.sample_steps >= 16,
-                           "noise": "Philox4x32-10 drawn inside the update kernel; step index in device memory",
-                           "imgs_per_s_1000_step": round(world * B_SAMPLE / (ms_rev * 1e-3 * 1000), 2),
-                           "tflops": round(FWD_FLOP_PER_SAMPLE * B_SAMPLE / (ms_rev * 1e-3) / 1e12, 2),
-                           "frac_hbm": round(sbytes / (ms_rev * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+        with torch.no_grad():
+            reverse_diffusion(model, xs, t_start=max(args.sample_steps, 16) - 1)   # warm-up: captures the two-step hipGraph
+        samp = {"batch_per_gpu": B_SAMPLE, "hipgraph": True,
+                "sharding": "chains sharded over ranks (B per rank fixed), no collective",
+                "noise": "Philox4x32-10 drawn inside the update kernel; step index in device memory"}
+        if args.sample_steps > 0:
+            ms_q = 1e3 * chain(args.sample_steps) / args.sample_steps
+            samp["quick"] = {"reverse_steps_timed": args.sample_steps, "ms_per_reverse_step": round(ms_q, 3),
+                             "imgs_per_s_1000_step_extrapolated": round(world * B_SAMPLE / ms_q, 2)}
+            ms_rev = ms_q
+        if args.sample_chains > 0:
+            els = sorted(chain(1000) for _ in range(args.sample_chains))
+            el_med = els[len(els) // 2]
+            ms_rev = el_med                     # seconds per 1000 steps == ms per reverse step
+            samp["full_chains"] = {"chains": args.sample_chains, "reverse_steps_each": 1000,
+                                   "seconds_each": [round(e, 4) for e in els], "median_s": round(el_med, 4)}
+        samp.update({"ms_per_reverse_step": round(ms_rev, 3),
+                     "reverse_steps_timed": 1000 if args.sample_chains > 0 else args.sample_steps,
+                     "imgs_per_s_1000_step": round(world * B_SAMPLE / ms_rev, 2),
+                     "measured": ("median of %d complete 1000-step chains" % args.sample_chains) if args.sample_chains > 0
+                                 else "extrapolated from the short chain",
+                     "tflops": round(FWD_FLOP_PER_SAMPLE * B_SAMPLE / (ms_rev * 1e-3) / 1e12, 2),
+                     "frac_hbm": round(sbytes / (ms_rev * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})
+        out["sampling"] = samp
         del xs
         model._samplers.clear()
 
@@ -568,7 +660,9 @@ def main():
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             cores = min(avail, 16)             # a 1-GPU box's CPU share is 16 cores
             out["cpu_baseline"] = cpu_baseline(cores)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     if world > 1:
         dist.barrier()
         dp.shutdown()

@@ -347,8 +347,8 @@ int tdm_layernorm_residual_bwd_f32(const float* dy, const float* s, const float*
  * forward reaches them: 0 input dropout (src/shakespeare.py:119); layer l: 1+4l attention
  * probabilities (B,H,L,L), 2+4l dropout1 (B,L,D), 3+4l FFN dropout (B,L,ffn), 4+4l dropout2. */
 int tdm_dropout_keep_u8(float p_drop, uint64_t seed, int site, int64_t idx0, int64_t n, uint8_t* keep_host);
-/* the same with the site key XORed with `salt` (what tdm_tt_loss_grad_philox_f32's kernels apply: salt = low word of the
- * advanced Philox offset)                                                                                            */
+/* the same with the site key salted, key' = hash32(key ^ salt * 0x9E3779B9) (what tdm_tt_loss_grad_philox_f32's kernels
+ * apply: salt = low word of the advanced Philox offset; any salt value, 0 included, gives a salted key)             */
 int tdm_dropout_keep_salted_u8(float p_drop, uint64_t seed, uint32_t salt, int site, int64_t idx0, int64_t n,
                                uint8_t* keep_host);
 /* ---- N1: learned embedding table and rounding head of the text train step

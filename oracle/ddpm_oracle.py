@@ -336,8 +336,9 @@ def _hash32(x):
     return x
 
 
-def dropout_keep(p: float, seed: int, site: int, shape, salt: int = 0) -> torch.Tensor:
-    """Boolean keep-mask of one dropout site (all True for p = 0)."""
+def dropout_keep(p: float, seed: int, site: int, shape, salt=None) -> torch.Tensor:
+    """Boolean keep-mask of one dropout site (all True for p = 0).  salt: None = the unsalted mask family; an int = the
+    per-step salt of the graph-replayed train step, mixed through the hash (tdm_dropout.h: tdm_salted_key)."""
     import numpy as np
     n = int(np.prod(shape))
     if not p > 0.0:
@@ -348,7 +349,8 @@ def dropout_keep(p: float, seed: int, site: int, shape, salt: int = 0) -> torch.
         seed_lo = np.array([seed & 0xFFFFFFFF], dtype=np.uint32)
         seed_hi = np.array([(seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
         key = _hash32(seed_lo ^ _hash32(seed_hi + np.uint32((0x9E3779B9 * (site + 1)) & 0xFFFFFFFF)))
-        key = key ^ np.uint32(salt & 0xFFFFFFFF)       # (DropArgs::salt: the device-drawn train step salts with its Philox offset)
+        if salt is not None:                           # (DropArgs::salt: the device-drawn train step salts with its Philox offset)
+            key = _hash32(key ^ np.array([(int(salt) * 0x9E3779B9) & 0xFFFFFFFF], dtype=np.uint32))
         idx = np.arange(n, dtype=np.uint64)
         lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
         hi = (idx >> np.uint64(32)).astype(np.uint32)
@@ -356,7 +358,7 @@ def dropout_keep(p: float, seed: int, site: int, shape, salt: int = 0) -> torch.
     return torch.from_numpy(u >= np.uint32(thr)).view(*shape)
 
 
-def _dropout(x: torch.Tensor, p: float, seed: int, site: int, salt: int = 0) -> torch.Tensor:
+def _dropout(x: torch.Tensor, p: float, seed: int, site: int, salt=None) -> torch.Tensor:
     if not p > 0.0:
         return x
     import numpy as np
@@ -366,7 +368,7 @@ def _dropout(x: torch.Tensor, p: float, seed: int, site: int, salt: int = 0) -> 
 
 def transformer_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor,
                         n_heads: int = 4, depth: int = 3, eps: float = 1e-5,
-                        p_drop: float = 0.0, seed: int = 0, salt: int = 0) -> torch.Tensor:
+                        p_drop: float = 0.0, seed: int = 0, salt=None) -> torch.Tensor:
     """src/shakespeare.py:115-120 with nn.TransformerEncoderLayer's defaults written out:
     post-LN, ReLU FFN, LayerNorm eps 1e-5, no mask, no positional encoding, no final
     norm.  p_drop = 0: eval mode; p_drop > 0: train mode with the hash-defined masks above.
@@ -395,7 +397,7 @@ def transformer_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.Te
 
 
 def transformer_loss_and_grads(p, x0, t, noise, tables, n_heads: int = 4, depth: int = 3,
-                               p_drop: float = 0.0, seed: int = 0, want_dx: bool = False, salt: int = 0):
+                               p_drop: float = 0.0, seed: int = 0, want_dx: bool = False, salt=None):
     """Denoiser part of src/shakespeare.py:230-236 (p_drop = 0: the eval-mode network)."""
     leaf = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
     x_noisy = q_sample(x0, t, noise, tables)

@@ -138,6 +138,40 @@ def test_transformer_train_mode_dropout(golden_dir, golden_tables, tag, dim):
     assert abs(keep.float().mean().item() - (1 - p_drop)) < 5e-3
 
 
+def test_salted_dropout_masks_of_consecutive_steps_are_independent():
+    """the graph-replayed text step salts its dropout masks with the Philox offset, which advances by 1 per step.
+    XORed into the key that made mask[s+1][i] == mask[s][i ^ (s ^ (s+1))] — one co-drop pattern, permuted, for the whole
+    run.  The salt now goes through the hash (tdm_dropout.h: tdm_salted_key; same integers here): consecutive steps' masks
+    are not XOR-translates of each other, per-block drop counts vary from step to step, the unsalted family (the golden
+    masks) is unchanged, and the library's host evaluation agrees with the oracle bit for bit."""
+    import ctypes
+    import numpy as np
+    p_drop, seed, site, n = 0.1, 0x1234ABCD5678EF01, 3, 1 << 14
+    masks = [O.dropout_keep(p_drop, seed, site, (n,), salt=s).numpy() for s in range(1000, 1009)]
+    idx = np.arange(n)
+    for a in range(len(masks) - 1):
+        sa, sb = 1000 + a, 1001 + a
+        assert not np.array_equal(masks[a + 1], masks[a][idx ^ (sa ^ sb)])          # the old failure, exactly
+        # ... and no other small XOR translation maps one step's mask to the next
+        assert all(not np.array_equal(masks[a + 1], masks[a][idx ^ c]) for c in range(64))
+        # agreement between consecutive steps is what independent Bernoulli(0.9) masks give: 0.9^2 + 0.1^2 = 0.82
+        assert abs((masks[a] == masks[a + 1]).mean() - 0.82) < 0.015
+    counts = np.stack([(~m).reshape(-1, 256).sum(axis=1) for m in masks])                # drops per 256-element block, per step
+    assert (counts.std(axis=0) > 0).mean() > 0.95                                        # (frozen under the XOR salt)
+    assert abs(counts.mean() - 25.6) < 1.0
+    # a salt of 0 is a salted key too; None is the unsalted family the goldens hold
+    assert not np.array_equal(O.dropout_keep(p_drop, seed, site, (n,), salt=0).numpy(), O.dropout_keep(p_drop, seed, site, (n,)).numpy())
+    from tinydiffusionmodels_amd import _lib
+    L = _lib.lib()
+    for salt in (0, 1, 1003, 0xFFFFFFFF):
+        keep = np.empty(4096, dtype=np.uint8)
+        _lib.check(L.tdm_dropout_keep_salted_u8(p_drop, seed, salt, site, 0, keep.size, keep.ctypes.data), "keep")
+        assert np.array_equal(keep.astype(bool), O.dropout_keep(p_drop, seed, site, (4096,), salt=salt).numpy()), salt
+    keep = np.empty(4096, dtype=np.uint8)
+    _lib.check(L.tdm_dropout_keep_u8(p_drop, seed, site, 0, keep.size, keep.ctypes.data), "keep")
+    assert np.array_equal(keep.astype(bool), O.dropout_keep(p_drop, seed, site, (4096,)).numpy())
+
+
 @pytest.mark.parametrize("tag", ["v1003", "v2048"])
 def test_text_head_oracle(golden_dir, tag):
     """Row N1: embedding lookup, rounding logits / cross-entropy / gradients / argmax of the oracle against

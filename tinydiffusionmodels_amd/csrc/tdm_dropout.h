@@ -6,6 +6,7 @@
 // so forward and backward regenerate it in registers (nothing is stored) and the
 // CPU oracle recomputes the identical mask with integer arithmetic:
 //   key  = hash32(seed_lo ^ hash32(seed_hi + 0x9E3779B9 * (site + 1)))
+//   key' = hash32(key ^ (salt * 0x9E3779B9))   when the step is salted (graph-replayed train step), key' = key otherwise
 //   u    = hash32((idx_lo ^ key) + 0x9E3779B9 * idx_hi)      (one hash per element; idx_hi = 0 below 2^32 elements)
 //   keep = u >= thr,  thr = round(p * 2^32)  =>  P(keep) = 1 - p
 //   y    = keep ? x * (1 / (1 - p)) : 0                (torch: x * (mask / (1 - p)))
@@ -20,9 +21,12 @@ struct DropArgs {
     uint32_t thr;   // 0 = dropout off
     uint32_t key;
     float scale;    // 1 / (1 - p)
-    // Optional per-step salt in DEVICE memory, XORed into the site key by the kernels: a hipGraph-captured train step bakes
+    // Optional per-step salt in DEVICE memory, mixed into the site key by the kernels: a hipGraph-captured train step bakes
     // `key` into its kernel arguments, so what changes from replay to replay has to be read from memory (the low word of the
     // step's Philox offset, tdm_tt_loss_grad_philox_f32).  nullptr (and always on the host) = unsalted.
+    // The salt goes THROUGH the hash (tdm_salted_key): the offset advances by 1 per step, and a salt merely XORed into the
+    // key made step s+1's mask an XOR-translate of step s's by the constant s ^ (s+1) — the same co-drop pattern, permuted,
+    // for the whole run.  Hashed, consecutive steps' keys are unrelated 32-bit values.
     const uint32_t* salt;
 };
 
@@ -33,10 +37,14 @@ __host__ __device__ __forceinline__ uint32_t tdm_hash32(uint32_t x) {
     return x;
 }
 
+__host__ __device__ __forceinline__ uint32_t tdm_salted_key(uint32_t key, uint32_t salt) {
+    return tdm_hash32(key ^ (salt * 0x9E3779B9U));
+}
+
 __host__ __device__ __forceinline__ bool tdm_keep(const DropArgs& d, unsigned long long idx) {
     uint32_t key = d.key;
 #ifdef __HIP_DEVICE_COMPILE__
-    if (d.salt != nullptr) key ^= *d.salt;     // (uniform address: one scalar load, hoisted out of the element loops)
+    if (d.salt != nullptr) key = tdm_salted_key(key, *d.salt);   // (uniform: one scalar load + scalar hash, hoisted out of the element loops)
 #endif
     const uint32_t u = tdm_hash32(((uint32_t)idx ^ key) + 0x9E3779B9U * (uint32_t)(idx >> 32));
     return u >= d.thr;

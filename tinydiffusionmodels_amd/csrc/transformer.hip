@@ -1149,16 +1149,19 @@ int tdm_layernorm_residual_bwd_f32(const float* dy, const float* s, const float*
 }
 
 // keep[i] = 1 if element idx0 + i of dropout site `site` survives (the mask the kernels regenerate in registers)
-int tdm_dropout_keep_u8(float p_drop, uint64_t seed, int site, int64_t idx0, int64_t n, uint8_t* keep_host) {
-    return tdm_dropout_keep_salted_u8(p_drop, seed, 0u, site, idx0, n, keep_host);
-}
-// ... with the site key salted (DropArgs::salt: the device-drawn train step salts with the low word of its Philox offset)
-int tdm_dropout_keep_salted_u8(float p_drop, uint64_t seed, uint32_t salt, int site, int64_t idx0, int64_t n, uint8_t* keep_host) {
+static int dropout_keep_host(float p_drop, uint64_t seed, bool salted, uint32_t salt, int site, int64_t idx0, int64_t n, uint8_t* keep_host) {
     TDM_REQUIRE(p_drop >= 0.f && p_drop < 1.f && keep_host != nullptr && n >= 0, "dropout_keep: bad arguments");
     DropArgs d = tdm_drop_site(p_drop, seed, site);
-    d.key ^= salt;
+    if (salted) d.key = tdm_salted_key(d.key, salt);
     for (int64_t i = 0; i < n; ++i) keep_host[i] = (d.thr == 0u || tdm_keep(d, (unsigned long long)(idx0 + i))) ? 1 : 0;
     return 0;
+}
+int tdm_dropout_keep_u8(float p_drop, uint64_t seed, int site, int64_t idx0, int64_t n, uint8_t* keep_host) {
+    return dropout_keep_host(p_drop, seed, false, 0u, site, idx0, n, keep_host);
+}
+// ... with the site key salted THROUGH the hash (tdm_salted_key; DropArgs::salt: the device-drawn train step salts with the low word of its Philox offset)
+int tdm_dropout_keep_salted_u8(float p_drop, uint64_t seed, uint32_t salt, int site, int64_t idx0, int64_t n, uint8_t* keep_host) {
+    return dropout_keep_host(p_drop, seed, true, salt, site, idx0, n, keep_host);
 }
 
 // out (S16, tdm_s16.h) = split of in, n % 16 == 0 elements: every 16 consecutive floats become hi[16] | lo[16] bf16

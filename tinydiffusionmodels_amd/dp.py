@@ -173,21 +173,26 @@ _graph_why: str = ""
 
 def graph_collective_ok() -> bool:
     """May the train step's all-reduce be CAPTURED into the step's hipGraph (one host call per step at world > 1)?
-    TDM_GRAPH_COLLECTIVE=0 / 1 forces the answer; the default ("auto") is a self-check, run once per process and agreed on by
-    all ranks (MIN): the native RCCL all-reduce of a probe buffer is captured on a side graph, replayed twice and compared with
-    torch.distributed's result.  Anything short of a clean pass on EVERY rank keeps the three-call form (graph replay,
-    all-reduce, AdamW), with the reason reported by collective_name()."""
+    Default (TDM_GRAPH_COLLECTIVE unset or 0): NO — the proven three-call form (graph replay, all-reduce, AdamW).  The
+    in-graph collective has never run on a multi-GPU node, and its self-check cannot catch a HANG inside a captured or
+    replayed RCCL call, which would stall every multi-GPU job at its second step; it is therefore opt-in until one real
+    multi-GPU run has recorded the self-check passing.  TDM_GRAPH_COLLECTIVE=1 forces it on; =auto runs the self-check,
+    once per process and agreed on by all ranks (MIN): the native RCCL all-reduce of a probe buffer is captured on a side
+    graph, replayed twice and compared with torch.distributed's result; anything short of a clean pass on EVERY rank keeps
+    the three-call form, with the reason reported by collective_name()."""
     global _graph_ok, _graph_why
     if _graph_ok is not None:
         return _graph_ok
     rank, world = world_info()
-    env = os.environ.get("TDM_GRAPH_COLLECTIVE", "auto")
+    env = os.environ.get("TDM_GRAPH_COLLECTIVE", "0")
     comm = native_comm() if world > 1 else None
     if world == 1 or comm is None:
         _graph_ok, _graph_why = False, "no native communicator"
         return False
     if env in ("0", "1"):
-        _graph_ok, _graph_why = env == "1", f"TDM_GRAPH_COLLECTIVE={env}"
+        _graph_ok = env == "1"
+        _graph_why = (f"TDM_GRAPH_COLLECTIVE={env}" if "TDM_GRAPH_COLLECTIVE" in os.environ else
+                      "default: the in-graph collective is opt-in (TDM_GRAPH_COLLECTIVE=1 or auto) until a multi-GPU run has verified it")
         return _graph_ok
     ok, why = True, "capture / replay / compare self-check passed"
     g = None
@@ -300,9 +305,15 @@ def allreduce_rows_(grad: torch.Tensor, ids: torch.Tensor) -> int:
 
 
 def broadcast_params_(flat_params: torch.Tensor, src: int = 0) -> None:
+    """Replicas start from rank `src`'s weights: `tdm_broadcast_f32` (RCCL behind the C ABI) when the native communicator
+    is up and the buffer is a contiguous fp32 device tensor, torch.distributed otherwise (gloo rehearsals, CPU tests)."""
     _, world = world_info()
     if world > 1:
-        dist.broadcast(flat_params, src=src)
+        comm = native_comm() if flat_params.is_cuda else None
+        if comm is not None and flat_params.dtype == torch.float32 and flat_params.is_contiguous():
+            comm.broadcast_(flat_params, src)
+        else:
+            dist.broadcast(flat_params, src=src)
 
 
 def shard_chains(n_total: int, rank: int, world: int) -> Tuple[int, int]:

@@ -491,9 +491,10 @@ class DDPMTrainer(DPStepper):
     With t / noise left to the trainer the whole step is ONE hipGraph replay: the draws come from a
     device-side Philox stream, AdamW's step count lives in device memory, nothing is written by the host
     (`graph=False` or TDM_TRAIN_GRAPH=0 runs the same launches eagerly).  At world > 1 the graph ends before
-    the collective (replay, all-reduce, AdamW = three host calls per step) unless dp.graph_collective_ok(): by default a
-    capture / replay / compare self-check of the native RCCL all-reduce that every rank must pass — then the all-reduce and
-    AdamW are captured too and a step is ONE host call at any world size (TDM_GRAPH_COLLECTIVE=0 / 1 forces it).  Explicit t / noise (teacher forcing, parity tests) run eagerly.
+    the collective (replay, all-reduce, AdamW = three host calls per step; the default) unless dp.graph_collective_ok():
+    opt-in (TDM_GRAPH_COLLECTIVE=1, or =auto for a capture / replay / compare self-check of the native RCCL all-reduce
+    that every rank must pass) — then the all-reduce and AdamW are captured too and a step is ONE host call at any
+    world size; unverified on hardware, hence not the default.  Explicit t / noise (teacher forcing, parity tests) run eagerly.
     One trainer serves every batch size (workspaces per size, optimiser state shared), and its constructor
     issues no collective unless `broadcast` (default: rank 0's weights to every replica, once)."""
 
