@@ -351,6 +351,19 @@ int tdm_dropout_keep_u8(float p_drop, uint64_t seed, int site, int64_t idx0, int
  * apply: salt = low word of the advanced Philox offset; any salt value, 0 included, gives a salted key)             */
 int tdm_dropout_keep_salted_u8(float p_drop, uint64_t seed, uint32_t salt, int site, int64_t idx0, int64_t n,
                                uint8_t* keep_host);
+/* Fused feed-forward chain of one encoder layer (src/shakespeare.py:108-111: linear1 -> ReLU -> dropout -> linear2) and of
+ * its data gradient, hidden tile in registers (csrc/ffn_chain.hip).  All matrix operands are S16 (tdm_split_s16_f32):
+ * x16 (M,256), wa16 (F,256), wb16 (256,F); y (M,256) fp32.  D must be 256, F a multiple of 32 (<= 2048).
+ *   mode 0: y = relu(x wa^T + bias_a) wb^T + bias_b                              (inference: no dropout)
+ *   mode 1: y = drop_out(drop_mid(relu(x wa^T + bias_a)) wb^T + bias_b)         (dropout sites site_mid / site_out of `seed`),
+ *           and mid16 (M,F) S16 = the hidden activation, mask = its sign bits (tdm_ffn_chain_mask_count 32-bit words)
+ *   mode 2: mid16 = (x wa^T) where the mask bit is set, times gate_scale, else 0;  y = mid wb^T   (biases / dropout unused)
+ * nprod 3 = bf16x3 split operands (parity arithmetic), 1 = plain bf16.                                              */
+int tdm_ffn_chain_f32(int mode, int nprod, const float* x16, const float* wa16, const float* bias_a, const float* wb16,
+                      const float* bias_b, float* y, float* mid16, uint32_t* mask, float gate_scale, float p_drop,
+                      uint64_t seed, int site_mid, int site_out, int64_t M, int D, int F, void* stream);
+int64_t tdm_ffn_chain_mask_count(int64_t M, int F);
+int tdm_ffn_chain_set_ablate(int bits);   /* timing diagnostics of tools/time_ffn.py (results are wrong when nonzero) */
 /* ---- N1: learned embedding table and rounding head of the text train step
  *      (src/shakespeare.py:46-102 modules, :225-243 train step, :387-390 decode) ----
  * table (V,D) fp32, ids (M,) int64 token ids in [0,V), W (V,D) / b (V,) = LearnedRounding.decoder.  */

@@ -105,6 +105,10 @@ _SIGS = {
     "tdm_broadcast_f32": ([c_f, c_f, c_i64, c_int, c_f], c_int),
     "tdm_cosine_argmax_f32": ([c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_f], c_int),
     "tdm_split_s16_f32": ([c_f, c_f, c_i64, c_f], c_int),
+    "tdm_ffn_chain_f32": ([c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_float, c_float, c_u64, c_int, c_int,
+                           c_i64, c_int, c_int, c_f], c_int),
+    "tdm_ffn_chain_mask_count": ([c_i64, c_int], c_i64),
+    "tdm_ffn_chain_set_ablate": ([c_int], c_int),
     "tdm_gemm_f32": ([c_f, c_i64, c_i64, c_f, c_i64, c_i64, c_f, c_i64, c_f, c_f, c_int, c_int, c_int, c_int, c_int,
                       c_i64, c_f], c_int),
 }

@@ -20,6 +20,8 @@ CFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", INCLUDE,
           # HIP defaults to -ffp-contract=fast; the bit-exact elementwise kernels (q_sample, p_sample update,
           # AdamW) must round every mul/add separately like the reference's ATen ops. FMAs are explicit (fmaf).
           "-ffp-contract=off"]
+# TDM_BUILD_DEFINES="-DTDM_DIAG": the diagnostic build (runtime ablation bits / phase probes in the hot kernels, tools/ only)
+CFLAGS += os.environ.get("TDM_BUILD_DEFINES", "").split()
 
 
 def _sources():

@@ -61,3 +61,11 @@ int tdm_launch_attn_mfma(int which, int hd, const float* qkv, const float* o, co
 // out16 != nullptr: the S16 twin of `out` is written too (backward: `out` may then be nullptr)
 int tdm_launch_attn_bf16(int which, int hd, const float* qkv, const float* o, const float* lse, const float* dO, float* out,
                          float* out16, float* aux, long B, int L, int D, int H, DropArgs dr, hipStream_t st);
+
+// Fused FFN chain (ffn_chain.hip): Y = mid(X Wa^T) Wb^T with the hidden tile in registers.  D must be 256, F % 32 == 0.
+// mode 0 forward (inference), 1 forward + hidden S16 / sign masks saved, 2 data gradient (gate by the saved masks)
+bool tdm_ffn_chain_ok(long M, int D, int F);
+int64_t tdm_ffn_chain_mask_elems(int64_t M, int F);   // 32-bit words of the sign-mask buffer
+int tdm_launch_ffn_chain(int mode, int nprod, const float* X16, const float* Wa16, const float* bias_a, const float* Wb16,
+                         const float* bias_b, float* Y, float* mid16, unsigned* mask, float gate_scale, DropArgs drop_mid,
+                         DropArgs drop_out, long M, int D, int F, hipStream_t st);

@@ -92,9 +92,10 @@ TTLayout tt_layout(int D, int depth, int F) {
 struct LayerWs {
     float *hin, *qkv, *o, *lse, *s1, *mean1, *rstd1, *h1, *f1, *s2, *mean2, *rstd2;
     float *hin16, *o16, *h1_16;   // S16 twins of the GEMM operands (bf16 GEMM modes; f1 itself is S16 there)
+    unsigned* fmask;              // sign masks of the FFN hidden activation (fused chain, ffn_chain.hip)
 };
 struct TTWs {
-    float *that, *tb, *abuf, *wT;
+    float *that, *tb, *abuf, *wT, *wT2;
     LayerWs L[8];
     // backward temporaries
     float *g_h, *g_s, *g_s1, *g_d, *g_f, *g_h1, *g_o, *g_qkv, *Dvec, *Sb, *part;
@@ -112,12 +113,14 @@ TTWs tt_carve(float* base, long B, int Lq, int D, int H, int depth, int F, int t
     const long M = B * Lq;
     w.that = take(B); w.tb = take(B * D); w.abuf = take(M * D);
     w.wT = take((long)(F > 3 * D ? F : 3 * D) * D);   // transposed weight of the current data-gradient GEMM
+    w.wT2 = take((long)F * D);                        // second transposed weight of the fused FFN data gradient
     for (int l = 0; l < depth; ++l) {
         LayerWs& x = w.L[l];
         x.hin = take(M * D); x.qkv = take(M * 3 * D); x.o = take(M * D); x.lse = take(B * H * Lq);
         x.s1 = take(M * D); x.mean1 = take(M); x.rstd1 = take(M); x.h1 = take(M * D); x.f1 = take(M * F);
         x.s2 = take(M * D); x.mean2 = take(M); x.rstd2 = take(M);
         x.hin16 = take(M * D); x.o16 = take(M * D); x.h1_16 = take(M * D);
+        x.fmask = reinterpret_cast<unsigned*>(take(tdm_ffn_chain_mask_elems(M, F)));
     }
     w.P16 = take(tt_layout(D, depth, F).total);
     if (training) {
@@ -743,6 +746,12 @@ int attn_dispatch(int which, int hd, const float* qkv, const float* o, const flo
 // pieces into LDS instead of converting: a row panel is re-read by N / 128 column tiles and by the weight-gradient GEMM, the
 // split happens once.  Needs D and the FFN width to be multiples of 16; otherwise (and in the fp32 GEMM mode) the fp32 path.
 inline bool tt_use16(int D, int F) { return g_gemm_mode != 0 && (D % 16) == 0 && (F % 16) == 0; }
+// linear1 -> ReLU -> dropout -> linear2 (and their data gradients) as ONE launch with the hidden tile in registers (ffn_chain.hip);
+// TDM_FFN_FUSED=0 keeps the two GEMM launches (A/B timing)
+inline bool tt_fused_ffn(long M, int D, int F) {
+    static const bool on = !(getenv("TDM_FFN_FUSED") && atoi(getenv("TDM_FFN_FUSED")) == 0);
+    return on && tt_use16(D, F) && tdm_ffn_chain_ok(M, D, F);
+}
 
 // Y[M][N] = dropout(relu(X[M][K] W[N][K]^T + bias (+res)));  s16: X and W are S16;  Y16: S16 twin of Y (Y may be nullptr)
 int linear_fwd(const float* X, const float* W, const float* bias, const float* res, float* Y, float* Y16, bool s16, long M,
@@ -846,7 +855,7 @@ int tt_check(long B, int L, int D, int H, int depth, int F) {
 }
 
 int tt_forward(const float* P, const TTLayout& lay, const float* x, const int64_t* t, float* out, const TTWs& w, long B,
-               int L, int D, int H, int depth, int F, Drop drop, hipStream_t st) {
+               int L, int D, int H, int depth, int F, Drop drop, hipStream_t st, bool save = true) {
     const long M = B * L;
     const DropArgs none{};
     const bool s16 = tt_use16(D, F);
@@ -870,10 +879,19 @@ int tt_forward(const float* P, const TTLayout& lay, const float* x, const int64_
         TDM_TRY(linear_fwd(s16 ? a.o16 : a.o, PW + o.out_w, P + o.out_b, nullptr, w.abuf, nullptr, s16, M, D, D, 0,
                            drop.site(2 + 4 * l), st));
         TDM_TRY(ln_fwd(a.hin, w.abuf, P + o.n1_w, P + o.n1_b, a.h1, s16 ? a.h1_16 : nullptr, a.s1, a.mean1, a.rstd1, M, D, st));
+        if (tt_fused_ffn(M, D, F)) {
+            // the hidden activation stays in registers; training additionally writes it once as S16 (for linear2's weight
+            // gradient) with its sign masks (the ReLU / dropout gate of the data gradient)
+            const bool keep = save || drop.p > 0.f;
+            TDM_TRY(tdm_launch_ffn_chain(keep ? 1 : 0, g_gemm_mode == 1 ? 3 : 1, a.h1_16, PW + o.l1_w, P + o.l1_b, PW + o.l2_w,
+                                         P + o.l2_b, w.abuf, keep ? a.f1 : nullptr, keep ? a.fmask : nullptr, 1.f,
+                                         drop.site(3 + 4 * l), drop.site(4 + 4 * l), M, D, F, st));
+        } else {
         // the FFN hidden activation: S16 only in the bf16 GEMM modes (read by linear2, its weight gradient and the ReLU gate)
         TDM_TRY(linear_fwd(s16 ? a.h1_16 : a.h1, PW + o.l1_w, P + o.l1_b, nullptr, s16 ? nullptr : a.f1, s16 ? a.f1 : nullptr, s16,
                            M, F, D, 1, drop.site(3 + 4 * l), st));
         TDM_TRY(linear_fwd(a.f1, PW + o.l2_w, P + o.l2_b, nullptr, w.abuf, nullptr, s16, M, D, F, 0, drop.site(4 + 4 * l), st));
+        }
         TDM_TRY(ln_fwd(a.h1, w.abuf, P + o.n2_w, P + o.n2_b, hout, hout16, a.s2, a.mean2, a.rstd2, M, D, st));
     }
     return 0;
@@ -897,13 +915,21 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
         const float* g2 = s16 ? w.g16 : (dropping ? w.g_d : w.g_s);
         // f2 = f1 W2^T + b2, f1 = dropout(relu(z1)): d(z1) = (g2 W2) * [f1 > 0] / (1 - p) in the GEMM epilogue
         TDM_TRY(linear_wgrad(g2, a.f1, slabs + sp.base[l][3], nullptr, s16, M, D, F, st));
+        const bool chain = tt_fused_ffn(M, D, F);
+        if (chain) {
+            // d(z1) = (g2 W2) gated by the saved sign masks, d(h1) = d(z1) W1: one launch, d(z1) written once (S16) for W1's gradient
+            TDM_TRY(tdm_launch_transpose_s16(P + o.l2_w, w.wT, D, F, st));    // W2^T: [F][D]
+            TDM_TRY(tdm_launch_transpose_s16(P + o.l1_w, w.wT2, F, D, st));   // W1^T: [D][F]
+            TDM_TRY(tdm_launch_ffn_chain(2, g_gemm_mode == 1 ? 3 : 1, g2, w.wT, nullptr, w.wT2, nullptr, w.g_h1, w.g_f, a.fmask,
+                                         dropping ? drop.site(3 + 4 * l).scale : 1.f, DropArgs{}, DropArgs{}, M, D, F, st));
+        } else
         TDM_TRY(linear_dgrad(g2, P + o.l2_w, w.wT, nullptr, a.f1, dropping ? drop.site(3 + 4 * l).scale : 1.f, s16 ? nullptr : w.g_f,
                              s16 ? w.g_f : nullptr, s16, M, D, F, st));
         // z1 = h1 W1^T + b1
         if (!fused_bias) TDM_TRY(bias_grad(w.g_f, w.part, G + o.l1_b, M, F, st));
         TDM_TRY(linear_wgrad(w.g_f, s16 ? a.h1_16 : a.h1, slabs + sp.base[l][2], fused_bias ? slabs + sp.bias_base[l][2] : nullptr,
                              s16, M, F, D, st));
-        TDM_TRY(linear_dgrad(w.g_f, P + o.l1_w, w.wT, nullptr, nullptr, 1.f, w.g_h1, nullptr, s16, M, F, D, st));
+        if (!chain) TDM_TRY(linear_dgrad(w.g_f, P + o.l1_w, w.wT, nullptr, nullptr, 1.f, w.g_h1, nullptr, s16, M, F, D, st));
         // LayerNorm 1: h1 = LN(hin + dropout1(a)); d(h1) = g_h1 (FFN path) + g_s (residual)
         TDM_TRY(ln_bwd(w.g_h1, w.g_s, a.s1, a.mean1, a.rstd1, P + o.n1_w, w.g_s1, (dropping && !s16) ? w.g_d : nullptr,
                        s16 ? w.g16 : nullptr, dropping, drop.site(2 + 4 * l), w.part, G, o.n1_w, o.out_b, M, D, st));
@@ -993,7 +1019,7 @@ int tdm_tt_fwd_f32(const float* params, const float* x, const int64_t* t, float*
     TDM_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "tt_fwd: dropout probability %g outside [0, 1)", (double)p_drop);
     const TTLayout lay = tt_layout(D, depth, ffn);
     const TTWs w = tt_carve(ws, B, L, D, H, depth, ffn, save);
-    return tt_forward(params, lay, x, t, out, w, B, L, D, H, depth, ffn, Drop{p_drop, seed}, (hipStream_t)stream);
+    return tt_forward(params, lay, x, t, out, w, B, L, D, H, depth, ffn, Drop{p_drop, seed}, (hipStream_t)stream, save != 0);
 }
 
 int tdm_tt_bwd_f32(const float* params, const float* dout, float* grads, float* dx, float* ws, float* slabs, int64_t B,
@@ -1057,7 +1083,7 @@ int tdm_tt_p_sample_step_f32(const float* params, const float* x, const int64_t*
     TDM_REQUIRE(params && x && t && eps && x_out && ws, "tt_p_sample_step: NULL pointer");
     const TTLayout lay = tt_layout(D, depth, ffn);
     const TTWs w = tt_carve(ws, B, L, D, H, depth, ffn, 0);
-    TDM_TRY(tt_forward(params, lay, x, t, eps, w, B, L, D, H, depth, ffn, Drop{0.f, 0}, (hipStream_t)stream));
+    TDM_TRY(tt_forward(params, lay, x, t, eps, w, B, L, D, H, depth, ffn, Drop{0.f, 0}, (hipStream_t)stream, false));
     return tdm_p_sample_update_f32(x, eps, t_index == 0 ? nullptr : noise, tab_recip, tab_eps, tab_sigma, t_index, x_out,
                                    B * L * D, stream);
 }
@@ -1072,7 +1098,7 @@ int tdm_tt_p_sample_step_philox_f32(const float* params, const float* x, int64_t
     TDM_REQUIRE(params && x && t_dev && eps && x_out && ws && rng_state, "tt_p_sample_step_philox: NULL pointer");
     const TTLayout lay = tt_layout(D, depth, ffn);
     const TTWs w = tt_carve(ws, B, L, D, H, depth, ffn, 0);
-    TDM_TRY(tt_forward(params, lay, x, t_dev, eps, w, B, L, D, H, depth, ffn, Drop{0.f, 0}, (hipStream_t)stream));
+    TDM_TRY(tt_forward(params, lay, x, t_dev, eps, w, B, L, D, H, depth, ffn, Drop{0.f, 0}, (hipStream_t)stream, false));
     return tdm_p_sample_update_philox_f32(x, eps, tab_recip, tab_eps, tab_sigma0, t_dev, seed, rng_state, x_out, B,
                                           (int64_t)L * D, stream);
 }
