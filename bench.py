@@ -254,9 +254,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-table", action="store_true", help="skip the per-launch replay timing")
     ap.add_argument("--no-graph", action="store_true", help="issue the train step's launches eagerly instead of one hipGraph replay")
-    ap.add_argument("--conv-mode", type=int, default=2, choices=[0, 1, 2],
-                    help="UNet conv arithmetic: 2 = bf16x3 split MFMA over pre-split tensors (default), "
-                         "1 = bf16x3 splitting while staging, 0 = exact fp32 MFMA")
+    ap.add_argument("--conv-mode", type=int, default=2, choices=[0, 2],
+                    help="UNet conv arithmetic: 2 = bf16x3 split MFMA over pre-split tensors (default), 0 = exact fp32 MFMA")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

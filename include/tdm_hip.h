@@ -226,23 +226,18 @@ int tdm_resblock_fwd_f32(const float* x, const float* that, const float* c1w, co
 
 /* Arithmetic of the UNet's MFMA convolutions (forward, data and weight gradient):
  *   0  exact fp32 (v_mfma_f32_32x32x2_f32, bitwise an fp32 fmaf chain)
- *   1  bf16x3 split operands on v_mfma_f32_32x32x16_bf16 (hi*hi + hi*lo + lo*hi,
- *      fp32 accumulate; ~1e-5 relative, 3/16 of the fp32 MFMA cycles); fp32
- *      tensors are split while staging
- *   2  same arithmetic over pre-split "S16" tensors (bf16 hi/lo per 16-channel
- *      group, same 4 B/element) that the producing kernels write — loaders are
- *      plain 16-byte copies — default
+ *   2  bf16x3 split operands on v_mfma_f32_32x32x16_bf16 (hi*hi + hi*lo + lo*hi,
+ *      fp32 accumulate; ~1e-5 relative, 3/16 of the fp32 MFMA cycles) over
+ *      pre-split "S16" tensors (bf16 hi/lo per 16-channel group, same
+ *      4 B/element) that the producing kernels write — loaders are plain
+ *      16-byte copies — default
+ *   (1, the same arithmetic with fp32 tensors split while staging, was superseded
+ *    by 2 in round 1 and is no longer built: tdm_set_conv_mode(1) fails)
  * The three arithmetic selectors (conv / gemm / attention mode) are THREAD-LOCAL: they configure the calls the calling
  * thread makes afterwards, every thread starts in the default arithmetic, and the library keeps no process-global mutable
  * state (a process's only shared object is an explicit tdm_ctx).                                                  */
 int tdm_set_conv_mode(int mode);
 int tdm_get_conv_mode(void);
-/* same contract as tdm_conv_nhwc_f32 through the bf16x3 kernel;
- * scratch >= ksize*ksize*Cin*Cout floats (pre-packed hi/lo weights)          */
-int tdm_conv_nhwc_bf16x3_f32(const float* in, const float* w, const float* bias, const float* res,
-                             const float* tb, float* out, float* aux_relu_out, float* scratch,
-                             int64_t B, int HW, int Cin, int Cout, int ksize, int flags, void* stream);
-
 /* per-layer entry points of the S16 pipeline (tests / profiling): the fp32 input is
  * pre-split into scratch first.  conv: scratch >= k*k*Cin*Cout + B*HW*HW*Cin + 64 floats;
  * out_s16 (optional, S16 layout: every 16-channel group = 16 bf16 hi then 16 bf16 lo)

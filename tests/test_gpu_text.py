@@ -604,6 +604,30 @@ def test_full_size_properties_config5(dev, gemm_mode):
     del st, st64
 
 
+def test_config5_forward_vs_oracle_on_a_slice(dev, golden_tables, gemm_mode):
+    """Predicted noise at config 5's size (B = 256, L = 128, D = 256: the fused-FFN / ring-GEMM / bf16x3-attention kernels at
+    the shape bench.py times) against the CPU oracle on an 8-sequence slice — the oracle runs those 8 sequences alone, the
+    HIP path all 256 (sequences are independent; src/shakespeare.py:115-120).  bf16x3 (the parity arithmetic) and fp32 are
+    held to 2e-4 (north_star's bound: 1e-3); plain bf16 operands (config 5's literal "bf16 MFMA") sit at ~3e-3 — OUTSIDE
+    north_star's bound, asserted at 1e-2 and labelled as such."""
+    dim, B, L = 256, 256, 128
+    p = O.transformer_init_params(dim, seed=7)
+    m = _model(dim, dev)
+    m.eval()
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, L, dim, generator=g) * 0.7
+    t = torch.randint(0, 1000, (B,), generator=g)
+    sl = slice(120, 128)
+    with torch.no_grad():
+        got = m(x.to(dev), t.to(dev))[sl].cpu()
+    err = O.rel_err(got, O.transformer_forward(p, x[sl], t[sl]))
+    print(f"config-5 forward vs oracle (8-sequence slice), gemm mode {gemm_mode}: {err:.2e}")
+    if gemm_mode == 2:
+        assert err < 1e-2          # plain bf16 operands: outside north_star's 1e-3 (reported, not the parity path)
+    else:
+        assert err < 2e-4
+
+
 def test_train_step_on_ring_kernels_vs_oracle(dev, golden_tables, gemm_mode):
     """A denoiser train step large enough for every K-contiguous linear layer product to run on the LDS-DMA ring kernel
     (gemm_ring.hip; 8,192 tokens) against the CPU oracle: loss and every gradient."""

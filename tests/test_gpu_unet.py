@@ -34,10 +34,11 @@ def _gtol():
     difference flips the sign of a few near-zero ReLU pre-activations relative to
     the reference; every flipped mask entry moves weight gradients by
     O(1/sqrt(#pixels)) (measured 1.8e-3 at B=37, falling as 1/sqrt(B)), so
-    gradients are held to 5e-3 there — the kernels themselves are pinned at 5e-5
-    by the per-layer tests and by the fp32 mode of this same test."""
+    gradients are held to 2.5e-3 there (round 4: what is measured at B >= 37 — 5.9e-4 at B = 37, 6e-4 at B = 512,
+    profiles/r04_parity.json — plus margin; it was 5e-3) — the kernels themselves are pinned at 5e-5
+    by the per-layer tests and by the fp32 mode of this same test, and at 2e-4 with the oracle's masks teacher-forced."""
     from tinydiffusionmodels_amd import _lib
-    return 5e-5 if _lib.lib().tdm_get_conv_mode() == 0 else 5e-3
+    return 5e-5 if _lib.lib().tdm_get_conv_mode() == 0 else 2.5e-3
 
 
 def _load(golden_dir, name):
@@ -65,7 +66,7 @@ def pinned_tables(golden_tables):
     schedule.set_tables(None)
 
 
-@pytest.fixture(scope="module", autouse=True, params=[2, 1, 0], ids=["bf16x3-s16", "bf16x3", "fp32"])
+@pytest.fixture(scope="module", autouse=True, params=[2, 0], ids=["bf16x3-s16", "fp32"])
 def conv_mode(request):
     """Run every test of this module under both conv arithmetics (include/tdm_hip.h: tdm_set_conv_mode)."""
     from tinydiffusionmodels_amd import _lib
@@ -142,10 +143,6 @@ def _run_conv(lib, conv_mode, dev, args, scratch_floats, B, hw, cin, cout, k, fl
     from tinydiffusionmodels_amd import _lib
     if conv_mode == 0:
         _lib.check(lib.tdm_conv_nhwc_f32(*[_lib.ptr(a) for a in args], B, hw, cin, cout, k, flags, _lib.stream()))
-    elif conv_mode == 1:
-        scratch = torch.empty(scratch_floats, device=dev)
-        _lib.check(lib.tdm_conv_nhwc_bf16x3_f32(*[_lib.ptr(a) for a in args], _lib.ptr(scratch), B, hw, cin, cout, k,
-                                                flags, _lib.stream()))
     else:   # S16 pipeline: also returns the pre-split copy of (result + tb_out)
         scratch = torch.empty(scratch_floats + B * hw * hw * cin + 128, device=dev)
         out_s16 = torch.zeros(B, hw, hw, cout, device=dev)
@@ -538,6 +535,35 @@ def test_reverse_chain_and_uint8_golden(dev, model, golden_dir):
     # end to end from shared noise: count differing pixels
     _, u8_e2e = to_image_range(x_end)
     assert (u8_e2e.cpu() != O.to_uint8(g["chain.x01"])).sum().item() == 0
+
+
+def test_eps_vs_oracle_at_the_benchmarked_sizes(dev, model, conv_mode, golden_tables):
+    """north_star's parity clause at the sizes bench.py times, against the CPU oracle itself (not the HIP path against itself):
+    predicted noise of the TRAIN forward at B = 512 (config 2; x_t = q_sample(x0, t, noise), src/mnist.py:156-157), and of one
+    REVERSE step at B = 4096 (config 4; src/mnist.py:174) on a 64-image slice — the oracle runs those 64 images alone, the
+    HIP path runs all 4096 (images are independent).  Bound 1e-3 relative; asserted at the usual 2e-4 / 2e-5."""
+    from tinydiffusionmodels_amd.mnist import q_sample
+    p = {k: v.cpu() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(77)
+    B = 512
+    x0 = torch.rand(B, 1, 28, 28, generator=g) * 2 - 1
+    t = torch.randint(0, 1000, (B,), generator=g)
+    noise = torch.randn(B, 1, 28, 28, generator=g)
+    with torch.no_grad():
+        xq = q_sample(x0.to(dev), t.to(dev), noise.to(dev))
+        eps = model(xq, t.to(dev)).cpu()
+    ref = O.unet_forward(p, O.q_sample(x0, t, noise, golden_tables), t)
+    e512 = O.rel_err(eps, ref)
+    B = 4096
+    x = torch.randn(B, 1, 28, 28, generator=g)
+    tt = torch.full((B,), 417, dtype=torch.long)
+    sl = slice(2000, 2064)
+    with torch.no_grad():
+        eps4096 = model(x.to(dev), tt.to(dev))[sl].cpu()
+    e4096 = O.rel_err(eps4096, O.unet_forward(p, x[sl], tt[sl]))
+    print(f"eps vs oracle: B=512 train forward {e512:.2e}, 64-image slice of a B=4096 reverse step {e4096:.2e}")
+    assert e512 < _tol() and e4096 < _tol()
+    assert max(e512, e4096) < NORTH_STAR_TOL
 
 
 def test_full_size_properties_b512(dev, model):

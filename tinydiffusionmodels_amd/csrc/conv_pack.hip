@@ -1,0 +1,49 @@
+// Weight pre-pack of the bf16x3 convolution kernels (conv_s16.hip): fp32 HWIO -> bf16 hi / lo planes in MFMA fragment
+// order, for the forward and for the transposed convolution, once per call, so that staging a K chunk of weights is a linear
+// 16-byte copy and the conv kernel itself is direction-agnostic.  (The kernels that split their ACTIVATIONS while staging —
+// "conv mode 1", round 1 — were superseded by the pre-split S16 pipeline and are no longer built: DESIGN.md section 4.)
+#include "tdm_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// weight pre-pack: fp32 HWIO -> bf16 hi/lo in MFMA B-fragment order
+//   forward : B[k = ci][n = co] = W[tap][ci][co]            chunks over ci
+//   dgrad   : B[k = co][n = ci] = W[8-tap][ci][co] (3x3)    chunks over co
+// element (chunk, tap, nt, part, lane, j):  n = nt*32 + (lane&31),  k = chunk*16 + 8*(lane>>5) + j
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ P, PackArgs pa,
+                                                           unsigned short* __restrict__ out) {
+    const PackDesc d = pa.d[blockIdx.y];
+    const int K = d.dgrad ? d.cout : d.cin;       // contraction length
+    const int Nn = d.dgrad ? d.cin : d.cout;      // output channels of this direction
+    const int NT = Nn / 32;
+    const int total = (K / 16) * d.taps * NT * 512;   // (hi, lo) pairs
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int jj = e & 7;
+        const int lane = (e >> 3) & 63;
+        int r = e >> 9;
+        const int nt = r % NT; r /= NT;
+        const int tap = r % d.taps; r /= d.taps;
+        const int chunk = r;
+        const int n = nt * 32 + (lane & 31);
+        const int k = chunk * 16 + 8 * (lane >> 5) + jj;
+        float x;
+        if (!d.dgrad) x = P[d.src_off + (long)(tap * d.cin + k) * d.cout + n];
+        else x = P[d.src_off + (long)((d.taps == 9 ? 8 - tap : 0) * d.cin + n) * d.cout + k];
+        const __bf16 hi = (__bf16)x;
+        const __bf16 lo = (__bf16)(x - (float)hi);
+        const long base = d.dst_off + ((long)((chunk * d.taps + tap) * NT + nt) * 2) * 512 + lane * 8 + jj;
+        out[base] = __builtin_bit_cast(unsigned short, hi);
+        out[base + 512] = __builtin_bit_cast(unsigned short, lo);
+    }
+}
+
+}  // namespace
+
+int tdm_launch_pack(const float* params, const PackArgs& pa, unsigned short* out, hipStream_t st) {
+    TDM_REQUIRE(pa.n >= 1 && pa.n <= TDM_MAX_PACK, "pack: %d descriptors", pa.n);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(36, pa.n), dim3(256), 0, st, params, pa, out);
+    TDM_CHECK_LAUNCH("pack_weights");
+    return 0;
+}

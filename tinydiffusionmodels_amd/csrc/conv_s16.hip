@@ -100,11 +100,14 @@ struct PinnedArgs {
     const unsigned short* skip_wp;
     __device__ __forceinline__ explicit PinnedArgs(const ConvArgs& k) {
         s0.load(k.src[0]); s1.load(k.src[1]);
-        nsrc = k.nsrc; relu = k.relu; B = k.B; ablate = k.ablate; tb_out_stride = k.tb_out_stride;
+        nsrc = k.nsrc; relu = k.relu; B = k.B; ablate = TDM_ABLATE(k.ablate); tb_out_stride = k.tb_out_stride;
         bias = k.bias; res = k.res; tb_out = k.tb_out; skip_bias = k.skip_bias;
         out = k.out; aux = k.aux; out_s16 = k.out_s16; sums = k.sums; skip_out = k.skip_out;
         mask_out = k.mask_out; relu_mask_in = k.relu_mask_in; skip_wp = k.skip_wp;
-        TDM_PIN(nsrc); TDM_PIN(relu); TDM_PIN(B); TDM_PIN(ablate); TDM_PIN(tb_out_stride);
+        TDM_PIN(nsrc); TDM_PIN(relu); TDM_PIN(B); TDM_PIN(tb_out_stride);
+#if TDM_DIAG_BUILD
+        TDM_PIN(ablate);
+#endif
         TDM_PIN(bias); TDM_PIN(res); TDM_PIN(tb_out); TDM_PIN(skip_bias);
         TDM_PIN(out); TDM_PIN(aux); TDM_PIN(out_s16); TDM_PIN(sums); TDM_PIN(skip_out);
         TDM_PIN(mask_out); TDM_PIN(relu_mask_in); TDM_PIN(skip_wp);
@@ -750,7 +753,8 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     const long Mtot = (long)a.B * G::H * G::W;
     const int ntiles = (int)((Mtot + TILE_PX * MT - 1) / (TILE_PX * MT));
     // ablate & 32 (probe): one workgroup per CU (LDS request > half of 160 KB) — phase times without a co-resident workgroup
-    const size_t lds_req = (a.ablate & 32) ? (size_t)110000 : lds;
+    const size_t lds_req = (TDM_ABLATE(a.ablate) & 32) ? (size_t)110000 : lds;
+#if TDM_DIAG_BUILD
     if constexpr (HW == 28 && NT == 1 && !SKIP && MT == 1) {
         if (a.ablate & 16) {   // the instrumented instantiation (diagnostics only)
             static bool probe_attr = false;
@@ -764,6 +768,7 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st) {
             return 0;
         }
     }
+#endif
     if constexpr (HW == 28 && NT == 1 && !SKIP && MT == 1) {
         if (a.o1_tgt != nullptr) {   // rb4.conv2 of a train step: output conv + MSE backward in the epilogue
             static bool mse_attr = false;
@@ -1138,7 +1143,7 @@ int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st) {
                                          ((long)a.B * 784) % 2 == 0),
                 "conv_s16: the paired d cat epilogue is built for the 28x28 N = 96 data gradient alone");
     TDM_REQUIRE(a.o1_tgt == nullptr || (a.o1_out != nullptr && a.o1_deps != nullptr && a.o1_sums != nullptr &&
-                                        a.r1_x == nullptr && a.relu_mask_in == nullptr && (a.ablate & 16) == 0),
+                                        a.r1_x == nullptr && a.relu_mask_in == nullptr && (TDM_ABLATE(a.ablate) & 16) == 0),
                 "conv_s16: the fused MSE backward needs the fused output conv, a deps buffer and the partial rows (and neither "
                 "the rank-1 residual nor a ReLU backward)");
     TDM_REQUIRE(a.o1_out == nullptr || (hw == 28 && N == 32 && a.skip_out == nullptr && a.o1_w != nullptr && a.o1_b != nullptr),

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(NT_THREADS, (WM == 1 ? 4 : 2)) void gemm_nt_bf16_ke
 
         for (int c = 0; c < nchunk; ++c) {
             __syncthreads();
-            if (!(g.ablate & 8) || c == 0) {
+            if (!(TDM_ABLATE(g.ablate) & 8) || c == 0) {
 #pragma unroll
                 for (int p = 0; p < NPA; ++p) {
                     const int f = tid + NT_THREADS * p;
@@ -226,11 +226,11 @@ __global__ __launch_bounds__(NT_THREADS, (WM == 1 ? 4 : 2)) void gemm_nt_bf16_ke
                 }
             }
             __syncthreads();
-            if (!(g.ablate & 1)) {
+            if (!(TDM_ABLATE(g.ablate) & 1)) {
                 if (c + 1 < nchunk) gload(tile, (c + 1) * BK);
                 else if (tile + 1 < t_end) gload(tile + 1, 0);
             }
-            if (g.ablate & 2) continue;
+            if (TDM_ABLATE(g.ablate) & 2) continue;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 xh[WM], xl[WM], wh[2], wl[2];
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(NT_THREADS, (WM == 1 ? 4 : 2)) void gemm_nt_bf16_ke
                         if (tg >= 0 && tg < 4 && tg < nq) g.ce_tgt[m] = lv[tg];
                     }
                 }
-                if (m < g.M && nq > 0 && nq < 4 && !(g.ablate & 4)) {   // ragged last quad (N % 4 != 0): plain epilogue
+                if (m < g.M && nq > 0 && nq < 4 && !(TDM_ABLATE(g.ablate) & 4)) {   // ragged last quad (N % 4 != 0): plain epilogue
                     const long o = (long)m * g.c_rs + n;
                     const float vv[3] = {v.x + bz.x, v.y + bz.y, v.z + bz.z};
                     for (int e = 0; e < nq; ++e) {
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(NT_THREADS, (WM == 1 ? 4 : 2)) void gemm_nt_bf16_ke
                             u = tdm_keep(g.drop, (unsigned long long)m * (unsigned)g.N + (unsigned)(n + e)) ? u * g.drop.scale : 0.f;
                         if (g.C != nullptr) g.C[o + e] = u;
                     }
-                } else if (m < g.M && nq >= 4 && !(g.ablate & 4)) {
+                } else if (m < g.M && nq >= 4 && !(TDM_ABLATE(g.ablate) & 4)) {
                     const long o = (long)m * g.c_rs + n;
                     v.x += bz.x; v.y += bz.y; v.z += bz.z; v.w += bz.w;
                     if (g.res != nullptr) {

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(WMS * 128, 2) void gemm_nt_ring_kernel(GemmArgs g, 
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] = tdm_keep(g.drop, e0 + e) ? v[e] * g.drop.scale : 0.f;
                         }
-                        if (g.ablate & 4) {   // timing diagnostics: the epilogue's arithmetic without its stores
+                        if (TDM_ABLATE(g.ablate) & 4) {   // timing diagnostics: the epilogue's arithmetic without its stores
                             float keep = 0.f;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) keep += v[e];
@@ -305,21 +305,21 @@ __global__ __launch_bounds__(WMS * 128, 2) void gemm_nt_ring_kernel(GemmArgs g, 
         if (behind > 0) --behind;
         __builtin_amdgcn_s_barrier();             // ... and every wave has finished reading stage (s - 1) % NSTAGE
         char* const st = lds + (s % NSTAGE) * STAGE;
-        const bool more = s + D < total && !(g.ablate & 1);   // pair s + D goes into the stage pair s - 1 occupied (free since the barrier)
+        const bool more = s + D < total && !(TDM_ABLATE(g.ablate) & 1);   // pair s + D goes into the stage pair s - 1 occupied (free since the barrier)
         // (requesting both K steps' fragments before the first MFMA was measured: K loop unchanged (81 -> 80 us), whole kernel
         //  153 -> 173 us on the N = 2048 layer — the longer live ranges cost the epilogue more than the loop gains)
-        if (!(g.ablate & 2)) kstep(st, 0);
+        if (!(TDM_ABLATE(g.ablate) & 2)) kstep(st, 0);
         if (more) issue_a(s + D);
-        if (!(g.ablate & 2)) kstep(st, 1);
+        if (!(TDM_ABLATE(g.ablate) & 2)) kstep(st, 1);
         if (more) issue_b();
         if (++cur_chunk == nchunk) {
             __builtin_amdgcn_s_barrier();         // all waves are done with the tile's last stage: it becomes the transpose space
             const int i0 = (cur_tile / ntx) * RM, j0 = (cur_tile % ntx) * RN;
             const bool interior = i0 + RM <= g.M && j0 + RN <= g.N;
-            if (!(g.ablate & 8)) epilogue(cur_tile, st);
+            if (!(TDM_ABLATE(g.ablate) & 8)) epilogue(cur_tile, st);
             zero_acc();
             cur_chunk = 0; cur_tile += qx;
-            if (loads_free && interior && estores > 0 && !(g.ablate & 12)) behind = D;
+            if (loads_free && interior && estores > 0 && !(TDM_ABLATE(g.ablate) & 12)) behind = D;
             else wait_vm<0>();                    // (ragged tile or loads in the epilogue: drain, keep the counts exact)
         }
     }

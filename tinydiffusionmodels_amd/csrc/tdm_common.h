@@ -24,6 +24,17 @@ void tdm_set_error(const char* fmt, ...);
         }                                      \
     } while (0)
 
+// Timing diagnostics (runtime `ablate` bits, shader-clock phase probes) exist in DIAGNOSTIC builds only
+// (TDM_BUILD_DEFINES=-DTDM_DIAG python -m tinydiffusionmodels_amd.build; tools/ablate_*.py, tools/phase_probe.py, tools/time_ring.py
+// --ablate): in the product build TDM_ABLATE(x) is the constant 0, so the hot kernels carry no diagnostic branch or register.
+#ifdef TDM_DIAG
+#define TDM_ABLATE(x) (x)
+#define TDM_DIAG_BUILD 1
+#else
+#define TDM_ABLATE(x) 0
+#define TDM_DIAG_BUILD 0
+#endif
+
 #define TDM_TRY(expr)               \
     do {                            \
         int rc__ = (expr);          \
@@ -121,8 +132,7 @@ struct ConvArgs {
 // hw in {28,14}; N in {32,64,96}; dgrad: transposed convolution with the forward weights
 int tdm_launch_conv(const ConvArgs& a, int hw, int N, bool dgrad, hipStream_t st);
 
-// bf16x3 split-operand variant (direction-agnostic: the pre-pack encodes fwd / dgrad)
-int tdm_launch_conv_bf16(const ConvArgs& a, int hw, int N, hipStream_t st);
+// weight pre-pack of the bf16x3 kernels (conv_pack.hip; direction-agnostic kernels: the pre-pack encodes fwd / dgrad)
 struct PackDesc { int src_off, cin, cout, taps, dgrad; long dst_off; };
 #define TDM_MAX_PACK 24
 struct PackArgs { PackDesc d[TDM_MAX_PACK]; int n; };
@@ -155,7 +165,6 @@ struct WgradArgs {
     int w_off2;
 };
 int tdm_launch_wgrad(const WgradArgs& a, int hw, int nslab, hipStream_t st);
-int tdm_launch_wgrad_bf16(const WgradArgs& a, int hw, int nslab, hipStream_t st);   // bf16x3 split operands
 int tdm_launch_wgrad_s16(const WgradArgs& a, int hw, int nslab, hipStream_t st);    // a.a.ptr and a.g are S16; no bias
 
 // slab reduction: out[off+i] = sum_s slab[s*stride + off + i]

@@ -164,7 +164,6 @@ ConvSrc mk_src(const float* ptr, int C, int c0, int nch, int up, int taps, const
 }
 
 int launch_conv_any(const ConvArgs& a, int hw, int N, bool dgrad, hipStream_t st) {
-    if (g_conv_mode == 1) return tdm_launch_conv_bf16(a, hw, N, st);
     return tdm_launch_conv(a, hw, N, dgrad, st);
 }
 
@@ -195,7 +194,6 @@ int wgrad(hipStream_t st, int hw, int B, const float* act, int C, int c_used, in
     const long M = (long)B * hw * hw;
     a.ntiles = (int)((M + 255) / 256);
     a.nci = c_used / 32;
-    if (g_conv_mode == 1) return tdm_launch_wgrad_bf16(a, hw, nslab, st);
     return tdm_launch_wgrad(a, hw, nslab, st);
 }
 
@@ -217,7 +215,6 @@ int unet_forward(const float* P, const float* x, const int64_t* t, float* eps, c
     const int teb[4] = {kL.rb[0].teb, kL.rb[1].teb, kL.rb[2].teb, kL.rb[3].teb};
     TDM_TRY(tdm_launch_timebias(t, P, tew, teb, w.that, w.tb, B, st));
     const BlockOff &r1 = kL.rb[0], &r2 = kL.rb[1], &r3 = kL.rb[2], &r4 = kL.rb[3];
-    if (g_conv_mode == 1) TDM_TRY(tdm_launch_pack(P, kPack.pa, w.wpack, st));
     // rb1 (1 -> 32 @ 28x28)
     TDM_TRY(tdm_launch_conv_first(x, P + r1.c1w, P + r1.c1b, P + r1.skw, P + r1.skb, w.a1_1, w.s1, B, st));
     TDM_TRY(conv1(st, w, 28, B, w.a1_1, 32, 9, P + r1.c2w, W_RB1C2, 32, P + r1.c2b, 1, w.tb + 0, w.s1,
@@ -729,37 +726,12 @@ int tdm_unet_replay_launch_f32(const float* params, const float* x_noisy, const 
 }
 
 int tdm_set_conv_mode(int mode) {
-    TDM_REQUIRE(mode >= 0 && mode <= 2, "conv mode %d (0 = fp32 MFMA, 1 = bf16x3, 2 = bf16x3 over pre-split tensors)", mode);
+    TDM_REQUIRE(mode == 0 || mode == 2, "conv mode %d (0 = exact fp32 MFMA, 2 = bf16x3 over pre-split tensors; mode 1, the "
+                "in-loader split, was superseded by mode 2 and is no longer built)", mode);
     g_conv_mode = mode;
     return 0;
 }
 int tdm_get_conv_mode(void) { return g_conv_mode; }
-
-// generic conv through the bf16x3 kernel: scratch >= ksize*ksize*Cin*Cout floats (packed hi/lo weights)
-int tdm_conv_nhwc_bf16x3_f32(const float* in, const float* w, const float* bias, const float* res, const float* tb,
-                             float* out, float* aux_relu_out, float* scratch, int64_t B, int HW, int Cin, int Cout,
-                             int ksize, int flags, void* stream) {
-    TDM_CHECK_B(B);
-    TDM_REQUIRE(ksize == 3 || ksize == 1, "conv: ksize %d", ksize);
-    TDM_REQUIRE(scratch != nullptr, "conv_bf16x3: scratch is NULL");
-    const bool dgrad = (flags & 2) != 0;
-    const int taps = ksize * ksize;
-    // forward weight tensor is [taps][wcin][wcout]; for dgrad the call's (Cin, Cout) are (wcout, wcin)
-    const int wcin = dgrad ? Cout : Cin, wcout = dgrad ? Cin : Cout;
-    PackArgs pa{};
-    pa.n = 1;
-    pa.d[0].src_off = 0; pa.d[0].cin = wcin; pa.d[0].cout = wcout; pa.d[0].taps = taps; pa.d[0].dgrad = dgrad ? 1 : 0;
-    pa.d[0].dst_off = 0;
-    unsigned short* wp = reinterpret_cast<unsigned short*>(scratch);
-    TDM_TRY(tdm_launch_pack(w, pa, wp, (hipStream_t)stream));
-    ConvArgs a{};
-    a.nsrc = 1;
-    a.src[0] = mk_src(in, Cin, 0, Cin, 0, taps, w, 0, 0, 0, tb, wp, 0);
-    a.src[0].tb_stride = Cin;
-    a.bias = bias; a.res = res; a.out = out; a.aux = aux_relu_out; a.relu = flags & 1; a.B = (int)B;
-    a.ablate = (flags >> 8) & 0xffff;   // timing diagnostics only (results are wrong when set)
-    return tdm_launch_conv_bf16(a, HW, Cout, (hipStream_t)stream);
-}
 
 // generic conv through the S16 pipeline: the fp32 input (+tb) is pre-split into scratch, then conv_s16 runs.
 // scratch >= ksize^2*Cin*Cout + B*HW*HW*Cin floats.  out_s16 (optional) receives split(result + tb_out).
@@ -854,8 +826,7 @@ int tdm_conv_wgrad_nhwc_f32(const float* in, const float* tb, const float* dout,
     a.g = dout; a.Cout = Cout; a.slab = slabs; a.slab_stride = stride; a.w_off = 0; a.b_off = wlen; a.B = (int)B;
     a.ntiles = (int)(((long)B * HW * HW + 255) / 256);
     a.nci = Cin / 32;
-    if (g_conv_mode == 1) TDM_TRY(tdm_launch_wgrad_bf16(a, HW, nslab, (hipStream_t)stream));
-    else TDM_TRY(tdm_launch_wgrad(a, HW, nslab, (hipStream_t)stream));
+    TDM_TRY(tdm_launch_wgrad(a, HW, nslab, (hipStream_t)stream));
     ReduceArgs ra{};
     ra.nsec = 1;
     ra.sec[0].off = 0; ra.sec[0].len = wlen + Cout; ra.sec[0].nslab = nslab;
@@ -905,7 +876,6 @@ int tdm_resblock_fwd_f32(const float* x, const float* that, const float* c1w, co
     auto conv = [&](const float* in, const float* w, const float* bias, const float* res, const float* tbi, float* o, int ci,
                     int k, int relu) -> int {
         if (g_conv_mode == 0) return tdm_conv_nhwc_f32(in, w, bias, res, tbi, o, nullptr, B, HW, ci, Cout, k, relu, stream);
-        if (g_conv_mode == 1) return tdm_conv_nhwc_bf16x3_f32(in, w, bias, res, tbi, o, nullptr, cs, B, HW, ci, Cout, k, relu, stream);
         return tdm_conv_nhwc_s16_f32(in, w, bias, res, tbi, o, nullptr, nullptr, nullptr, cs, B, HW, ci, Cout, k, relu, stream);
     };
     TDM_TRY(tdm_launch_timebias_float(that, tew, teb, tb, (int)B, Cout, st));

@@ -1,15 +1,167 @@
-"""Achieved forward / gradient error of the default (bf16x3, S16) pipeline against the committed goldens."""
-import sys, numpy as np, torch
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
-from tinydiffusionmodels_amd import unet_engine as E, mnist
-from oracle import ddpm_oracle as O
-dev = torch.device("cuda:0")
-g = {k: torch.from_numpy(v) for k, v in np.load("tests/golden/unet_forward.npz").items()}
-model = mnist.SimpleUNet().to(dev)
-sd = {k[2:]: v for k, v in g.items() if k.startswith("w.")}
-model.load_state_dict(sd)
-x, t = g["x_noisy"].to(dev), g["t"].to(dev)
-ws = E.UNetWorkspace(x.shape[0], dev, training=True)
-eps = E.unet_forward(model.flat.detach(), x, t, ws, save=True)
-print("forward rel err (max|d| / max|ref|):", {k: float(O.rel_err(E.get_activation(ws, k).cpu(), g[k])) for k in ("h1", "h2", "h3", "h4")},
-      "eps", float(O.rel_err(eps.cpu(), g["eps"])))
+#!/usr/bin/env python3
+"""Measured parity of the HIP path against the CPU oracle / the committed goldens, written where a reader can see it
+("weak" #1 / "next" #6):  python tools/parity_report.py [--out profiles/r04_parity.json]
+
+All errors are max|d| / max|ref| per tensor ("rel fp32" of BASELINE.json) unless named rel-L2.  north_star's bound: 1e-3 on
+the predicted noise; integer-valued outputs bit-exact.  The oracle (oracle/ddpm_oracle.py) is the checker here, never the
+thing measured."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ddpm_oracle as O                                    # noqa: E402  (checker)
+from tinydiffusionmodels_amd import _lib, schedule, unet_engine as E   # noqa: E402
+from tinydiffusionmodels_amd import mnist                              # noqa: E402
+
+
+def load(name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(ROOT, "tests", "golden", name)).items()}
+
+
+def mask_io(ws, B, blk, which, put=None):
+    HW, C = [(784, 32), (196, 64), (196, 64), (784, 32)][blk]
+    buf = put if put is not None else torch.empty(B, C, int(HW ** 0.5), int(HW ** 0.5), dtype=torch.uint8, device=ws.ws.device)
+    _lib.check(_lib.lib().tdm_unet_relu_mask_io(_lib.ptr(ws.ws), B, blk, which, _lib.ptr(buf), 1 if put is not None else 0,
+                                                _lib.stream()), "relu_mask_io")
+    return buf
+
+
+def unet_report(dev):
+    out = {}
+    g = load("unet_forward.npz")
+    tabs = load("schedule.npz")
+    schedule.set_tables(tabs)                      # the golden host's tables (torch.sqrt differs by 1 ulp between hosts)
+    model = mnist.SimpleUNet().to(dev)
+    sd = {k[2:]: v for k, v in g.items() if k.startswith("w.")}
+    model.load_state_dict(sd)
+    p = {k: v.cpu() for k, v in model.state_dict().items()}
+    flat = model.flat.detach()
+    x, t = g["x_noisy"].to(dev), g["t"].to(dev)
+    ws = E.UNetWorkspace(x.shape[0], dev, training=True)
+    eps = E.unet_forward(flat, x, t, ws, save=True)
+    out["golden_batch_forward"] = {**{k: O.rel_err(E.get_activation(ws, k).cpu(), g[k]) for k in ("h1", "h2", "h3", "h4")},
+                                   "eps": O.rel_err(eps.cpu(), g["eps"]), "B": int(x.shape[0])}
+    gen = torch.Generator().manual_seed(77)
+    # predicted noise at the benchmarked sizes
+    B = 512
+    x0 = torch.rand(B, 1, 28, 28, generator=gen) * 2 - 1
+    tt = torch.randint(0, 1000, (B,), generator=gen)
+    noise = torch.randn(B, 1, 28, 28, generator=gen)
+    with torch.no_grad():
+        xq = mnist.q_sample(x0.to(dev), tt.to(dev), noise.to(dev))
+        e512 = O.rel_err(model(xq, tt.to(dev)).cpu(), O.unet_forward(p, O.q_sample(x0, tt, noise, tabs), tt))
+        xs = torch.randn(4096, 1, 28, 28, generator=gen)
+        ts = torch.full((4096,), 417, dtype=torch.long)
+        sl = slice(2000, 2064)
+        e4096 = O.rel_err(model(xs.to(dev), ts.to(dev))[sl].cpu(), O.unet_forward(p, xs[sl], ts[sl]))
+    out["eps_at_benchmarked_sizes"] = {"train_forward_B512": e512, "reverse_step_B4096_slice64": e4096, "bound": 1e-3}
+    # gradients: end to end, and with the oracle's ReLU masks teacher-forced
+    grads = {}
+    for Bg in (37, 512):
+        x0 = torch.rand(Bg, 1, 28, 28, generator=gen) * 2 - 1
+        tt = torch.randint(0, 1000, (Bg,), generator=gen)
+        noise = torch.randn(Bg, 1, 28, 28, generator=gen)
+        _, gref = O.unet_loss_and_grads(p, x0, tt, noise, tabs)
+        _, inter = O.unet_forward(p, O.q_sample(x0, tt, noise, tabs), tt, return_intermediates=True)
+        xq = mnist.q_sample(x0.to(dev), tt.to(dev), noise.to(dev))
+        ws = E.UNetWorkspace(Bg, dev, training=True)
+        eps = E.unet_forward(flat, xq, tt.to(dev), ws, save=True)
+        deps = (2.0 / eps.numel()) * (eps - noise.to(dev))
+        flipped = total = 0
+        worst_kink = 0.0
+        for blk, name in enumerate(("rb1", "rb2", "rb3", "rb4")):
+            for which in (1, 2):
+                a = inter[f"{name}.a{which}"]
+                diff = mask_io(ws, Bg, blk, which).cpu().bool() != (a > 0)
+                flipped += int(diff.sum()); total += diff.numel()
+                if diff.any():
+                    worst_kink = max(worst_kink, float(a[diff].abs().max()))
+        e2e = E.state_dict_from_flat(E.unet_backward(flat, xq, deps, ws))
+        w_e2e = max(O.rel_err(e2e[k].cpu(), v) for k, v in gref.items())
+        l2_e2e = max(O.rel_l2(e2e[k].cpu(), v) for k, v in gref.items())
+        for blk, name in enumerate(("rb1", "rb2", "rb3", "rb4")):
+            for which in (1, 2):
+                mask_io(ws, Bg, blk, which, (inter[f"{name}.a{which}"] > 0).to(torch.uint8).to(dev))
+        tf = E.state_dict_from_flat(E.unet_backward(flat, xq, deps, ws))
+        w_tf = max(O.rel_err(tf[k].cpu(), v) for k, v in gref.items())
+        grads[f"B{Bg}"] = {"end_to_end_max": w_e2e, "end_to_end_rel_l2_max": l2_e2e, "teacher_forced_relu_masks_max": w_tf,
+                           "flipped_relu_mask_entries": flipped, "mask_entries": total,
+                           "largest_|pre-activation|_at_a_flip": worst_kink}
+        del ws
+    out["gradients"] = {**grads, "asserted": {"end_to_end": 2.5e-3, "teacher_forced": 2e-4},
+                        "note": "end-to-end error is ReLU-mask flips at pre-activations within ~1e-5 of zero; with the oracle's masks "
+                                "installed the same backward kernels agree to the teacher-forced figure"}
+    # bit-exact pieces
+    out["bit_exact"] = {"q_sample": bool(torch.equal(mnist.q_sample(g["x0"].to(dev), g["t"].to(dev), g["noise"].to(dev)).cpu(), g["x_noisy"]))}
+    schedule.set_tables(None)
+    return out
+
+
+def text_report(dev):
+    from tinydiffusionmodels_amd.shakespeare import TinyTransformer
+    from tinydiffusionmodels_amd import transformer_engine as TE
+    L = _lib.lib()
+    out = {}
+    dim, B, Lq = 256, 256, 128
+    p = O.transformer_init_params(dim, seed=7)
+    m = TinyTransformer(dim, dropout=0.0)
+    m.load_state_dict(p)
+    m = m.to(dev).eval()
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn(B, Lq, dim, generator=gen) * 0.7
+    t = torch.randint(0, 1000, (B,), generator=gen)
+    sl = slice(120, 128)
+    ref = O.transformer_forward(p, x[sl], t[sl])
+    names = {0: "fp32 MFMA", 1: "bf16x3 (parity arithmetic, default)", 2: "plain bf16 operands (config 5's literal arithmetic)"}
+    fwd = {}
+    for mode in (1, 0, 2):
+        _lib.check(L.tdm_set_gemm_mode(mode))
+        _lib.check(L.tdm_set_attn_mode(1 if mode == 0 else 2))
+        with torch.no_grad():
+            fwd[names[mode]] = O.rel_err(m(x.to(dev), t.to(dev))[sl].cpu(), ref)
+    out["config5_forward_slice8_vs_oracle"] = {**fwd, "bound": 1e-3,
+                                               "note": "plain bf16 operands are OUTSIDE north_star's bound: reported, not the parity path"}
+    # gradients of a train step (dropout 0) vs the oracle, B = 8 sequences of 128 tokens
+    tabs = load("schedule.npz")
+    schedule.set_tables(tabs)
+    gr = {}
+    xb, tb = x[:8] * 0.03, t[:8]
+    nb = torch.randn(8, Lq, dim, generator=gen)
+    loss_ref, gref = O.transformer_loss_and_grads(p, xb, tb, nb, tabs)
+    for mode in (1, 0, 2):
+        _lib.check(L.tdm_set_gemm_mode(mode))
+        _lib.check(L.tdm_set_attn_mode(1 if mode == 0 else 2))
+        st = TE.TTTrainState(m.cfg, m.flat.detach(), 8, Lq)
+        TE.tt_loss_and_grad(m.flat.detach(), st, xb.to(dev), nb.to(dev), tb.to(dev))
+        got = TE.state_dict_from_flat(st.grads, dim)
+        gr[names[mode]] = {"loss_rel": abs(st.loss.item() - loss_ref.item()) / abs(loss_ref.item()),
+                           "grad_max": max(O.rel_err(got[k].cpu(), v) for k, v in gref.items()),
+                           "grad_rel_l2_max": max(O.rel_l2(got[k].cpu(), v) for k, v in gref.items())}
+    out["train_step_B8_L128_vs_oracle"] = gr
+    _lib.check(L.tdm_set_gemm_mode(1)); _lib.check(L.tdm_set_attn_mode(2))
+    schedule.set_tables(None)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_parity.json"))
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    rep = {"what": "measured parity of the HIP path vs the CPU oracle / goldens (tools/parity_report.py); max|d|/max|ref| unless named",
+           "device": torch.cuda.get_device_name(0), "unet": unet_report(dev), "text_denoiser": text_report(dev)}
+    rep = json.loads(json.dumps(rep, default=float))
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    with open(a.out, "w") as f:
+        json.dump(rep, f, indent=1)
+    print(json.dumps(rep, indent=1))
+
+
+if __name__ == "__main__":
+    main()
