@@ -653,6 +653,46 @@ def main():
                                                  "stored_logits_form": {"ms": round(ms_s, 3), "workspace_gb": round(gb_s, 2)},
                                                  "loss": round(loss_h, 4)}
         del xh, Wh, bh, idh, dxh, dWh, dbh
+        # the FULL text train step (src/shakespeare.py:221-250 with learned embeddings: gather, device-drawn t / noise, q_sample,
+        # denoiser fwd / bwd, fused rounding CE over V = 50,257, embedding scatter-add, AdamW over all four tensors, LR schedule)
+        # as ONE hipGraph replay per batch — what `python -m src.shakespeare --train` runs per iteration (TextTrainStep)
+        def time_full(Bf, steps):
+            torch.manual_seed(0)
+            fm = TinyTransformer(Dt, dropout=0.1).to(dev)
+            fm.train()
+            femb, frnd = _S.LearnedEmbedding(Vh, Dt).to(dev), _S.LearnedRounding(Dt, Vh).to(dev)
+            st_ = _S.TextTrainStep(fm, frnd, femb, lr=1e-4, weight_decay=1e-4, rounding_weight=1.0,
+                                   lr_lambda=_S.cosine_warmup_lambda(100, 10000), total_steps=10000)
+            ids_ = torch.randint(0, Vh, (Bf, Lt), device=dev, generator=torch.Generator(device=dev).manual_seed(3 + rank))
+            for _ in range(3):
+                st_.step(ids_)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                st_.step(ids_)
+            sync()
+            el = time.perf_counter() - t0
+            if world > 1:
+                tt = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = tt.item()
+            ls = st_.losses.tolist()
+            caps = st_.captures
+            del st_, fm, femb, frnd
+            _S._round_ws.clear()
+            return 1e3 * el / steps, ls, caps
+        nfull = max(2, args.text_steps // 2)
+        ms32, l32, c32 = time_full(32, nfull)
+        ms256, l256, c256 = time_full(256, nfull)
+        out["text_train_full"] = {
+            "what": "whole text train step incl. learned embedding + rounding head over V = 50,257 + AdamW on all tensors + "
+                    "warm-up / cosine LR table, ONE hipGraph replay per batch (TextTrainStep = the step of shakespeare.train())",
+            "vocab": Vh, "seq_len": Lt, "dim": Dt, "dropout": 0.1,
+            "b32": {"ms_per_step": round(ms32, 3), "tokens_per_s": round(world * 32 * Lt * 1e3 / ms32, 0), "graph_captures": c32,
+                    "losses_diff_rnd_total": [round(x, 4) for x in l32]},
+            "b256": {"ms_per_step": round(ms256, 3), "tokens_per_s": round(world * 256 * Lt * 1e3 / ms256, 0), "graph_captures": c256,
+                     "losses_diff_rnd_total": [round(x, 4) for x in l256]},
+            "cpu_reference_point": "cpu_baseline.points[*].text_train_b32_l128_d256 is the DENOISER part only of the B = 32 step"}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -359,6 +359,26 @@ int tdm_ffn_chain_f32(int mode, int nprod, const float* x16, const float* wa16, 
                       uint64_t seed, int site_mid, int site_out, int64_t M, int D, int F, void* stream);
 int64_t tdm_ffn_chain_mask_count(int64_t M, int F);
 int tdm_ffn_chain_set_ablate(int bits);   /* timing diagnostics of tools/time_ffn.py (results are wrong when nonzero) */
+/* ---- the FULL text train step as one replayable launch sequence (src/shakespeare.py:221-250) ----
+ * tdm_tt_loss_grad_philox_f32 with dx_noisy (B,L,D; nullable) = d loss / d x_noisy: what learned embeddings receive
+ * through q_sample (:225-233).                                                                                      */
+int tdm_tt_loss_grad_philox_dx_f32(const float* params, const float* x0, const float* sqrt_acp, const float* sqrt_1m_acp,
+                                   uint64_t seed, int64_t* rng_state, int64_t* t_buf, float* noise, float* x_noisy, float* pred,
+                                   float* dpred, float* loss_out, float* grads, float* dx_noisy, float* ws, float* slabs,
+                                   int64_t B, int L, int D, int H, int depth, int ffn, float p_drop, uint64_t drop_seed,
+                                   void* stream);
+/* AdamW with the learning rate and (optionally) a gradient factor in DEVICE memory, so that a captured step survives the
+ * reference's per-step LambdaLR (:200-202, :250) and per-epoch rounding weight (:216, :243):
+ * lr = lr_tab[min(steps taken, lr_n - 1)], gradient = g * grad_scale * (grad_scale_dev ? *grad_scale_dev : 1).  step_state as
+ * tdm_adamw_flat_devstep_f32; several tensors of one optimizer step share it: pass bump = 1 for the last one only.   */
+int tdm_adamw_flat_devsched_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_tab, int lr_n,
+                                float beta1, float beta2, float eps, float weight_decay, int64_t* step_state, float grad_scale,
+                                const float* grad_scale_dev, int bump, void* stream);
+/* out = sqrt_acp[t[b]] * dx_noisy + rw * dx_round over (B, inner): d total / d x0 of a learned embedding (:225-243)  */
+int tdm_text_combine_dx0_f32(const float* dx_noisy, const int64_t* t, const float* sqrt_acp, const float* dx_round,
+                             const float* rw_dev, float* out, int64_t B, int64_t inner, void* stream);
+/* losses3 = {diff, rnd, diff + rw * rnd};  acc4 += {diff, rnd, total, 1}  (the epoch's running sums, :252-255)       */
+int tdm_text_loss_f32(const float* diff, const float* rnd, const float* rw_dev, float* losses3, float* acc4, void* stream);
 /* ---- N1: learned embedding table and rounding head of the text train step
  *      (src/shakespeare.py:46-102 modules, :225-243 train step, :387-390 decode) ----
  * table (V,D) fp32, ids (M,) int64 token ids in [0,V), W (V,D) / b (V,) = LearnedRounding.decoder.  */

@@ -448,6 +448,27 @@ def text_p_sample(p, x, t, noise, tables, n_heads: int = 4, depth: int = 3):
 # --------------------------------------------------------------------------
 # helpers shared by tests / bench
 # --------------------------------------------------------------------------
+def text_full_step_loss_and_grads(p, table, W, b, ids, t, noise, tables, rounding_weight: float, n_heads: int = 4, depth: int = 3,
+                                  p_drop: float = 0.0, seed: int = 0, salt=None):
+    """The whole text train step's losses and gradients with LEARNED embeddings (src/shakespeare.py:225-243):
+    x0 = embedding_fn(ids); x_noisy = q_sample(x0, t, noise); diff = mse(model(x_noisy, t), noise);
+    rnd = cross_entropy(rounding_fn(x0), ids); total = diff + rounding_weight * rnd; total.backward().
+    Returns (diff, rnd, total, grads of the denoiser parameters, d table, d W, d b)."""
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    tab, Wl, bl = (v.detach().clone().requires_grad_(True) for v in (table, W, b))
+    x0 = tab[ids]
+    a = tables["sqrt_alphas_cumprod"][t].view(-1, 1, 1)
+    s = tables["sqrt_one_minus_alphas_cumprod"][t].view(-1, 1, 1)
+    x_noisy = a * x0 + s * noise
+    pred = transformer_forward(leaf, x_noisy, t, n_heads, depth, p_drop=p_drop, seed=seed, salt=salt)
+    diff = F.mse_loss(pred, noise)
+    logits = F.linear(x0, Wl, bl)
+    rnd = F.cross_entropy(logits.reshape(-1, logits.size(-1)), ids.reshape(-1))
+    total = diff + rounding_weight * rnd
+    total.backward()
+    return (diff.detach(), rnd.detach(), total.detach(), {k: v.grad for k, v in leaf.items()}, tab.grad, Wl.grad, bl.grad)
+
+
 def rel_err(a: torch.Tensor, ref: torch.Tensor) -> float:
     """max|a-ref| / max|ref| — the 'rel fp32' measure of BASELINE.json."""
     a = a.detach().double().cpu()

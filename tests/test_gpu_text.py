@@ -569,6 +569,113 @@ def test_device_drawn_text_step_vs_oracle_and_graph_equals_eager(dev, golden_tab
     assert len(set(runs[0][0].reshape(-1).tolist())) == 5       # fresh draws / masks every step
 
 
+def _text_modules(dev, V, D, p_drop, seed=5):
+    from tinydiffusionmodels_amd import shakespeare as S
+    torch.manual_seed(seed)
+    m = S.TinyTransformer(D, dropout=p_drop).to(dev)
+    emb, rnd = S.LearnedEmbedding(V, D).to(dev), S.LearnedRounding(D, V).to(dev)
+    with torch.no_grad():
+        emb.embeddings.weight.mul_(25.0)        # O(0.5) embeddings: both losses and all four gradients carry weight
+    m.train()
+    return m, emb, rnd
+
+
+def test_full_text_step_vs_oracle(dev, golden_tables, gemm_mode):
+    """TextTrainStep (the FULL step of src/shakespeare.py:221-250 with learned embeddings, device-drawn t / noise): its losses
+    and the gradients it leaves for AdamW — denoiser, embedding table (through q_sample AND the rounding head), rounding
+    weight / bias (before the epoch's weight, applied inside AdamW) — against the oracle's autograd on the draws the step made."""
+    from tinydiffusionmodels_amd import shakespeare as S, transformer_engine as TE
+    V, D, B, L, rw = 211, 32, 6, 10, 0.7
+    m, emb, rnd = _text_modules(dev, V, D, 0.0)
+    p = {k: v.cpu() for k, v in m.state_dict().items()}
+    table, W, b = (x.detach().cpu().clone() for x in (emb.embeddings.weight, rnd.decoder.weight, rnd.decoder.bias))
+    ids = torch.randint(0, V, (B, L), generator=torch.Generator().manual_seed(3))
+    step = S.TextTrainStep(m, rnd, emb, lr=1e-3, rounding_weight=rw, graph=False)
+    out = step.step(ids.to(dev)).cpu()
+    st = step._cur
+    t_d, nz_d = st.tt.t.cpu(), st.tt.noise.cpu()
+    diff, rl, tot, gp, gtab, gW, gb = O.text_full_step_loss_and_grads(p, table, W, b, ids, t_d, nz_d, golden_tables, rw)
+    tol = _ftol(gemm_mode)
+    assert abs(out[0].item() - diff.item()) < tol * abs(diff.item()) and abs(out[1].item() - rl.item()) < 5e-5 * abs(rl.item())
+    assert abs(out[2].item() - tot.item()) < max(tol, 5e-5) * abs(tot.item())
+    l2tol = {0: 1e-3, 1: 1e-2, 2: 1e-1}[gemm_mode]
+    got = TE.state_dict_from_flat(step.g_flat, D, m.cfg.depth, m.cfg.ffn)
+    for k, v in gp.items():
+        assert O.rel_l2(got[k].cpu(), v) < l2tol, k
+    assert O.rel_l2(step.g_tab.cpu(), gtab) < l2tol
+    assert O.rel_l2(step.g_W.cpu() * rw, gW) < 1e-4 and O.rel_l2(step.g_b.cpu() * rw, gb) < 1e-4
+    assert step.steps_taken == 1
+
+
+def test_full_text_step_graph_equals_eager_under_the_lr_schedule(dev, gemm_mode):
+    """One hipGraph for the real text train step: ten steps under the reference's warm-up + cosine LambdaLR
+    (src/shakespeare.py:159-167, :250), with the rounding weight changed half way (:216) — the captured step is captured ONCE
+    (the lr and the weight are read from device memory) and equals the eagerly issued launches bit for bit: losses, all four
+    parameter tensors, Philox offset, step count.  The LR table equals what LambdaLR drives through NativeAdamW's param group."""
+    if gemm_mode == 0:
+        pytest.skip("same host logic in every arithmetic; run in the two bf16 modes")
+    from tinydiffusionmodels_amd import shakespeare as S
+    V, D, B, L = 300, 32, 4, 16
+    lam = S.cosine_warmup_lambda(3, 10)
+    runs = []
+    for use_graph in (True, False):
+        m, emb, rnd = _text_modules(dev, V, D, 0.1, seed=11)
+        torch.manual_seed(123)
+        step = S.TextTrainStep(m, rnd, emb, lr=2e-3, rounding_weight=1.0, lr_lambda=lam, total_steps=10, graph=use_graph)
+        gen = torch.Generator().manual_seed(9)
+        losses = []
+        for i in range(10):
+            if i == 5:
+                step.set_rounding_weight(0.55)
+            # (distinct token ids inside a batch: the embedding gradient's scatter-add uses float atomics, so repeated ids add in
+            #  an order that varies from run to run — in either form)
+            losses.append(step.step(torch.randperm(V, generator=gen)[:B * L].view(B, L).to(dev)).clone())
+        torch.cuda.synchronize()
+        assert step.captures == (1 if use_graph else 0) and step.steps_taken == 10
+        runs.append((torch.stack(losses), m.flat.detach().clone(), emb.embeddings.weight.detach().clone(),
+                     rnd.decoder.weight.detach().clone(), rnd.decoder.bias.detach().clone(), step.rng_state.clone(),
+                     step.epoch_sums().clone()))
+    for a, bb in zip(*runs):
+        assert torch.equal(a, bb)
+    assert torch.isfinite(runs[0][0]).all() and len(set(runs[0][0][:, 0].tolist())) == 10
+    # the device LR table = the sequence LambdaLR gives a torch optimizer
+    w = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([w], lr=2e-3)
+    sch = torch.optim.lr_scheduler.LambdaLR(opt, lam)
+    want = []
+    for _ in range(10):
+        want.append(opt.param_groups[0]["lr"])
+        opt.step(); sch.step()
+    assert torch.equal(step.lr_tab.cpu(), torch.tensor(want, dtype=torch.float64).to(torch.float32))
+
+
+def test_text_train_uses_the_graph_step_and_matches_the_autograd_form(dev, tmp_path, monkeypatch, gemm_mode):
+    """shakespeare.train() drives TextTrainStep (one graph replay per batch) when every piece is native; with TDM_TEXT_STEP=eager
+    it runs the autograd-bridge form (ATen draws, NativeAdamW + LambdaLR).  Different RNG streams, same mathematics: both
+    reach comparable losses on the same data, and the graph form writes the same checkpoint keys."""
+    if gemm_mode != 1:
+        pytest.skip("host control flow; run once in the default arithmetic")
+    from tinydiffusionmodels_amd import shakespeare as S
+    V, D, L = 64, 32, 16
+    gen = torch.Generator().manual_seed(2)
+    data = [torch.randint(0, V, (8, L), generator=gen) for _ in range(12)]
+    finals = {}
+    for mode in ("graph", "eager"):
+        monkeypatch.setenv("TDM_TEXT_STEP", mode)
+        m, emb, rnd = _text_modules(dev, V, D, 0.0, seed=4)
+        ck = str(tmp_path / f"{mode}.pth")
+        with torch.no_grad():
+            first = rnd.cross_entropy(emb(data[0].to(dev)), data[0].to(dev)).item()
+        S.train(m, rnd, emb, data, data[:2], dev, ckpt_path=ck, epochs=6, lr=5e-3, warmup_steps=4)
+        sd = torch.load(ck, map_location="cpu", weights_only=True)
+        assert set(sd) == {"diffusion_model", "rounding_fn", "embedding_fn", "epoch", "final_training"}
+        with torch.no_grad():
+            x0 = emb(data[0].to(dev))
+            finals[mode] = rnd.cross_entropy(x0, data[0].to(dev)).item()
+    assert finals["graph"] < first - 0.3 and finals["eager"] < first - 0.3          # both forms train (rounding CE of a train batch fell)
+    assert abs(finals["graph"] - finals["eager"]) < 0.25 * finals["eager"]
+
+
 def test_full_size_properties_config5(dev, gemm_mode):
     """BASELINE config 5 size (B=256, L=128, D=256; 32,768 tokens): sequences are independent (a slice of the batch
     gives bitwise the same output), and the batch gradient of the mean loss equals the mean of the per-chunk

@@ -103,6 +103,12 @@ _SIGS = {
     "tdm_broadcast_f32": ([c_f, c_f, c_i64, c_int, c_f], c_int),
     "tdm_cosine_argmax_f32": ([c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_f], c_int),
     "tdm_split_s16_f32": ([c_f, c_f, c_i64, c_f], c_int),
+    "tdm_tt_loss_grad_philox_dx_f32": ([c_f, c_f, c_f, c_f, c_u64] + [c_f] * 11 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_float,
+                                       c_u64, c_f], c_int),
+    "tdm_adamw_flat_devsched_f32": ([c_f, c_f, c_f, c_f, c_i64, c_f, c_int, c_float, c_float, c_float, c_float, c_f, c_float, c_f,
+                                    c_int, c_f], c_int),
+    "tdm_text_combine_dx0_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_f], c_int),
+    "tdm_text_loss_f32": ([c_f, c_f, c_f, c_f, c_f, c_f], c_int),
     "tdm_ffn_chain_f32": ([c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_float, c_float, c_u64, c_int, c_int,
                            c_i64, c_int, c_int, c_f], c_int),
     "tdm_ffn_chain_mask_count": ([c_i64, c_int], c_i64),

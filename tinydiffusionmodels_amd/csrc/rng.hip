@@ -141,6 +141,64 @@ __global__ __launch_bounds__(RB) void adamw_devstep_kernel(float* __restrict__ p
     }
 }
 
+// AdamW whose learning rate and gradient scale come from DEVICE memory, so that a hipGraph-captured step survives a per-step LR
+// schedule (src/shakespeare.py:200-202, :250: LambdaLR stepped after every optimizer step) and a per-epoch loss weight
+// (:216, :243): lr = lr_tab[min(steps taken, lr_n - 1)] — the host computes the whole schedule once with the reference's own
+// Python arithmetic (lr_tab[i] = float(base_lr * lr_lambda(i)), what param_groups[0]['lr'] holds during step i + 1) — and the
+// gradient is read as g * gscale * (gscale_dev ? *gscale_dev : 1).  Same update arithmetic as adamw_devstep_kernel.
+__global__ __launch_bounds__(RB) void adamw_devsched_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                            const float* __restrict__ lr_tab, int lr_n, float beta1, float beta2,
+                                                            float eps, float wd, const int64_t* __restrict__ state, float gscale,
+                                                            const float* __restrict__ gscale_dev) {
+    const int64_t taken = state[0];
+    const float lr = lr_tab[taken < (int64_t)lr_n ? (int)taken : lr_n - 1];
+    const float gs = gscale_dev != nullptr ? gscale * gscale_dev[0] : gscale;
+    const double b1p = (taken == 0 ? 1.0 : __longlong_as_double(state[2])) * (double)beta1;
+    const double b2p = (taken == 0 ? 1.0 : __longlong_as_double(state[3])) * (double)beta2;
+    const float step_size = (float)((double)lr / (1.0 - b1p)), bc2_sqrt = (float)sqrt(1.0 - b2p);
+    const float decay = (float)(1.0 - (double)lr * (double)wd);
+    const float one_m_b1 = (float)(1.0 - (double)beta1), one_m_b2 = (float)(1.0 - (double)beta2);
+    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += (int64_t)gridDim.x * RB) {
+        const float gi = g[i] * gs;
+        float pi = p[i] * decay;
+        float mi = m[i];
+        mi = mi + one_m_b1 * (gi - mi);
+        const float vi = v[i] * beta2 + one_m_b2 * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi = pi - step_size * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+
+// text train step glue (src/shakespeare.py:225-243 with learned embeddings):
+//   dx0[b][i] = sqrt_acp[t[b]] * dxn[b][i] + rw * dxr[b][i]      (d total / d x0: the q_sample path + the rounding path)
+__global__ __launch_bounds__(RB) void combine_dx0_kernel(const float* __restrict__ dxn, const int64_t* __restrict__ t,
+                                                         const float* __restrict__ ta, const float* __restrict__ dxr,
+                                                         const float* __restrict__ rw, float* __restrict__ out, int64_t B,
+                                                         int64_t inner4) {
+    const float w = rw[0];
+    const int64_t n4 = B * inner4;
+    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * RB) {
+        const float a = ta[t[i / inner4]];
+        const float4 x = reinterpret_cast<const float4*>(dxn)[i], r = reinterpret_cast<const float4*>(dxr)[i];
+        float4 o;
+        o.x = __fadd_rn(__fmul_rn(a, x.x), __fmul_rn(w, r.x)); o.y = __fadd_rn(__fmul_rn(a, x.y), __fmul_rn(w, r.y));
+        o.z = __fadd_rn(__fmul_rn(a, x.z), __fmul_rn(w, r.z)); o.w = __fadd_rn(__fmul_rn(a, x.w), __fmul_rn(w, r.w));
+        reinterpret_cast<float4*>(out)[i] = o;
+    }
+}
+//   losses[0..2] = {diff, rnd, diff + rw * rnd};  acc[0..3] += {diff, rnd, total, 1}   (the epoch's running sums, :252-255)
+__global__ __launch_bounds__(64) void text_loss_kernel(const float* __restrict__ diff, const float* __restrict__ rnd,
+                                                       const float* __restrict__ rw, float* __restrict__ losses,
+                                                       float* __restrict__ acc) {
+    if (threadIdx.x == 0) {
+        const float d = diff[0], r = rnd[0], tot = __fadd_rn(d, __fmul_rn(rw[0], r));
+        losses[0] = d; losses[1] = r; losses[2] = tot;
+        acc[0] += d; acc[1] += r; acc[2] += tot; acc[3] += 1.f;
+    }
+}
+
 }  // namespace
 
 // internal: the fused train step advances the offset in its next kernel (timebias) instead of a bump launch
@@ -213,6 +271,39 @@ int tdm_adamw_flat_devstep_f32(float* p, const float* g, float* m, float* v, int
     TDM_CHECK_LAUNCH("adamw_devstep");
     hipLaunchKernelGGL(bump_adam_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_state, beta1, beta2);
     TDM_CHECK_LAUNCH("bump_adam");
+    return 0;
+}
+
+int tdm_adamw_flat_devsched_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_tab, int lr_n,
+                                float beta1, float beta2, float eps, float weight_decay, int64_t* step_state, float grad_scale,
+                                const float* grad_scale_dev, int bump, void* stream) {
+    TDM_REQUIRE(p && g && m && v && step_state && lr_tab && n > 0 && lr_n >= 1, "adamw_devsched: bad arguments (n=%lld, lr_n=%d)",
+                (long long)n, lr_n);
+    hipLaunchKernelGGL(adamw_devsched_kernel, dim3(rng_grid(n)), dim3(RB), 0, (hipStream_t)stream, p, g, m, v, n, lr_tab, lr_n,
+                       beta1, beta2, eps, weight_decay, step_state, grad_scale, grad_scale_dev);
+    TDM_CHECK_LAUNCH("adamw_devsched");
+    if (bump) {   // the LAST tensor of a step advances the shared step count (several tensors, one optimizer step)
+        hipLaunchKernelGGL(bump_adam_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_state, beta1, beta2);
+        TDM_CHECK_LAUNCH("bump_adam");
+    }
+    return 0;
+}
+
+int tdm_text_combine_dx0_f32(const float* dx_noisy, const int64_t* t, const float* sqrt_acp, const float* dx_round,
+                             const float* rw_dev, float* out, int64_t B, int64_t inner, void* stream) {
+    TDM_REQUIRE(dx_noisy && t && sqrt_acp && dx_round && rw_dev && out, "text_combine_dx0: NULL pointer");
+    TDM_REQUIRE(B > 0 && inner > 0 && (inner & 3) == 0, "text_combine_dx0: B=%lld inner=%lld (inner must be a multiple of 4)",
+                (long long)B, (long long)inner);
+    hipLaunchKernelGGL(combine_dx0_kernel, dim3(rng_grid(B * inner / 4)), dim3(RB), 0, (hipStream_t)stream, dx_noisy, t, sqrt_acp,
+                       dx_round, rw_dev, out, B, inner / 4);
+    TDM_CHECK_LAUNCH("text_combine_dx0");
+    return 0;
+}
+
+int tdm_text_loss_f32(const float* diff, const float* rnd, const float* rw_dev, float* losses3, float* acc4, void* stream) {
+    TDM_REQUIRE(diff && rnd && rw_dev && losses3 && acc4, "text_loss: NULL pointer");
+    hipLaunchKernelGGL(text_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, diff, rnd, rw_dev, losses3, acc4);
+    TDM_CHECK_LAUNCH("text_loss");
     return 0;
 }
 

@@ -1059,6 +1059,17 @@ int tdm_tt_loss_grad_philox_f32(const float* params, const float* x0, const floa
                                 uint64_t seed, int64_t* rng_state, int64_t* t_buf, float* noise, float* x_noisy, float* pred,
                                 float* dpred, float* loss_out, float* grads, float* ws, float* slabs, int64_t B, int L, int D,
                                 int H, int depth, int ffn, float p_drop, uint64_t drop_seed, void* stream) {
+    return tdm_tt_loss_grad_philox_dx_f32(params, x0, sqrt_acp, sqrt_1m_acp, seed, rng_state, t_buf, noise, x_noisy, pred, dpred,
+                                          loss_out, grads, nullptr, ws, slabs, B, L, D, H, depth, ffn, p_drop, drop_seed, stream);
+}
+
+// ... with dx_noisy (nullable) = d loss / d x_noisy, the gradient that reaches LEARNED embeddings through q_sample
+// (src/shakespeare.py:225-233: x0 = embedding_fn(token_ids) carries a gradient)
+int tdm_tt_loss_grad_philox_dx_f32(const float* params, const float* x0, const float* sqrt_acp, const float* sqrt_1m_acp,
+                                   uint64_t seed, int64_t* rng_state, int64_t* t_buf, float* noise, float* x_noisy, float* pred,
+                                   float* dpred, float* loss_out, float* grads, float* dx_noisy, float* ws, float* slabs,
+                                   int64_t B, int L, int D, int H, int depth, int ffn, float p_drop, uint64_t drop_seed,
+                                   void* stream) {
     TDM_TRY(tt_check(B, L, D, H, depth, ffn));
     TDM_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "tt_loss_grad_philox: dropout probability %g outside [0, 1)", (double)p_drop);
     TDM_REQUIRE(params && x0 && sqrt_acp && sqrt_1m_acp && rng_state && t_buf && noise && x_noisy && pred && dpred && loss_out &&
@@ -1072,7 +1083,7 @@ int tdm_tt_loss_grad_philox_f32(const float* params, const float* x0, const floa
     TDM_TRY(tdm_launch_draw_q_sample(x0, sqrt_acp, sqrt_1m_acp, seed, rng_state, t_buf, noise, x_noisy, B, (int64_t)L * D, true, st));
     TDM_TRY(tt_forward(params, lay, x_noisy, t_buf, pred, w, B, L, D, H, depth, ffn, drop, st));
     TDM_TRY(tdm_mse_fwd_bwd_f32(pred, noise, loss_out, dpred, w.part, B * L * D, stream));
-    return tt_backward(params, lay, dpred, grads, nullptr, w, slabs, B, L, D, H, depth, ffn, drop, st);
+    return tt_backward(params, lay, dpred, grads, dx_noisy, w, slabs, B, L, D, H, depth, ffn, drop, st);
 }
 
 int tdm_tt_p_sample_step_f32(const float* params, const float* x, const int64_t* t, const float* noise,

@@ -421,14 +421,29 @@ def tokenize_corpus(text: str, tokenizer, seq_len: int, val_split=0.1, generator
     return torch.utils.data.random_split(chunks, [n_chunks - n_val, n_val], generator=generator)
 
 
-def get_cosine_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps, eta_min=0):
-    """Cosine annealing with linear warm-up; lr_lambda(0) = 0 (src/shakespeare.py:159-167)."""
+def cosine_warmup_lambda(num_warmup_steps, num_training_steps, eta_min=0):
+    """The lr_lambda of src/shakespeare.py:161-166 (linear warm-up from 0, then cosine annealing)."""
     def lr_lambda(step):
         if step < num_warmup_steps:
             return float(step) / float(max(1, num_warmup_steps))
         progress = float(step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
         return max(eta_min, 0.5 * (1.0 + math.cos(math.pi * progress)))
-    return torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda)
+    return lr_lambda
+
+
+def get_cosine_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps, eta_min=0):
+    """Cosine annealing with linear warm-up; lr_lambda(0) = 0 (src/shakespeare.py:159-167)."""
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, cosine_warmup_lambda(num_warmup_steps, num_training_steps, eta_min))
+
+
+def lr_schedule_table(base_lr: float, lr_lambda, n_steps: int, device) -> torch.Tensor:
+    """lr_tab[i] = the value `param_groups[0]['lr']` holds during optimizer step i + 1 under LambdaLR(lr_lambda) stepped once after
+    every optimizer step (src/shakespeare.py:200-202, :250): base_lr * lr_lambda(i), computed with the reference's own Python
+    arithmetic and rounded to fp32 exactly as passing the float to the kernel would.  The device-scheduled AdamW
+    (tdm_adamw_flat_devsched_f32) indexes it with its device-resident step count, so a captured train step never sees a
+    host-written learning rate.  Steps past the table keep its last entry."""
+    vals = [base_lr * lr_lambda(i) for i in range(max(1, n_steps))] if lr_lambda is not None else [base_lr]
+    return torch.tensor(vals, dtype=torch.float64).to(torch.float32).to(device)
 
 
 def dynamic_rounding_weight_schedule(epoch, total_epochs, initial_weight=1.0, final_weight=0.1):
@@ -463,7 +478,19 @@ class DenoiserTrainer:
         # rank-distinct streams, governed by torch.manual_seed: the draw key and the dropout mask family of this trainer
         self.seed = (int(torch.randint(0, 2 ** 62, (1,)).item()) ^ (self.rank * 0x9E3779B97F4A7C15)) & (2 ** 64 - 1)
         self.drop_seed = (int(torch.randint(0, 2 ** 62, (1,)).item()) ^ (self.rank * 0xC2B2AE3D27D4EB4F)) & (2 ** 64 - 1)
+        # the learning rate lives in DEVICE memory (a table indexed by the device-resident step count; one entry = a constant
+        # lr that step(lr=...) rewrites when it changes): an LR schedule never recaptures the step's hipGraph
+        self.lr_tab = torch.tensor([lr], dtype=torch.float32, device=dev)
+        self._lr_written = float(lr)
+        self._scheduled = False
         dp.broadcast_params_(self.flat, src=0)
+
+    def set_lr_schedule(self, lr_lambda, n_steps: int) -> None:
+        """Per-step schedule of the reference's LambdaLR (src/shakespeare.py:200-202, :250) evaluated once on the host into a
+        device table (lr_schedule_table): step i + 1 of this trainer uses base lr * lr_lambda(i), with no host write per step."""
+        self.lr_tab = lr_schedule_table(self.lr, lr_lambda, n_steps, self.flat.device)
+        self._scheduled = True
+        self.state.graph = None                    # (the table's address is baked into a captured step)
 
     @property
     def steps_taken(self) -> int:
@@ -472,11 +499,19 @@ class DenoiserTrainer:
     def _p_drop(self) -> float:
         return self.model.p_drop if self.model.training else 0.0   # model.train() -> the reference's dropout
 
+    def _sync_lr(self, lr: float) -> None:
+        if not self._scheduled and float(lr) != self._lr_written:   # a changed constant lr: one tiny fill, no recapture
+            self.lr_tab.fill_(float(lr))
+            self._lr_written = float(lr)
+
+    def _adamw(self, st, scale: float) -> None:
+        E.adamw_step_devsched(self.flat, st.grads, st.m, st.v, self.step_state, self.lr_tab, self.betas, self.eps, self.wd,
+                              grad_scale=scale)
+
     def _device_step(self, st, x0, lr: float, whole: bool):
         TE.tt_loss_and_grad_philox(self.flat, st, x0, self.seed, self.rng_state, p_drop=self._p_drop(), drop_seed=self.drop_seed)
         if whole:
-            scale = dp.allreduce_grads_(st.grads)
-            E.adamw_step_dev(self.flat, st.grads, st.m, st.v, self.step_state, lr, self.betas, self.eps, self.wd, grad_scale=scale)
+            self._adamw(st, dp.allreduce_grads_(st.grads))
 
     def step(self, x0, t=None, noise=None, lr: Optional[float] = None):
         st = self.state
@@ -489,17 +524,18 @@ class DenoiserTrainer:
             p_drop = self._p_drop()
             seed = self.model.next_dropout_seed() if p_drop > 0.0 else 0
             loss = TE.tt_loss_and_grad(self.flat, st, x0, noise, t, p_drop=p_drop, seed=seed)
-            scale = dp.allreduce_grads_(st.grads)
             # (the same device-side step count as the graph form: a trainer may mix teacher-forced and device-drawn steps)
-            E.adamw_step_dev(self.flat, st.grads, st.m, st.v, self.step_state, lr, self.betas, self.eps, self.wd, grad_scale=scale)
+            self._sync_lr(lr)
+            self._adamw(st, dp.allreduce_grads_(st.grads))
             return loss
+        self._sync_lr(lr)
         if not self.use_graph or st.warm < 1:          # first step eagerly (lazy kernel attributes, allocator warm-up)
             st.warm += 1
             self._device_step(st, x0, lr, True)
             return st.loss
         if x0.data_ptr() != st.x0.data_ptr():
             st.x0.copy_(x0)                            # the graph reads a fixed address
-        key = (schedule_generation(), float(lr), self._p_drop(), self.drop_seed)
+        key = (schedule_generation(), self._p_drop(), self.drop_seed)      # (NOT the lr: it is read from device memory)
         if st.graph is None or st.graph_key != key:
             whole = self.world == 1 or dp.graph_collective_ok()
             g = torch.cuda.CUDAGraph()
@@ -508,9 +544,202 @@ class DenoiserTrainer:
             st.graph, st.graph_whole, st.graph_key = g, whole, key
         st.graph.replay()
         if not st.graph_whole:
-            scale = dp.allreduce_grads_(st.grads)
-            E.adamw_step_dev(self.flat, st.grads, st.m, st.v, self.step_state, lr, self.betas, self.eps, self.wd, grad_scale=scale)
+            self._adamw(st, dp.allreduce_grads_(st.grads))
         return st.loss
+
+
+class _TextStepState:
+    """Fixed-address buffers (and the captured hipGraph) of TextTrainStep for one (batch, sequence length)."""
+
+    def __init__(self, cfg, flat, B, L, V, grads, m, v):
+        dev = flat.device
+        D = cfg.dim
+        self.B, self.L = B, L
+        self.tt = TE.TTTrainState(cfg, flat, B, L)
+        self.tt.grads, self.tt.m, self.tt.v = grads, m, v          # optimizer state is shared between the shapes
+        self.ids = torch.zeros(B, L, dtype=torch.long, device=dev)
+        self.dxn = torch.empty(B, L, D, device=dev)
+        self.dxr = torch.empty(B * L, D, device=dev)
+        self.dx0 = torch.empty(B, L, D, device=dev)
+        self.rnd_loss = torch.zeros(1, device=dev)
+        self.losses = torch.zeros(3, device=dev)
+        self.graph, self.graph_key, self.warm = None, None, 0
+        M = B * L
+        self.chunk = round_ce_chunk(M, V)
+        n = (_lib.lib().tdm_round_workspace_chunked_floats(M, V, D, self.chunk) if self.chunk
+             else _lib.lib().tdm_round_workspace_floats(M, V, D))
+        self.round_ws = torch.empty(n, dtype=torch.float32, device=dev)
+
+
+class TextTrainStep:
+    """The FULL text train step of src/shakespeare.py:221-250 with learned embeddings, as ONE hipGraph replay per batch:
+
+        x0 = embedding_fn(token_ids)                                    native gather
+        t ~ U{0..T-1}, noise ~ N(0,1), x_noisy = q_sample(x0, t, noise)  drawn on the device (Philox), one pass
+        diffusion_loss = mse(model(x_noisy, t), noise)                  denoiser forward / backward (+ d loss / d x_noisy)
+        rounding_loss = cross_entropy(rounding_fn(x0), token_ids)       fused rounding head (loss, dx, dW, db)
+        total = diffusion_loss + rounding_weight * rounding_loss
+        backward into the embedding table (scatter-add of sqrt_acp[t] * dx_noisy + rw * dx_round), AdamW over all four tensors
+        (denoiser flat vector, embedding table, rounding weight and bias), LR schedule stepped
+
+    Nothing the host writes per step reaches a kernel argument: the draws and dropout salts come from a device-side Philox
+    offset, AdamW's step count lives in device memory and indexes a device-resident LEARNING-RATE TABLE (the reference's
+    LambdaLR evaluated once on the host, lr_schedule_table), and the rounding weight of the epoch is a device scalar — so the
+    graph survives the per-step LR schedule and the per-epoch weight without recapture (`graph=False` / TDM_TRAIN_GRAPH=0
+    issue the same launches eagerly, bit for bit).  Under torch.distributed the graph ends before the collectives
+    (denoiser / rounding gradients dense, embedding gradient row-wise) and AdamW is issued after them.  Per-epoch loss sums
+    accumulate on the device (`acc`); `losses` holds the last step's (diff, rnd, total)."""
+
+    def __init__(self, model: TinyTransformer, rounding_fn: "LearnedRounding", embedding_fn: "LearnedEmbedding", lr: float = 1e-4,
+                 weight_decay: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, rounding_weight: float = 1.0,
+                 lr_lambda=None, total_steps: int = 1, graph: Optional[bool] = None):
+        self.model, self.rounding_fn, self.embedding_fn = model, rounding_fn, embedding_fn
+        self.flat = model.flat.detach()
+        self.table = embedding_fn.embeddings.weight.detach()
+        self.W, self.b = rounding_fn.decoder.weight.detach(), rounding_fn.decoder.bias.detach()
+        E._need_cuda(self.flat, self.table, self.W, self.b)
+        for t_ in (self.table, self.W, self.b):
+            if not t_.is_contiguous() or t_.dtype != torch.float32:
+                raise RuntimeError("TextTrainStep: contiguous fp32 parameters expected")
+        self.V, self.D = self.W.shape
+        if self.table.shape != (self.V, self.D) or self.D != model.cfg.dim or self.D % 4 != 0:
+            raise RuntimeError("TextTrainStep: embedding table, rounding head and denoiser must share (V, D), D % 4 == 0")
+        dev = self.flat.device
+        self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, eps
+        self.rank, self.world = dp.world_info()
+        self.use_graph = (os.environ.get("TDM_TRAIN_GRAPH", "1") != "0") if graph is None else bool(graph)
+        z = lambda t_: torch.zeros_like(t_)    # noqa: E731
+        self.g_flat, self.m_flat, self.v_flat = z(self.flat), z(self.flat), z(self.flat)
+        self.g_tab, self.m_tab, self.v_tab = z(self.table), z(self.table), z(self.table)
+        self.g_W, self.m_W, self.v_W = z(self.W), z(self.W), z(self.W)
+        self.g_b, self.m_b, self.v_b = z(self.b), z(self.b), z(self.b)
+        self.step_state = torch.zeros(4, dtype=torch.long, device=dev)
+        self.rng_state = torch.zeros(2, dtype=torch.long, device=dev)
+        self.seed = (int(torch.randint(0, 2 ** 62, (1,)).item()) ^ (self.rank * 0x9E3779B97F4A7C15)) & (2 ** 64 - 1)
+        self.drop_seed = (int(torch.randint(0, 2 ** 62, (1,)).item()) ^ (self.rank * 0xC2B2AE3D27D4EB4F)) & (2 ** 64 - 1)
+        self.lr_tab = lr_schedule_table(self.lr, lr_lambda, total_steps, dev)
+        self.rw = torch.tensor([float(rounding_weight)], dtype=torch.float32, device=dev)
+        self.acc = torch.zeros(4, device=dev)              # running sums of (diff, rnd, total) and the step count
+        self._states = {}
+        self._cur = None
+        self.captures = 0                                   # graphs captured so far (tests: an LR change must not add one)
+        for p_ in (self.flat, self.table, self.W, self.b):
+            dp.broadcast_params_(p_, src=0)
+
+    def set_rounding_weight(self, w: float) -> None:
+        """dynamic_rounding_weight_schedule's value of the epoch (src/shakespeare.py:216): one device write per EPOCH."""
+        self.rw.fill_(float(w))
+
+    def epoch_sums(self, reset: bool = True) -> torch.Tensor:
+        out = self.acc.clone()
+        if reset:
+            self.acc.zero_()
+        return out
+
+    @property
+    def steps_taken(self) -> int:
+        return int(self.step_state[0].item())
+
+    @property
+    def losses(self) -> torch.Tensor:
+        return self._cur.losses
+
+    def _state(self, B: int, L: int) -> _TextStepState:
+        st = self._states.get((B, L))
+        if st is None:
+            st = self._states[(B, L)] = _TextStepState(self.model.cfg, self.flat, B, L, self.V, self.g_flat, self.m_flat, self.v_flat)
+        return st
+
+    def _p_drop(self) -> float:
+        return self.model.p_drop if self.model.training else 0.0
+
+    def _loss_and_grads(self, st: _TextStepState) -> None:
+        L_, tt, cfg = _lib.lib(), st.tt, self.model.cfg
+        B, L, D, V, M = st.B, st.L, self.D, self.V, st.B * st.L
+        tabs = device_tables(self.flat.device)
+        stream = _lib.stream()
+        _lib.check(L_.tdm_embed_gather_f32(_lib.ptr(self.table), _lib.ptr(st.ids), _lib.ptr(tt.x0), M, V, D, stream), "embed_gather")
+        _lib.check(L_.tdm_tt_loss_grad_philox_dx_f32(
+            _lib.ptr(self.flat), _lib.ptr(tt.x0), _lib.ptr(tabs["sqrt_alphas_cumprod"]), _lib.ptr(tabs["sqrt_one_minus_alphas_cumprod"]),
+            self.seed, _lib.ptr(self.rng_state), _lib.ptr(tt.t), _lib.ptr(tt.noise), _lib.ptr(tt.x_noisy), _lib.ptr(tt.pred),
+            _lib.ptr(tt.dpred), _lib.ptr(tt.loss), _lib.ptr(self.g_flat), _lib.ptr(st.dxn), _lib.ptr(tt.ws.ws),
+            _lib.ptr(TE.slabs_for(cfg, self.flat.device)), B, L, D, cfg.n_heads, cfg.depth, cfg.ffn, float(self._p_drop()),
+            self.drop_seed, stream), "tt_loss_grad_philox_dx")
+        if st.chunk:
+            _lib.check(L_.tdm_round_ce_loss_grad_chunked_f32(
+                _lib.ptr(tt.x0), _lib.ptr(self.W), _lib.ptr(self.b), _lib.ptr(st.ids), 1.0, _lib.ptr(st.rnd_loss), _lib.ptr(st.dxr),
+                _lib.ptr(self.g_W), _lib.ptr(self.g_b), _lib.ptr(st.round_ws), M, V, D, st.chunk, stream), "round_ce_chunked")
+        else:
+            _lib.check(L_.tdm_round_ce_loss_grad_f32(
+                _lib.ptr(tt.x0), _lib.ptr(self.W), _lib.ptr(self.b), _lib.ptr(st.ids), 1.0, _lib.ptr(st.rnd_loss), _lib.ptr(st.dxr),
+                _lib.ptr(self.g_W), _lib.ptr(self.g_b), _lib.ptr(st.round_ws), M, V, D, stream), "round_ce")
+        _lib.check(L_.tdm_text_combine_dx0_f32(_lib.ptr(st.dxn), _lib.ptr(tt.t), _lib.ptr(tabs["sqrt_alphas_cumprod"]), _lib.ptr(st.dxr),
+                                               _lib.ptr(self.rw), _lib.ptr(st.dx0), B, L * D, stream), "combine_dx0")
+        self.g_tab.zero_()
+        _lib.check(L_.tdm_embed_scatter_add_f32(_lib.ptr(st.dx0), _lib.ptr(st.ids), _lib.ptr(self.g_tab), M, V, D, 1.0, stream),
+                   "embed_scatter_add")
+        _lib.check(L_.tdm_text_loss_f32(_lib.ptr(tt.loss), _lib.ptr(st.rnd_loss), _lib.ptr(self.rw), _lib.ptr(st.losses),
+                                        _lib.ptr(self.acc), stream), "text_loss")
+
+    def _optimizer_step(self, scale: float = 1.0) -> None:
+        kw = dict(betas=self.betas, eps=self.eps, weight_decay=self.wd)
+        E.adamw_step_devsched(self.flat, self.g_flat, self.m_flat, self.v_flat, self.step_state, self.lr_tab, grad_scale=scale,
+                              bump=False, **kw)
+        E.adamw_step_devsched(self.table.view(-1), self.g_tab.view(-1), self.m_tab.view(-1), self.v_tab.view(-1), self.step_state,
+                              self.lr_tab, grad_scale=scale, bump=False, **kw)
+        # the rounding head's gradients are d rounding_loss: the epoch's weight multiplies them on the way into AdamW
+        E.adamw_step_devsched(self.W.view(-1), self.g_W.view(-1), self.m_W.view(-1), self.v_W.view(-1), self.step_state, self.lr_tab,
+                              grad_scale=scale, grad_scale_dev=self.rw, bump=False, **kw)
+        E.adamw_step_devsched(self.b, self.g_b, self.m_b, self.v_b, self.step_state, self.lr_tab, grad_scale=scale,
+                              grad_scale_dev=self.rw, bump=True, **kw)
+
+    def _sync_and_step(self, ids: torch.Tensor, weight: float) -> None:
+        """world > 1: average the gradients over the ranks, then AdamW.  weight = B_local * world / B_global (1 for equal shards;
+        a ragged tail weights each rank's mean-loss gradient by its share BEFORE the sum, so every rank applies the same
+        reduced gradient)."""
+        if weight != 1.0:
+            for gbuf in (self.g_flat, self.g_tab, self.g_W, self.g_b):
+                gbuf.mul_(weight)
+        for gbuf in (self.g_flat, self.g_W, self.g_b):
+            dp.allreduce_grads_(gbuf.view(-1))
+        dp.allreduce_rows_(self.g_tab, ids)
+        self._optimizer_step(1.0 / self.world)
+
+    def step(self, token_ids: torch.Tensor, global_batch: Optional[int] = None) -> torch.Tensor:
+        """One optimisation step on token_ids (B, L) int64 (any device; copied into the step's fixed-address buffer).  Returns
+        the device tensor (diff, rnd, total) of this step — no host sync."""
+        B, L = int(token_ids.shape[0]), int(token_ids.shape[1])
+        if B == 0:                                          # a rank without samples still joins the step's collectives
+            if self.world == 1:
+                return self._cur.losses if self._cur is not None else torch.zeros(3, device=self.flat.device)
+            st = self._cur if self._cur is not None else self._state(1, L)
+            for gbuf in (self.g_flat, self.g_tab, self.g_W, self.g_b):
+                gbuf.zero_()
+            self._sync_and_step(st.ids[:0], 1.0)
+            return st.losses
+        st = self._cur = self._state(B, L)
+        st.ids.copy_(token_ids)
+        weight = 1.0 if (global_batch is None or self.world == 1) else B * self.world / float(global_batch)
+        whole = self.world == 1
+        if not self.use_graph or st.warm < 1:               # first step of a shape eagerly (lazy kernel attributes, allocator warm-up)
+            st.warm += 1
+            self._loss_and_grads(st)
+            if whole:
+                self._optimizer_step(1.0)
+        else:
+            key = (schedule_generation(), self._p_drop(), self.lr_tab.data_ptr())
+            if st.graph is None or st.graph_key != key:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._loss_and_grads(st)
+                    if whole:
+                        self._optimizer_step(1.0)
+                st.graph, st.graph_key = g, key
+                self.captures += 1
+            st.graph.replay()
+        if not whole:
+            self._sync_and_step(st.ids, weight)
+        return st.losses
 
 
 def p_sample(model, x, t, noise=None):
@@ -738,9 +967,24 @@ def train(model, rounding_fn, embedding_fn, data_loader, val_loader, device, ckp
             else:
                 dp.allreduce_grads_(p_.grad.view(-1))
             p_.grad.mul_(1.0 / world)
-    optim = (optimizer_cls or NativeAdamW)(params, lr=lr, weight_decay=weight_decay)   # torch.optim.AdamW's update on tdm_adamw_flat_f32
     total_steps = len(data_loader) * epochs
-    scheduler = get_cosine_schedule_with_warmup(optim, warmup_steps, total_steps) if use_lr_scheduling else None
+    # The train loop's step as ONE hipGraph replay (TextTrainStep: device-drawn t / noise, device-resident LR table and rounding
+    # weight, AdamW over all four tensors) whenever every piece is the native one; otherwise (pre-trained embedding matrix,
+    # injected loss closure / optimizer of the host-logic tests, TDM_TEXT_STEP=eager) the autograd-bridge form below.
+    fused = (losses_fn is None and optimizer_cls is None and use_learned_embeddings and isinstance(model, TinyTransformer)
+             and isinstance(rounding_fn, LearnedRounding) and isinstance(embedding_fn, LearnedEmbedding)
+             and model.flat.is_cuda and embedding_fn.embeddings.weight.is_cuda and rounding_fn.decoder.weight.is_cuda
+             and model.cfg.dim % 4 == 0 and embedding_fn.embeddings.weight.shape[1] == model.cfg.dim
+             and os.environ.get("TDM_TEXT_STEP", "graph") != "eager")
+    stepper = None
+    if fused:
+        stepper = TextTrainStep(model, rounding_fn, embedding_fn, lr=lr, weight_decay=weight_decay, rounding_weight=rounding_weight,
+                                lr_lambda=cosine_warmup_lambda(warmup_steps, total_steps) if use_lr_scheduling else None,
+                                total_steps=total_steps)
+        optim = scheduler = None
+    else:
+        optim = (optimizer_cls or NativeAdamW)(params, lr=lr, weight_decay=weight_decay)   # torch.optim.AdamW's update on tdm_adamw_flat_f32
+        scheduler = get_cosine_schedule_with_warmup(optim, warmup_steps, total_steps) if use_lr_scheduling else None
     best_val_loss, patience_counter = float("inf"), 0
     global_batch = getattr(data_loader, "global_batch", None)
 
@@ -761,7 +1005,15 @@ def train(model, rounding_fn, embedding_fn, data_loader, val_loader, device, ckp
             embedding_fn.train()
         rw = dynamic_rounding_weight_schedule(epoch, epochs, rounding_weight)
         tr = torch.zeros(4, device=device)                 # sums of the per-batch (diff, rnd, total) and the batch count
-        for it, token_ids in enumerate(data_loader):
+        if stepper is not None:
+            stepper.set_rounding_weight(rw)
+            for it, token_ids in enumerate(data_loader):
+                gb = None
+                if world > 1:
+                    gb = global_batch(it) if global_batch is not None else _global_count(int(token_ids.shape[0]), device)
+                stepper.step(token_ids, global_batch=gb)
+            tr = stepper.epoch_sums()
+        for it, token_ids in enumerate(data_loader if stepper is None else ()):
             token_ids = token_ids.to(device)
             b_local = int(token_ids.shape[0])
             optim.zero_grad()
@@ -770,8 +1022,10 @@ def train(model, rounding_fn, embedding_fn, data_loader, val_loader, device, ckp
                 total.backward()
                 tr += torch.stack([diff.detach(), rnd.detach(), total.detach(), torch.ones_like(diff.detach())])
             if world > 1:
-                gb = global_batch(it) if global_batch is not None else b_local * world
-                sync_grads(token_ids, b_local * world / float(gb))
+                # (a loader without global_batch(): the ranks' batch sizes are summed — an empty or ragged shard must not be
+                #  weighted as if all ranks held equal shares)
+                gb = global_batch(it) if global_batch is not None else _global_count(b_local, device)
+                sync_grads(token_ids, b_local * world / float(max(gb, 1)))
             elif not b_local:
                 continue
             optim.step()
@@ -822,6 +1076,13 @@ def train(model, rounding_fn, embedding_fn, data_loader, val_loader, device, ckp
     if use_learned_embeddings:
         final_checkpoint["embedding_fn"] = embedding_fn.state_dict()
     save_checkpoint(final_checkpoint, final_ckpt_path)
+
+
+def _global_count(b_local: int, device) -> int:
+    """Samples all ranks hold together in this iteration (one small SUM all-reduce; loaders without global_batch())."""
+    n = torch.tensor([b_local], dtype=torch.int64, device=device)
+    dp.allreduce_host_(n, "sum")
+    return int(n.item())
 
 
 def load_text_checkpoint(ckpt, model, rounding_fn, embedding_fn=None):
@@ -909,6 +1170,11 @@ def main(argv=None):
         print(f"Using pre-trained embeddings (dim={embed_dim})")
     diff_model = TinyTransformer(embed_dim, dropout=args.dropout).to(device)
     rounding_fn = LearnedRounding(embed_dim, vocab_size).to(device)
+    if args.seed is not None and world > 1:
+        # identical construction on every rank (same seed above; train() broadcasts rank 0's weights anyway), but the t / noise /
+        # dropout streams of the train loop must differ per rank: a global batch of world * B samples would otherwise see only
+        # B distinct draws.  (The split / shuffle generator below stays rank-identical.)
+        torch.manual_seed(args.seed + 1000003 * rank)
 
     if args.train:
         raw = load_text_dataset(args.corpus)

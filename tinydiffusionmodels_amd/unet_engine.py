@@ -231,6 +231,22 @@ def adamw_step_dev(flat: torch.Tensor, grads: torch.Tensor, m: torch.Tensor, v: 
                                                      grad_scale, _lib.stream()), "adamw_devstep")
 
 
+def adamw_step_devsched(p: torch.Tensor, grads: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step_state: torch.Tensor,
+                        lr_tab: torch.Tensor, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
+                        weight_decay: float = 0.01, grad_scale: float = 1.0, grad_scale_dev: Optional[torch.Tensor] = None,
+                        bump: bool = True):
+    """adamw_step_dev with the learning rate (lr_tab[min(steps taken, len - 1)], fp32 device table) and an optional gradient
+    factor (grad_scale_dev, 1-element device tensor) read from DEVICE memory: nothing about the step is baked into a captured
+    graph except addresses.  bump=False: another tensor of the same optimizer step follows (shared step count)."""
+    _need_cuda(p, grads, m, v, step_state, lr_tab)
+    if step_state.numel() < 4 or step_state.dtype != torch.int64 or lr_tab.dtype != torch.float32:
+        raise RuntimeError("adamw_step_devsched: step_state int64[4], lr_tab float32")
+    _lib.check(_lib.lib().tdm_adamw_flat_devsched_f32(_lib.ptr(p), _lib.ptr(grads), _lib.ptr(m), _lib.ptr(v), p.numel(), _lib.ptr(lr_tab),
+                                                      lr_tab.numel(), betas[0], betas[1], eps, weight_decay, _lib.ptr(step_state),
+                                                      grad_scale, _lib.ptr(grad_scale_dev), 1 if bump else 0, _lib.stream()),
+               "adamw_devsched")
+
+
 def adamw_step(flat: torch.Tensor, grads: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int,
                lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
                weight_decay: float = 0.01, grad_scale: float = 1.0):
