@@ -640,16 +640,40 @@ def main():
             del wsh
             return ms, gb
 
+        def time_fused(nseg):
+            wsh = torch.empty(L.tdm_round_workspace_fused_floats(Mh, Vh, Dt, nseg), device=dev)
+
+            def head():
+                _lib.check(L.tdm_round_ce_loss_grad_fused_f32(_lib.ptr(xh), _lib.ptr(Wh), _lib.ptr(bh), _lib.ptr(idh), 1.0, _lib.ptr(lossh),
+                                                              _lib.ptr(dxh), _lib.ptr(dWh), _lib.ptr(dbh), _lib.ptr(wsh), Mh, Vh, Dt, nseg,
+                                                              _lib.stream()), "round_ce_fused")
+            head()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(nh):
+                head()
+            sync()
+            ms = 1e3 * (time.perf_counter() - t0) / nh
+            gb = wsh.numel() * 4 / 1e9
+            del wsh
+            return ms, gb
+
         chunk_h = _S.round_ce_chunk(Mh, Vh)
-        ms_h, gb_h = time_head(chunk_h)
+        nseg_h = _S.round_fused_nseg(Mh, Vh, Dt)
+        ms_c, gb_c = time_head(chunk_h)
+        ms_s, gb_s = time_head(0) if chunk_h else (ms_c, gb_c)
+        if nseg_h:
+            ms_h, gb_h = time_fused(nseg_h)
+            form_h = (f"logits in registers only (csrc/ce_chain.hip): token-stationary online-softmax + dX pass, vocabulary-stationary "
+                      f"dW / db pass over {nseg_h} token segments")
+        else:
+            ms_h, gb_h, form_h = ms_c, gb_c, f"logits never held: statistics pass + {chunk_h}-entry vocabulary chunks recomputed"
         loss_h = float(lossh.item())
-        ms_s, gb_s = time_head(0) if chunk_h else (ms_h, gb_h)
-        out["text_denoiser"]["rounding_head"] = {"vocab": Vh, "tokens": Mh, "ms": round(ms_h, 3),
-                                                 "form": (f"logits never held: statistics pass + {chunk_h}-entry vocabulary chunks recomputed"
-                                                          if chunk_h else "logits stored once"),
-                                                 "gemm_passes": 4 if chunk_h else 3,
-                                                 "tflops": round((4 if chunk_h else 3) * 2.0 * Mh * Vh * Dt / (ms_h * 1e-3) / 1e12, 1),
+        out["text_denoiser"]["rounding_head"] = {"vocab": Vh, "tokens": Mh, "ms": round(ms_h, 3), "form": form_h, "gemm_passes": 4,
+                                                 "tflops": round(4 * 2.0 * Mh * Vh * Dt / (ms_h * 1e-3) / 1e12, 1),
+                                                 "frac_bf16_mfma_issue": round(3 * 4 * 2.0 * Mh * Vh * Dt / (ms_h * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                                                  "workspace_gb": round(gb_h, 2),
+                                                 "chunked_form": {"ms": round(ms_c, 3), "workspace_gb": round(gb_c, 2)},
                                                  "stored_logits_form": {"ms": round(ms_s, 3), "workspace_gb": round(gb_s, 2)},
                                                  "loss": round(loss_h, 4)}
         del xh, Wh, bh, idh, dxh, dWh, dbh

@@ -409,6 +409,14 @@ int64_t tdm_round_workspace_chunked_floats(int64_t M, int V, int D, int Vc);
 int tdm_round_ce_loss_grad_chunked_f32(const float* x, const float* W, const float* b, const int64_t* ids,
                                        float grad_scale, float* loss_out, float* dx, float* dW, float* db,
                                        float* ws, int64_t M, int V, int D, int Vc, void* stream);
+/* The same contract with the logits in REGISTERS only (csrc/ce_chain.hip: two chained-MFMA passes — token-stationary online
+ * softmax + dX, vocabulary-stationary dW / db; no logits tensor, no per-chunk scratch, no split-K slabs).  D must be 256
+ * (tdm_round_fused_ok).  nseg (1..8): token segments of the weight-gradient pass.  ws: tdm_round_workspace_fused_floats.  */
+int tdm_round_fused_ok(int64_t M, int V, int D);
+int64_t tdm_round_workspace_fused_floats(int64_t M, int V, int D, int nseg);
+int tdm_round_ce_loss_grad_fused_f32(const float* x, const float* W, const float* b, const int64_t* ids, float grad_scale,
+                                     float* loss_out, float* dx, float* dW, float* db, float* ws, int64_t M, int V, int D,
+                                     int nseg, void* stream);
 /* logits (M, ld >= V, ld % 4 == 0) = x W^T + b   (LearnedRounding.forward, src/shakespeare.py:101) */
 int tdm_round_logits_f32(const float* x, const float* W, const float* b, float* logits, int64_t ld,
                          int64_t M, int V, int D, void* stream);

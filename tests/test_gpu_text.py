@@ -929,6 +929,64 @@ def test_rounding_ce_c_abi_vs_oracle(dev, gemm_mode, M, V, D):
     assert torch.equal(dW2, dW) and torch.equal(db2, db)      # deterministic (fixed-order slab sums)
 
 
+@pytest.mark.parametrize("M,V,nseg", [(384, 5000, 1), (300, 1003, 3), (1000, 2077, 2), (48, 64, 1)])
+def test_rounding_ce_logits_in_registers_vs_oracle(dev, gemm_mode, monkeypatch, M, V, nseg):
+    """tdm_round_ce_loss_grad_fused_f32 (csrc/ce_chain.hip, the product's form at D = 256): rounding loss and its three gradients
+    with the logits in registers only — token-stationary online softmax + dX, vocabulary-stationary dW / db over `nseg` token
+    segments.  Ragged M (not a multiple of 128 / 32) and V (not a multiple of 32): tails of both passes; targets in the first
+    and the last vocabulary block; a NaN-filled workspace (nothing stale is read).  Against the oracle at the stored-logits
+    form's tolerance, deterministic, and through LearnedRounding.cross_entropy (which picks this form at D = 256)."""
+    if gemm_mode != 1:
+        pytest.skip("the rounding head has one arithmetic (bf16x3)")
+    from tinydiffusionmodels_amd import _lib, shakespeare as S
+    L = _lib.lib()
+    D = 256
+    gen = torch.Generator().manual_seed(M + V)
+    x = torch.randn(M, D, generator=gen) * 0.8
+    W = torch.randn(V, D, generator=gen) * (2.0 / D ** 0.5)
+    b = torch.randn(V, generator=gen) * 0.1
+    ids = torch.randint(0, V, (M,), generator=gen)
+    ids[0], ids[-1] = V - 1, 0
+    loss_ref, dx_ref, dW_ref, db_ref = O.rounding_ce_and_grads(x, W, b, ids)
+    xd, Wd, bd, idd = x.to(dev), W.to(dev), b.to(dev), ids.to(dev)
+    assert L.tdm_round_fused_ok(M, V, D) == 1 and L.tdm_round_fused_ok(M, V, 64) == 0
+    n = L.tdm_round_workspace_fused_floats(M, V, D, nseg)
+    assert 0 < n < L.tdm_round_workspace_floats(M, V, D) or M * V < 1 << 16
+    ws = torch.full((n,), float("nan"), device=dev)
+    loss, dx, dW, db = torch.empty(1, device=dev), torch.empty(M, D, device=dev), torch.empty(V, D, device=dev), torch.empty(V, device=dev)
+    _lib.check(L.tdm_round_ce_loss_grad_fused_f32(_lib.ptr(xd), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(idd), 0.25, _lib.ptr(loss),
+                                                  _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db), _lib.ptr(ws), M, V, D, nseg, _lib.stream()))
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_ref.item()) < 2e-5 * abs(loss_ref.item())
+    assert O.rel_err(dx.cpu(), 0.25 * dx_ref) < 1e-4
+    assert O.rel_err(dW.cpu(), 0.25 * dW_ref) < 1e-4
+    assert O.rel_err(db.cpu(), 0.25 * db_ref) < 1e-4
+    dW2, db2 = torch.empty_like(dW), torch.empty_like(db)
+    _lib.check(L.tdm_round_ce_loss_grad_fused_f32(_lib.ptr(xd), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(idd), 0.25, _lib.ptr(loss),
+                                                  None, _lib.ptr(dW2), _lib.ptr(db2), _lib.ptr(ws), M, V, D, nseg, _lib.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(dW2, dW) and torch.equal(db2, db)      # deterministic (fixed-order sums), dx optional
+    # an id outside [0, V) (F.cross_entropy raises, src/shakespeare.py:240): the loss is NaN, nothing is read out of bounds
+    bad = idd.clone()
+    bad[3] = V + 5
+    _lib.check(L.tdm_round_ce_loss_grad_fused_f32(_lib.ptr(xd), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(bad), 0.25, _lib.ptr(loss),
+                                                  _lib.ptr(dx), _lib.ptr(dW2), _lib.ptr(db2), _lib.ptr(ws), M, V, D, nseg, _lib.stream()))
+    torch.cuda.synchronize()
+    assert torch.isnan(loss).all() and torch.isfinite(dx).all() and torch.isfinite(dW2).all()
+    # the module picks this form at D = 256
+    assert S.round_fused_nseg(M, V, D) >= 1
+    rnd = S.LearnedRounding(D, V).to(dev)
+    with torch.no_grad():
+        rnd.decoder.weight.copy_(Wd); rnd.decoder.bias.copy_(bd)
+    xg = xd.clone().requires_grad_(True)
+    ce = rnd.cross_entropy(xg, idd)
+    ce.backward()
+    assert abs(ce.item() - loss_ref.item()) < 2e-5 * abs(loss_ref.item())
+    assert O.rel_err(xg.grad.cpu(), dx_ref) < 1e-4 and O.rel_err(rnd.decoder.weight.grad.cpu(), dW_ref) < 1e-4
+    monkeypatch.setenv("TDM_ROUND_FUSED", "0")
+    assert S.round_fused_nseg(M, V, D) == 0
+
+
 @pytest.mark.parametrize("M,V,D,Vc", [(384, 5000, 256, 1024), (100, 777, 64, 256), (200, 1000, 32, 128), (64, 300, 64, 512)])
 def test_rounding_ce_without_stored_logits_vs_oracle(dev, gemm_mode, monkeypatch, M, V, D, Vc):
     """tdm_round_ce_loss_grad_chunked_f32: the rounding loss and its three gradients with the (M, V) logits never held — a

@@ -79,6 +79,9 @@ _SIGS = {
     "tdm_round_workspace_floats": ([c_i64, c_int, c_int], c_i64),
     "tdm_round_ce_loss_grad_f32": ([c_f, c_f, c_f, c_f, c_float, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_f], c_int),
     "tdm_round_workspace_chunked_floats": ([c_i64, c_int, c_int, c_int], c_i64),
+    "tdm_round_fused_ok": ([c_i64, c_int, c_int], c_int),
+    "tdm_round_workspace_fused_floats": ([c_i64, c_int, c_int, c_int], c_i64),
+    "tdm_round_ce_loss_grad_fused_f32": ([c_f, c_f, c_f, c_f, c_float, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_f], c_int),
     "tdm_round_ce_loss_grad_chunked_f32": ([c_f, c_f, c_f, c_f, c_float, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_f], c_int),
     "tdm_round_logits_f32": ([c_f, c_f, c_f, c_f, c_i64, c_i64, c_int, c_int, c_f], c_int),
     "tdm_round_argmax_f32": ([c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_f], c_int),

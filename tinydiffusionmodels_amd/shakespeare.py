@@ -134,6 +134,46 @@ def round_ce_chunk(M: int, V: int) -> int:
     return 0 if M * V * 4 <= ROUND_LOGITS_BYTES_MAX else ROUND_CHUNK
 
 
+def round_fused_nseg(M: int, V: int, D: int) -> int:
+    """Token segments of the fused rounding head's weight-gradient pass (csrc/ce_chain.hip), or 0 when the fused form does not
+    serve the problem (D != 256, TDM_ROUND_FUSED=0).  The pass runs ceil(V / 128) vocabulary tiles x nseg segments on 256 CUs:
+    the smallest nseg within 5 % of the best rounds-per-segment (V = 50,257: 393 tiles -> 3 segments, 5 rounds of 256)."""
+    if os.environ.get("TDM_ROUND_FUSED", "1") == "0" or not _lib.lib().tdm_round_fused_ok(M, V, D):
+        return 0
+    tiles = (V + 127) // 128
+    nmax = max(1, min(6, ((M + 31) // 32) // 4))       # a segment should hold a few token blocks
+    cost = {n: math.ceil(tiles * n / 256) / n for n in range(1, nmax + 1)}
+    best = min(cost.values())
+    return min(n for n, c in cost.items() if c <= 1.05 * best)
+
+
+def round_ce_workspace(M: int, V: int, D: int, device):
+    """(form, parameter, workspace) of the rounding cross-entropy at this size: ("fused", nseg, ws) — logits in registers only —
+    when D = 256; else ("chunked", chunk, ws) above ROUND_LOGITS_BYTES_MAX of logits, else ("stored", 0, ws)."""
+    nseg = round_fused_nseg(M, V, D)
+    if nseg:
+        n = _lib.lib().tdm_round_workspace_fused_floats(M, V, D, nseg)
+        return "fused", nseg, torch.empty(n, dtype=torch.float32, device=device)
+    chunk = round_ce_chunk(M, V)
+    n = _lib.lib().tdm_round_workspace_chunked_floats(M, V, D, chunk) if chunk else _lib.lib().tdm_round_workspace_floats(M, V, D)
+    return ("chunked" if chunk else "stored"), chunk, torch.empty(n, dtype=torch.float32, device=device)
+
+
+def round_ce_launch(form, param, ws, x, W, b, ids, scale, loss, dx, dW, db, M, V, D):
+    L_ = _lib.lib()
+    args = (_lib.ptr(x), _lib.ptr(W), _lib.ptr(b), _lib.ptr(ids), float(scale), _lib.ptr(loss), _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db),
+            _lib.ptr(ws), M, V, D)
+    if form == "fused":
+        _lib.check(L_.tdm_round_ce_loss_grad_fused_f32(*args, param, _lib.stream()), "round_ce_loss_grad_fused")
+    elif form == "chunked":
+        _lib.check(L_.tdm_round_ce_loss_grad_chunked_f32(*args, param, _lib.stream()), "round_ce_loss_grad_chunked")
+    else:
+        _lib.check(L_.tdm_round_ce_loss_grad_f32(*args, _lib.stream()), "round_ce_loss_grad")
+
+
+_round_ce_ws = {}
+
+
 class _RoundCEFunction(torch.autograd.Function):
     """cross_entropy(Linear(D,V)(x), ids) (src/shakespeare.py:239-240) with loss and all three
     gradients from one native call (tdm_round_ce_loss_grad_f32)."""
@@ -150,16 +190,13 @@ class _RoundCEFunction(torch.autograd.Function):
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
         dx = torch.empty_like(xc) if ctx.needs_input_grad[0] else None
         dW, db = torch.empty_like(Wc), torch.empty_like(bc)
-        chunk = round_ce_chunk(M, V)
-        ws = _round_workspace(M, V, D, x.device, chunk)
-        if chunk:
-            _lib.check(_lib.lib().tdm_round_ce_loss_grad_chunked_f32(
-                _lib.ptr(xc), _lib.ptr(Wc), _lib.ptr(bc), _lib.ptr(idc), 1.0, _lib.ptr(loss), _lib.ptr(dx), _lib.ptr(dW),
-                _lib.ptr(db), _lib.ptr(ws), M, V, D, chunk, _lib.stream()), "round_ce_loss_grad_chunked")
-        else:
-            _lib.check(_lib.lib().tdm_round_ce_loss_grad_f32(_lib.ptr(xc), _lib.ptr(Wc), _lib.ptr(bc), _lib.ptr(idc), 1.0,
-                                                             _lib.ptr(loss), _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db),
-                                                             _lib.ptr(ws), M, V, D, _lib.stream()), "round_ce_loss_grad")
+        key = (str(x.device), M, V, D, os.environ.get("TDM_ROUND_FUSED", "1"), os.environ.get("TDM_ROUND_CHUNK"))
+        if key not in _round_ce_ws:
+            _round_ce_ws.clear()       # one live workspace
+            _round_ws.clear()
+            _round_ce_ws[key] = round_ce_workspace(M, V, D, x.device)
+        form, param, ws = _round_ce_ws[key]
+        round_ce_launch(form, param, ws, xc, Wc, bc, idc, 1.0, loss, dx, dW, db, M, V, D)
         ctx.grads = (dx, dW, db)
         ctx.xshape = x.shape
         return loss[0]
@@ -564,11 +601,7 @@ class _TextStepState:
         self.rnd_loss = torch.zeros(1, device=dev)
         self.losses = torch.zeros(3, device=dev)
         self.graph, self.graph_key, self.warm = None, None, 0
-        M = B * L
-        self.chunk = round_ce_chunk(M, V)
-        n = (_lib.lib().tdm_round_workspace_chunked_floats(M, V, D, self.chunk) if self.chunk
-             else _lib.lib().tdm_round_workspace_floats(M, V, D))
-        self.round_ws = torch.empty(n, dtype=torch.float32, device=dev)
+        self.round_form, self.round_param, self.round_ws = round_ce_workspace(B * L, V, D, dev)
 
 
 class TextTrainStep:
@@ -665,14 +698,8 @@ class TextTrainStep:
             _lib.ptr(tt.dpred), _lib.ptr(tt.loss), _lib.ptr(self.g_flat), _lib.ptr(st.dxn), _lib.ptr(tt.ws.ws),
             _lib.ptr(TE.slabs_for(cfg, self.flat.device)), B, L, D, cfg.n_heads, cfg.depth, cfg.ffn, float(self._p_drop()),
             self.drop_seed, stream), "tt_loss_grad_philox_dx")
-        if st.chunk:
-            _lib.check(L_.tdm_round_ce_loss_grad_chunked_f32(
-                _lib.ptr(tt.x0), _lib.ptr(self.W), _lib.ptr(self.b), _lib.ptr(st.ids), 1.0, _lib.ptr(st.rnd_loss), _lib.ptr(st.dxr),
-                _lib.ptr(self.g_W), _lib.ptr(self.g_b), _lib.ptr(st.round_ws), M, V, D, st.chunk, stream), "round_ce_chunked")
-        else:
-            _lib.check(L_.tdm_round_ce_loss_grad_f32(
-                _lib.ptr(tt.x0), _lib.ptr(self.W), _lib.ptr(self.b), _lib.ptr(st.ids), 1.0, _lib.ptr(st.rnd_loss), _lib.ptr(st.dxr),
-                _lib.ptr(self.g_W), _lib.ptr(self.g_b), _lib.ptr(st.round_ws), M, V, D, stream), "round_ce")
+        round_ce_launch(st.round_form, st.round_param, st.round_ws, tt.x0.view(M, D), self.W, self.b, st.ids.view(-1), 1.0, st.rnd_loss,
+                        st.dxr, self.g_W, self.g_b, M, V, D)
         _lib.check(L_.tdm_text_combine_dx0_f32(_lib.ptr(st.dxn), _lib.ptr(tt.t), _lib.ptr(tabs["sqrt_alphas_cumprod"]), _lib.ptr(st.dxr),
                                                _lib.ptr(self.rw), _lib.ptr(st.dx0), B, L * D, stream), "combine_dx0")
         self.g_tab.zero_()
