@@ -325,6 +325,12 @@ int tdm_attention_fwd_f32(const float* qkv, float* o, float* lse, int64_t B, int
 int tdm_attention_bwd_f32(const float* qkv, const float* o, const float* lse, const float* dO, float* dqkv,
                           float* Dvec, int64_t B, int L, int D, int H, float p_drop, uint64_t seed, int site,
                           void* stream);
+/* One attention kernel in the form the train step launches it (S16 twin outputs): which = 0 forward (out = O, out16 = its
+ * S16 twin or NULL, aux = lse), 1 dQ (aux = Dvec, written), 2 dK/dV (aux = Dvec, read); backward with out16 != NULL writes
+ * d(qkv) as S16 only (out may be NULL).  Per-kernel timing / parity (tools/time_attn.py). */
+int tdm_attention_step_form_f32(int which, const float* qkv, const float* o, const float* lse, const float* dO, float* out,
+                                float* out16, float* aux, int64_t B, int L, int D, int H, float p_drop, uint64_t seed, int site,
+                                void* stream);
 /* Per-op residual LayerNorm of the post-LN encoder layer (norm1 / norm2 of nn.TransformerEncoderLayer,
  * src/shakespeare.py:108-111): s = x + r (r may be NULL); y = (s - mean) * rstd * gamma + beta over the last dim
  * (biased variance, eps 1e-5).  x, r, y, s: (M, D) fp32; mean, rstd: (M).  s / mean / rstd are optional (all or none):
@@ -358,6 +364,7 @@ int tdm_ffn_chain_f32(int mode, int nprod, const float* x16, const float* wa16, 
                       const float* bias_b, float* y, float* mid16, uint32_t* mask, float gate_scale, float p_drop,
                       uint64_t seed, int site_mid, int site_out, int64_t M, int D, int F, void* stream);
 int64_t tdm_ffn_chain_mask_count(int64_t M, int F);
+int tdm_attn_set_ablate(int bits);        /* same, attention kernels (tools/time_attn.py --ablate) */
 int tdm_ffn_chain_set_ablate(int bits);   /* timing diagnostics of tools/time_ffn.py (results are wrong when nonzero) */
 /* ---- the FULL text train step as one replayable launch sequence (src/shakespeare.py:221-250) ----
  * tdm_tt_loss_grad_philox_f32 with dx_noisy (B,L,D; nullable) = d loss / d x_noisy: what learned embeddings receive

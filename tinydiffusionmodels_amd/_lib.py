@@ -66,6 +66,7 @@ _SIGS = {
     "tdm_get_attn_mode": ([], c_int),
     "tdm_attention_fwd_f32": ([c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_float, c_u64, c_int, c_f], c_int),
     "tdm_attention_bwd_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_float, c_u64, c_int, c_f], c_int),
+    "tdm_attention_step_form_f32": ([c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_float, c_u64, c_int, c_f], c_int),
     "tdm_dropout_keep_u8": ([c_float, c_u64, c_int, c_i64, c_i64, c_f], c_int),
     "tdm_dropout_keep_salted_u8": ([c_float, c_u64, ctypes.c_uint32, c_int, c_i64, c_i64, c_f], c_int),
     "tdm_tt_loss_grad_philox_f32": ([c_f, c_f, c_f, c_f, c_u64] + [c_f] * 10 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_float, c_u64, c_f], c_int),
@@ -116,6 +117,7 @@ _SIGS = {
                            c_i64, c_int, c_int, c_f], c_int),
     "tdm_ffn_chain_mask_count": ([c_i64, c_int], c_i64),
     "tdm_ffn_chain_set_ablate": ([c_int], c_int),
+    "tdm_attn_set_ablate": ([c_int], c_int),
     "tdm_gemm_f32": ([c_f, c_i64, c_i64, c_f, c_i64, c_i64, c_f, c_i64, c_f, c_f, c_int, c_int, c_int, c_int, c_int,
                       c_i64, c_f], c_int),
 }

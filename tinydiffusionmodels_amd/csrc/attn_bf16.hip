@@ -22,6 +22,7 @@
 // A workgroup = 4 waves = 128 queries (keys) of one (batch, head); the other side is streamed
 // through LDS in blocks of 64 rows; any L, head_dim in {8, 16, 32, 64}.
 #include <math.h>
+#include <algorithm>
 #include "tdm_common.h"
 #include "tdm_transformer.h"
 #include "tdm_s16.h"
@@ -30,6 +31,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+#ifdef TDM_DIAG
+__device__ int g_attn_abl_dev = 0;   // diagnostics: 1 = no chunk compute, 2 = no staging, 4 = no stores (tools/time_attn.py --ablate)
+#define ATTN_ABL (g_attn_abl_dev)
+#else
+#define ATTN_ABL 0
+#endif
 
 namespace {
 
@@ -44,6 +52,9 @@ template <int HD> struct Cfg {
     static constexpr int ROWPL = RB * RP;                // one plane (hi or lo) of a row image
     static constexpr int TRPL = NT * RB * 64;            // one plane of a token-major image: [d block][position][32 d]
     static constexpr int ROWIMG = 2 * ROWPL, TRIMG = 2 * TRPL;
+    static constexpr int TP = HD * 4 + 16;               // fp32 row pitch of a wave's epilogue tile (odd number of 16-B slots)
+    static constexpr int EPI = 4 * 32 * TP;              // the four waves' epilogue tiles (reuse the staging area after the loop)
+    static constexpr int PRO = 4 * 2 * 32 * RP + 512;    // the four waves' own-row images (both planes) + 32 floats each, before the loop
 };
 
 __device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
@@ -174,6 +185,107 @@ __device__ __forceinline__ void store_rows(float* __restrict__ dst_row, float* _
         }
 }
 
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// B-operand registers of the wave's 32 own rows (lane (j, h): row j), loaded COALESCED — HD/4 lanes per row, 16 B each —
+// split, passed through a wave-private LDS row image and read back as fragments.  (load_breg's row-per-lane global loads
+// touch 32 rows x 64 B per instruction: the dQ kernel's 32 such loads per lane were a third of its time.)
+// DOT: also dots[row] = sum_d src[row][d] * other[row][d] (exact fp32; the D_i of the backward), other has row stride ldo.
+template <int HD, bool DOT>
+__device__ __forceinline__ void load_breg_lds(bf16x8 (&hi)[Cfg<HD>::KS], bf16x8 (&lo)[Cfg<HD>::KS], char* img, float* dots,
+                                              const float* __restrict__ src, long ld, const float* __restrict__ other, long ldo,
+                                              int nvalid, int lane) {
+    using C = Cfg<HD>;
+    constexpr int LPR = HD / 4, RPP = 64 / LPR, NP = 32 / RPP;
+    float4 v[NP], w[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int rr = p * RPP + lane / LPR, d4 = lane % LPR;
+        v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        w[p] = v[p];
+        if (rr < nvalid) {
+            v[p] = *reinterpret_cast<const float4*>(src + (long)rr * ld + d4 * 4);
+            if (DOT) w[p] = *reinterpret_cast<const float4*>(other + (long)rr * ldo + d4 * 4);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int rr = p * RPP + lane / LPR, d4 = lane % LPR;
+        tdm_bf16x4 h4, l4;
+        tdm_split4(v[p], h4, l4);
+        *reinterpret_cast<tdm_bf16x4*>(img + rr * C::RP + d4 * 8) = h4;
+        *reinterpret_cast<tdm_bf16x4*>(img + 32 * C::RP + rr * C::RP + d4 * 8) = l4;
+        if (DOT) {
+            float s = fmaf(v[p].x, w[p].x, fmaf(v[p].y, w[p].y, fmaf(v[p].z, w[p].z, v[p].w * w[p].w)));
+#pragma unroll
+            for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
+            if (d4 == 0) dots[rr] = s;
+        }
+    }
+    wave_lds_fence();
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+        const char* p = img + j * C::RP + ks * 32 + h * 16;
+        if (16 * ks + 8 * h < HD) {
+            hi[ks] = *reinterpret_cast<const bf16x8*>(p);
+            lo[ks] = *reinterpret_cast<const bf16x8*>(p + 32 * C::RP);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { hi[ks][i] = (__bf16)0.f; lo[ks][i] = (__bf16)0.f; }
+        }
+    }
+    wave_lds_fence();
+}
+
+// the transposed accumulator tiles of the wave's 32 own rows -> rows, through a wave-private LDS tile: every store
+// instruction then writes whole 32-byte (fp32) / 16-byte (S16 piece) runs, HD/8 lanes per row.  (store_rows' row-per-lane
+// stores — 64 rows x 16 B, or x 8 B for the S16 twin — were a quarter of the backward kernels' time.)
+// dst: fp32 tensor [rows][ld] or nullptr, dst16: its S16 twin or nullptr; m0 = the wave's first row, col0 = first column.
+template <int HD>
+__device__ __forceinline__ void store_rows_lds(char* tile, float* __restrict__ dst, float* __restrict__ dst16, long m0, int nvalid,
+                                               int ld, int col0, const f32x16 (&out)[Cfg<HD>::NT], int lane, float mul) {
+    using C = Cfg<HD>;
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < C::NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int d = 32 * t + 8 * q + 4 * h;
+            if (d < HD)
+                *reinterpret_cast<float4*>(tile + j * C::TP + d * 4) =
+                    make_float4(out[t][4 * q] * mul, out[t][4 * q + 1] * mul, out[t][4 * q + 2] * mul, out[t][4 * q + 3] * mul);
+        }
+    wave_lds_fence();
+    constexpr int LPR = HD / 8, RPP = 64 / LPR, NP = (32 + RPP - 1) / RPP;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int rr = p * RPP + lane / LPR, d8 = lane % LPR;
+        if (rr < 32 && rr < nvalid) {
+            const float4 a = *reinterpret_cast<const float4*>(tile + rr * C::TP + d8 * 32);
+            const float4 b = *reinterpret_cast<const float4*>(tile + rr * C::TP + d8 * 32 + 16);
+            const int c = col0 + 8 * d8;
+            if (dst != nullptr) {
+                float* r = dst + (m0 + rr) * ld + c;
+                *reinterpret_cast<float4*>(r) = a;
+                *reinterpret_cast<float4*>(r + 4) = b;
+            }
+            if (dst16 != nullptr) {
+                bf16x8 vh, vl;
+                split8(a, b, vh, vl);
+                char* g = reinterpret_cast<char*>(dst16 + (m0 + rr) * ld + (c & ~15)) + (c & 8) * 2;
+                *reinterpret_cast<bf16x8*>(g) = vh;
+                *reinterpret_cast<bf16x8*>(g + 32) = vl;
+            }
+        }
+    }
+    wave_lds_fence();
+}
+
 __device__ __forceinline__ void clear_lds(char* lds, int bytes, int tid) {
     for (int e = tid * 16; e < bytes; e += 256 * 16) *reinterpret_cast<float4*>(lds + e) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
@@ -206,11 +318,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const float* __re
 
     for (int k0 = 0; k0 < L; k0 += RB) {
         __syncthreads();
+        if (!(ATTN_ABL & 2)) {
         stage_block<HD>(Kr, nullptr, base + D, 3L * D, k0, L, tid);
         stage_block<HD>(nullptr, Vt, base + 2 * D, 3L * D, k0, L, tid);
+        }
         __syncthreads();
         if (qw0 >= L) continue;   // wave-uniform: this wave has no query rows
-        const int nchunk = min(RB / 32, (L - k0 + 31) / 32);
+        const int nchunk = (ATTN_ABL & 1) ? 0 : min(RB / 32, (L - k0 + 31) / 32);
         for (int c = 0; c < nchunk; ++c) {
             f32x16 s = rows_dot_reg<HD>(Kr, c * 32, j, h, qh, ql);
             float mloc = -INFINITY;
@@ -246,9 +360,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const float* __re
             accum_T_times<HD>(acc_o, Vt, c * 32, lane, s);
         }
     }
-    if (qvalid) {
-        store_rows<HD>(o + ((long)b * L + qi) * D + hh * HD, o16, (long)b * L + qi, D, hh * HD, acc_o, h, 1.f / l);
-        if (h == 0) lse[(long)bh * L + qi] = m + logf(l);
+    __syncthreads();   // every wave is done with the staged images: their space holds the epilogue tiles now
+    if (qw0 < L && !(ATTN_ABL & 4)) {
+        store_rows_lds<HD>(Kr + wave * 32 * C::TP, o, o16, (long)b * L + qw0, min(32, L - qw0), D, hh * HD, acc_o, lane, 1.f / l);
+        if (qvalid && h == 0) lse[(long)bh * L + qi] = m + logf(l);
     }
 }
 
@@ -270,23 +385,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const float* _
     const int qi = qw0 + j;
     const bool qvalid = qi < L;
     const float* base = qkv + (long)b * L * 3 * D + hh * HD;
-    if (HD < 32) clear_lds(Kr, 2 * C::ROWIMG + C::TRIMG, tid);
-
     bf16x8 qh[C::KS], ql[C::KS], gh[C::KS], gl[C::KS];
-    load_breg<HD>(qh, ql, base + (long)qi * 3 * D, h, qvalid);
-    load_breg<HD>(gh, gl, dO + ((long)b * L + qi) * D + hh * HD, h, qvalid);
-    float Di = 0.f;   // exact fp32, as in the fp32 kernels: D_i multiplies every probability of the row
-    if (qvalid) {
-        const float* orow = o + ((long)b * L + qi) * D + hh * HD;
-        const float* grow = dO + ((long)b * L + qi) * D + hh * HD;
-#pragma unroll
-        for (int c8 = 0; c8 < HD / 8; ++c8) {
-            const float4 ov = *reinterpret_cast<const float4*>(orow + 8 * c8 + 4 * h);
-            const float4 gv = *reinterpret_cast<const float4*>(grow + 8 * c8 + 4 * h);
-            Di = fmaf(gv.x, ov.x, Di); Di = fmaf(gv.y, ov.y, Di); Di = fmaf(gv.z, ov.z, Di); Di = fmaf(gv.w, ov.w, Di);
-        }
+    float Di = 0.f;   // D_i = dO_i . O_i, exact fp32 as in the fp32 kernels: it multiplies every probability of the row
+    {
+        char* img = Kr + wave * (2 * 32 * C::RP);
+        float* dots = reinterpret_cast<float*>(Kr + 4 * 2 * 32 * C::RP) + wave * 32;
+        const int nv = max(0, min(32, L - qw0));
+        load_breg_lds<HD, false>(qh, ql, img, nullptr, base + (long)qw0 * 3 * D, 3L * D, nullptr, 0, nv, lane);
+        const long r0 = ((long)b * L + qw0) * D + hh * HD;
+        load_breg_lds<HD, true>(gh, gl, img, dots, dO + r0, (long)D, o + r0, (long)D, nv, lane);
+        if (qvalid) Di = dots[j];
     }
-    Di += __shfl_xor(Di, 32);
+    __syncthreads();
+    if (HD < 32) clear_lds(Kr, 2 * C::ROWIMG + C::TRIMG, tid);
     const float lse_i = qvalid ? lse[(long)bh * L + qi] : 0.f;
     f32x16 acc_dq[C::NT];
 #pragma unroll
@@ -296,11 +407,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const float* _
 
     for (int k0 = 0; k0 < L; k0 += RB) {
         __syncthreads();
+        if (!(ATTN_ABL & 2)) {
         stage_block<HD>(Kr, Kt, base + D, 3L * D, k0, L, tid);
         stage_block<HD>(Vr, nullptr, base + 2 * D, 3L * D, k0, L, tid);
+        }
         __syncthreads();
         if (qw0 >= L) continue;
-        const int nchunk = min(RB / 32, (L - k0 + 31) / 32);
+        const int nchunk = (ATTN_ABL & 1) ? 0 : min(RB / 32, (L - k0 + 31) / 32);
         for (int c = 0; c < nchunk; ++c) {
             f32x16 s = rows_dot_reg<HD>(Kr, c * 32, j, h, qh, ql);
             const f32x16 dp = rows_dot_reg<HD>(Vr, c * 32, j, h, gh, gl);
@@ -316,10 +429,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const float* _
             accum_T_times<HD>(acc_dq, Kt, c * 32, lane, s);
         }
     }
-    if (qvalid) {
-        store_rows<HD>(dqkv != nullptr ? dqkv + ((long)b * L + qi) * 3 * D + hh * HD : nullptr, dqkv16, (long)b * L + qi, 3 * D,
-                       hh * HD, acc_dq, h, scale);
-        if (h == 0) Dvec[(long)bh * L + qi] = Di;
+    __syncthreads();
+    if (qw0 < L && !(ATTN_ABL & 4)) {
+        store_rows_lds<HD>(Kr + wave * 32 * C::TP, dqkv, dqkv16, (long)b * L + qw0, min(32, L - qw0), 3 * D, hh * HD, acc_dq, lane, scale);
+        if (qvalid && h == 0) Dvec[(long)bh * L + qi] = Di;
     }
 }
 
@@ -343,11 +456,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const float* 
     const int kj = kw0 + j;
     const bool kvalid = kj < L;
     const float* base = qkv + (long)b * L * 3 * D + hh * HD;
-    if (HD < 32) clear_lds(Qr, 2 * C::ROWIMG + 2 * C::TRIMG, tid);
-
     bf16x8 kh[C::KS], kl[C::KS], vh[C::KS], vl[C::KS];
-    load_breg<HD>(kh, kl, base + (long)kj * 3 * D + D, h, kvalid);
-    load_breg<HD>(vh, vl, base + (long)kj * 3 * D + 2 * D, h, kvalid);
+    {
+        char* img = Qr + wave * (2 * 32 * C::RP);
+        const int nv = max(0, min(32, L - kw0));
+        load_breg_lds<HD, false>(kh, kl, img, nullptr, base + (long)kw0 * 3 * D + D, 3L * D, nullptr, 0, nv, lane);
+        load_breg_lds<HD, false>(vh, vl, img, nullptr, base + (long)kw0 * 3 * D + 2 * D, 3L * D, nullptr, 0, nv, lane);
+    }
+    __syncthreads();
+    if (HD < 32) clear_lds(Qr, 2 * C::ROWIMG + 2 * C::TRIMG, tid);
     f32x16 acc_dk[C::NT], acc_dv[C::NT];
 #pragma unroll
     for (int t = 0; t < C::NT; ++t)
@@ -356,8 +473,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const float* 
 
     for (int i0 = 0; i0 < L; i0 += RB) {
         __syncthreads();
+        if (!(ATTN_ABL & 2)) {
         stage_block<HD>(Qr, Qt, base, 3L * D, i0, L, tid);
         stage_block<HD>(Gr, Gt, dO + (long)b * L * D + hh * HD, (long)D, i0, L, tid);
+        }
         if (tid < RB) {
             const int ig = i0 + tid;
             Ls[tid] = ig < L ? lse[(long)bh * L + ig] : INFINITY;
@@ -365,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const float* 
         }
         __syncthreads();
         if (kw0 >= L) continue;
-        const int nchunk = min(RB / 32, (L - i0 + 31) / 32);
+        const int nchunk = (ATTN_ABL & 1) ? 0 : min(RB / 32, (L - i0 + 31) / 32);
         for (int c = 0; c < nchunk; ++c) {
             f32x16 s = rows_dot_reg<HD>(Qr, c * 32, j, h, kh, kl);     // S[query][key]
             f32x16 dp = rows_dot_reg<HD>(Gr, c * 32, j, h, vh, vl);    // dP[query][key]
@@ -393,10 +512,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const float* 
             accum_T_times<HD>(acc_dk, Qt, c * 32, lane, dp);
         }
     }
-    if (kvalid) {
-        float* dst = dqkv != nullptr ? dqkv + ((long)b * L + kj) * 3 * D + hh * HD : nullptr;
-        store_rows<HD>(dst != nullptr ? dst + D : nullptr, dqkv16, (long)b * L + kj, 3 * D, D + hh * HD, acc_dk, h, scale);
-        store_rows<HD>(dst != nullptr ? dst + 2 * D : nullptr, dqkv16, (long)b * L + kj, 3 * D, 2 * D + hh * HD, acc_dv, h, 1.f);
+    __syncthreads();
+    if (kw0 < L && !(ATTN_ABL & 4)) {
+        char* tile = Qr + wave * 32 * C::TP;
+        const int nv = min(32, L - kw0);
+        store_rows_lds<HD>(tile, dqkv, dqkv16, (long)b * L + kw0, nv, 3 * D, D + hh * HD, acc_dk, lane, scale);
+        store_rows_lds<HD>(tile, dqkv, dqkv16, (long)b * L + kw0, nv, 3 * D, 2 * D + hh * HD, acc_dv, lane, 1.f);
     }
 }
 
@@ -406,8 +527,9 @@ int attn_bf16_launch(int which, const float* qkv, const float* o, const float* l
     using C = Cfg<HD>;
     const float scale = 1.0f / sqrtf((float)HD);
     dim3 grid((unsigned)(B * H), (L + QB - 1) / QB);
-    const size_t lds_f = C::ROWIMG + C::TRIMG, lds_q = 2 * C::ROWIMG + C::TRIMG,
-                 lds_kv = 2 * C::ROWIMG + 2 * C::TRIMG + 2 * RB * sizeof(float);
+    constexpr size_t lds_f = std::max(C::ROWIMG + C::TRIMG, C::EPI),
+                     lds_q = std::max(2 * C::ROWIMG + C::TRIMG, std::max(C::EPI, C::PRO)),
+                     lds_kv = std::max(2 * C::ROWIMG + 2 * C::TRIMG + 2 * RB * (int)sizeof(float), std::max(C::EPI, C::PRO));
     static bool attr_set = false;
     if (!attr_set) {   // head_dim 64: the dK/dV kernel stages ~69 KB
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<HD>),
@@ -438,6 +560,16 @@ int attn_bf16_launch(int which, const float* qkv, const float* o, const float* l
 }
 
 }  // namespace
+
+// diagnostics (effective in -DTDM_DIAG builds only)
+extern "C" int tdm_attn_set_ablate(int bits) {
+#ifdef TDM_DIAG
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_abl_dev), &bits, sizeof(int)) == hipSuccess ? 0 : 1;
+#else
+    (void)bits;
+    return 0;
+#endif
+}
 
 // which: 0 forward (out = O, aux = lse), 1 dQ (out = dqkv, aux = D written), 2 dK/dV (out = dqkv, aux = D read);
 // out16 != nullptr: the S16 twin of `out` is written too (forward: `out` stays required; backward: `out` may be nullptr)

@@ -1152,6 +1152,23 @@ int tdm_attention_bwd_f32(const float* qkv, const float* o, const float* lse, co
     return attn_dispatch(2, D / H, qkv, nullptr, lse, dO, dqkv, Dvec, B, L, D, H, da, (hipStream_t)stream);
 }
 
+// The forms the train step launches (tt_forward / tt_backward), one kernel per call: which = 0 forward (out = O fp32, out16 =
+// its S16 twin, aux = lse), 1 dQ (aux = Dvec written), 2 dK/dV (aux = Dvec read); with out16 != NULL the backward writes
+// d(qkv) as S16 only.  For per-kernel timing and parity (tools/time_attn.py, tests); o / dO may be NULL where unused.
+int tdm_attention_step_form_f32(int which, const float* qkv, const float* o, const float* lse, const float* dO, float* out,
+                                float* out16, float* aux, int64_t B, int L, int D, int H, float p_drop, uint64_t seed, int site,
+                                void* stream) {
+    TDM_REQUIRE(which >= 0 && which <= 2 && qkv != nullptr && aux != nullptr && (out != nullptr || out16 != nullptr) && B >= 0 &&
+                    L > 0 && H > 0 && D > 0 && D % H == 0,
+                "attention_step_form: bad arguments (which=%d B=%lld L=%d D=%d H=%d)", which, (long long)B, L, D, H);
+    TDM_REQUIRE(which == 0 ? out != nullptr : (lse != nullptr && dO != nullptr && (which == 2 || o != nullptr)),
+                "attention_step_form: missing operand for which=%d", which);
+    TDM_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "attention_step_form: p_drop %g", (double)p_drop);
+    if (B == 0) return 0;
+    return attn_dispatch(which, D / H, qkv, o, which == 0 ? nullptr : lse, dO, out, aux, B, L, D, H, tdm_drop_site(p_drop, seed, site),
+                         (hipStream_t)stream, out16);
+}
+
 // Per-op post-LN residual LayerNorm of nn.TransformerEncoderLayer (norm1 / norm2, src/shakespeare.py:108-111):
 //   s = x + r (r may be NULL); y = (s - mean(s)) / sqrt(var(s) + 1e-5) * gamma + beta, statistics over the last dim (biased).
 // s / mean / rstd (optional, all or none) are what the backward twin reads.  Dropout-free: the train-mode mask of the
