@@ -44,8 +44,7 @@ _C1 = lambda ci, co, px: 2 * ci * co * px
 _T28, _T14 = lambda c: 784 * c * 4, lambda c: 196 * c * 4     # one fp32 / S16 tensor per sample
 _M28, _M14 = lambda c: 784 * c // 4, lambda c: 196 * c // 4   # one byte mask per sample
 LAUNCH_WORK = [
-    (0, 776, 0),                                                             # timebias
-    (0, 0, 181_473 * 4 + 1_451_520),                                         # pack_weights (read fp32, write bf16 hi/lo x 2 dirs)
+    (0, 776, 181_473 * 4 + 1_451_520),                                       # pack_timebias (weights: read fp32, write bf16 hi/lo x 2 dirs; + timestep biases)
     (_C3(1, 32, 784), 3136 + _T28(32) + _M28(32), 0),                        # rb1.conv1
     (_C3(32, 32, 784) + _C1(1, 32, 784), 2 * _T28(32) + _M28(32) + 3136, 0),  # rb1.conv2 (+ rank-1 skip)
     (_C1(32, 64, 196), _T28(32) + _T14(32) + _T14(64), 0),                   # avgpool + rb2.skip

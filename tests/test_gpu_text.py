@@ -347,6 +347,23 @@ def test_attention_per_op_vs_torch(dev, attn_mode, B, L, D, H, p_drop):
     e_o, e_l, e_g = O.rel_err(o.cpu(), ref_o.detach()), O.rel_err(lse.cpu(), ref_lse), O.rel_err(dqkv.cpu(), x.grad)
     print(f"[parity] attention per-op B={B} L={L} D={D} H={H} p={p_drop} mode {attn_mode}: o {e_o:.1e} lse {e_l:.1e} dqkv {e_g:.1e}")
     assert e_o < tol and e_l < tol and e_g < tol
+    if D % 16 == 0:
+        # the forms the train step launches (tdm_attention_step_form_f32): O with its S16 twin, d(qkv) as S16 ONLY — the twin
+        # must be exactly split(fp32 result) of the same kernel, every element written
+        def split(t):
+            out = torch.empty_like(t)
+            _lib.check(L_.tdm_split_s16_f32(_lib.ptr(t), _lib.ptr(out), t.numel(), _lib.stream()))
+            return out
+        o2 = torch.empty_like(o); o16 = torch.full_like(o, float("nan")); lse2 = torch.empty_like(lse)
+        dq16 = torch.full_like(dqkv, float("nan")); Dv2 = torch.empty_like(Dv)
+        dq32 = torch.empty_like(dqkv)   # the fp32 cross-check modes write it first; the bf16 kernels skip it
+        sf = L_.tdm_attention_step_form_f32
+        _lib.check(sf(0, _lib.ptr(qd), None, None, None, _lib.ptr(o2), _lib.ptr(o16), _lib.ptr(lse2), B, L, D, H, p_drop, seed, site, _lib.stream()))
+        _lib.check(sf(1, _lib.ptr(qd), _lib.ptr(o), _lib.ptr(lse), _lib.ptr(dOd), _lib.ptr(dq32), _lib.ptr(dq16), _lib.ptr(Dv2), B, L, D, H, p_drop, seed, site, _lib.stream()))
+        _lib.check(sf(2, _lib.ptr(qd), None, _lib.ptr(lse), _lib.ptr(dOd), _lib.ptr(dq32), _lib.ptr(dq16), _lib.ptr(Dv2), B, L, D, H, p_drop, seed, site, _lib.stream()))
+        assert torch.equal(o2, o) and torch.equal(lse2, lse)
+        assert torch.equal(o16.view(torch.int32), split(o).view(torch.int32))
+        assert torch.equal(dq16.view(torch.int32), split(dqkv).view(torch.int32))
 
 
 @pytest.mark.parametrize("M,D,with_res", [(32768, 256, True), (301, 64, True), (5, 1024, False), (1, 32, True), (1000, 512, True),

@@ -3,6 +3,7 @@
 // 16-byte copy and the conv kernel itself is direction-agnostic.  (The kernels that split their ACTIVATIONS while staging —
 // "conv mode 1", round 1 — were superseded by the pre-split S16 pipeline and are no longer built: DESIGN.md section 4.)
 #include "tdm_common.h"
+#include "tdm_timebias.h"
 
 namespace {
 
@@ -12,14 +13,13 @@ namespace {
 //   dgrad   : B[k = co][n = ci] = W[8-tap][ci][co] (3x3)    chunks over co
 // element (chunk, tap, nt, part, lane, j):  n = nt*32 + (lane&31),  k = chunk*16 + 8*(lane>>5) + j
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ P, PackArgs pa,
-                                                           unsigned short* __restrict__ out) {
-    const PackDesc d = pa.d[blockIdx.y];
+__device__ __forceinline__ void pack_body(const float* __restrict__ P, const PackDesc& d, unsigned short* __restrict__ out, int bx,
+                                          int nbx) {
     const int K = d.dgrad ? d.cout : d.cin;       // contraction length
     const int Nn = d.dgrad ? d.cin : d.cout;      // output channels of this direction
     const int NT = Nn / 32;
     const int total = (K / 16) * d.taps * NT * 512;   // (hi, lo) pairs
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    for (int e = bx * 256 + threadIdx.x; e < total; e += nbx * 256) {
         const int jj = e & 7;
         const int lane = (e >> 3) & 63;
         int r = e >> 9;
@@ -39,11 +39,41 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
 }
 
+constexpr int PACK_WGS = 36;   // workgroups per descriptor
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ P, PackArgs pa,
+                                                           unsigned short* __restrict__ out) {
+    pack_body(P, pa.d[blockIdx.y], out, blockIdx.x, gridDim.x);
+}
+
+// The S16 forward's two prologue launches as one (neither reads what the other writes): workgroups [0, 36 n) pack the
+// weights, the rest compute the timestep biases.
+__global__ __launch_bounds__(256) void pack_timebias_kernel(const float* __restrict__ P, PackArgs pa,
+                                                            unsigned short* __restrict__ out, TimebiasArgs ta) {
+    const int npack = PACK_WGS * pa.n;
+    if ((int)blockIdx.x < npack) pack_body(P, pa.d[blockIdx.x / PACK_WGS], out, blockIdx.x % PACK_WGS, PACK_WGS);
+    else tdm_timebias_body(ta, blockIdx.x - npack, gridDim.x - npack);
+}
+
 }  // namespace
 
 int tdm_launch_pack(const float* params, const PackArgs& pa, unsigned short* out, hipStream_t st) {
     TDM_REQUIRE(pa.n >= 1 && pa.n <= TDM_MAX_PACK, "pack: %d descriptors", pa.n);
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(36, pa.n), dim3(256), 0, st, params, pa, out);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(PACK_WGS, pa.n), dim3(256), 0, st, params, pa, out);
     TDM_CHECK_LAUNCH("pack_weights");
+    return 0;
+}
+
+int tdm_launch_pack_timebias(const float* params, const PackArgs& pa, unsigned short* out, const int64_t* t, const int* te_w_off,
+                             const int* te_b_off, float* that, float* tb, int B, int64_t* bump, float* u96, int skw4_off,
+                             int outw_off, hipStream_t st) {
+    TDM_REQUIRE(pa.n >= 1 && pa.n <= TDM_MAX_PACK, "pack: %d descriptors", pa.n);
+    TimebiasArgs ta{};
+    for (int i = 0; i < 4; ++i) { ta.o.w[i] = te_w_off[i]; ta.o.b[i] = te_b_off[i]; }
+    ta.o.skw4 = skw4_off; ta.o.outw = outw_off;
+    ta.t = t; ta.params = params; ta.that = that; ta.tb = tb; ta.B = B; ta.bump = bump; ta.u96 = u96;
+    const long nb = ((long)B * 192 + 255) / 256;
+    const int ntb = (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+    hipLaunchKernelGGL(pack_timebias_kernel, dim3(PACK_WGS * pa.n + ntb), dim3(256), 0, st, params, pa, out, ta);
+    TDM_CHECK_LAUNCH("pack_timebias");
     return 0;
 }

@@ -4,6 +4,7 @@
 // with the timestep-bias gradient, AdamW.  All float4-coalesced, 64-lane
 // wavefront reductions, deterministic (no float atomics).
 #include "tdm_common.h"
+#include "tdm_timebias.h"
 #include "tdm_s16.h"
 
 namespace {
@@ -133,31 +134,9 @@ __global__ __launch_bounds__(EW_BLOCK) void to_unit_u8_kernel(const float* __res
 // ---- timestep bias ----------------------------------------------------------
 // src/mnist.py:77 and :58: that = t.float()/1000; tb[b][c] = w[c]*that + bias[c]
 // for the four blocks (32+64+64+32 = 192 channels per sample).
-struct TeOffs { int w[4]; int b[4]; int skw4, outw; };
-__global__ __launch_bounds__(EW_BLOCK) void timebias_kernel(const int64_t* __restrict__ t,
-                                                            const float* __restrict__ params, TeOffs o,
-                                                            float* __restrict__ that, float* __restrict__ tb, int B,
-                                                            int64_t* __restrict__ bump, float* __restrict__ u96) {
-    if (bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0) bump[0] += 1;
-    // u[ci] = sum_co W_skip(rb4)[ci][co] * w_out[co]: the vector that turns d(loss)/d(eps) into the skip path's share of
-    // d(loss)/d(cat) (out_bwd_s16_kernel's header), 96 x 32 products by the launch's first workgroup
-    if (u96 != nullptr && blockIdx.x == 0 && threadIdx.x < 96) {
-        float acc = 0.f;
-        for (int co = 0; co < 32; ++co) acc = fmaf(params[o.skw4 + threadIdx.x * 32 + co], params[o.outw + co], acc);
-        u96[threadIdx.x] = acc;
-    }
-    const int total = B * 192;
-    for (int i = blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += gridDim.x * EW_BLOCK) {
-        const int b = i / 192, c = i - b * 192;
-        const float th = __fdiv_rn((float)t[b], 1000.f);
-        int blk, cc;
-        if (c < 32) { blk = 0; cc = c; }
-        else if (c < 96) { blk = 1; cc = c - 32; }
-        else if (c < 160) { blk = 2; cc = c - 96; }
-        else { blk = 3; cc = c - 160; }
-        tb[i] = fmaf(params[o.w[blk] + cc], th, params[o.b[blk] + cc]);
-        if (c == 0) that[b] = th;
-    }
+__global__ __launch_bounds__(EW_BLOCK) void timebias_kernel(TimebiasArgs a) {
+    static_assert(EW_BLOCK == 256, "tdm_timebias_body assumes 256 threads");
+    tdm_timebias_body(a, blockIdx.x, gridDim.x);
 }
 
 // tb[b][c] = fma(w[c], that[b], bias[c]) for ONE residual block whose caller already holds t-hat as floats
@@ -1016,7 +995,7 @@ int tdm_launch_timebias(const int64_t* t, const float* params, const int* te_w_o
     TeOffs o;
     for (int i = 0; i < 4; ++i) { o.w[i] = te_w_off[i]; o.b[i] = te_b_off[i]; }
     o.skw4 = skw4_off; o.outw = outw_off;
-    hipLaunchKernelGGL(timebias_kernel, dim3(ew_grid((int64_t)B * 192)), dim3(EW_BLOCK), 0, st, t, params, o, that, tb, B, bump, u96);
+    hipLaunchKernelGGL(timebias_kernel, dim3(ew_grid((int64_t)B * 192)), dim3(EW_BLOCK), 0, st, TimebiasArgs{t, params, o, that, tb, B, bump, u96});
     TDM_CHECK_LAUNCH("timebias");
     return 0;
 }

@@ -137,6 +137,9 @@ struct PackDesc { int src_off, cin, cout, taps, dgrad; long dst_off; };
 #define TDM_MAX_PACK 24
 struct PackArgs { PackDesc d[TDM_MAX_PACK]; int n; };
 int tdm_launch_pack(const float* params, const PackArgs& pa, unsigned short* out, hipStream_t st);
+int tdm_launch_pack_timebias(const float* params, const PackArgs& pa, unsigned short* out, const int64_t* t, const int* te_w_off,
+                             const int* te_b_off, float* that, float* tb, int B, int64_t* bump, float* u96, int skw4_off,
+                             int outw_off, hipStream_t st);
 
 // S16 pipeline: pre-split sources, float4 epilogue (conv_s16.hip)
 // pixel-count limit of its 32-bit addressing (__mul24 on the pixel index): B * H * W < 2^23, i.e. B <= 10,699 at 28x28

@@ -1163,6 +1163,9 @@ int tdm_attention_step_form_f32(int which, const float* qkv, const float* o, con
                 "attention_step_form: bad arguments (which=%d B=%lld L=%d D=%d H=%d)", which, (long long)B, L, D, H);
     TDM_REQUIRE(which == 0 ? out != nullptr : (lse != nullptr && dO != nullptr && (which == 2 || o != nullptr)),
                 "attention_step_form: missing operand for which=%d", which);
+    TDM_REQUIRE(out != nullptr || g_attn_mode == 2,
+                "attention_step_form: the fp32 attention modes write the fp32 result first (out must not be NULL; only the bf16 "
+                "kernels skip it)");
     TDM_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "attention_step_form: p_drop %g", (double)p_drop);
     if (B == 0) return 0;
     return attn_dispatch(which, D / H, qkv, o, which == 0 ? nullptr : lse, dO, out, aux, B, L, D, H, tdm_drop_site(p_drop, seed, site),

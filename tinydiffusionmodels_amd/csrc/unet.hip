@@ -282,7 +282,7 @@ int wgrad_s16(hipStream_t st, int hw, int B, const float* act_s16, int C, int c_
 // Every launch of the default (S16) train step has an id: tdm_unet_replay_launch_f32 re-issues ONE of them on a
 // workspace a full step has filled (bench.py times each launch alone with events; tools/ collect PMC per kernel).
 #define TDM_UNET_LAUNCHES(X)                                                                                             \
-    X(F_TIMEBIAS, "timebias") X(F_PACK, "pack_weights") X(F_CONV_FIRST, "rb1.conv1 (conv_first_s16)")                  \
+    X(F_PROLOGUE, "weight pre-pack + timestep biases (pack_timebias)") X(F_CONV_FIRST, "rb1.conv1 (conv_first_s16)")                  \
     X(F_RB1C2, "rb1.conv2 fwd 32->32 @28 (conv_s16<28,1>)") X(F_POOL_SKIP, "avgpool + rb2.skip (pool_skip_s16)")        \
     X(F_RB2C1, "rb2.conv1 fwd 32->64 @14 (conv_s16<14,2>)") X(F_RB2C2, "rb2.conv2 fwd 64->64 @14 (conv_s16<14,2>)")     \
     X(F_RB3C1, "rb3.conv1 fwd 64->64 @14 (conv_s16<14,2>)") X(F_RB3C2, "rb3.conv2 fwd 64->64 @14 (conv_s16<14,2>)")     \
@@ -323,8 +323,8 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
                      hipStream_t st, const MseIn* mse) {
     const int tew[4] = {kL.rb[0].tew, kL.rb[1].tew, kL.rb[2].tew, kL.rb[3].tew};
     const int teb[4] = {kL.rb[0].teb, kL.rb[1].teb, kL.rb[2].teb, kL.rb[3].teb};
-    RUN(F_TIMEBIAS, tdm_launch_timebias(t, P, tew, teb, w.that, w.tb, B, st, w.rng_bump, w.u96, kL.rb[3].skw, kL.outw));
-    RUN(F_PACK, tdm_launch_pack(P, kPack.pa, w.wpack, st));
+    RUN(F_PROLOGUE, tdm_launch_pack_timebias(P, kPack.pa, w.wpack, t, tew, teb, w.that, w.tb, B, w.rng_bump, w.u96, kL.rb[3].skw,
+                                             kL.outw, st));
     const BlockOff &r1 = kL.rb[0], &r2 = kL.rb[1], &r3 = kL.rb[2], &r4 = kL.rb[3];
     // rb1: conv1 (Cin = 1) writes a1 (mask) and split(a1 + tb) for conv2
     // (rb1.skip has one input channel: its output is not materialised; rb1.conv2's epilogue recomputes it from x)

@@ -26,7 +26,10 @@ def run(B, L, D, H, p_drop):
         def sf(which, out, out16, aux):
             return lambda: _lib.check(L_.tdm_attention_step_form_f32(which, _lib.ptr(qkv), _lib.ptr(o), _lib.ptr(lse), _lib.ptr(dO), _lib.ptr(out) if out is not None else None,
                                                                      _lib.ptr(out16), _lib.ptr(aux), B, L, D, H, p_drop, 7, 1, _lib.stream()))
-        for fn, nm in ((f, "fwd"), (b, "bwd"), (sf(0, o, o16, lse), "step.fwd"), (sf(1, None, dq16, Dv), "step.dq"), (sf(2, None, dq16, Dv), "step.dkv")):
+        forms = ((f, "fwd"), (b, "bwd"))
+        if mode == 2:   # the S16-only backward outputs exist in the bf16 kernels only
+            forms += ((sf(0, o, o16, lse), "step.fwd"), (sf(1, None, dq16, Dv), "step.dq"), (sf(2, None, dq16, Dv), "step.dkv"))
+        for fn, nm in forms:
             s = f"mode{mode}.{nm}={timeit(fn):.0f}us"
             for ab in [int(x) for x in a.ablate.split(",") if x]:
                 L_.tdm_attn_set_ablate(ab)
