@@ -410,12 +410,12 @@ FusedWs fused_carve(float* base, long M, int V, int nseg) {
 extern "C" {
 
 int tdm_round_fused_ok(int64_t M, int V, int D) {
-    return D == tdm_cechain::DK && M >= 1 && V >= 32 && M * (long)D * 4 < 2147483647L && (long)V * D * 4 < 2147483647L &&
+    return D == tdm_cechain::DK && M >= 1 && M < (1L << 31) && V >= 32 && M * (long)D * 4 < 2147483647L && (long)V * D * 4 < 2147483647L &&
            ((M + 31) & ~31L) * (long)D * 4 < 2147483647L;
 }
 
 int64_t tdm_round_workspace_fused_floats(int64_t M, int V, int D, int nseg) {
-    if (!tdm_round_fused_ok(M, V, D) || nseg < 1 || nseg > 8) return -1;
+    if (!tdm_round_fused_ok(M, V, D) || nseg < 1 || nseg > 8 || M > ((int64_t)1 << 31)) return -1;
     return tdm_cechain::fused_carve(nullptr, M, V, nseg).total;
 }
 

@@ -455,7 +455,9 @@ int tdm_ffn_chain_f32(int mode, int nprod, const float* x16, const float* wa16, 
                                 (hipStream_t)stream);
 }
 
-int64_t tdm_ffn_chain_mask_count(int64_t M, int F) { return tdm_ffn_chain_mask_elems(M, F); }
+int64_t tdm_ffn_chain_mask_count(int64_t M, int F) {
+    return (M < 1 || F < 32 || M > ((int64_t)1 << 40)) ? -1 : tdm_ffn_chain_mask_elems(M, F);
+}
 
 int tdm_ffn_chain_set_ablate(int bits) { g_chain_ablate = bits; return 0; }
 

@@ -226,7 +226,7 @@ int tdm_embed_scatter_add_f32(const float* g, const int64_t* ids, float* dtable,
 }
 
 int64_t tdm_round_workspace_floats(int64_t M, int V, int D) {
-    if (M < 1 || V < 2 || D < 4) return -1;
+    if (M < 1 || V < 2 || D < 4 || M > ((int64_t)1 << 31) || D > 8192) return -1;
     return round_carve(nullptr, M, V, D).total;
 }
 
@@ -309,7 +309,7 @@ RoundChunkWs round_chunk_carve(float* base, long M, int V, int D, int Vc) {
 }
 
 int64_t tdm_round_workspace_chunked_floats(int64_t M, int V, int D, int Vc) {
-    if (M < 1 || V < 2 || D < 4 || Vc < 128 || (Vc % 128) != 0) return -1;
+    if (M < 1 || V < 2 || D < 4 || Vc < 128 || (Vc % 128) != 0 || M > ((int64_t)1 << 31) || D > 8192) return -1;
     return round_chunk_carve(nullptr, M, V, D, Vc).total;
 }
 

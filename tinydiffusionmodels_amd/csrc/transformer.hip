@@ -993,22 +993,28 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
 
 extern "C" {
 
-int64_t tdm_tt_param_count(int D, int depth, int ffn) { return tt_layout(D, depth, ffn).total; }
+// (size queries return -1 for shapes the layouts are not defined for: the tables hold at most 8 layers)
+int64_t tdm_tt_param_count(int D, int depth, int ffn) {
+    if (depth < 1 || depth > 8 || D <= 0 || ffn <= 0 || D > 8192 || ffn > 65536) return -1;
+    return tt_layout(D, depth, ffn).total;
+}
 
 int tdm_tt_param_offsets(int D, int depth, int ffn, int64_t* offs) {
     TDM_REQUIRE(depth >= 1 && depth <= 8, "tt_param_offsets: depth %d", depth);
+    TDM_REQUIRE(offs != nullptr && D > 0 && ffn > 0, "tt_param_offsets: bad arguments (D=%d ffn=%d)", D, ffn);
     const TTLayout t = tt_layout(D, depth, ffn);
     for (int i = 0; i <= t.ntensor; ++i) offs[i] = t.tensor_off[i];
     return 0;
 }
 
 int64_t tdm_tt_workspace_floats(int64_t B, int L, int D, int H, int depth, int ffn, int training) {
-    if (depth < 1 || depth > 8) return -1;
+    if (depth < 1 || depth > 8 || B < 0 || L <= 0 || D <= 0 || H <= 0 || D % H != 0 || ffn <= 0) return -1;
+    if (B > (1 << 24) || L > (1 << 20) || D > 8192 || ffn > 65536 || B * (int64_t)L > ((int64_t)1 << 31)) return -1;   // (no overflow below)
     return tt_carve(nullptr, B, L, D, H, depth, ffn, training).total;
 }
 
 int64_t tdm_tt_slab_floats(int D, int depth, int ffn) {
-    if (depth < 1 || depth > 8) return -1;
+    if (depth < 1 || depth > 8 || D <= 0 || ffn <= 0 || D > 8192 || ffn > 65536) return -1;
     return slab_plan(D, depth, ffn).total;
 }
 
@@ -1188,7 +1194,7 @@ int tdm_layernorm_residual_fwd_f32(const float* x, const float* r, const float* 
 // Backward twin: given dy and the saved (s, mean, rstd): ds[M][D] = d(loss)/d(s) — the gradient of BOTH x and r — and
 // dgamma_dbeta[2][D] = (sum_m dy * xhat, sum_m dy).  scratch: tdm_layernorm_scratch_floats(D) floats (per-workgroup
 // partials, reduced in fixed order: deterministic).
-int64_t tdm_layernorm_scratch_floats(int D) { return (int64_t)LN_SLABS * 3 * D + 3 * (int64_t)D + 64; }
+int64_t tdm_layernorm_scratch_floats(int D) { return D < 1 ? -1 : (int64_t)LN_SLABS * 3 * D + 3 * (int64_t)D + 64; }
 int tdm_layernorm_residual_bwd_f32(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
                                    float* ds, float* dgamma_dbeta, float* scratch, int64_t M, int D, void* stream) {
     TDM_REQUIRE(dy && s && mean && rstd && gamma && ds && dgamma_dbeta && scratch && M >= 1 && D > 0 && D % 4 == 0 && D <= 1024,

@@ -591,11 +591,16 @@ int forward_loss_backward(const float* P, const float* x_noisy, const int64_t* t
 extern "C" {
 
 int tdm_unet_param_offsets(int32_t* offs) {
+    TDM_REQUIRE(offs != nullptr, "unet_param_offsets: NULL output");
     for (int i = 0; i <= TDM_UNET_NTENSOR; ++i) offs[i] = kL.tensor_off[i];
     return 0;
 }
 
-int64_t tdm_unet_workspace_floats(int64_t B, int training) { return carve(nullptr, B, training).total; }
+// (-1 for a batch no entry point accepts: the queries are range-checked like the calls, so their arithmetic cannot overflow)
+int64_t tdm_unet_workspace_floats(int64_t B, int training) {
+    if (B < 0 || B > 16384) return -1;
+    return carve(nullptr, B, training).total;
+}
 int64_t tdm_unet_slab_floats(void) { return (int64_t)NSLAB * SLAB_STRIDE + (int64_t)EROWS * ESTRIDE; }
 
 // Batch limit: 16384 for the fp32 / in-loader-split arithmetics (64-bit indexing); the default S16 pipeline addresses
@@ -849,6 +854,7 @@ int tdm_conv_wgrad_nhwc_f32(const float* in, const float* tb, const float* dout,
 // forward receives as (B,1,1,1).  skw == NULL: identity skip (Cin == Cout).  Geometries: the MFMA kernels' (HW in
 // {14, 28}, Cin a multiple of 32, Cout in {32, 64}) and the first block's (HW 28, Cin 1, Cout 32).
 int64_t tdm_resblock_scratch_floats(int64_t B, int HW, int Cin, int Cout) {
+    if (B < 1 || B > 16384 || HW < 1 || HW > 1024 || Cin < 1 || Cout < 1 || Cin > 4096 || Cout > 4096) return -1;
     const int64_t M = B * HW * HW;
     const int64_t cmax = Cin > Cout ? Cin : Cout;
     // tb | a1 | s | per-conv scratch of the largest conv (packed weights + an S16 copy of its input)
