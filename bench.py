@@ -461,20 +461,22 @@ def main():
         # 160 channels x 4 B x 784 pixels x B.  `tensor_bytes_per_launch` is what the launch AS BUILT reads + writes
         # (the rank-one skip gradient and the pair-summed output make the data gradient touch less than the algorithm names);
         # `traffic` = HBM bytes from the PMC passes of the round-end profile (profiles/r03_conv_traffic.json, per launch id).
-        ALGO_CH = {9: 96 + 32 + 32, 16: 32 + 32 + 96, 3: 32 + 32 + 1, 10: 32 + 32 + 32 + 1, 13: 64, 29: 64}
-        traffic_by_id, traffic_src = {}, None
+        # (keyed by the launch NAME — tdm_unet_launch_name — not its id: ids shift when launches are merged)
+        ALGO_CH = {"rb4.conv1 + rb4.skip fwd": 96 + 32 + 32, "rb4.conv1 dgrad": 32 + 32 + 96, "rb1.conv2 fwd": 32 + 32 + 1,
+                   "rb4.conv2 + out conv fwd": 32 + 32 + 32 + 1, "rb4.conv2 dgrad": 64, "rb1.conv2 dgrad": 64}
+        traffic_by_name, traffic_src = {}, None
         for tname in ("r04_conv_traffic.json", "r03_conv_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
-                traffic_by_id = {int(k): v for k, v in json.load(open(tpath)).get("by_launch_id", {}).items()}
+                traffic_by_name = {v.get("launch", k): v for k, v in json.load(open(tpath)).get("by_launch_id", {}).items()}
                 traffic_src = f"profiles/{tname}: FETCH_SIZE x2 + WRITE_SIZE PMC passes of the round-end profile (NOT collected in this run)"
                 break
 
         def roof(r):
-            kb = ALGO_CH.get(r["id"], 0) * 4 * 784 * B_TRAIN or r["bytes"]
+            kb = next((c for n, c in ALGO_CH.items() if r["launch"].startswith(n)), 0) * 4 * 784 * B_TRAIN or r["bytes"]
             ms_ = r["us"] * 1e-3
             ach = kb / (ms_ * 1e-3) / 1e9
-            tr = traffic_by_id.get(r["id"], {})
+            tr = traffic_by_name.get(r["launch"], {})
             return {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
                     "traffic": tr.get("hbm_bytes_per_launch"), "traffic_source": traffic_src if tr else None, "kernel": r["launch"] + f", B={B_TRAIN}, in-pipeline arguments (launch id {r['id']})",
                     "ms_per_launch": round(ms_, 4), "flop_per_launch": r["flop"], "algorithmic_bytes_per_launch": kb,
@@ -484,8 +486,8 @@ def main():
                               "kernel-trace average and the PMC passes of the same launch"}
         dom = max((r for r in rows if any(k in r["launch"] for k in MFMA_LAUNCH)), key=lambda r: r["us"])
         out["roofline"] = roof(dom)
-        r9 = next(r for r in rows if r["id"] == 9)
-        if dom["id"] != 9:
+        r9 = next(r for r in rows if r["launch"].startswith("rb4.conv1 + rb4.skip fwd"))
+        if dom["id"] != r9["id"]:
             out["roofline"]["second"] = roof(r9)      # the forward twin (round 2's roofline launch), for continuity
         del sts, gscratch
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Attribute the rocprofv3 passes over tools/pmc_replay.py to the train step's launch ids.
 
-    python tools/pmc_by_id.py <dir with pass sub-directories> <out.json> --ids 16,9,... --iters 5 [--trace-iters 21]
+    python tools/pmc_by_id.py <dir with pass sub-directories> <out.json> --ids 15,8,... --iters 5 [--trace-iters 21]
 
 pmc_replay.py issues, after its set-up, `iters` replays of each id in order and then 3 operand splits + `iters` NT GEMMs;
 the library's dispatches (everything that is not a torch / runtime kernel) are consumed from the END of each pass in that

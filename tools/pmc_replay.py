@@ -4,7 +4,7 @@ workspaces, replays the chosen launches (tdm_unet_replay_launch_f32, in-pipeline
 workspaces so the 256 MB Infinity Cache cannot serve one launch's inputs to the next) and one NT GEMM of the text
 denoiser's FFN shape.
 
-    python tools/pmc_replay.py [--iters 5] [--ids 16,9,3,...] [--B 512] [--names-out names.json]
+    python tools/pmc_replay.py [--iters 5] [--ids 15,8,2,...] [--B 512] [--names-out names.json]
 """
 import argparse
 import os
@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--ids", type=str, default="16,9,3,13,7,14,12,18,11,17")
+    ap.add_argument("--ids", type=str, default="15,8,2,12,6,13,11,17,10,16")
     ap.add_argument("--names-out", type=str, default=None)
     ap.add_argument("--B", type=int, default=512)
     args = ap.parse_args()

@@ -4,7 +4,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r4
-IDS=16,9,3,13,7,14,12,18,11,17
+IDS=15,8,2,12,6,13,11,17,10,16
 rm -rf $O && mkdir -p $O
 timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -n 3 $O/pytest_gpu.log
 timeout -k 10 700 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-200 $O/bench.json
