@@ -450,15 +450,23 @@ __global__ __launch_bounds__(EW_BLOCK) void combine_dh1_kernel(const float* __re
 }
 
 // weight gradients of rb1.conv1 (Cin = 1, 3x3) and rb1.skip (1x1), per-block slabs.
-// 1024 threads (16 waves per CU: the kernel is latency-bound, one workgroup per slab); thread (c4 = tid & 7,
-// g = tid >> 3) owns channels 4*c4 .. +3 of pixels g, g + 128, ... of the block's range (float4 gradient loads, two
-// pixels in flight); partial sums: lanes of a wave by shuffles, the 16 waves through LDS, fixed order.
+// 1024 threads (16 waves per CU: one workgroup per slab); thread (c4 = tid & 7, g = tid >> 3) owns channels 4*c4 .. +3 of
+// pixels g, g + 128, ... of the block's range.  The input pixels of the range (+ one image row and one pixel either side)
+// are staged in LDS once per 4096-pixel piece: a tap is then an LDS broadcast read at a constant offset, masked by 3 row +
+// 3 column validity bits, instead of a bounds-checked global load per tap and thread (the kernel issued 9 of them per 16-byte
+// gradient load and ran at 2.3 TB/s); the pixel's (row, column) advances incrementally (no division in the loop), and
+// four pixels' gradient loads are in flight per thread.  Partial sums: lanes of a wave by shuffles, the 16 waves through
+// LDS, fixed order.
 constexpr int FW_BLOCK = 1024;
+constexpr int FW_PIECE = 4096;                 // pixels per staged piece
+constexpr int FW_HALO = 32;                    // staged floats before the piece's first pixel (>= 29)
+template <bool SKIP>   // SKIP: rb1.skip's weight / bias gradients are taken too (from dout1); the S16 pipeline takes them elsewhere
 __global__ __launch_bounds__(FW_BLOCK) void first_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dc1,
                                                                const float* __restrict__ dout1, float* __restrict__ slab,
                                                                long slab_stride, int w1_off, int b1_off, int ws_off,
                                                                int bs_off, int B) {
     __shared__ float sh[16][12][32];
+    __shared__ float xs[FW_PIECE + 2 * FW_HALO];
     const int c4 = threadIdx.x & 7, g = threadIdx.x >> 3;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t M = (int64_t)B * 784;
@@ -470,39 +478,61 @@ __global__ __launch_bounds__(FW_BLOCK) void first_wgrad_kernel(const float* __re
     auto fma4 = [](float a, const float4& d, float4& r) {
         r.x = fmaf(a, d.x, r.x); r.y = fmaf(a, d.y, r.y); r.z = fmaf(a, d.z, r.z); r.w = fmaf(a, d.w, r.w);
     };
-    auto one = [&](int64_t p, const float4& d1, const float4& d2) {
-        const int b = (int)(p / 784);
-        const int rem = (int)(p - (int64_t)b * 784);
-        const int y = rem / 28, xx = rem - y * 28;
-        float xc = 0.f;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yy = y + tap / 3 - 1, xq = xx + tap % 3 - 1;
-            float xv = 0.f;
-            if (yy >= 0 && yy < 28 && xq >= 0 && xq < 28) xv = x[(int64_t)b * 784 + yy * 28 + xq];
-            if (tap == 4) xc = xv;
-            fma4(xv, d1, acc[tap]);
+    constexpr bool skip = SKIP;
+    constexpr int NF = SKIP ? 2 : 3;                             // pixels in flight per thread (register budget: 128 at this block size)
+    for (int64_t q0 = p0; q0 < p1; q0 += FW_PIECE) {           // (one piece at B <= 1024 with 256 slabs)
+        const int np = (int)min((int64_t)FW_PIECE, p1 - q0);
+        __syncthreads();                                        // the previous piece's readers are done
+        for (int e = threadIdx.x; e < np + 2 * FW_HALO; e += FW_BLOCK) {
+            const int64_t m = q0 - FW_HALO + e;
+            xs[e] = (m >= 0 && m < M) ? x[m] : 0.f;
         }
-        acc[9].x += d1.x; acc[9].y += d1.y; acc[9].z += d1.z; acc[9].w += d1.w;
-        fma4(xc, d2, acc[10]);
-        acc[11].x += d2.x; acc[11].y += d2.y; acc[11].z += d2.z; acc[11].w += d2.w;
-    };
-    int64_t p = p0 + g;
-    for (; p + 128 < p1; p += 256) {   // 2 pixels per trip: the 4 gradient loads are independent
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);   // dout1 == nullptr: the skip gradients come from elsewhere
-        const float4 a0 = reinterpret_cast<const float4*>(dc1 + p * 32)[c4];
-        const float4 b0 = dout1 != nullptr ? reinterpret_cast<const float4*>(dout1 + p * 32)[c4] : z4;
-        const float4 a1 = reinterpret_cast<const float4*>(dc1 + (p + 128) * 32)[c4];
-        const float4 b1 = dout1 != nullptr ? reinterpret_cast<const float4*>(dout1 + (p + 128) * 32)[c4] : z4;
-        one(p, a0, b0);
-        one(p + 128, a1, b1);
+        __syncthreads();
+        // (row, column) of this thread's first pixel of the piece; then + 128 pixels = + 4 rows + 16 columns per step
+        int q = g;
+        const int rem = (int)((q0 + g) % 784);
+        int y = rem / 28, xx = rem - y * 28;
+        auto one = [&](int ql, int yy, int xc_, const float4& d1, const float4& d2) {
+            const float* c = xs + FW_HALO + ql;
+            const bool r0 = yy >= 1, r2 = yy <= 26, c0 = xc_ >= 1, c2 = xc_ <= 26;
+            const float v0 = (r0 && c0) ? c[-29] : 0.f, v1 = r0 ? c[-28] : 0.f, v2 = (r0 && c2) ? c[-27] : 0.f;
+            const float v3 = c0 ? c[-1] : 0.f, v4 = c[0], v5 = c2 ? c[1] : 0.f;
+            const float v6 = (r2 && c0) ? c[27] : 0.f, v7 = r2 ? c[28] : 0.f, v8 = (r2 && c2) ? c[29] : 0.f;
+            fma4(v0, d1, acc[0]); fma4(v1, d1, acc[1]); fma4(v2, d1, acc[2]);
+            fma4(v3, d1, acc[3]); fma4(v4, d1, acc[4]); fma4(v5, d1, acc[5]);
+            fma4(v6, d1, acc[6]); fma4(v7, d1, acc[7]); fma4(v8, d1, acc[8]);
+            acc[9].x += d1.x; acc[9].y += d1.y; acc[9].z += d1.z; acc[9].w += d1.w;
+            if (skip) {
+                fma4(v4, d2, acc[10]);
+                acc[11].x += d2.x; acc[11].y += d2.y; acc[11].z += d2.z; acc[11].w += d2.w;
+            }
+        };
+        auto advance = [&]() {   // the pixel 128 further on
+            q += 128; xx += 16; y += 4;
+            if (xx >= 28) { xx -= 28; ++y; }
+            if (y >= 28) y -= 28;
+        };
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* gd = dc1 + q0 * 32 + c4 * 4;
+        const float* gs = skip ? dout1 + q0 * 32 + c4 * 4 : nullptr;
+        for (; q + 128 * (NF - 1) < np; ) {   // NF pixels per trip: their gradient loads are independent
+            float4 d[NF], e2[NF]; int qs[NF], ys[NF], xq[NF];
+#pragma unroll
+            for (int u = 0; u < NF; ++u) {
+                qs[u] = q; ys[u] = y; xq[u] = xx;
+                d[u] = *reinterpret_cast<const float4*>(gd + (long)q * 32);
+                e2[u] = skip ? *reinterpret_cast<const float4*>(gs + (long)q * 32) : z4;
+                advance();
+            }
+#pragma unroll
+            for (int u = 0; u < NF; ++u) one(qs[u], ys[u], xq[u], d[u], e2[u]);
+        }
+        for (; q < np; advance())
+            one(q, y, xx, *reinterpret_cast<const float4*>(gd + (long)q * 32), skip ? *reinterpret_cast<const float4*>(gs + (long)q * 32) : z4);
     }
-    for (; p < p1; p += 128)
-        one(p, reinterpret_cast<const float4*>(dc1 + p * 32)[c4],
-            dout1 != nullptr ? reinterpret_cast<const float4*>(dout1 + p * 32)[c4] : make_float4(0.f, 0.f, 0.f, 0.f));
     // lanes with the same c4 (lane & 7) hold different pixels: sum over lane bits 3..5
 #pragma unroll
-    for (int k = 0; k < 12; ++k) {
+    for (int k = 0; k < (SKIP ? 12 : 10); ++k) {
 #pragma unroll
         for (int o = 8; o <= 32; o <<= 1) {
             acc[k].x += __shfl_xor(acc[k].x, o); acc[k].y += __shfl_xor(acc[k].y, o);
@@ -512,14 +542,13 @@ __global__ __launch_bounds__(FW_BLOCK) void first_wgrad_kernel(const float* __re
     }
     __syncthreads();
     float* dst = slab + (long)blockIdx.x * slab_stride;
-    for (int e = threadIdx.x; e < 12 * 32; e += FW_BLOCK) {
+    for (int e = threadIdx.x; e < (SKIP ? 12 : 10) * 32; e += FW_BLOCK) {
         const int k = e >> 5, cc = e & 31;
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 16; ++w) s += sh[w][k][cc];
         if (k < 9) dst[w1_off + k * 32 + cc] = s;
         else if (k == 9) dst[b1_off + cc] = s;
-        else if (dout1 == nullptr) continue;
         else if (k == 10) dst[ws_off + cc] = s;
         else dst[bs_off + cc] = s;
     }
@@ -557,7 +586,14 @@ __global__ __launch_bounds__(EW_BLOCK) void adamw_kernel(float* __restrict__ p, 
 }  // namespace
 
 // ======================= S16-pipeline producers (tdm_s16.h) =======================
-// rb1.conv1 + skip as conv_first_kernel, plus the pre-split copy split(a1 + tb) that rb1.conv2 reads
+// rb1.conv1 + skip as conv_first_kernel, plus the pre-split copy split(a1 + tb) that rb1.conv2 reads.
+// A workgroup owns a CONTIGUOUS pixel range; thread (c8 = tid & 3, g = tid >> 2) computes channels 8 c8 .. + 7 of pixels
+// g, g + 64, ...: its 72 tap weights live in registers, the input pixels of the range (+ one image row and one pixel either
+// side) are staged in LDS once, so a tap is an LDS broadcast read at a constant offset masked by 3 row + 3 column validity
+// bits, and the pixel's (image, row, column) advances incrementally.  Stores are 16-byte pieces (hi / lo halves of a 16-channel
+// S16 group), the ReLU mask 2 bytes.  (The previous form — 4 channels per thread, grid-stride — issued 9 tap loads and an
+// index division chain per 16 bytes of output and ran at 2.8 TB/s.)
+constexpr int CF_PIECE = 2048, CF_HALO = 32;
 __global__ __launch_bounds__(EW_BLOCK) void conv_first_s16_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ w1,
                                                                   const float* __restrict__ b1,
@@ -566,51 +602,94 @@ __global__ __launch_bounds__(EW_BLOCK) void conv_first_s16_kernel(const float* _
                                                                   const float* __restrict__ tb, int tb_stride,
                                                                   float* __restrict__ a1, unsigned char* __restrict__ a1m,
                                                                   float* __restrict__ a1_s16, float* __restrict__ s, int B) {
-    // The kernel was VALU-bound (~250 instructions per output quad: 64-bit index math, a bounds-checked address per tap).
-    // Now: 32-bit indices; the thread's channel quad is fixed (the grid stride is a multiple of 8), so its 9 tap weights,
-    // biases and skip weights are loaded once; the 9 input taps are buffer loads at constant pixel offsets (reads before or
-    // past the tensor return 0) masked by 3 row + 3 column validity bits.
-    const int total = B * 784 * 8;
-    const int c4 = threadIdx.x & 7;
-    float4 wv[9];
+    __shared__ float xs[CF_PIECE + 2 * CF_HALO];
+    const int c8 = threadIdx.x & 3, g = threadIdx.x >> 2;
+    float wv[9][8];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) wv[tap] = *reinterpret_cast<const float4*>(w1 + tap * 32 + c4 * 4);
-    const float4 b1v = *reinterpret_cast<const float4*>(b1 + c4 * 4);
-    const float4 wsv = *reinterpret_cast<const float4*>(ws + c4 * 4);
-    const float4 bsv = *reinterpret_cast<const float4*>(bs + c4 * 4);
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, B * 784 * 4, 0x00020000);
-    for (int i = blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += gridDim.x * EW_BLOCK) {
-        const int m = i >> 3;
-        const int b = m / 784;
-        const int rem = m - b * 784;
-        const int y = rem / 28, xx = rem - y * 28;
-        float xv[9];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)   // (m + offset < 0 only for taps above the first image: a negative = huge offset, reads 0)
-            xv[tap] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, (m + (tap / 3 - 1) * 28 + (tap % 3 - 1)) * 4, 0, 0));
-        const float4 t4 = *reinterpret_cast<const float4*>(tb + b * tb_stride + c4 * 4);
-        const bool r0 = y >= 1, r2 = y <= 26, c0 = xx >= 1, c2 = xx <= 26;
-        xv[0] = (r0 && c0) ? xv[0] : 0.f; xv[1] = r0 ? xv[1] : 0.f; xv[2] = (r0 && c2) ? xv[2] : 0.f;
-        xv[3] = c0 ? xv[3] : 0.f;                                    xv[5] = c2 ? xv[5] : 0.f;
-        xv[6] = (r2 && c0) ? xv[6] : 0.f; xv[7] = r2 ? xv[7] : 0.f; xv[8] = (r2 && c2) ? xv[8] : 0.f;
-        float4 acc = b1v;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            acc.x = fmaf(xv[tap], wv[tap].x, acc.x); acc.y = fmaf(xv[tap], wv[tap].y, acc.y);
-            acc.z = fmaf(xv[tap], wv[tap].z, acc.z); acc.w = fmaf(xv[tap], wv[tap].w, acc.w);
+    for (int tap = 0; tap < 9; ++tap) {
+        const float4 lo = *reinterpret_cast<const float4*>(w1 + tap * 32 + c8 * 8), hi = *reinterpret_cast<const float4*>(w1 + tap * 32 + c8 * 8 + 4);
+        wv[tap][0] = lo.x; wv[tap][1] = lo.y; wv[tap][2] = lo.z; wv[tap][3] = lo.w;
+        wv[tap][4] = hi.x; wv[tap][5] = hi.y; wv[tap][6] = hi.z; wv[tap][7] = hi.w;
+    }
+    float bv[8];
+    {
+        const float4 lo = *reinterpret_cast<const float4*>(b1 + c8 * 8), hi = *reinterpret_cast<const float4*>(b1 + c8 * 8 + 4);
+        bv[0] = lo.x; bv[1] = lo.y; bv[2] = lo.z; bv[3] = lo.w; bv[4] = hi.x; bv[5] = hi.y; bv[6] = hi.z; bv[7] = hi.w;
+    }
+    const int M = B * 784;
+    const int per = (M + gridDim.x - 1) / gridDim.x;
+    const int p0 = min((int)blockIdx.x * per, M), p1 = min(p0 + per, M);
+    for (int q0 = p0; q0 < p1; q0 += CF_PIECE) {
+        const int np = min(CF_PIECE, p1 - q0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < np + 2 * CF_HALO; e += EW_BLOCK) {
+            const int m = q0 - CF_HALO + e;
+            xs[e] = (m >= 0 && m < M) ? x[m] : 0.f;
         }
-        const float xc = xv[4];
-        acc.x = acc.x < 0.f ? 0.f : acc.x; acc.y = acc.y < 0.f ? 0.f : acc.y;
-        acc.z = acc.z < 0.f ? 0.f : acc.z; acc.w = acc.w < 0.f ? 0.f : acc.w;
-        if (a1 != nullptr) *reinterpret_cast<float4*>(a1 + (long)m * 32 + c4 * 4) = acc;
-        if (a1m != nullptr)
-            a1m[i] = (unsigned char)((acc.x > 0.f ? 1 : 0) | (acc.y > 0.f ? 2 : 0) | (acc.z > 0.f ? 4 : 0) | (acc.w > 0.f ? 8 : 0));
-        tdm_store_s16_4(a1_s16, m, 32, c4 * 4, make_float4(acc.x + t4.x, acc.y + t4.y, acc.z + t4.z, acc.w + t4.w));
-        if (s != nullptr) {
-            float4 sv;
-            sv.x = fmaf(xc, wsv.x, bsv.x); sv.y = fmaf(xc, wsv.y, bsv.y);
-            sv.z = fmaf(xc, wsv.z, bsv.z); sv.w = fmaf(xc, wsv.w, bsv.w);
-            *reinterpret_cast<float4*>(s + (long)m * 32 + c4 * 4) = sv;
+        __syncthreads();
+        int b = (q0 + g) / 784;
+        const int rem = (q0 + g) - b * 784;
+        int y = rem / 28, xx = rem - y * 28;
+        // time biases of the (at most two, for ranges up to one image) images this thread meets: loaded before the loop, so
+        // that no pixel waits for a dependent global load
+        const int bA = b, bB = min(b + 1, B - 1);
+        const float4 tA0 = *reinterpret_cast<const float4*>(tb + bA * tb_stride + c8 * 8), tA1 = *reinterpret_cast<const float4*>(tb + bA * tb_stride + c8 * 8 + 4);
+        const float4 tB0 = *reinterpret_cast<const float4*>(tb + bB * tb_stride + c8 * 8), tB1 = *reinterpret_cast<const float4*>(tb + bB * tb_stride + c8 * 8 + 4);
+        for (int q = g; q < np; q += 64) {
+            const float* c = xs + CF_HALO + q;
+            const bool r0 = y >= 1, r2 = y <= 26, c0 = xx >= 1, c2 = xx <= 26;
+            float xv[9];
+            xv[0] = (r0 && c0) ? c[-29] : 0.f; xv[1] = r0 ? c[-28] : 0.f; xv[2] = (r0 && c2) ? c[-27] : 0.f;
+            xv[3] = c0 ? c[-1] : 0.f;          xv[4] = c[0];              xv[5] = c2 ? c[1] : 0.f;
+            xv[6] = (r2 && c0) ? c[27] : 0.f;  xv[7] = r2 ? c[28] : 0.f;  xv[8] = (r2 && c2) ? c[29] : 0.f;
+            float4 t0 = b == bA ? tA0 : tB0, t1 = b == bA ? tA1 : tB1;
+            if (b != bA && b != bB) {   // (ranges longer than an image: a third image)
+                t0 = *reinterpret_cast<const float4*>(tb + b * tb_stride + c8 * 8);
+                t1 = *reinterpret_cast<const float4*>(tb + b * tb_stride + c8 * 8 + 4);
+            }
+            float acc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = bv[k];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] = fmaf(xv[tap], wv[tap][k], acc[k]);
+            unsigned mk = 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { acc[k] = acc[k] < 0.f ? 0.f : acc[k]; mk |= (acc[k] > 0.f ? 1u : 0u) << ((k & 3) + 8 * (k >> 2)); }
+            const int m = q0 + q;
+            if (a1 != nullptr) {
+                *reinterpret_cast<float4*>(a1 + (long)m * 32 + c8 * 8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                *reinterpret_cast<float4*>(a1 + (long)m * 32 + c8 * 8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            }
+            if (a1m != nullptr)   // one byte per channel quad (bits 0..3), as the quad-per-thread consumers read it
+                *reinterpret_cast<unsigned short*>(a1m + (long)m * 8 + c8 * 2) = (unsigned short)mk;
+            {
+                const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                tdm_bf16x4 h0, l0, h1, l1;
+                tdm_split4(make_float4(acc[0] + tv[0], acc[1] + tv[1], acc[2] + tv[2], acc[3] + tv[3]), h0, l0);
+                tdm_split4(make_float4(acc[4] + tv[4], acc[5] + tv[5], acc[6] + tv[6], acc[7] + tv[7]), h1, l1);
+                typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+                bf16x8_ vh, vl;
+                vh[0] = h0[0]; vh[1] = h0[1]; vh[2] = h0[2]; vh[3] = h0[3]; vh[4] = h1[0]; vh[5] = h1[1]; vh[6] = h1[2]; vh[7] = h1[3];
+                vl[0] = l0[0]; vl[1] = l0[1]; vl[2] = l0[2]; vl[3] = l0[3]; vl[4] = l1[0]; vl[5] = l1[1]; vl[6] = l1[2]; vl[7] = l1[3];
+                char* gp = reinterpret_cast<char*>(a1_s16 + (long)m * 32 + (c8 >> 1) * 16) + (c8 & 1) * 16;   // group c8 >> 1, piece c8 & 1
+                *reinterpret_cast<bf16x8_*>(gp) = vh;
+                *reinterpret_cast<bf16x8_*>(gp + 32) = vl;
+            }
+            if (s != nullptr) {
+                const float4 w0 = *reinterpret_cast<const float4*>(ws + c8 * 8), w1_ = *reinterpret_cast<const float4*>(ws + c8 * 8 + 4);
+                const float4 s0 = *reinterpret_cast<const float4*>(bs + c8 * 8), s1 = *reinterpret_cast<const float4*>(bs + c8 * 8 + 4);
+                const float xc = xv[4];
+                *reinterpret_cast<float4*>(s + (long)m * 32 + c8 * 8) =
+                    make_float4(fmaf(xc, w0.x, s0.x), fmaf(xc, w0.y, s0.y), fmaf(xc, w0.z, s0.z), fmaf(xc, w0.w, s0.w));
+                *reinterpret_cast<float4*>(s + (long)m * 32 + c8 * 8 + 4) =
+                    make_float4(fmaf(xc, w1_.x, s1.x), fmaf(xc, w1_.y, s1.y), fmaf(xc, w1_.z, s1.z), fmaf(xc, w1_.w, s1.w));
+            }
+            // the pixel 64 further on: + 2 rows + 8 columns
+            xx += 8; y += 2;
+            if (xx >= 28) { xx -= 28; ++y; }
+            if (y >= 28) { y -= 28; ++b; }
         }
     }
 }
@@ -1106,8 +1185,12 @@ int tdm_launch_combine_dh1(const float* dcat, const float* dp1, float* dout1, in
 }
 int tdm_launch_first_wgrad(const float* x, const float* dc1, const float* dout1, float* slab, long slab_stride,
                            int w1_off, int b1_off, int ws_off, int bs_off, int B, int nslab, hipStream_t st) {
-    hipLaunchKernelGGL(first_wgrad_kernel, dim3(nslab), dim3(FW_BLOCK), 0, st, x, dc1, dout1, slab, slab_stride, w1_off,
-                       b1_off, ws_off, bs_off, B);
+    if (dout1 != nullptr)
+        hipLaunchKernelGGL(first_wgrad_kernel<true>, dim3(nslab), dim3(FW_BLOCK), 0, st, x, dc1, dout1, slab, slab_stride, w1_off,
+                           b1_off, ws_off, bs_off, B);
+    else
+        hipLaunchKernelGGL(first_wgrad_kernel<false>, dim3(nslab), dim3(FW_BLOCK), 0, st, x, dc1, dout1, slab, slab_stride, w1_off,
+                           b1_off, ws_off, bs_off, B);
     TDM_CHECK_LAUNCH("first_wgrad");
     return 0;
 }
@@ -1143,7 +1226,9 @@ int tdm_launch_s16_to_nchw(const float* in_s16, float* out, int B, int HWpix, in
 int tdm_launch_conv_first_s16(const float* x, const float* w1, const float* b1, const float* ws, const float* bs,
                               const float* tb, int tb_stride, float* a1, unsigned char* a1m, float* a1_s16, float* s, int B,
                               hipStream_t st) {
-    hipLaunchKernelGGL(conv_first_s16_kernel, dim3(ew_grid((int64_t)B * 784 * 8)), dim3(EW_BLOCK), 0, st, x, w1, b1, ws, bs,
+    // contiguous pixel ranges of ~392 pixels (half an image) per workgroup, at most 2048 workgroups
+    const int64_t want = ((int64_t)B * 784 + 391) / 392;
+    hipLaunchKernelGGL(conv_first_s16_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(EW_BLOCK), 0, st, x, w1, b1, ws, bs,
                        tb, tb_stride, a1, a1m, a1_s16, s, B);
     TDM_CHECK_LAUNCH("conv_first_s16");
     return 0;
