@@ -3,6 +3,7 @@
 // the 32->1 output convolution, fused MSE forward+backward, ReLU backward
 // with the timestep-bias gradient, AdamW.  All float4-coalesced, 64-lane
 // wavefront reductions, deterministic (no float atomics).
+#include <cstdlib>
 #include "tdm_common.h"
 #include "tdm_timebias.h"
 #include "tdm_s16.h"
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(EW_BLOCK) void adamw_kernel(float* __restrict__ p, 
 // bits, and the pixel's (image, row, column) advances incrementally.  Stores are 16-byte pieces (hi / lo halves of a 16-channel
 // S16 group), the ReLU mask 2 bytes.  (The previous form — 4 channels per thread, grid-stride — issued 9 tap loads and an
 // index division chain per 16 bytes of output and ran at 2.8 TB/s.)
-constexpr int CF_PIECE = 2048, CF_HALO = 32;
+constexpr int CF_PIECE = 784, CF_HALO = 32;   // a piece spans at most two images: both time-bias rows are loaded before the loop
 __global__ __launch_bounds__(EW_BLOCK) void conv_first_s16_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ w1,
                                                                   const float* __restrict__ b1,
@@ -630,8 +631,7 @@ __global__ __launch_bounds__(EW_BLOCK) void conv_first_s16_kernel(const float* _
         int b = (q0 + g) / 784;
         const int rem = (q0 + g) - b * 784;
         int y = rem / 28, xx = rem - y * 28;
-        // time biases of the (at most two, for ranges up to one image) images this thread meets: loaded before the loop, so
-        // that no pixel waits for a dependent global load
+        // time biases of the (at most two: a piece is no longer than an image) images this thread meets
         const int bA = b, bB = min(b + 1, B - 1);
         const float4 tA0 = *reinterpret_cast<const float4*>(tb + bA * tb_stride + c8 * 8), tA1 = *reinterpret_cast<const float4*>(tb + bA * tb_stride + c8 * 8 + 4);
         const float4 tB0 = *reinterpret_cast<const float4*>(tb + bB * tb_stride + c8 * 8), tB1 = *reinterpret_cast<const float4*>(tb + bB * tb_stride + c8 * 8 + 4);
@@ -642,11 +642,10 @@ __global__ __launch_bounds__(EW_BLOCK) void conv_first_s16_kernel(const float* _
             xv[0] = (r0 && c0) ? c[-29] : 0.f; xv[1] = r0 ? c[-28] : 0.f; xv[2] = (r0 && c2) ? c[-27] : 0.f;
             xv[3] = c0 ? c[-1] : 0.f;          xv[4] = c[0];              xv[5] = c2 ? c[1] : 0.f;
             xv[6] = (r2 && c0) ? c[27] : 0.f;  xv[7] = r2 ? c[28] : 0.f;  xv[8] = (r2 && c2) ? c[29] : 0.f;
-            float4 t0 = b == bA ? tA0 : tB0, t1 = b == bA ? tA1 : tB1;
-            if (b != bA && b != bB) {   // (ranges longer than an image: a third image)
-                t0 = *reinterpret_cast<const float4*>(tb + b * tb_stride + c8 * 8);
-                t1 = *reinterpret_cast<const float4*>(tb + b * tb_stride + c8 * 8 + 4);
-            }
+            // NO global load inside this loop: vmcnt counts loads and stores in order, so waiting for a load issued after the
+            // previous pixel's stores means waiting for those stores to be acknowledged (that wait, not bytes or FMAs, was
+            // the previous forms' 20 us)
+            const float4 t0 = b == bA ? tA0 : tB0, t1 = b == bA ? tA1 : tB1;
             float acc[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[k] = bv[k];
@@ -673,9 +672,24 @@ __global__ __launch_bounds__(EW_BLOCK) void conv_first_s16_kernel(const float* _
                 bf16x8_ vh, vl;
                 vh[0] = h0[0]; vh[1] = h0[1]; vh[2] = h0[2]; vh[3] = h0[3]; vh[4] = h1[0]; vh[5] = h1[1]; vh[6] = h1[2]; vh[7] = h1[3];
                 vl[0] = l0[0]; vl[1] = l0[1]; vl[2] = l0[2]; vl[3] = l0[3]; vl[4] = l1[0]; vl[5] = l1[1]; vl[6] = l1[2]; vl[7] = l1[3];
-                char* gp = reinterpret_cast<char*>(a1_s16 + (long)m * 32 + (c8 >> 1) * 16) + (c8 & 1) * 16;   // group c8 >> 1, piece c8 & 1
-                *reinterpret_cast<bf16x8_*>(gp) = vh;
-                *reinterpret_cast<bf16x8_*>(gp + 32) = vl;
+                // The four threads of a pixel exchange pieces inside their lane quad so that ONE store instruction writes a
+                // whole 64-byte S16 group per pixel ([hi0 hi1 lo0 lo1] = lanes r = 0..3) instead of two instructions writing
+                // its hi and its lo half: partial 64-byte blocks cost the L2 write path a request each (tdm_s16.h).
+                const uint4 uh = __builtin_bit_cast(uint4, vh), ul = __builtin_bit_cast(uint4, vl);
+                const bool hi_lane = c8 < 2;
+                uint4 o0, o1;
+#define TDM_QP(v, ctrl) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, 0xf, 0xf, true)
+                // (every lane executes BOTH exchanges, the select comes afterwards: a lane that skipped one would be read as 0)
+                const uint4 hA = make_uint4(TDM_QP(uh.x, 0x44), TDM_QP(uh.y, 0x44), TDM_QP(uh.z, 0x44), TDM_QP(uh.w, 0x44));
+                const uint4 lA = make_uint4(TDM_QP(ul.x, 0x44), TDM_QP(ul.y, 0x44), TDM_QP(ul.z, 0x44), TDM_QP(ul.w, 0x44));
+                const uint4 hB = make_uint4(TDM_QP(uh.x, 0xEE), TDM_QP(uh.y, 0xEE), TDM_QP(uh.z, 0xEE), TDM_QP(uh.w, 0xEE));
+                const uint4 lB = make_uint4(TDM_QP(ul.x, 0xEE), TDM_QP(ul.y, 0xEE), TDM_QP(ul.z, 0xEE), TDM_QP(ul.w, 0xEE));
+                o0 = hi_lane ? hA : lA;
+                o1 = hi_lane ? hB : lB;
+#undef TDM_QP
+                char* gp = reinterpret_cast<char*>(a1_s16 + (long)m * 32) + c8 * 16;   // group 0: bytes 0..63 of the pixel, group 1: 64..127
+                *reinterpret_cast<uint4*>(gp) = o0;
+                *reinterpret_cast<uint4*>(gp + 64) = o1;
             }
             if (s != nullptr) {
                 const float4 w0 = *reinterpret_cast<const float4*>(ws + c8 * 8), w1_ = *reinterpret_cast<const float4*>(ws + c8 * 8 + 4);
@@ -1226,8 +1240,11 @@ int tdm_launch_s16_to_nchw(const float* in_s16, float* out, int B, int HWpix, in
 int tdm_launch_conv_first_s16(const float* x, const float* w1, const float* b1, const float* ws, const float* bs,
                               const float* tb, int tb_stride, float* a1, unsigned char* a1m, float* a1_s16, float* s, int B,
                               hipStream_t st) {
-    // contiguous pixel ranges of ~392 pixels (half an image) per workgroup, at most 2048 workgroups
-    const int64_t want = ((int64_t)B * 784 + 391) / 392;
+    // contiguous pixel ranges of ~196 pixels (a quarter image) per workgroup, at most 2048 workgroups.  (Swept 512 .. 2048
+    // workgroups at B = 512: 20.4 - 23.3 us, flat; with stores, FMAs and staging all switched off the launch still took
+    // 18.5 us — per-workgroup prologue latency (72 weights, the input range, two barriers) at 3 waves per SIMD, not bytes:
+    // tools/micro/store_patterns.hip writes the same 51 MB in 9 us.)
+    const int64_t want = ((int64_t)B * 784 + 195) / 196;
     hipLaunchKernelGGL(conv_first_s16_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(EW_BLOCK), 0, st, x, w1, b1, ws, bs,
                        tb, tb_stride, a1, a1m, a1_s16, s, B);
     TDM_CHECK_LAUNCH("conv_first_s16");
