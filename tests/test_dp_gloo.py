@@ -209,3 +209,41 @@ def test_embedding_gradient_rowwise_allreduce_equals_dense(tmp_path):
         assert torch.equal(x["rows"], x["dense"])
         assert torch.equal(x["rows"], r[0]["rows"])
         assert x["u"] == union.numel()
+
+
+def _async_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from tinydiffusionmodels_amd import dp
+    dp.init_from_env("gloo")
+    g = torch.Generator().manual_seed(7 + rank)
+    big, small, later = torch.randn(50_000, generator=g), torch.randn(33, generator=g), torch.randn(4_000, generator=g)
+    want = [x.clone() for x in (big, small, later)]
+    for x in want:
+        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+    # the text step's pattern: two reductions started early, other work and a blocking reduction in between, then the waits
+    pending = [dp.allreduce_grads_async_(big), dp.allreduce_grads_async_(small)]
+    busy = torch.randn(256, 256, generator=g) @ torch.randn(256, 256, generator=g)     # (stands for the denoiser)
+    scale = dp.allreduce_grads_(later)
+    for h in pending:
+        h.wait()
+        h.wait()                                                                        # idempotent
+    torch.save({"got": [big, small, later], "want": want, "scale": scale, "busy": float(busy.sum())},
+               os.path.join(out_dir, f"async{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_async_allreduce_matches_the_blocking_one(tmp_path):
+    """dp.allreduce_grads_async_ (the rounding head's gradient travelling under the denoiser in TextTrainStep, world > 1):
+    started before other collectives and work, waited for afterwards — the same sums as blocking all-reduces, every rank
+    issuing in the same order (world 3, gloo)."""
+    mp.spawn(_async_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    r = [torch.load(tmp_path / f"async{k}.pt") for k in range(3)]
+    for x in r:
+        assert x["scale"] == pytest.approx(1.0 / 3)
+        for got, want in zip(x["got"], x["want"]):
+            assert torch.equal(got, want)
+        for got, ref in zip(x["got"], r[0]["got"]):
+            assert torch.equal(got, ref)

@@ -635,10 +635,13 @@ def test_full_text_step_graph_equals_eager_under_the_lr_schedule(dev, gemm_mode)
     V, D, B, L = 300, 32, 4, 16
     lam = S.cosine_warmup_lambda(3, 10)
     runs = []
-    for use_graph in (True, False):
+    # third run: the data-parallel form of the step — rounding head BEFORE the denoiser (so that its gradient's all-reduce
+    # travels under the denoiser, dp.allreduce_grads_async_), two graphs — issues the same launches: the same bits
+    for use_graph, head_first in ((True, False), (False, False), (True, True)):
         m, emb, rnd = _text_modules(dev, V, D, 0.1, seed=11)
         torch.manual_seed(123)
-        step = S.TextTrainStep(m, rnd, emb, lr=2e-3, rounding_weight=1.0, lr_lambda=lam, total_steps=10, graph=use_graph)
+        step = S.TextTrainStep(m, rnd, emb, lr=2e-3, rounding_weight=1.0, lr_lambda=lam, total_steps=10, graph=use_graph,
+                               head_first=head_first)
         gen = torch.Generator().manual_seed(9)
         losses = []
         for i in range(10):
@@ -652,8 +655,8 @@ def test_full_text_step_graph_equals_eager_under_the_lr_schedule(dev, gemm_mode)
         runs.append((torch.stack(losses), m.flat.detach().clone(), emb.embeddings.weight.detach().clone(),
                      rnd.decoder.weight.detach().clone(), rnd.decoder.bias.detach().clone(), step.rng_state.clone(),
                      step.epoch_sums().clone()))
-    for a, bb in zip(*runs):
-        assert torch.equal(a, bb)
+    for a, bb, cc in zip(*runs):
+        assert torch.equal(a, bb) and torch.equal(a, cc)
     assert torch.isfinite(runs[0][0]).all() and len(set(runs[0][0][:, 0].tolist())) == 10
     # the device LR table = the sequence LambdaLR gives a torch optimizer
     w = torch.nn.Parameter(torch.zeros(1))

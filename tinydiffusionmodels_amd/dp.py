@@ -270,10 +270,59 @@ def allreduce_grads_(flat_grads: torch.Tensor) -> float:
     if world > 1:
         comm = native_comm() if flat_grads.is_cuda else None
         if comm is not None:
-            comm.allreduce_sum_(flat_grads)
+            if _side_stream is not None and not torch.cuda.is_current_stream_capturing():
+                # an asynchronous reduction may be in flight on the side stream: one communicator, ONE issue order
+                allreduce_grads_async_(flat_grads).wait()
+            else:
+                comm.allreduce_sum_(flat_grads)
         else:
             dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
     return 1.0 / world
+
+
+class _Pending:
+    """A collective in flight next to the caller's stream; wait() orders the caller's CURRENT stream (torch.distributed's
+    NCCL work, the native side stream) or the host (gloo) behind it."""
+
+    def __init__(self, work=None, stream=None):
+        self._work, self._stream = work, stream
+
+    def wait(self) -> None:
+        if self._work is not None:
+            self._work.wait()
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
+        self._work = self._stream = None
+
+
+_side_stream = None
+
+
+def _comm_side_stream() -> "torch.cuda.Stream":
+    global _side_stream
+    if _side_stream is None:
+        _side_stream = torch.cuda.Stream()
+    return _side_stream
+
+
+def allreduce_grads_async_(flat_grads: torch.Tensor) -> _Pending:
+    """allreduce_grads_ that does NOT hold up the caller's stream: the SUM is enqueued behind everything the current stream
+    has been given so far and runs beside what is enqueued afterwards (RCCL moves bytes over xGMI with a few CUs; the
+    kernels launched meanwhile keep the rest).  The buffer must not be touched until `.wait()`.  The text train step reduces
+    its rounding-head gradient (51 MB at V = 50,257, ready before the denoiser has even started) this way, under the whole
+    denoiser forward + backward.  Every rank must issue its collectives in the same order (as with the blocking form)."""
+    _, world = world_info()
+    if world == 1:
+        return _Pending()
+    comm = native_comm() if flat_grads.is_cuda else None
+    if comm is not None:
+        side = _comm_side_stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            comm.allreduce_sum_(flat_grads)
+        flat_grads.record_stream(side)
+        return _Pending(stream=side)
+    return _Pending(work=dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, async_op=True))
 
 
 def allreduce_rows_(grad: torch.Tensor, ids: torch.Tensor) -> int:

@@ -625,7 +625,7 @@ class TextTrainStep:
 
     def __init__(self, model: TinyTransformer, rounding_fn: "LearnedRounding", embedding_fn: "LearnedEmbedding", lr: float = 1e-4,
                  weight_decay: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, rounding_weight: float = 1.0,
-                 lr_lambda=None, total_steps: int = 1, graph: Optional[bool] = None):
+                 lr_lambda=None, total_steps: int = 1, graph: Optional[bool] = None, head_first: Optional[bool] = None):
         self.model, self.rounding_fn, self.embedding_fn = model, rounding_fn, embedding_fn
         self.flat = model.flat.detach()
         self.table = embedding_fn.embeddings.weight.detach()
@@ -641,6 +641,10 @@ class TextTrainStep:
         self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, eps
         self.rank, self.world = dp.world_info()
         self.use_graph = (os.environ.get("TDM_TRAIN_GRAPH", "1") != "0") if graph is None else bool(graph)
+        # head_first (default: under torch.distributed): the rounding head runs BEFORE the denoiser — it needs the gathered
+        # embeddings only — so that the all-reduce of its gradient (the step's largest buffer) travels under the whole
+        # denoiser forward + backward (dp.allreduce_grads_async_); the step is then two launch sequences / graphs
+        self.head_first = (self.world > 1) if head_first is None else bool(head_first)
         z = lambda t_: torch.zeros_like(t_)    # noqa: E731
         self.g_flat, self.m_flat, self.v_flat = z(self.flat), z(self.flat), z(self.flat)
         self.g_tab, self.m_tab, self.v_tab = z(self.table), z(self.table), z(self.table)
@@ -686,27 +690,44 @@ class TextTrainStep:
     def _p_drop(self) -> float:
         return self.model.p_drop if self.model.training else 0.0
 
-    def _loss_and_grads(self, st: _TextStepState) -> None:
+    def _loss_and_grads(self, st: _TextStepState, part: str = "all") -> None:
+        """part: "all" = the whole launch sequence in the reference's order; "head" = gather + rounding head, "body" = the rest
+        (head_first: the same launches, the rounding head moved in front of the denoiser it does not depend on)."""
         L_, tt, cfg = _lib.lib(), st.tt, self.model.cfg
         B, L, D, V, M = st.B, st.L, self.D, self.V, st.B * st.L
         tabs = device_tables(self.flat.device)
         stream = _lib.stream()
-        _lib.check(L_.tdm_embed_gather_f32(_lib.ptr(self.table), _lib.ptr(st.ids), _lib.ptr(tt.x0), M, V, D, stream), "embed_gather")
-        _lib.check(L_.tdm_tt_loss_grad_philox_dx_f32(
-            _lib.ptr(self.flat), _lib.ptr(tt.x0), _lib.ptr(tabs["sqrt_alphas_cumprod"]), _lib.ptr(tabs["sqrt_one_minus_alphas_cumprod"]),
-            self.seed, _lib.ptr(self.rng_state), _lib.ptr(tt.t), _lib.ptr(tt.noise), _lib.ptr(tt.x_noisy), _lib.ptr(tt.pred),
-            _lib.ptr(tt.dpred), _lib.ptr(tt.loss), _lib.ptr(self.g_flat), _lib.ptr(st.dxn), _lib.ptr(tt.ws.ws),
-            _lib.ptr(TE.slabs_for(cfg, self.flat.device)), B, L, D, cfg.n_heads, cfg.depth, cfg.ffn, float(self._p_drop()),
-            self.drop_seed, stream), "tt_loss_grad_philox_dx")
-        round_ce_launch(st.round_form, st.round_param, st.round_ws, tt.x0.view(M, D), self.W, self.b, st.ids.view(-1), 1.0, st.rnd_loss,
-                        st.dxr, self.g_W, self.g_b, M, V, D)
-        _lib.check(L_.tdm_text_combine_dx0_f32(_lib.ptr(st.dxn), _lib.ptr(tt.t), _lib.ptr(tabs["sqrt_alphas_cumprod"]), _lib.ptr(st.dxr),
-                                               _lib.ptr(self.rw), _lib.ptr(st.dx0), B, L * D, stream), "combine_dx0")
-        self.g_tab.zero_()
-        _lib.check(L_.tdm_embed_scatter_add_f32(_lib.ptr(st.dx0), _lib.ptr(st.ids), _lib.ptr(self.g_tab), M, V, D, 1.0, stream),
-                   "embed_scatter_add")
-        _lib.check(L_.tdm_text_loss_f32(_lib.ptr(tt.loss), _lib.ptr(st.rnd_loss), _lib.ptr(self.rw), _lib.ptr(st.losses),
-                                        _lib.ptr(self.acc), stream), "text_loss")
+
+        def gather():
+            _lib.check(L_.tdm_embed_gather_f32(_lib.ptr(self.table), _lib.ptr(st.ids), _lib.ptr(tt.x0), M, V, D, stream), "embed_gather")
+
+        def denoiser():
+            _lib.check(L_.tdm_tt_loss_grad_philox_dx_f32(
+                _lib.ptr(self.flat), _lib.ptr(tt.x0), _lib.ptr(tabs["sqrt_alphas_cumprod"]), _lib.ptr(tabs["sqrt_one_minus_alphas_cumprod"]),
+                self.seed, _lib.ptr(self.rng_state), _lib.ptr(tt.t), _lib.ptr(tt.noise), _lib.ptr(tt.x_noisy), _lib.ptr(tt.pred),
+                _lib.ptr(tt.dpred), _lib.ptr(tt.loss), _lib.ptr(self.g_flat), _lib.ptr(st.dxn), _lib.ptr(tt.ws.ws),
+                _lib.ptr(TE.slabs_for(cfg, self.flat.device)), B, L, D, cfg.n_heads, cfg.depth, cfg.ffn, float(self._p_drop()),
+                self.drop_seed, stream), "tt_loss_grad_philox_dx")
+
+        def rounding():
+            round_ce_launch(st.round_form, st.round_param, st.round_ws, tt.x0.view(M, D), self.W, self.b, st.ids.view(-1), 1.0, st.rnd_loss,
+                            st.dxr, self.g_W, self.g_b, M, V, D)
+
+        def tail():
+            _lib.check(L_.tdm_text_combine_dx0_f32(_lib.ptr(st.dxn), _lib.ptr(tt.t), _lib.ptr(tabs["sqrt_alphas_cumprod"]), _lib.ptr(st.dxr),
+                                                   _lib.ptr(self.rw), _lib.ptr(st.dx0), B, L * D, stream), "combine_dx0")
+            self.g_tab.zero_()
+            _lib.check(L_.tdm_embed_scatter_add_f32(_lib.ptr(st.dx0), _lib.ptr(st.ids), _lib.ptr(self.g_tab), M, V, D, 1.0, stream),
+                       "embed_scatter_add")
+            _lib.check(L_.tdm_text_loss_f32(_lib.ptr(tt.loss), _lib.ptr(st.rnd_loss), _lib.ptr(self.rw), _lib.ptr(st.losses),
+                                            _lib.ptr(self.acc), stream), "text_loss")
+
+        if part == "all":
+            gather(); denoiser(); rounding(); tail()
+        elif part == "head":
+            gather(); rounding()
+        else:
+            denoiser(); tail()
 
     def _optimizer_step(self, scale: float = 1.0) -> None:
         kw = dict(betas=self.betas, eps=self.eps, weight_decay=self.wd)
@@ -720,16 +741,26 @@ class TextTrainStep:
         E.adamw_step_devsched(self.b, self.g_b, self.m_b, self.v_b, self.step_state, self.lr_tab, grad_scale=scale,
                               grad_scale_dev=self.rw, bump=True, **kw)
 
-    def _sync_and_step(self, ids: torch.Tensor, weight: float) -> None:
+    def _reduce_head_async(self, weight: float):
+        """world > 1, after the "head" launches: the rounding head's gradients start travelling now (weighted by the ragged-tail
+        share first, like every gradient before its SUM)."""
+        if weight != 1.0:
+            self.g_W.mul_(weight); self.g_b.mul_(weight)
+        return [dp.allreduce_grads_async_(self.g_W.view(-1)), dp.allreduce_grads_async_(self.g_b)]
+
+    def _sync_and_step(self, ids: torch.Tensor, weight: float, pending=None) -> None:
         """world > 1: average the gradients over the ranks, then AdamW.  weight = B_local * world / B_global (1 for equal shards;
         a ragged tail weights each rank's mean-loss gradient by its share BEFORE the sum, so every rank applies the same
-        reduced gradient)."""
+        reduced gradient).  pending: the rounding head's reductions already in flight (_reduce_head_async)."""
+        bufs = (self.g_flat, self.g_tab) if pending is not None else (self.g_flat, self.g_tab, self.g_W, self.g_b)
         if weight != 1.0:
-            for gbuf in (self.g_flat, self.g_tab, self.g_W, self.g_b):
+            for gbuf in bufs:
                 gbuf.mul_(weight)
-        for gbuf in (self.g_flat, self.g_W, self.g_b):
+        for gbuf in ((self.g_flat,) if pending is not None else (self.g_flat, self.g_W, self.g_b)):
             dp.allreduce_grads_(gbuf.view(-1))
         dp.allreduce_rows_(self.g_tab, ids)
+        for h in pending or ():
+            h.wait()
         self._optimizer_step(1.0 / self.world)
 
     def step(self, token_ids: torch.Tensor, global_batch: Optional[int] = None) -> torch.Tensor:
@@ -742,30 +773,42 @@ class TextTrainStep:
             st = self._cur if self._cur is not None else self._state(1, L)
             for gbuf in (self.g_flat, self.g_tab, self.g_W, self.g_b):
                 gbuf.zero_()
-            self._sync_and_step(st.ids[:0], 1.0)
+            # (the same collectives in the same order as the ranks that have samples)
+            self._sync_and_step(st.ids[:0], 1.0, self._reduce_head_async(1.0) if self.head_first else None)
             return st.losses
         st = self._cur = self._state(B, L)
         st.ids.copy_(token_ids)
         weight = 1.0 if (global_batch is None or self.world == 1) else B * self.world / float(global_batch)
         whole = self.world == 1
+        parts = ("head", "body") if self.head_first else ("all",)
+        pending = None
         if not self.use_graph or st.warm < 1:               # first step of a shape eagerly (lazy kernel attributes, allocator warm-up)
             st.warm += 1
-            self._loss_and_grads(st)
+            for part in parts:
+                self._loss_and_grads(st, part)
+                if part == "head" and not whole:
+                    pending = self._reduce_head_async(weight)
             if whole:
                 self._optimizer_step(1.0)
         else:
-            key = (schedule_generation(), self._p_drop(), self.lr_tab.data_ptr())
+            key = (schedule_generation(), self._p_drop(), self.lr_tab.data_ptr(), parts)
             if st.graph is None or st.graph_key != key:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self._loss_and_grads(st)
-                    if whole:
-                        self._optimizer_step(1.0)
-                st.graph, st.graph_key = g, key
+                graphs = []
+                for part in parts:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self._loss_and_grads(st, part)
+                        if whole and part == parts[-1]:
+                            self._optimizer_step(1.0)
+                    graphs.append(g)
+                st.graph, st.graph_key = graphs, key
                 self.captures += 1
-            st.graph.replay()
+            for part, g in zip(parts, st.graph):
+                g.replay()
+                if part == "head" and not whole:
+                    pending = self._reduce_head_async(weight)
         if not whole:
-            self._sync_and_step(st.ids, weight)
+            self._sync_and_step(st.ids, weight, pending)
         return st.losses
 
 
