@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TDM_VERSION 300
+#define TDM_VERSION 400
 #define TDM_TIMESTEPS 1000
 #define TDM_UNET_NPARAM 181473      /* SimpleUNet(), src/mnist.py:64-74 */
 #define TDM_UNET_NTENSOR 32         /* number of state_dict entries      */
