@@ -160,6 +160,16 @@ int tdm_unet_loss_grad_philox_f32(const float* params, const float* x0, const fl
                                   const float* sqrt_1m_acp, uint64_t seed, int64_t* rng_state, int64_t* t_buf,
                                   float* noise, float* x_noisy, float* eps, float* deps, float* loss_out,
                                   float* grads, float* ws, float* slabs, int64_t B, void* stream);
+/* ... with the BATCH gathered on the fly from a device-resident dataset (src/mnist.py:150-152): image b = row
+ * perm[(step_state[0] - epoch_base[0]) * stride + offset + b] of data (n_rows, 784); step_state is AdamW's device-side
+ * step count (tdm_adamw_flat_devstep_f32), epoch_base its value at the start of the epoch (one device write per epoch),
+ * stride = batch x world, offset = rank x batch.  Whole batches only ((steps - base + 1) * stride <= n_rows).  A train loop
+ * is then ONE hipGraph replay per batch: no gather launch, no host-written index.                                         */
+int tdm_unet_loss_grad_philox_epoch_f32(const float* params, const float* data, const int64_t* perm, const int64_t* step_state,
+                                        const int64_t* epoch_base, int64_t n_rows, int64_t stride, int64_t offset,
+                                        const float* sqrt_acp, const float* sqrt_1m_acp, uint64_t seed, int64_t* rng_state,
+                                        int64_t* t_buf, float* noise, float* x_noisy, float* eps, float* deps, float* loss_out,
+                                        float* grads, float* ws, float* slabs, int64_t B, void* stream);
 /* tdm_unet_p_sample_step_f32 with device-resident t and device-drawn noise: one reverse step of
  * src/mnist.py:190-193 with no host-written scalar                                                   */
 int tdm_unet_p_sample_step_philox_f32(const float* params, const float* x, int64_t* t_dev, const float* tab_recip,

@@ -628,3 +628,44 @@ def test_mnist_cli_train_then_sample_end_to_end(dev, conv_mode, tmp_path, monkey
     assert "samples.png" in pngs and "epoch_001.png" in pngs
     png = (tmp_path / "samples" / "samples.png").read_bytes()
     assert png[:8] == b"\x89PNG\r\n\x1a\n"
+
+
+def test_epoch_mode_gathers_inside_the_step_and_equals_the_gather_per_step_loop(dev, conv_mode, tmp_path, monkeypatch):
+    """mnist.train() with the batch gathered INSIDE the captured step (DDPMTrainer.begin_epoch / step_epoch: dataset and
+    permutation resident on the device, position = AdamW's device-side step count minus its value at the start of the epoch —
+    one hipGraph replay per batch and nothing between two replays) against the same loop with a gather launch per batch
+    (TDM_EPOCH_GATHER=0): same draws, same batches, so the same weights bit for bit — two epochs of five whole batches and a
+    ragged tail of three samples each (the tail runs through step() in both forms)."""
+    if conv_mode != 2:
+        pytest.skip("host-side loop logic; the default arithmetic is enough")
+    from tinydiffusionmodels_amd import mnist as M
+    B = 16
+    data = M.synthetic_mnist(5 * B + 3, seed=77)
+    finals = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TDM_EPOCH_GATHER", flag)
+        torch.manual_seed(5)
+        m = M.SimpleUNet().to(dev)
+        M.train(m, str(dev), epochs=2, batch_size=B, lr=1e-3, ckpt_path=str(tmp_path / f"ck{flag}.pth"), sample_every_epoch=False,
+                data=data, log_every=0)
+        torch.cuda.synchronize()
+        finals.append(m.flat.detach().clone())
+    assert torch.equal(finals[0], finals[1])
+    # the epoch position really comes from the device-side step count: a fresh trainer, three steps, then the batch the
+    # fourth step would read is perm[3 B : 4 B]
+    torch.manual_seed(6)
+    m = M.SimpleUNet().to(dev)
+    tr = M.DDPMTrainer(m, B, lr=1e-3)
+    d = data.to(dev)
+    perm = torch.randperm(d.shape[0], generator=torch.Generator().manual_seed(1)).to(dev)
+    tr.begin_epoch(d, perm)
+    for _ in range(3):
+        tr.step_epoch()
+    torch.cuda.synchronize()
+    assert tr.steps_taken == 3
+    # (x_noisy of the next step = q_sample of exactly that batch with the step's own draws)
+    tr.step_epoch()
+    torch.cuda.synchronize()
+    st = tr.state
+    want = M.q_sample(d[perm[3 * B:4 * B]], st.t, st.noise)
+    assert torch.equal(st.x_noisy, want)

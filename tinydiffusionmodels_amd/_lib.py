@@ -94,6 +94,7 @@ _SIGS = {
     "tdm_adamw_flat_devstep_f32": ([c_f, c_f, c_f, c_f, c_i64, c_float, c_float, c_float, c_float, c_float, c_f,
                                     c_float, c_f], c_int),
     "tdm_unet_loss_grad_philox_f32": ([c_f, c_f, c_f, c_f, c_u64] + [c_f] * 10 + [c_i64, c_f], c_int),
+    "tdm_unet_loss_grad_philox_epoch_f32": ([c_f] * 5 + [c_i64] * 3 + [c_f, c_f, c_u64] + [c_f] * 10 + [c_i64, c_f], c_int),
     "tdm_unet_p_sample_step_philox_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_u64, c_f, c_f, c_f, c_f, c_i64, c_f], c_int),
     "tdm_ctx_create": ([c_int, ctypes.POINTER(ctypes.c_void_p)], c_int),
     "tdm_ctx_destroy": ([c_f], c_int),

@@ -63,19 +63,32 @@ __global__ __launch_bounds__(RB) void philox_u32_kernel(uint64_t seed, uint64_t 
 }
 
 // state[0] = Philox offset of this call (advanced afterwards by bump_offset_kernel / the next kernel of the step)
+// Batch source: x0 (B, inner) directly, or — EpochSrc::perm != nullptr — gathered on the fly from a device-resident dataset:
+// image b of the step is row perm[(steps - base) * stride + offset + b] of `x0` (= the dataset), where steps = AdamW's
+// device-side step count and base = its value when the epoch began: the train loop's per-step gather needs no launch and no
+// host-written index (src/mnist.py:150-152's DataLoader batch; the positions are dp.shard_batch_indices').
+struct EpochSrc { const int64_t* perm; const int64_t* steps; const int64_t* base; int64_t n, stride, offset; };
 __global__ __launch_bounds__(RB) void draw_q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ ta,
                                                            const float* __restrict__ ts, uint64_t seed,
                                                            int64_t* __restrict__ state, int64_t* __restrict__ t_out,
                                                            float* __restrict__ noise_out, float* __restrict__ xn_out,
-                                                           int64_t B, int64_t inner4) {
+                                                           int64_t B, int64_t inner4, EpochSrc es) {
     const uint64_t offset = (uint64_t)state[0];
     const int64_t n4 = B * inner4;
+    int64_t pos0 = 0;
+    if (es.perm != nullptr) pos0 = (es.steps[0] - es.base[0]) * es.stride + es.offset;
     for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * RB) {
         const int64_t b = i / inner4;
         const int64_t tt = tdm_philox_step(seed, offset, (uint64_t)b, TDM_TIMESTEPS);
         if (i - b * inner4 == 0) t_out[b] = tt;
         const float a = ta[tt], s = ts[tt];
-        const float4 x = reinterpret_cast<const float4*>(x0)[i];
+        int64_t src = i;
+        if (es.perm != nullptr) {   // (clamped: a position or row outside the dataset is the host's bug, not a fault)
+            const int64_t pos = min(max(pos0 + b, (int64_t)0), es.n - 1);
+            const int64_t row = min(max(es.perm[pos], (int64_t)0), es.n - 1);
+            src = row * inner4 + (i - b * inner4);
+        }
+        const float4 x = reinterpret_cast<const float4*>(x0)[src];
         const float4 n = tdm_philox_normal4(seed, offset, (uint64_t)i);
         float4 o;
         o.x = __fadd_rn(__fmul_rn(a, x.x), __fmul_rn(s, n.x));
@@ -202,11 +215,14 @@ __global__ __launch_bounds__(64) void text_loss_kernel(const float* __restrict__
 }  // namespace
 
 // internal: the fused train step advances the offset in its next kernel (timebias) instead of a bump launch
+// (perm != nullptr: x0 is the whole dataset and the batch is gathered on the fly, see EpochSrc)
 int tdm_launch_draw_q_sample(const float* x0, const float* sqrt_acp, const float* sqrt_1m_acp, uint64_t seed, int64_t* rng_state,
                              int64_t* t_out, float* noise_out, float* x_noisy_out, int64_t B, int64_t inner, bool bump,
-                             hipStream_t st) {
+                             hipStream_t st, const int64_t* perm, const int64_t* steps, const int64_t* base, int64_t n_rows,
+                             int64_t stride, int64_t offset) {
+    const EpochSrc es{perm, steps, base, n_rows, stride, offset};
     hipLaunchKernelGGL(draw_q_sample_kernel, dim3(rng_grid(B * inner / 4)), dim3(RB), 0, st, x0, sqrt_acp, sqrt_1m_acp, seed,
-                       rng_state, t_out, noise_out, x_noisy_out, B, inner / 4);
+                       rng_state, t_out, noise_out, x_noisy_out, B, inner / 4, es);
     TDM_CHECK_LAUNCH("draw_q_sample");
     if (bump) {
         hipLaunchKernelGGL(bump_offset_kernel, dim3(1), dim3(64), 0, st, rng_state);

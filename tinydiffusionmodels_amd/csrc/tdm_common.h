@@ -202,7 +202,8 @@ int tdm_launch_timebias(const int64_t* t, const float* params, const int* te_w_o
 int tdm_launch_timebias_float(const float* that, const float* w, const float* bias, float* tb, int B, int C, hipStream_t st);
 int tdm_launch_draw_q_sample(const float* x0, const float* sqrt_acp, const float* sqrt_1m_acp, uint64_t seed, int64_t* rng_state,
                              int64_t* t_out, float* noise_out, float* x_noisy_out, int64_t B, int64_t inner, bool bump,
-                             hipStream_t st);
+                             hipStream_t st, const int64_t* perm = nullptr, const int64_t* steps = nullptr,
+                             const int64_t* base = nullptr, int64_t n_rows = 0, int64_t stride = 0, int64_t offset = 0);
 int tdm_launch_conv_first(const float* x, const float* w1, const float* b1, const float* ws, const float* bs,
                           float* a1, float* s, int B, hipStream_t st);
 int tdm_launch_avgpool(const float* in, float* out, int B, int Hout, int C, hipStream_t st);

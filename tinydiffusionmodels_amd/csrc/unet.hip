@@ -697,6 +697,33 @@ int tdm_unet_loss_grad_philox_f32(const float* params, const float* x0, const fl
     return forward_loss_backward(params, x_noisy, t_buf, noise, eps, deps, loss_out, grads, w, slabs, (int)B, st);
 }
 
+// The same step with its BATCH taken from a device-resident dataset (src/mnist.py:150-152: `for x, _ in train_loader`):
+// image b is row perm[(steps - base) * stride + offset + b] of data (n_rows, 784), steps = step_state[0] (AdamW's device-side
+// step count, tdm_adamw_flat_devstep_f32), base = epoch_base[0] (its value when the epoch began, written once per epoch),
+// stride = batch x world, offset = rank x batch (dp.shard_batch_indices).  Nothing the host writes per step: a train loop is
+// one hipGraph replay per batch with no gather launch in between.  The caller guarantees whole batches
+// ((steps - base + 1) * stride <= n_rows); positions / rows outside the dataset are clamped, never dereferenced.
+int tdm_unet_loss_grad_philox_epoch_f32(const float* params, const float* data, const int64_t* perm, const int64_t* step_state,
+                                        const int64_t* epoch_base, int64_t n_rows, int64_t stride, int64_t offset,
+                                        const float* sqrt_acp, const float* sqrt_1m_acp, uint64_t seed, int64_t* rng_state,
+                                        int64_t* t_buf, float* noise, float* x_noisy, float* eps, float* deps, float* loss_out,
+                                        float* grads, float* ws, float* slabs, int64_t B, void* stream) {
+    TDM_CHECK_B(B);
+    TDM_REQUIRE(params && data && perm && step_state && epoch_base && rng_state && t_buf && noise && x_noisy && eps && deps &&
+                    loss_out && grads && ws && slabs && sqrt_acp && sqrt_1m_acp,
+                "unet_loss_grad_philox_epoch: NULL pointer");
+    TDM_REQUIRE(n_rows >= B && stride >= B && offset >= 0 && offset + B <= stride,
+                "unet_loss_grad_philox_epoch: bad sharding (n_rows=%lld stride=%lld offset=%lld B=%lld)", (long long)n_rows,
+                (long long)stride, (long long)offset, (long long)B);
+    Ws w = carve(ws, B, 1);
+    hipStream_t st = (hipStream_t)stream;
+    const bool fold = g_conv_mode == 2;
+    TDM_TRY(tdm_launch_draw_q_sample(data, sqrt_acp, sqrt_1m_acp, seed, rng_state, t_buf, noise, x_noisy, B, 784, !fold, st, perm,
+                                     step_state, epoch_base, n_rows, stride, offset));
+    if (fold) w.rng_bump = rng_state;
+    return forward_loss_backward(params, x_noisy, t_buf, noise, eps, deps, loss_out, grads, w, slabs, (int)B, st);
+}
+
 // One reverse step with device-resident step index and device-drawn noise (src/mnist.py:191-193, :167-180):
 // eps = UNet(x, t_dev); x_out = update(x, eps, z ~ Philox); t_dev -= 1 (floor 0).  tab_sigma0[0] must be 0.
 int tdm_unet_p_sample_step_philox_f32(const float* params, const float* x, int64_t* t_dev, const float* tab_recip,

@@ -517,6 +517,13 @@ class DDPMTrainer(DPStepper):
         self.use_graph = (os.environ.get("TDM_TRAIN_GRAPH", "1") != "0") if graph is None else bool(graph)
         self._states = {}
         self._cur = self._state(batch_size)
+        # epoch mode (begin_epoch / step_epoch): dataset and permutation resident on the device, the batch gathered inside the step
+        self._epoch_data = None
+        self._epoch_perm = None
+        self._epoch_base = torch.zeros(1, dtype=torch.long, device=dev)
+        self._epoch_graph = None
+        self._epoch_key = None
+        self._epoch_whole = False
         if broadcast:
             dp.broadcast_params_(self.flat, src=0)   # identical replicas: rank 0's weights everywhere
 
@@ -591,6 +598,54 @@ class DDPMTrainer(DPStepper):
         return st.loss
 
 
+    # ---- epoch mode: the loop `for x, _ in train_loader: step(x)` (src/mnist.py:150-158) with NOTHING issued between two
+    #      graph replays — the dataset and the epoch's permutation live on the device, the captured step gathers its own batch
+    #      (position = AdamW's device-side step count minus its value at begin_epoch) ----
+    def begin_epoch(self, data: torch.Tensor, perm: torch.Tensor) -> None:
+        """data (N,1,28,28) fp32 on the device (the same tensor every epoch keeps the captured step), perm (N,) int64: the
+        epoch's sample order, identical on every rank.  Iteration k of the epoch trains on positions
+        (k * world + rank) * batch_size ... + batch_size of perm (dp.shard_batch_indices)."""
+        E._need_cuda(data, perm)
+        if self._epoch_perm is None or self._epoch_perm.numel() != perm.numel():
+            self._epoch_perm = torch.empty(perm.numel(), dtype=torch.long, device=self.flat.device)
+        self._epoch_perm.copy_(perm)                       # fixed address: the captured step reads it
+        self._epoch_data = data
+        self._epoch_base.copy_(self.step_state[:1])        # device -> device, no host sync
+
+    def step_epoch(self):
+        """One optimisation step on the next whole batch of the epoch begun with begin_epoch (every rank holds batch_size
+        samples; the caller runs ragged tail iterations through step()).  Returns the loss as a 1-element device tensor."""
+        if self._epoch_data is None:
+            raise RuntimeError("step_epoch() before begin_epoch()")
+        B = self.batch_size
+        st = self._cur = self._state(B)
+        stride, offset = B * self.world, B * self.rank
+
+        def launch():
+            E.loss_and_grad_philox_epoch(self.flat, st, self._epoch_data, self._epoch_perm, self.step_state, self._epoch_base, stride,
+                                         offset, self.seed, self.rng_state)
+
+        if not self.use_graph or st.warm < 1:              # first step of a batch size eagerly (lazy kernel attributes, allocator warm-up)
+            st.warm += 1
+            launch()
+            self.optimizer_step(dp.allreduce_grads_(self.grads))
+            return st.loss
+        key = (schedule_generation(), float(self.lr), float(self.weight_decay), self._epoch_data.data_ptr(), self._epoch_perm.data_ptr(),
+               int(self._epoch_data.shape[0]), B)
+        if self._epoch_graph is None or self._epoch_key != key:
+            whole = self.world == 1 or dp.graph_collective_ok()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                launch()
+                if whole:
+                    self.optimizer_step(dp.allreduce_grads_(self.grads))
+            self._epoch_graph, self._epoch_key, self._epoch_whole = g, key, whole
+        self._epoch_graph.replay()
+        if not self._epoch_whole:
+            self.optimizer_step(dp.allreduce_grads_(self.grads))
+        return st.loss
+
+
 def train(model: nn.Module,
           device: str,
           epochs: int = 5,
@@ -617,13 +672,23 @@ def train(model: nn.Module,
     if trainer is None:
         trainer = DDPMTrainer(model, batch_size, lr=lr)          # the ONLY broadcast of the run happens here
     nb = (n + batch_size * world - 1) // (batch_size * world)
+    # (TDM_EPOCH_GATHER=0: gather every batch with a separate launch, as before round 4 — A/B and the equality test)
+    epoch_mode = (hasattr(trainer, "begin_epoch") and data.is_cuda and data.dtype == torch.float32 and data.is_contiguous()
+                  and os.environ.get("TDM_EPOCH_GATHER", "1") != "0")
     for epoch in range(epochs):
         g = torch.Generator().manual_seed(epoch)          # same shuffle on every rank
         perm = torch.randperm(n, generator=g).to(device)
+        if epoch_mode:
+            trainer.begin_epoch(data, perm)
         last = None
         for it in range(nb):
-            idx = dp.shard_batch_indices(perm, it, batch_size, rank, world)
             gb = dp.global_batch_count(n, it, batch_size, world)
+            if epoch_mode and gb == batch_size * world:   # whole batches everywhere: the captured step gathers its own batch
+                last = trainer.step_epoch()
+                if log_every and (it + 1) % log_every == 0 and rank == 0:
+                    print(f"Epoch {epoch + 1}/{epochs} it {it + 1}/{nb} loss={last.item():.4f}", flush=True)
+                continue
+            idx = dp.shard_batch_indices(perm, it, batch_size, rank, world)
             if idx.numel() == 0:
                 x = None
             elif hasattr(trainer, "batch_buffer"):          # gather straight into the captured step's input buffer

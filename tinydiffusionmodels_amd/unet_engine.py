@@ -218,6 +218,25 @@ def loss_and_grad_philox(flat: torch.Tensor, st: TrainState, x0: torch.Tensor, s
     return st.loss
 
 
+def loss_and_grad_philox_epoch(flat: torch.Tensor, st: TrainState, data: torch.Tensor, perm: torch.Tensor, step_state: torch.Tensor,
+                               epoch_base: torch.Tensor, stride: int, offset: int, seed: int, rng_state: torch.Tensor):
+    """loss_and_grad_philox with the batch gathered on the fly from the device-resident dataset `data` (N,1,28,28): image b of
+    the step is data[perm[(step_state[0] - epoch_base[0]) * stride + offset + b]] (src/mnist.py:150-152's DataLoader batch;
+    dp.shard_batch_indices' positions) — no gather launch, no host-written index."""
+    _need_cuda(flat, data, perm, step_state, epoch_base, rng_state)
+    if data.dtype != torch.float32 or not data.is_contiguous() or data[0].numel() != 784:
+        raise RuntimeError("loss_and_grad_philox_epoch: data must be a contiguous fp32 (N,1,28,28) tensor")
+    if perm.dtype != torch.int64 or not perm.is_contiguous() or perm.numel() < data.shape[0]:
+        raise RuntimeError("loss_and_grad_philox_epoch: perm must be a contiguous int64 tensor with one entry per image")
+    tabs = device_tables(data.device)
+    _lib.check(_lib.lib().tdm_unet_loss_grad_philox_epoch_f32(
+        _lib.ptr(flat), _lib.ptr(data), _lib.ptr(perm), _lib.ptr(step_state), _lib.ptr(epoch_base), int(data.shape[0]), int(stride),
+        int(offset), _lib.ptr(tabs["sqrt_alphas_cumprod"]), _lib.ptr(tabs["sqrt_one_minus_alphas_cumprod"]), seed, _lib.ptr(rng_state),
+        _lib.ptr(st.t), _lib.ptr(st.noise), _lib.ptr(st.x_noisy), _lib.ptr(st.eps), _lib.ptr(st.deps), _lib.ptr(st.loss),
+        _lib.ptr(st.grads), _lib.ptr(st.ws.ws), _lib.ptr(slabs_for(data.device)), st.B, _lib.stream()), "unet_loss_grad_philox_epoch")
+    return st.loss
+
+
 def adamw_step_dev(flat: torch.Tensor, grads: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step_state: torch.Tensor,
                    lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
                    weight_decay: float = 0.01, grad_scale: float = 1.0):
