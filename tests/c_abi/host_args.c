@@ -138,6 +138,8 @@ int main(void) {
         REFUSED(tdm_unet_bwd_f32(NULL, NULL, NULL, NULL, NULL, NULL, 4, NULL));
         REFUSED(tdm_unet_loss_grad_f32(NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 4, NULL));
         REFUSED(tdm_unet_loss_grad_philox_f32(NULL, NULL, NULL, NULL, 1, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 4, NULL));
+        REFUSED(tdm_unet_loss_grad_philox_epoch_f32(NULL, NULL, NULL, NULL, NULL, 64, 16, 0, NULL, NULL, 1, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 16, NULL));
+        REFUSED(tdm_unet_loss_grad_philox_epoch_f32(p, p, ip, ip, ip, 64, 8, 0, p, p, 1, ip, ip, p, p, p, p, p, p, p, p, 16, NULL));   /* stride < B */
         REFUSED(tdm_unet_p_sample_step_philox_f32(NULL, NULL, NULL, NULL, NULL, NULL, 1, NULL, NULL, NULL, NULL, 4, NULL));
         REFUSED(tdm_unet_get_activation(NULL, 4, 0, NULL, NULL));
         REFUSED(tdm_unet_get_activation(p, 4, 99, p, NULL));
