@@ -612,38 +612,66 @@ class DDPMTrainer(DPStepper):
         self._epoch_data = data
         self._epoch_base.copy_(self.step_state[:1])        # device -> device, no host sync
 
-    def step_epoch(self):
-        """One optimisation step on the next whole batch of the epoch begun with begin_epoch (every rank holds batch_size
-        samples; the caller runs ragged tail iterations through step()).  Returns the loss as a 1-element device tensor."""
-        if self._epoch_data is None:
-            raise RuntimeError("step_epoch() before begin_epoch()")
+    # steps per replay of the unrolled epoch graph (nothing in an epoch-mode step comes from the host); TDM_EPOCH_UNROLL=1: one per replay
+    EPOCH_UNROLL = max(1, int(os.environ.get("TDM_EPOCH_UNROLL", "4")))
+
+    def _epoch_launch(self, st) -> None:
         B = self.batch_size
-        st = self._cur = self._state(B)
-        stride, offset = B * self.world, B * self.rank
+        E.loss_and_grad_philox_epoch(self.flat, st, self._epoch_data, self._epoch_perm, self.step_state, self._epoch_base,
+                                     B * self.world, B * self.rank, self.seed, self.rng_state)
 
-        def launch():
-            E.loss_and_grad_philox_epoch(self.flat, st, self._epoch_data, self._epoch_perm, self.step_state, self._epoch_base, stride,
-                                         offset, self.seed, self.rng_state)
-
-        if not self.use_graph or st.warm < 1:              # first step of a batch size eagerly (lazy kernel attributes, allocator warm-up)
-            st.warm += 1
-            launch()
-            self.optimizer_step(dp.allreduce_grads_(self.grads))
-            return st.loss
+    def _epoch_graphs(self, st):
+        """(single-step graph, EPOCH_UNROLL-step graph or None, whole) for the current dataset / schedule / optimiser constants."""
         key = (schedule_generation(), float(self.lr), float(self.weight_decay), self._epoch_data.data_ptr(), self._epoch_perm.data_ptr(),
-               int(self._epoch_data.shape[0]), B)
+               int(self._epoch_data.shape[0]), self.batch_size)
         if self._epoch_graph is None or self._epoch_key != key:
             whole = self.world == 1 or dp.graph_collective_ok()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                launch()
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                self._epoch_launch(st)
                 if whole:
                     self.optimizer_step(dp.allreduce_grads_(self.grads))
-            self._epoch_graph, self._epoch_key, self._epoch_whole = g, key, whole
-        self._epoch_graph.replay()
-        if not self._epoch_whole:
-            self.optimizer_step(dp.allreduce_grads_(self.grads))
+            gn = None
+            if whole and self.EPOCH_UNROLL > 1:
+                # consecutive steps in ONE replay: the ~20 us between two graph launches (the queue's end-of-graph / start-of-
+                # graph handshake) is paid once per EPOCH_UNROLL steps
+                gn = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gn, capture_error_mode="thread_local"):
+                    for _ in range(self.EPOCH_UNROLL):
+                        self._epoch_launch(st)
+                        self.optimizer_step(dp.allreduce_grads_(self.grads))
+            self._epoch_graph, self._epoch_key, self._epoch_whole = (g1, gn), key, whole
+        return self._epoch_graph[0], self._epoch_graph[1], self._epoch_whole
+
+    def steps_epoch(self, n: int = 1):
+        """The next n optimisation steps of the epoch begun with begin_epoch, each on the next whole batch (every rank holds
+        batch_size samples; the caller runs ragged tail iterations through step()).  Returns the last step's loss as a
+        1-element device tensor (no host sync)."""
+        if self._epoch_data is None:
+            raise RuntimeError("steps_epoch() before begin_epoch()")
+        st = self._cur = self._state(self.batch_size)
+        done = 0
+        while done < n:
+            if not self.use_graph or st.warm < 1:          # first step of a batch size eagerly (lazy kernel attributes, allocator warm-up)
+                st.warm += 1
+                self._epoch_launch(st)
+                self.optimizer_step(dp.allreduce_grads_(self.grads))
+                done += 1
+                continue
+            g1, gn, whole = self._epoch_graphs(st)
+            if gn is not None and n - done >= self.EPOCH_UNROLL:
+                gn.replay()
+                done += self.EPOCH_UNROLL
+                continue
+            g1.replay()
+            if not whole:
+                self.optimizer_step(dp.allreduce_grads_(self.grads))
+            done += 1
         return st.loss
+
+    def step_epoch(self):
+        """One step of the epoch (steps_epoch(1))."""
+        return self.steps_epoch(1)
 
 
 def train(model: nn.Module,
@@ -681,14 +709,21 @@ def train(model: nn.Module,
         if epoch_mode:
             trainer.begin_epoch(data, perm)
         last = None
-        for it in range(nb):
+        it = 0
+        while it < nb:
             gb = dp.global_batch_count(n, it, batch_size, world)
             if epoch_mode and gb == batch_size * world:   # whole batches everywhere: the captured step gathers its own batch
-                last = trainer.step_epoch()
-                if log_every and (it + 1) % log_every == 0 and rank == 0:
-                    print(f"Epoch {epoch + 1}/{epochs} it {it + 1}/{nb} loss={last.item():.4f}", flush=True)
+                # as many whole-batch iterations as lie before the next log line (and before the ragged tail) in one call
+                run = n // (batch_size * world) - it
+                if log_every:
+                    run = min(run, log_every - it % log_every)
+                last = trainer.steps_epoch(run)
+                it += run
+                if log_every and it % log_every == 0 and rank == 0:
+                    print(f"Epoch {epoch + 1}/{epochs} it {it}/{nb} loss={last.item():.4f}", flush=True)
                 continue
-            idx = dp.shard_batch_indices(perm, it, batch_size, rank, world)
+            it += 1
+            idx = dp.shard_batch_indices(perm, it - 1, batch_size, rank, world)
             if idx.numel() == 0:
                 x = None
             elif hasattr(trainer, "batch_buffer"):          # gather straight into the captured step's input buffer
@@ -697,8 +732,8 @@ def train(model: nn.Module,
                 x = data[idx]
             loss = trainer.step(x, global_batch=None if gb == batch_size * world else gb)
             last = loss if loss is not None else last
-            if log_every and (it + 1) % log_every == 0 and rank == 0 and last is not None:
-                print(f"Epoch {epoch + 1}/{epochs} it {it + 1}/{nb} loss={last.item():.4f}", flush=True)
+            if log_every and it % log_every == 0 and rank == 0 and last is not None:
+                print(f"Epoch {epoch + 1}/{epochs} it {it}/{nb} loss={last.item():.4f}", flush=True)
         if rank == 0 and last is not None:
             print(f"Epoch {epoch + 1}/{epochs} done, loss={last.item():.4f}", flush=True)
         if sample_every_epoch and rank == 0:
