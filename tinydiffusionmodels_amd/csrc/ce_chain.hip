@@ -53,6 +53,11 @@ struct CeArgs {
     float* lse_id;         // out: [Mp / 32][64]
     float* rowloss;        // out: [M]
     int Mp;
+    // pass A split over the vocabulary (nseg > 1; few token tiles — a small batch — would leave most CUs idle): segment s of
+    // the vocabulary blocks yields the token's running maximum, exp-sum and UNNORMALISED dX numerator; ce_combine_kernel merges them
+    float* pm;             // [nseg][Mp]
+    float* ps;             // [nseg][Mp]
+    float* pacc;           // [nseg][Mp][256]
     // pass B
     const float* bias;     // [V]
     float* dW;             // [nseg][V][256]
@@ -77,14 +82,15 @@ __global__ __launch_bounds__(512, 2) void ce_chain_kernel(CeArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, c = lane & 15;
-    const int tile = PASS == 0 ? (int)blockIdx.x : (int)blockIdx.x / a.nseg;
-    const int seg = PASS == 0 ? 0 : (int)blockIdx.x % a.nseg;
+    const int tile = (int)blockIdx.x / a.nseg;
+    const int seg = (int)blockIdx.x % a.nseg;
     const int col = (tile * WAVES + wave) * WCOL + c;         // this lane's stationary column (token / vocabulary row)
     const bool col_ok = col < a.NC;
     const int nblk_all = a.NRp >> 5;
-    // streamed blocks of this workgroup: all of them (pass A), or segment `seg` of the token blocks (pass B)
-    const int fb0 = PASS == 0 ? 0 : (int)((long)nblk_all * seg / a.nseg);
-    const int NFB = (PASS == 0 ? nblk_all : (int)((long)nblk_all * (seg + 1) / a.nseg)) - fb0;
+    // streamed blocks of this workgroup: segment `seg` of the vocabulary blocks (pass A; one segment unless the batch is small)
+    // or of the token blocks (pass B)
+    const int fb0 = (int)((long)nblk_all * seg / a.nseg);
+    const int NFB = (int)((long)nblk_all * (seg + 1) / a.nseg) - fb0;
     const int total = 2 * NFB;
     if (NFB <= 0) return;
 
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(512, 2) void ce_chain_kernel(CeArgs a) {
         if constexpr (PASS == 0) {
             // online softmax over the vocabulary: this lane's 8 logits are entries 32 (fb0 + fb) + 8 g + 0..7 of its token
             float z[8] = {zc0[0], zc0[1], zc0[2], zc0[3], zc1[0], zc1[1], zc1[2], zc1[3]};
-            if (fb == NFB - 1) {   // the last block may run past V: those rows are zero weights + zero bias, not vocabulary
+            if (fb0 + fb == nblk_all - 1) {   // the last block may run past V: those rows are zero weights + zero bias, not vocabulary
                 const int left = a.NR - (32 * (fb0 + fb) + 8 * g);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) z[e] = e < left ? z[e] : -INFINITY;
@@ -305,8 +311,17 @@ __global__ __launch_bounds__(512, 2) void ce_chain_kernel(CeArgs a) {
     if constexpr (PASS == 0) {
         float st = ssum + xor16(ssum);
         st += xor32(st);
-        const float lse = m_ref + __logf(st);
         const int tok = col;
+        if (a.nseg > 1) {   // a vocabulary segment: partial statistics and the unnormalised numerator (merged by ce_combine_kernel)
+            if (tok >= a.Mp) return;
+            if (g == 0) { a.pm[(long)seg * a.Mp + tok] = m_ref; a.ps[(long)seg * a.Mp + tok] = st; }
+            float* const prow = a.pacc + ((long)seg * a.Mp + tok) * DK;
+#pragma unroll
+            for (int ob = 0; ob < 16; ++ob)
+                *reinterpret_cast<float4*>(prow + ob * 16 + 4 * g) = make_float4(accY[ob][0], accY[ob][1], accY[ob][2], accY[ob][3]);
+            return;
+        }
+        const float lse = m_ref + __logf(st);
         if (tok < a.Mp && g == 0) {      // lse | id block of pass B (padding tokens: +inf / -1 -> zero gradient)
             float* blk = a.lse_id + (long)(tok >> 5) * 64 + (tok & 31);
             long id = col_ok ? a.ids[tok] : -1;
@@ -339,6 +354,41 @@ __global__ __launch_bounds__(512, 2) void ce_chain_kernel(CeArgs a) {
         for (int ob = 0; ob < 16; ++ob)
             *reinterpret_cast<float4*>(wrow + ob * 16 + 4 * g) = make_float4(accY[ob][0], accY[ob][1], accY[ob][2], accY[ob][3]);
     }
+}
+
+// merges the vocabulary segments of a split pass A: per token m = max_s m_s, l = sum_s l_s e^(m_s - m), lse = m + log l,
+// dX = scale/M (sum_s acc_s e^(m_s - m) / l - W[id]); writes pass B's lse | id blocks and the loss rows like the unsplit epilogue.
+// One thread per (token, 4 columns); fixed summation order.
+__global__ __launch_bounds__(256) void ce_combine_kernel(CeArgs a) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int tok = (int)(i >> 6), o = (int)(i & 63) * 4;
+    if (tok >= a.Mp) return;
+    const bool tok_ok = tok < a.NC;
+    float m = -INFINITY;
+    for (int s = 0; s < a.nseg; ++s) m = fmaxf(m, a.pm[(long)s * a.Mp + tok]);
+    float l = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < a.nseg; ++s) {
+        const float f = __expf(a.pm[(long)s * a.Mp + tok] - m);
+        l = fmaf(a.ps[(long)s * a.Mp + tok], f, l);
+        const float4 p = *reinterpret_cast<const float4*>(a.pacc + ((long)s * a.Mp + tok) * DK + o);
+        acc.x = fmaf(p.x, f, acc.x); acc.y = fmaf(p.y, f, acc.y); acc.z = fmaf(p.z, f, acc.z); acc.w = fmaf(p.w, f, acc.w);
+    }
+    const float lse = m + __logf(l);
+    long id = tok_ok ? a.ids[tok] : -1;
+    const bool idok = id >= 0 && id < a.NR;
+    if (o == 0) {
+        float* blk = a.lse_id + (long)(tok >> 5) * 64 + (tok & 31);
+        blk[0] = tok_ok ? lse : INFINITY;
+        blk[32] = __int_as_float(idok ? (int)id : -1);
+        if (tok_ok) a.rowloss[tok] = lse - a.tl[tok];
+    }
+    if (!tok_ok || a.dx == nullptr) return;
+    float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idok) w4 = *reinterpret_cast<const float4*>(a.W + id * DK + o);
+    const float inv = 1.f / l;
+    *reinterpret_cast<float4*>(a.dx + (long)tok * DK + o) =
+        make_float4((acc.x * inv - w4.x) * a.gscale, (acc.y * inv - w4.y) * a.gscale, (acc.z * inv - w4.z) * a.gscale, (acc.w * inv - w4.w) * a.gscale);
 }
 
 // out S16 [C][Rp] = in [R][C]^T, rows r >= R zero (Rp a multiple of 32, C a multiple of 32): 32 x 32 tiles through LDS
@@ -390,7 +440,14 @@ __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ row
     if (threadIdx.x == 0) out[0] = sh[0] / (float)M;
 }
 
-struct FusedWs { float *x16, *w16, *wT16, *xT16, *lse_id, *rowloss, *tl, *dWs, *dbs; int Vp, Mp; long total; };
+// vocabulary segments of pass A: one unless the batch has too few 128-token tiles to fill the chip (B = 32 x 128 tokens: 32
+// tiles on 256 CUs ran pass A at an eighth of the machine — 3.5 of the step's 6.5 ms)
+inline int pass_a_segments(long M) {
+    const long tiles = (((M + 31) & ~31L) + COLS - 1) / COLS;
+    const long s = 256 / (tiles < 1 ? 1 : tiles);
+    return (int)(s < 1 ? 1 : (s > 8 ? 8 : s));
+}
+struct FusedWs { float *x16, *w16, *wT16, *xT16, *lse_id, *rowloss, *tl, *dWs, *dbs, *pm, *ps, *pacc; int Vp, Mp, nsegA; long total; };
 FusedWs fused_carve(float* base, long M, int V, int nseg) {
     FusedWs w{};
     long off = 0;
@@ -401,6 +458,9 @@ FusedWs fused_carve(float* base, long M, int V, int nseg) {
     w.lse_id = take((long)(w.Mp / 32) * 64); w.rowloss = take(M); w.tl = take(M);
     w.dWs = nseg > 1 ? take((long)nseg * V * DK) : nullptr;
     w.dbs = take((long)nseg * w.Vp);
+    w.nsegA = pass_a_segments(M);
+    if (w.nsegA > w.Vp / 32) w.nsegA = w.Vp / 32;      // every vocabulary segment owns at least one 32-row block
+    if (w.nsegA > 1) { w.pm = take((long)w.nsegA * w.Mp); w.ps = take((long)w.nsegA * w.Mp); w.pacc = take((long)w.nsegA * w.Mp * DK); }
     w.total = off;
     return w;
 }
@@ -458,8 +518,14 @@ int tdm_round_ce_loss_grad_fused_f32(const float* x, const float* W, const float
         CeArgs a{};
         a.C16 = w.x16; a.Wa16 = w.w16; a.Wb16 = w.wT16; a.aux = b; a.NC = (int)M; a.NR = V; a.NRp = w.Vp; a.gscale = gscale;
         a.ids = ids; a.W = W; a.tl = w.tl; a.dx = dx; a.lse_id = w.lse_id; a.rowloss = w.rowloss; a.Mp = w.Mp;
-        hipLaunchKernelGGL((ce_chain_kernel<0>), dim3((unsigned)(w.Mp / COLS + ((w.Mp % COLS) ? 1 : 0))), dim3(512), NSLOT * SLOT, st, a);
+        a.nseg = w.nsegA; a.pm = w.pm; a.ps = w.ps; a.pacc = w.pacc;
+        const unsigned tiles = (unsigned)(w.Mp / COLS + ((w.Mp % COLS) ? 1 : 0));
+        hipLaunchKernelGGL((ce_chain_kernel<0>), dim3(tiles * w.nsegA), dim3(512), NSLOT * SLOT, st, a);
         TDM_CHECK_LAUNCH("ce_chain(A)");
+        if (w.nsegA > 1) {
+            hipLaunchKernelGGL(ce_combine_kernel, dim3((unsigned)(((long)w.Mp * 64 + 255) / 256)), dim3(256), 0, st, a);
+            TDM_CHECK_LAUNCH("ce_combine");
+        }
     }
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, w.rowloss, loss_out, (long)M);
     TDM_CHECK_LAUNCH("ce_mean");

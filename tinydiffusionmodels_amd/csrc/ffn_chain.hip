@@ -65,6 +65,11 @@ struct ChainArgs {
     int M, F;
     float gate_scale;
     DropArgs drop_mid, drop_out;
+    // hidden-range segments (few token tiles — a small batch — would leave most CUs idle): workgroup (tile, seg) runs the hidden
+    // blocks [seg, seg + 1) * (F / 32) / nseg and writes its RAW partial Y to ypart[seg][M][256]; ffn_combine_kernel sums them
+    // and applies bias_b / the output dropout.  nseg == 1: the kernel finishes Y itself.  (F / 32) % (4 nseg) == 0.
+    int nseg;
+    float* ypart;
     int ablate;            // timing diagnostics (tools/time_ffn.py --ablate; results are wrong when set): 1 no DMA after the prologue,
                            // 2 no first-product MFMAs, 4 no second-product MFMAs, 8 no mid-op arithmetic, 16 no barriers, 32 no stores
 };
@@ -84,11 +89,15 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(ChainArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, c = lane & 15;
-    const int tblk = blockIdx.x * WAVES + wave;           // the wave's 16-token block
+    const int tile_id = (int)blockIdx.x / a.nseg, seg = (int)blockIdx.x % a.nseg;
+    const int tblk = tile_id * WAVES + wave;              // the wave's 16-token block
     const int tok = tblk * WTOK + c;
     const bool tok_ok = tok < a.M;
     const bool blk_ok = tblk * WTOK < a.M;                // wave-uniform: the block has at least one token
-    const int F = a.F, NFB = F >> 5, total = 2 * NFB, NMW = (NFB + 3) >> 2;
+    // this workgroup's hidden blocks: fb0 .. fb0 + NFB - 1 of the F / 32 (fb0 a multiple of 4: whole sign-mask words)
+    const int F = a.F, NFB_all = F >> 5, NFB = NFB_all / a.nseg, fb0 = seg * NFB, total = 2 * NFB;
+    const int NMW = (NFB_all + 3) >> 2;                   // sign-mask words per token block (all segments)
+    const int NMWs = (NFB + 3) >> 2, mw0 = fb0 >> 2;      // ... of this segment, and its first word
 #ifdef TDM_DIAG
     int abl = a.ablate;            // (diagnostic builds only: TDM_BUILD_DEFINES=-DTDM_DIAG python -m tinydiffusionmodels_amd.build)
     asm volatile("" : "+s"(abl));
@@ -127,9 +136,9 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(ChainArgs a) {
     // register array would live in scratch)
     unsigned mw[MODE == 2 ? 16 : 1];
     if constexpr (MODE == 2) {
-        const unsigned* mp = a.mask + ((long)tblk * NMW) * 64 + lane;
+        const unsigned* mp = a.mask + ((long)tblk * NMW + mw0) * 64 + lane;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) mw[q] = (blk_ok && q < NMW) ? mp[q * 64] : 0u;
+        for (int q = 0; q < 16; ++q) mw[q] = (blk_ok && q < NMWs) ? mp[q * 64] : 0u;
     }
     // forward: bias_a to LDS (read 8 values per hidden block and lane)
     if constexpr (MODE != 2) {
@@ -157,12 +166,12 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(ChainArgs a) {
         const int fbq = (q - 1) >> 1;
         const bool isA = q == 0 || (((q - 1) & 1) == 0 && fbq + 1 < NFB);
         if (isA) {
-            const int fa = q == 0 ? 0 : fbq + 1;
+            const int fa = fb0 + (q == 0 ? 0 : fbq + 1);
 #pragma unroll
             for (int i = 0; i < DPW; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, TDM_LDS(dst + i * 1024), 16, voA[i], fa * (32 * DK * 4), 0, 0);
         } else {
-            const int fbb = ((q - 1) & 1) == 0 ? fbq : (q >> 1) - 1;
+            const int fbb = fb0 + (((q - 1) & 1) == 0 ? fbq : (q >> 1) - 1);
 #pragma unroll
             for (int i = 0; i < DPW; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, TDM_LDS(dst + i * 1024), 16, voB[i], fbb * 128, 0, 0);
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(ChainArgs a) {
         if constexpr (MODE != 2) {
             // (read as bf16x8: next to LDS-DMA in flight a float-typed LDS read makes hipcc wait vmcnt(0) — type-based
             //  alias analysis against the DMA's LDS write — and drain the ring every block; tools/isa_loopwaits.py)
-            const char* bl = lds + BIAS_OFF + (fbn * 32 + 8 * g) * 4;
+            const char* bl = lds + BIAS_OFF + ((fb0 + fbn) * 32 + 8 * g) * 4;
             z0 = __builtin_bit_cast(f32x4, *reinterpret_cast<const bf16x8*>(bl));
             z1 = __builtin_bit_cast(f32x4, *reinterpret_cast<const bf16x8*>(bl + 16));
         } else {
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(ChainArgs a) {
         mid.bits = 0;
         unsigned m8 = 0;
         if constexpr (MODE == 2) m8 = (mw[0] >> ((fb & 3) * 8)) & 0xffu;
-        const unsigned ebase = (unsigned)tok * (unsigned)F + (unsigned)(fb * 32 + 8 * g);   // flat index of the lane's first hidden unit
+        const unsigned ebase = (unsigned)tok * (unsigned)F + (unsigned)((fb0 + fb) * 32 + 8 * g);   // flat index of the lane's first hidden unit
         f32x4 zn0, zn1;
         gemm1(fb + 1 < NFB ? fb + 1 : fb, qA & (NSLOT - 1), std::true_type{}, mid, zc0, zc1, ebase, m8, zn0, zn1);
         bf16x8 ph = pack8(mid.v), pl;
@@ -312,13 +321,13 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(ChainArgs a) {
             const u32x4 s0 = __builtin_bit_cast(u32x4, *reinterpret_cast<const bf16x8*>(tile_r));
             const u32x4 s1 = __builtin_bit_cast(u32x4, *reinterpret_cast<const bf16x8*>(tile_r + 8 * TROW));
             if (!(abl & 32)) {
-                __builtin_amdgcn_raw_buffer_store_b128(s0, rsM, mvo[0], fb * 128, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(s1, rsM, mvo[1], fb * 128, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(s0, rsM, mvo[0], (fb0 + fb) * 128, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(s1, rsM, mvo[1], (fb0 + fb) * 128, 0);
             } else asm volatile("" :: "v"(s0), "v"(s1));
             if constexpr (MODE == 1) {
                 wbits |= mid.bits << ((fb & 3) * 8);
                 if ((fb & 3) == 3 || fb + 1 == NFB) {
-                    __builtin_amdgcn_raw_buffer_store_b32(wbits, rsK, kvo, (fb >> 2) * 256, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(wbits, rsK, kvo, ((fb0 + fb) >> 2) * 256, 0);
                     wbits = 0;
                 }
             }
@@ -366,6 +375,13 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(ChainArgs a) {
 
     // ---- epilogue: register r of block ob = output 16 ob + 4 g + r of the lane's token
     if (!tok_ok) return;
+    if (a.nseg > 1) {   // a hidden-range segment: the raw partial sums (ffn_combine_kernel finishes Y)
+        float* const prow = a.ypart + ((long)seg * a.M + tok) * DK;
+#pragma unroll
+        for (int ob = 0; ob < 16; ++ob)
+            *reinterpret_cast<float4*>(prow + ob * 16 + 4 * g) = make_float4(accY[ob][0], accY[ob][1], accY[ob][2], accY[ob][3]);
+        return;
+    }
     float* const yrow = a.Y + (long)tok * DK;
 #pragma unroll
     for (int ob = 0; ob < 16; ++ob) {
@@ -386,6 +402,32 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(ChainArgs a) {
     }
 }
 
+// Y = dropout_out(sum over the hidden-range segments of ypart + bias_b): the epilogue of a segmented launch.  One thread per
+// (token, 4 outputs); fixed summation order; the same counter hash as the kernel's own epilogue.
+__global__ __launch_bounds__(256) void ffn_combine_kernel(ChainArgs a) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long tok = i >> 6;
+    const int o = (int)(i & 63) * 4;
+    if (tok >= a.M) return;
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < a.nseg; ++s) {
+        const float4 p = *reinterpret_cast<const float4*>(a.ypart + ((long)s * a.M + tok) * DK + o);
+        y.x += p.x; y.y += p.y; y.z += p.z; y.w += p.w;
+    }
+    if (a.bias_b != nullptr) {
+        const float4 b = *reinterpret_cast<const float4*>(a.bias_b + o);
+        y.x += b.x; y.y += b.y; y.z += b.z; y.w += b.w;
+    }
+    if (a.drop_out.thr != 0u) {
+        const unsigned long long e0 = (unsigned long long)tok * (unsigned)DK + (unsigned)o;
+        y.x = tdm_keep(a.drop_out, e0) ? y.x * a.drop_out.scale : 0.f;
+        y.y = tdm_keep(a.drop_out, e0 + 1) ? y.y * a.drop_out.scale : 0.f;
+        y.z = tdm_keep(a.drop_out, e0 + 2) ? y.z * a.drop_out.scale : 0.f;
+        y.w = tdm_keep(a.drop_out, e0 + 3) ? y.w * a.drop_out.scale : 0.f;
+    }
+    *reinterpret_cast<float4*>(a.Y + tok * DK + o) = y;
+}
+
 template <int NPROD, int MODE>
 int launch_chain(const ChainArgs& a, hipStream_t st) {
     static bool attr = false;
@@ -399,8 +441,12 @@ int launch_chain(const ChainArgs& a, hipStream_t st) {
         }
         attr = true;
     }
-    hipLaunchKernelGGL((ffn_chain_kernel<NPROD, MODE>), dim3((unsigned)((a.M + TOK - 1) / TOK)), dim3(512), ldsb, st, a);
+    hipLaunchKernelGGL((ffn_chain_kernel<NPROD, MODE>), dim3((unsigned)((a.M + TOK - 1) / TOK) * a.nseg), dim3(512), ldsb, st, a);
     TDM_CHECK_LAUNCH("ffn_chain");
+    if (a.nseg > 1) {
+        hipLaunchKernelGGL(ffn_combine_kernel, dim3((unsigned)(((long)a.M * 64 + 255) / 256)), dim3(256), 0, st, a);
+        TDM_CHECK_LAUNCH("ffn_combine");
+    }
     return 0;
 }
 
@@ -418,9 +464,23 @@ int64_t tdm_ffn_chain_mask_elems(int64_t M, int F) { return ((M + 15) / 16) * (i
 
 // mode 0 / 1: forward (Y = dropout_out(dropout_mid(relu(X Wa^T + bias_a)) Wb^T + bias_b)); 1 also writes mid16 / mask
 // mode 2: data gradient (mid = (X Wa^T) gated by the mask * gate_scale, written to mid16; Y = mid Wb^T)
+// hidden-range segments for M tokens (1 = none): as many as fill 256 CUs with the M / 128 token tiles, at most 8, whole
+// sign-mask words per segment
+int tdm_ffn_chain_segments(long M, int F) {
+    const long tiles = (M + tdm_chain::TOK - 1) / tdm_chain::TOK;
+    int n = 1;
+    while (n < 8 && tiles * (2 * n) <= 256 && ((F >> 5) % (4 * 2 * n)) == 0) n *= 2;
+    return n;
+}
+// floats of the partial-sum buffer a segmented launch needs (0: none)
+long tdm_ffn_chain_part_floats(long M, int F) {
+    const int n = tdm_ffn_chain_segments(M, F);
+    return n > 1 ? (long)n * M * tdm_chain::DK : 0;
+}
+
 int tdm_launch_ffn_chain(int mode, int nprod, const float* X16, const float* Wa16, const float* bias_a, const float* Wb16,
                          const float* bias_b, float* Y, float* mid16, unsigned* mask, float gate_scale, DropArgs drop_mid,
-                         DropArgs drop_out, long M, int D, int F, hipStream_t st) {
+                         DropArgs drop_out, long M, int D, int F, hipStream_t st, float* ypart) {
     using namespace tdm_chain;
     TDM_REQUIRE(tdm_ffn_chain_ok(M, D, F), "ffn_chain: unsupported shape M=%ld D=%d F=%d", M, D, F);
     TDM_REQUIRE(X16 && Wa16 && Wb16 && Y, "ffn_chain: NULL pointer");
@@ -430,6 +490,8 @@ int tdm_launch_ffn_chain(int mode, int nprod, const float* X16, const float* Wa1
     a.X16 = X16; a.Wa16 = Wa16; a.Wb16 = Wb16; a.bias_a = bias_a; a.bias_b = bias_b; a.Y = Y; a.mid16 = mid16; a.mask = mask;
     a.M = (int)M; a.F = F; a.gate_scale = gate_scale; a.drop_mid = drop_mid; a.drop_out = drop_out;
     a.ablate = g_chain_ablate;
+    a.nseg = ypart != nullptr ? tdm_ffn_chain_segments(M, F) : 1;    // (without a partial-sum buffer: one segment)
+    a.ypart = ypart;
     if (nprod == 3) {
         if (mode == 0) return launch_chain<3, 0>(a, st);
         if (mode == 1) return launch_chain<3, 1>(a, st);
@@ -452,7 +514,7 @@ int tdm_ffn_chain_f32(int mode, int nprod, const float* x16, const float* wa16, 
     DropArgs dm{}, dout{};
     if (p_drop > 0.f && mode == 1) { dm = tdm_drop_site(p_drop, seed, site_mid); dout = tdm_drop_site(p_drop, seed, site_out); }
     return tdm_launch_ffn_chain(mode, nprod, x16, wa16, bias_a, wb16, bias_b, y, mid16, mask, gate_scale, dm, dout, (long)M, D, F,
-                                (hipStream_t)stream);
+                                (hipStream_t)stream, nullptr);
 }
 
 int64_t tdm_ffn_chain_mask_count(int64_t M, int F) {

@@ -66,6 +66,10 @@ int tdm_launch_attn_bf16(int which, int hd, const float* qkv, const float* o, co
 // mode 0 forward (inference), 1 forward + hidden S16 / sign masks saved, 2 data gradient (gate by the saved masks)
 bool tdm_ffn_chain_ok(long M, int D, int F);
 int64_t tdm_ffn_chain_mask_elems(int64_t M, int F);   // 32-bit words of the sign-mask buffer
+// hidden-range segments of the chain for M tokens / floats of the partial-sum buffer they need (ffn_chain.hip)
+int tdm_ffn_chain_segments(long M, int F);
+long tdm_ffn_chain_part_floats(long M, int F);
+// ypart: partial-sum buffer of tdm_ffn_chain_part_floats(M, F) floats, or nullptr (then one segment: small batches use M / 128 CUs)
 int tdm_launch_ffn_chain(int mode, int nprod, const float* X16, const float* Wa16, const float* bias_a, const float* Wb16,
                          const float* bias_b, float* Y, float* mid16, unsigned* mask, float gate_scale, DropArgs drop_mid,
-                         DropArgs drop_out, long M, int D, int F, hipStream_t st);
+                         DropArgs drop_out, long M, int D, int F, hipStream_t st, float* ypart = nullptr);

@@ -100,6 +100,7 @@ struct TTWs {
     // backward temporaries
     float *g_h, *g_s, *g_s1, *g_d, *g_f, *g_h1, *g_o, *g_qkv, *Dvec, *Sb, *part;
     float *P16, *g16, *g_qkv16;   // S16: the parameter vector, the D-wide gradient operand of the current GEMM pair, d(qkv)
+    float* ypart;                 // partial sums of a hidden-range-segmented FFN chain (small batches; ffn_chain.hip), or nullptr
     long total;
 };
 TTWs tt_carve(float* base, long B, int Lq, int D, int H, int depth, int F, int training) {
@@ -123,6 +124,10 @@ TTWs tt_carve(float* base, long B, int Lq, int D, int H, int depth, int F, int t
         x.fmask = reinterpret_cast<unsigned*>(take(tdm_ffn_chain_mask_elems(M, F)));
     }
     w.P16 = take(tt_layout(D, depth, F).total);
+    {
+        const long np = (D == 256 && (F % 32) == 0 && F >= 64 && F <= 2048) ? tdm_ffn_chain_part_floats(M, F) : 0;
+        w.ypart = np > 0 ? take(np) : nullptr;
+    }
     if (training) {
         w.g_h = take(M * D); w.g_s = take(M * D); w.g_s1 = take(M * D); w.g_d = take(M * D); w.g_f = take(M * F); w.g_h1 = take(M * D);
         w.g_o = take(M * D); w.g_qkv = take(M * 3 * D); w.Dvec = take(B * H * Lq); w.Sb = take(B * D);
@@ -885,7 +890,7 @@ int tt_forward(const float* P, const TTLayout& lay, const float* x, const int64_
             const bool keep = save || drop.p > 0.f;
             TDM_TRY(tdm_launch_ffn_chain(keep ? 1 : 0, g_gemm_mode == 1 ? 3 : 1, a.h1_16, PW + o.l1_w, P + o.l1_b, PW + o.l2_w,
                                          P + o.l2_b, w.abuf, keep ? a.f1 : nullptr, keep ? a.fmask : nullptr, 1.f,
-                                         drop.site(3 + 4 * l), drop.site(4 + 4 * l), M, D, F, st));
+                                         drop.site(3 + 4 * l), drop.site(4 + 4 * l), M, D, F, st, w.ypart));
         } else {
         // the FFN hidden activation: S16 only in the bf16 GEMM modes (read by linear2, its weight gradient and the ReLU gate)
         TDM_TRY(linear_fwd(s16 ? a.h1_16 : a.h1, PW + o.l1_w, P + o.l1_b, nullptr, s16 ? nullptr : a.f1, s16 ? a.f1 : nullptr, s16,
@@ -921,7 +926,7 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
             TDM_TRY(tdm_launch_transpose_s16(P + o.l2_w, w.wT, D, F, st));    // W2^T: [F][D]
             TDM_TRY(tdm_launch_transpose_s16(P + o.l1_w, w.wT2, F, D, st));   // W1^T: [D][F]
             TDM_TRY(tdm_launch_ffn_chain(2, g_gemm_mode == 1 ? 3 : 1, g2, w.wT, nullptr, w.wT2, nullptr, w.g_h1, w.g_f, a.fmask,
-                                         dropping ? drop.site(3 + 4 * l).scale : 1.f, DropArgs{}, DropArgs{}, M, D, F, st));
+                                         dropping ? drop.site(3 + 4 * l).scale : 1.f, DropArgs{}, DropArgs{}, M, D, F, st, w.ypart));
         } else
         TDM_TRY(linear_dgrad(g2, P + o.l2_w, w.wT, nullptr, a.f1, dropping ? drop.site(3 + 4 * l).scale : 1.f, s16 ? nullptr : w.g_f,
                              s16 ? w.g_f : nullptr, s16, M, D, F, st));
