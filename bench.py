@@ -741,6 +741,71 @@ def main():
                      "losses_diff_rnd_total": [round(x, 4) for x in l256]},
             "cpu_reference_point": "cpu_baseline.points[*].text_train_b32_l128_d256 is the DENOISER part only of the B = 32 step"}
 
+    # ---- the reference's OWN small configurations (BASELINE.md section 2's protocol; cpu_baseline.points times the CPU oracle on
+    #      the same ones): what a user of the reference's CLI defaults runs.  Graph-replayed like the product loops. ----
+    if rank == 0 and world == 1 and args.text_steps > 0:
+        from tinydiffusionmodels_amd import shakespeare as _S2
+        from tinydiffusionmodels_amd.shakespeare import TinyTransformer as _TT, DenoiserTrainer as _DT
+        pp = {}
+        torch.manual_seed(11)
+        m64 = SimpleUNet().to(dev)
+        tr64 = DDPMTrainer(m64, batch_size=64, lr=1e-3, broadcast=False)
+        d64 = torch.rand(64 * 32, 1, 28, 28, device=dev) * 2 - 1
+        p64 = torch.randperm(64 * 32).to(dev)
+
+        def steps64(n):
+            while n > 0:
+                tr64.begin_epoch(d64, p64)
+                k = min(n, 32)
+                tr64.steps_epoch(k)
+                n -= k
+        steps64(32)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        steps64(256)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / 256
+        pp["mnist_train_b64"] = {"ms_per_step": round(ms, 4), "steps_per_s": round(1e3 / ms, 1), "img_per_s": round(64e3 / ms, 0)}
+        m64.eval()
+        for nb_ in (25, 64):
+            with torch.no_grad():
+                reverse_diffusion(m64, torch.randn(nb_, 1, 28, 28, device=dev), t_start=63)      # warm-up: captures the two-step graph
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                reverse_diffusion(m64, torch.randn(nb_, 1, 28, 28, device=dev))
+                torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            pp[f"mnist_p_sample_b{nb_}"] = {"ms_per_step": round(el, 4), "img_per_s_1000_step": round(nb_ / el, 1),
+                                            "measured": "one complete 1000-step chain"}
+        del tr64, m64, d64
+        torch.manual_seed(12)
+        mt = _TT(256, dropout=0.1).to(dev)
+        mt.train()
+        trt = _DT(mt, 32, 128, lr=1e-4)
+        xt = torch.randn(32, 128, 256, device=dev) * 0.02
+        for _ in range(4):
+            trt.step(xt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(40):
+            trt.step(xt)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / 40
+        pp["text_train_b32_l128_d256"] = {"ms_per_step": round(ms, 4), "tokens_per_s": round(32 * 128e3 / ms, 0),
+                                          "what": "denoiser step only (the CPU point's scope); text_train_full.b32 is the whole step"}
+        mt.eval()
+        with torch.no_grad():
+            _S2.reverse_diffusion(mt, torch.randn(10, 128, 256, device=dev), t_start=63)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _S2.reverse_diffusion(mt, torch.randn(10, 128, 256, device=dev))
+            torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        pp["text_p_sample_b10"] = {"ms_per_step": round(el, 4), "measured": "one complete 1000-step chain"}
+        del trt, mt
+        out["protocol_points"] = {"what": "the reference's own small configurations on this GPU (BASELINE.md section 2; the CPU oracle's numbers "
+                                          "for the same points are cpu_baseline.points)", **pp}
+
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
