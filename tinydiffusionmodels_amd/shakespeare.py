@@ -136,15 +136,25 @@ def round_ce_chunk(M: int, V: int) -> int:
 
 def round_fused_nseg(M: int, V: int, D: int) -> int:
     """Token segments of the fused rounding head's weight-gradient pass (csrc/ce_chain.hip), or 0 when the fused form does not
-    serve the problem (D != 256, TDM_ROUND_FUSED=0).  The pass runs ceil(V / 128) vocabulary tiles x nseg segments on 256 CUs:
-    the smallest nseg within 5 % of the best rounds-per-segment (V = 50,257: 393 tiles -> 3 segments, 5 rounds of 256)."""
+    serve the problem (D != 256, TDM_ROUND_FUSED=0).  The pass runs ceil(V / 128) vocabulary tiles x nseg segments on 256 CUs, a
+    workgroup streams (M / 32) / nseg token blocks, and nseg > 1 costs nseg slabs of dW written and reduced.  Modelled time
+    (measured on MI355X: ~54 us per workgroup + ~1.6 us per token block, slabs at ~5 TB/s):
+        rounds(tiles * nseg / 256) * (54 + 1.6 * blocks / nseg) + (nseg > 1) * 2 * nseg * V * D * 4 B / 5 TB/s
+    -> 3 segments at 32,768 tokens and V = 50,257 (393 tiles: 5 rounds of 256), 1 at 4,096 tokens (the default batch of 32:
+    two rounds of long workgroups beat five rounds of short ones plus the slab reduction: 0.74 -> 0.52 ms)."""
     if os.environ.get("TDM_ROUND_FUSED", "1") == "0" or not _lib.lib().tdm_round_fused_ok(M, V, D):
         return 0
     tiles = (V + 127) // 128
-    nmax = max(1, min(6, ((M + 31) // 32) // 4))       # a segment should hold a few token blocks
-    cost = {n: math.ceil(tiles * n / 256) / n for n in range(1, nmax + 1)}
-    best = min(cost.values())
-    return min(n for n, c in cost.items() if c <= 1.05 * best)
+    blocks = (M + 31) // 32
+    nmax = max(1, min(6, blocks // 4))       # a segment should hold a few token blocks
+    forced = os.environ.get("TDM_ROUND_NSEG")
+    if forced:
+        return max(1, min(nmax, int(forced)))
+
+    def cost(n):
+        return math.ceil(tiles * n / 256) * (54.0 + 1.6 * blocks / n) + (2.0 * n * V * D * 4 / 5e6 if n > 1 else 0.0)
+
+    return min(range(1, nmax + 1), key=lambda n: (cost(n), n))
 
 
 def round_ce_workspace(M: int, V: int, D: int, device):
