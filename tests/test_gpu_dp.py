@@ -71,6 +71,49 @@ def test_two_rank_train_step_equals_global_batch_step(tmp_path):
     assert close > 0.98, close                                      # sign flips of ~zero gradients aside
 
 
+def _epoch_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from tinydiffusionmodels_amd import dp
+    from tinydiffusionmodels_amd import mnist as M
+    dp.init_from_env("gloo")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(200 + rank)
+    model = M.SimpleUNet().to(dev)
+    B = 8
+    data = M.synthetic_mnist(5 * B * world + 3, seed=9).to(dev)       # five whole global batches and a ragged tail
+    # (1) the loop itself: two epochs, replicas identical afterwards
+    M.train(model, str(dev), epochs=2, batch_size=B, lr=1e-3, ckpt_path=os.path.join(out_dir, f"ck{rank}.pth"),
+            sample_every_epoch=False, data=data, log_every=0)
+    torch.cuda.synchronize()
+    flat = model.flat.detach().cpu()
+    # (2) the positions: after k steps of an epoch this rank's batch is perm[(k * world + rank) * B : ... + B]
+    tr = M.DDPMTrainer(model, B, lr=1e-3)
+    perm = torch.randperm(data.shape[0], generator=torch.Generator().manual_seed(3)).to(dev)
+    tr.begin_epoch(data, perm)
+    tr.steps_epoch(3)
+    tr.steps_epoch(1)
+    torch.cuda.synchronize()
+    st = tr.state
+    k = 3
+    want = M.q_sample(data[perm[(k * world + rank) * B:(k * world + rank + 1) * B]], st.t, st.noise)
+    torch.save({"flat": flat, "shard_ok": bool(torch.equal(st.x_noisy, want))}, os.path.join(out_dir, f"e{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_epoch_mode_shards_inside_the_step(tmp_path):
+    """mnist.train() under torch.distributed (2 ranks sharing the GPU, gloo) with the batch gathered INSIDE the captured step:
+    every rank's step reads its own shard of the global batch (stride = batch x world, offset = rank x batch, position from the
+    device-side step count), the ragged tail goes through step(), and the replicas end bit-identical."""
+    mp.spawn(_epoch_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "e0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "e1.pt", weights_only=True)
+    assert r0["shard_ok"] and r1["shard_ok"]
+    assert torch.equal(r0["flat"], r1["flat"]) and torch.isfinite(r0["flat"]).all()
+
+
 def _text_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
