@@ -729,6 +729,27 @@ __global__ __launch_bounds__(256) void transpose_s16_kernel(const float* __restr
     const int c = bx + cr, r0 = by + q4;
     if (c < Cn && r0 < R) tdm_store_s16_4(out, c, R, r0, make_float4(t[q4][cr], t[q4 + 1][cr], t[q4 + 2][cr], t[q4 + 3][cr]));
 }
+// the same for up to TDM_TRANSPOSE_BATCH matrices in ONE launch (all weight matrices of a backward pass: 4 per layer)
+__global__ __launch_bounds__(256) void transpose_s16_batch_kernel(TransposeBatch tb) {
+    __shared__ float t[32][33];
+    int j = 0;
+    while (j + 1 < tb.n && (int)blockIdx.x >= tb.blk0[j + 1]) ++j;
+    const float* __restrict__ in = tb.in[j];
+    float* __restrict__ out = tb.out[j];
+    const int R = tb.R[j], Cn = tb.Cn[j];
+    const int local = (int)blockIdx.x - tb.blk0[j], gx = (Cn + 31) / 32;
+    const int bx = (local % gx) * 32, by = (local / gx) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = by + ty + 8 * k, c = bx + tx;
+        t[ty + 8 * k][tx] = (r < R && c < Cn) ? in[(long)r * Cn + c] : 0.f;
+    }
+    __syncthreads();
+    const int cr = threadIdx.x >> 3, q4 = (threadIdx.x & 7) * 4;
+    const int c = bx + cr, r0 = by + q4;
+    if (c < Cn && r0 < R) tdm_store_s16_4(out, c, R, r0, make_float4(t[q4][cr], t[q4 + 1][cr], t[q4 + 2][cr], t[q4 + 3][cr]));
+}
 __global__ __launch_bounds__(256) void split_s16_kernel(const float* __restrict__ in, float* __restrict__ out, long n4) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const long e = i * 4;
@@ -753,6 +774,20 @@ int tdm_launch_transpose_s16(const float* in, float* out, int R, int Cn, hipStre
     dim3 grid((Cn + 31) / 32, (R + 31) / 32);
     hipLaunchKernelGGL(transpose_s16_kernel, grid, dim3(256), 0, st, in, out, R, Cn);
     TDM_CHECK_LAUNCH("transpose_s16");
+    return 0;
+}
+
+int tdm_launch_transpose_s16_batch(TransposeBatch& tb, hipStream_t st) {
+    TDM_REQUIRE(tb.n >= 1 && tb.n <= TDM_TRANSPOSE_BATCH, "transpose_s16_batch: %d matrices", tb.n);
+    int nb = 0;
+    for (int j = 0; j < tb.n; ++j) {
+        TDM_REQUIRE((tb.R[j] % 16) == 0 && tb.in[j] != nullptr && tb.out[j] != nullptr, "transpose_s16_batch: matrix %d", j);
+        tb.blk0[j] = nb;
+        nb += ((tb.Cn[j] + 31) / 32) * ((tb.R[j] + 31) / 32);
+    }
+    tb.blk0[tb.n] = nb;
+    hipLaunchKernelGGL(transpose_s16_batch_kernel, dim3(nb), dim3(256), 0, st, tb);
+    TDM_CHECK_LAUNCH("transpose_s16_batch");
     return 0;
 }
 

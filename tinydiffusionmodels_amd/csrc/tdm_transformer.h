@@ -51,6 +51,10 @@ int tdm_launch_gemm_nt_ring(const GemmArgs& g, int nprod, hipStream_t st);
 int tdm_launch_transpose(const float* in, float* out, int R, int Cn, hipStream_t st);
 // out[c][r] = in[r][c] written as S16 (R % 16 == 0); out = S16 of in, elementwise over n (n % 16 == 0) floats
 int tdm_launch_transpose_s16(const float* in, float* out, int R, int Cn, hipStream_t st);
+// several matrices in one launch: out[j] (S16, [Cn][R]) = transpose of in[j] ([R][Cn] fp32); blk0 is filled by the launcher
+constexpr int TDM_TRANSPOSE_BATCH = 32;
+struct TransposeBatch { int n; const float* in[TDM_TRANSPOSE_BATCH]; float* out[TDM_TRANSPOSE_BATCH]; int R[TDM_TRANSPOSE_BATCH], Cn[TDM_TRANSPOSE_BATCH], blk0[TDM_TRANSPOSE_BATCH + 1]; };
+int tdm_launch_transpose_s16_batch(TransposeBatch& tb, hipStream_t st);
 int tdm_launch_split_s16(const float* in, float* out, long n, hipStream_t st);
 
 // fp32-MFMA attention (attn_mfma.hip). which: 0 forward (out = O, aux = lse), 1 dQ (out = dqkv, aux = D written),

@@ -100,6 +100,7 @@ struct TTWs {
     // backward temporaries
     float *g_h, *g_s, *g_s1, *g_d, *g_f, *g_h1, *g_o, *g_qkv, *Dvec, *Sb, *part;
     float *P16, *g16, *g_qkv16;   // S16: the parameter vector, the D-wide gradient operand of the current GEMM pair, d(qkv)
+    float* wT_all;                // [depth][in_w^T | out_w^T | l1_w^T | l2_w^T] S16 (backward), or nullptr
     float* ypart;                 // partial sums of a hidden-range-segmented FFN chain (small batches; ffn_chain.hip), or nullptr
     long total;
 };
@@ -115,6 +116,8 @@ TTWs tt_carve(float* base, long B, int Lq, int D, int H, int depth, int F, int t
     w.that = take(B); w.tb = take(B * D); w.abuf = take(M * D);
     w.wT = take((long)(F > 3 * D ? F : 3 * D) * D);   // transposed weight of the current data-gradient GEMM
     w.wT2 = take((long)F * D);                        // second transposed weight of the fused FFN data gradient
+    // all four weight matrices of every layer, transposed (S16), written by ONE launch at the start of a backward pass
+    w.wT_all = (training && depth <= 8) ? take((long)depth * (4L * D * D + 2L * F * D)) : nullptr;
     for (int l = 0; l < depth; ++l) {
         LayerWs& x = w.L[l];
         x.hin = take(M * D); x.qkv = take(M * 3 * D); x.o = take(M * D); x.lse = take(B * H * Lq);
@@ -772,12 +775,14 @@ int linear_fwd(const float* X, const float* W, const float* bias, const float* r
 }
 // dX[M][K] = dY[M][N] W[N][K] (+res), then dX = gate > 0 ? dX * gate_scale : 0 (ReLU / FFN-dropout backward)
 // s16: dY and the gate are S16, the transposed weight is built as S16;  dX16: S16 twin of dX (dX may be nullptr)
+// (wT_ready: wT already holds W^T — the backward pass transposes all its weights in one launch)
 int linear_dgrad(const float* dY, const float* W, float* wT, const float* res, const float* gate, float gate_scale,
-                 float* dX, float* dX16, bool s16, long M, int N, int K, hipStream_t st) {
+                 float* dX, float* dX16, bool s16, long M, int N, int K, hipStream_t st, bool wT_ready = false) {
     GemmArgs g{};
     g.gate = gate; g.gate_scale = gate_scale;
     if (g_gemm_mode != 0) {   // dX = dY . (W^T)^T as a K-contiguous (NT) product on the transposed weight
-        if (s16) TDM_TRY(tdm_launch_transpose_s16(W, wT, N, K, st));
+        if (wT_ready) {}
+        else if (s16) TDM_TRY(tdm_launch_transpose_s16(W, wT, N, K, st));
         else TDM_TRY(tdm_launch_transpose(W, wT, N, K, st));
         g.A = dY; g.a_rs = N; g.a_cs = 1;
         g.B = wT; g.b_rs = 1; g.b_cs = N;
@@ -911,9 +916,28 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
     const bool s16 = tt_use16(D, F);            // GEMM operands pre-split (see tt_use16): S16 twins / S16-only tensors
     const float* gh = dout;  // gradient w.r.t. the current layer's output
     float* gout = nullptr;
+    // transposed weights of all layers in ONE launch (12 launches of ~5 us otherwise: the weights do not change inside a step)
+    const bool pre = s16 && g_gemm_mode != 0 && w.wT_all != nullptr && 4 * depth <= TDM_TRANSPOSE_BATCH;
+    const long per_layer = 4L * D * D + 2L * F * D;
+    if (pre) {
+        TransposeBatch tb{};
+        for (int l = 0; l < depth; ++l) {
+            const LayerOff& o = lay.L[l];
+            float* base = w.wT_all + l * per_layer;
+            const float* src[4] = {P + o.in_w, P + o.out_w, P + o.l1_w, P + o.l2_w};
+            float* dst[4] = {base, base + 3L * D * D, base + 4L * D * D, base + 4L * D * D + (long)F * D};
+            const int Rv[4] = {3 * D, D, F, D}, Cv[4] = {D, D, D, F};     // W[R][Cn] -> W^T[Cn][R]
+            for (int k = 0; k < 4; ++k) { tb.in[tb.n] = src[k]; tb.out[tb.n] = dst[k]; tb.R[tb.n] = Rv[k]; tb.Cn[tb.n] = Cv[k]; ++tb.n; }
+        }
+        TDM_TRY(tdm_launch_transpose_s16_batch(tb, st));
+    }
     for (int l = depth - 1; l >= 0; --l) {
         const LayerOff& o = lay.L[l];
         const LayerWs& a = w.L[l];
+        float* const wT_in = pre ? w.wT_all + l * per_layer : w.wT;
+        float* const wT_out = pre ? wT_in + 3L * D * D : w.wT;
+        float* const wT_l1 = pre ? wT_in + 4L * D * D : w.wT2;              // W1^T: [D][F]
+        float* const wT_l2 = pre ? wT_l1 + (long)F * D : w.wT;               // W2^T: [F][D]
         // LayerNorm 2: hout = LN(h1 + dropout2(f2)); g_s = d(h1) residual part, g2 = d(f2); db2 = colsum(g2)
         TDM_TRY(ln_bwd(gh, nullptr, a.s2, a.mean2, a.rstd2, P + o.n2_w, w.g_s, (dropping && !s16) ? w.g_d : nullptr,
                        s16 ? w.g16 : nullptr, dropping, drop.site(4 + 4 * l), w.part, G, o.n2_w, o.l2_b, M, D, st));
@@ -923,25 +947,27 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
         const bool chain = tt_fused_ffn(M, D, F);
         if (chain) {
             // d(z1) = (g2 W2) gated by the saved sign masks, d(h1) = d(z1) W1: one launch, d(z1) written once (S16) for W1's gradient
-            TDM_TRY(tdm_launch_transpose_s16(P + o.l2_w, w.wT, D, F, st));    // W2^T: [F][D]
-            TDM_TRY(tdm_launch_transpose_s16(P + o.l1_w, w.wT2, F, D, st));   // W1^T: [D][F]
-            TDM_TRY(tdm_launch_ffn_chain(2, g_gemm_mode == 1 ? 3 : 1, g2, w.wT, nullptr, w.wT2, nullptr, w.g_h1, w.g_f, a.fmask,
+            if (!pre) {
+                TDM_TRY(tdm_launch_transpose_s16(P + o.l2_w, wT_l2, D, F, st));    // W2^T: [F][D]
+                TDM_TRY(tdm_launch_transpose_s16(P + o.l1_w, wT_l1, F, D, st));    // W1^T: [D][F]
+            }
+            TDM_TRY(tdm_launch_ffn_chain(2, g_gemm_mode == 1 ? 3 : 1, g2, wT_l2, nullptr, wT_l1, nullptr, w.g_h1, w.g_f, a.fmask,
                                          dropping ? drop.site(3 + 4 * l).scale : 1.f, DropArgs{}, DropArgs{}, M, D, F, st, w.ypart));
         } else
-        TDM_TRY(linear_dgrad(g2, P + o.l2_w, w.wT, nullptr, a.f1, dropping ? drop.site(3 + 4 * l).scale : 1.f, s16 ? nullptr : w.g_f,
-                             s16 ? w.g_f : nullptr, s16, M, D, F, st));
+        TDM_TRY(linear_dgrad(g2, P + o.l2_w, wT_l2, nullptr, a.f1, dropping ? drop.site(3 + 4 * l).scale : 1.f, s16 ? nullptr : w.g_f,
+                             s16 ? w.g_f : nullptr, s16, M, D, F, st, pre));
         // z1 = h1 W1^T + b1
         if (!fused_bias) TDM_TRY(bias_grad(w.g_f, w.part, G + o.l1_b, M, F, st));
         TDM_TRY(linear_wgrad(w.g_f, s16 ? a.h1_16 : a.h1, slabs + sp.base[l][2], fused_bias ? slabs + sp.bias_base[l][2] : nullptr,
                              s16, M, F, D, st));
-        if (!chain) TDM_TRY(linear_dgrad(w.g_f, P + o.l1_w, w.wT, nullptr, nullptr, 1.f, w.g_h1, nullptr, s16, M, F, D, st));
+        if (!chain) TDM_TRY(linear_dgrad(w.g_f, P + o.l1_w, pre ? wT_l1 : w.wT, nullptr, nullptr, 1.f, w.g_h1, nullptr, s16, M, F, D, st, pre));
         // LayerNorm 1: h1 = LN(hin + dropout1(a)); d(h1) = g_h1 (FFN path) + g_s (residual)
         TDM_TRY(ln_bwd(w.g_h1, w.g_s, a.s1, a.mean1, a.rstd1, P + o.n1_w, w.g_s1, (dropping && !s16) ? w.g_d : nullptr,
                        s16 ? w.g16 : nullptr, dropping, drop.site(2 + 4 * l), w.part, G, o.n1_w, o.out_b, M, D, st));
         const float* g1 = s16 ? w.g16 : (dropping ? w.g_d : w.g_s1);
         // a = o Wout^T + bout
         TDM_TRY(linear_wgrad(g1, s16 ? a.o16 : a.o, slabs + sp.base[l][1], nullptr, s16, M, D, D, st));
-        TDM_TRY(linear_dgrad(g1, P + o.out_w, w.wT, nullptr, nullptr, 1.f, w.g_o, nullptr, s16, M, D, D, st));
+        TDM_TRY(linear_dgrad(g1, P + o.out_w, wT_out, nullptr, nullptr, 1.f, w.g_o, nullptr, s16, M, D, D, st, pre));
         // attention
         const DropArgs da = drop.site(1 + 4 * l);
         TDM_TRY(attn_dispatch(1, D / H, a.qkv, a.o, a.lse, w.g_o, w.g_qkv, w.Dvec, B, L, D, H, da, st, s16 ? w.g_qkv16 : nullptr));
@@ -952,7 +978,7 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
         TDM_TRY(linear_wgrad(gq, s16 ? a.hin16 : a.hin, slabs + sp.base[l][0], fused_bias ? slabs + sp.bias_base[l][0] : nullptr, s16,
                              M, 3 * D, D, st));
         gout = (l == 0 && dx != nullptr) ? dx : w.g_h;   // layer 0: this is d(loss)/d(dropout0(x + time bias))
-        TDM_TRY(linear_dgrad(gq, P + o.in_w, w.wT, w.g_s1, nullptr, 1.f, gout, nullptr, s16, M, 3 * D, D, st));
+        TDM_TRY(linear_dgrad(gq, P + o.in_w, wT_in, w.g_s1, nullptr, 1.f, gout, nullptr, s16, M, 3 * D, D, st, pre));
         gh = gout;
     }
     if (dropping) {   // input dropout: d(x + time bias) = mask * g / (1 - p)
