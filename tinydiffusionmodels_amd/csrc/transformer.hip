@@ -776,10 +776,13 @@ int linear_fwd(const float* X, const float* W, const float* bias, const float* r
 // dX[M][K] = dY[M][N] W[N][K] (+res), then dX = gate > 0 ? dX * gate_scale : 0 (ReLU / FFN-dropout backward)
 // s16: dY and the gate are S16, the transposed weight is built as S16;  dX16: S16 twin of dX (dX may be nullptr)
 // (wT_ready: wT already holds W^T — the backward pass transposes all its weights in one launch)
+// (dr: a dropout mask applied to dX in the epilogue — bf16 GEMM modes only; the fp32 mode's caller applies it afterwards)
 int linear_dgrad(const float* dY, const float* W, float* wT, const float* res, const float* gate, float gate_scale,
-                 float* dX, float* dX16, bool s16, long M, int N, int K, hipStream_t st, bool wT_ready = false) {
+                 float* dX, float* dX16, bool s16, long M, int N, int K, hipStream_t st, bool wT_ready = false,
+                 DropArgs dr = DropArgs{}) {
     GemmArgs g{};
     g.gate = gate; g.gate_scale = gate_scale;
+    if (g_gemm_mode != 0) g.drop = dr;
     if (g_gemm_mode != 0) {   // dX = dY . (W^T)^T as a K-contiguous (NT) product on the transposed weight
         if (wT_ready) {}
         else if (s16) TDM_TRY(tdm_launch_transpose_s16(W, wT, N, K, st));
@@ -978,10 +981,13 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
         TDM_TRY(linear_wgrad(gq, s16 ? a.hin16 : a.hin, slabs + sp.base[l][0], fused_bias ? slabs + sp.bias_base[l][0] : nullptr, s16,
                              M, 3 * D, D, st));
         gout = (l == 0 && dx != nullptr) ? dx : w.g_h;   // layer 0: this is d(loss)/d(dropout0(x + time bias))
-        TDM_TRY(linear_dgrad(gq, P + o.in_w, wT_in, w.g_s1, nullptr, 1.f, gout, nullptr, s16, M, 3 * D, D, st, pre));
+        // (layer 0 in the bf16 GEMM modes: the input dropout's mask — d(x + time bias) = mask * g / (1 - p) — in this epilogue)
+        const bool drop_here = dropping && l == 0 && g_gemm_mode != 0;
+        TDM_TRY(linear_dgrad(gq, P + o.in_w, wT_in, w.g_s1, nullptr, 1.f, gout, nullptr, s16, M, 3 * D, D, st, pre,
+                             drop_here ? drop.site(0) : DropArgs{}));
         gh = gout;
     }
-    if (dropping) {   // input dropout: d(x + time bias) = mask * g / (1 - p)
+    if (dropping && g_gemm_mode == 0) {   // input dropout: d(x + time bias) = mask * g / (1 - p)
         const long n4 = M * D / 4;
         int grid = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
         hipLaunchKernelGGL(drop_apply_kernel, dim3(grid), dim3(256), 0, st, gout, n4, drop.site(0));
