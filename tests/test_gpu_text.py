@@ -448,6 +448,34 @@ def test_transformer_oracle_shapes_and_autograd_bridge(dev, golden_tables, gemm_
     assert O.rel_l2(xd.grad.cpu(), xr.grad) < l2tol
 
 
+def test_depth_8_forward_and_grads_vs_oracle(dev, golden_tables, gemm_mode):
+    """The deepest model the layouts admit (depth = 8; the reference builds 3, src/shakespeare.py:105-113): forward and every
+    gradient against the oracle — 48 slab sections + biases, more than ONE slab-reduction launch's table holds (the backward
+    used to overrun it on the host for depth >= 7)."""
+    from tinydiffusionmodels_amd.shakespeare import TinyTransformer
+    from tinydiffusionmodels_amd import transformer_engine as TE
+    dim, depth, B, L = 64, 8, 2, 48
+    p = O.transformer_init_params(dim, depth=depth, seed=5)
+    m = TinyTransformer(dim, depth=depth, dropout=0.0).to(dev)
+    m.load_state_dict(p)
+    m.train()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, L, dim, generator=g) * 0.7
+    t = torch.randint(0, 1000, (B,), generator=g)
+    target = torch.randn(B, L, dim, generator=g)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ref = O.transformer_forward(leaf, x, t, depth=depth)
+    F.mse_loss(ref, target).backward()
+    out = m(x.to(dev), t.to(dev))
+    assert O.rel_err(out.detach().cpu(), ref.detach()) < (2e-5 if gemm_mode == 0 else 2e-4 if gemm_mode == 1 else 3e-2)
+    F.mse_loss(out, target.to(dev)).backward()
+    got = TE.state_dict_from_flat(m.flat.grad, dim, depth)
+    l2tol = {0: 1e-3, 1: 2e-2, 2: 2e-1}[gemm_mode]
+    assert set(got) == set(leaf)
+    for k, v in leaf.items():
+        assert O.rel_l2(got[k].cpu(), v.grad) < l2tol, k
+
+
 def test_width_not_a_multiple_of_16_takes_the_fp32_operand_path(dev, golden_tables, gemm_mode):
     """dim = 40 with 5 heads (head_dim 8): D % 16 != 0, so the bf16 GEMM modes cannot use pre-split (S16) operands and fall
     back to splitting in the loaders — the same forward and gradients as the oracle, through the nn.Module surface."""

@@ -1001,6 +1001,12 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
     ReduceArgs ra{};
     int n = 0;
     for (int l = 0; l < depth; ++l) {
+        if (n + 6 > TDM_MAX_SECS) {   // (depth 7 and 8 need more sections than one launch's table holds)
+            ra.nsec = n;
+            TDM_TRY(tdm_launch_reduce(slabs, 0, ra, G, st));
+            ra = ReduceArgs{};
+            n = 0;
+        }
         const LayerOff& o = lay.L[l];
         const long offs[4] = {o.in_w, o.out_w, o.l1_w, o.l2_w};
         const long lens[4] = {3L * D * D, (long)D * D, (long)F * D, (long)D * F};
