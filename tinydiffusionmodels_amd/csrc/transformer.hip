@@ -45,7 +45,7 @@ inline int wgrad_splitk(int N, int K) {
     return sk;
 }
 // slab regions (floats) of the 4 weight matrices of one layer, in order in_w, out_w, l1_w, l2_w
-struct SlabPlan { long base[8][4]; long bias_base[8][4]; int sk[4]; long len[4]; int nout[4]; long total; };
+struct SlabPlan { long base[8][4]; long bias_base[8][4]; long ln_base[8][2]; int sk[4]; long len[4]; int nout[4]; long total; };
 SlabPlan slab_plan(int D, int depth, int F) {
     SlabPlan p{};
     const int Ns[4] = {3 * D, D, F, D}, Ks[4] = {D, D, D, F};
@@ -56,6 +56,10 @@ SlabPlan slab_plan(int D, int depth, int F) {
     // per-split partial bias gradients written by the weight-gradient GEMMs (bf16 modes)
     for (int l = 0; l < depth; ++l)
         for (int k = 0; k < 4; ++k) { p.bias_base[l][k] = off; off += (long)p.sk[k] * ((Ns[k] + 63) & ~63); }
+    // workgroup partials of the two LayerNorm backward launches of every layer ([LN_SLABS][3 D]: d gamma | d beta | column sums):
+    // summed by the backward's ONE slab-reduction launch instead of a reduction launch per LayerNorm
+    for (int l = 0; l < depth; ++l)
+        for (int k = 0; k < 2; ++k) { p.ln_base[l][k] = off; off += (long)LN_SLABS * 3 * D; }
     p.total = off;
     return p;
 }
@@ -827,13 +831,18 @@ int bias_grad(const float* dY, float* part, float* db, long M, int N, hipStream_
 }
 // LayerNorm backward; G = gradient buffer base: dgamma/dbeta go to G[gamma_off .. +2D), the column sums of the
 // (dropped) input gradient to G[bias_off .. +D) (the bias gradient of the linear layer feeding the residual add)
-int ln_bwd(const float* dy, const float* dy2, const float* s, const float* mean, const float* rstd, const float* gamma,
-           float* ds, float* ds_drop, float* op16, bool dropping, DropArgs dr, float* part, float* G, long gamma_off,
-           long bias_off, long M, int D, hipStream_t st) {
+inline int ln_bwd_nb(long M, int D) {   // partial rows a LayerNorm backward launch writes
     const int NQ = D <= 256 ? 1 : (D <= 512 ? 2 : 4);
     const int R = 4 / NQ;
-    long nb = (M + 4 * R - 1) / (4 * R);
-    if (nb > LN_SLABS) nb = LN_SLABS;
+    const long nb = (M + 4 * R - 1) / (4 * R);
+    return (int)(nb > LN_SLABS ? LN_SLABS : nb);
+}
+// (defer: the partial rows in `part` are summed later — by the caller's slab reduction — not by a launch of their own)
+int ln_bwd(const float* dy, const float* dy2, const float* s, const float* mean, const float* rstd, const float* gamma,
+           float* ds, float* ds_drop, float* op16, bool dropping, DropArgs dr, float* part, float* G, long gamma_off,
+           long bias_off, long M, int D, hipStream_t st, bool defer = false) {
+    const int NQ = D <= 256 ? 1 : (D <= 512 ? 2 : 4);
+    const long nb = ln_bwd_nb(M, D);
     if (!dropping) dr = DropArgs{};
     if (NQ == 1)
         hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, dy, dy2, s, mean, rstd, gamma, ds, ds_drop, op16, part, M, D, dr);
@@ -842,6 +851,7 @@ int ln_bwd(const float* dy, const float* dy2, const float* s, const float* mean,
     else
         hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3((unsigned)nb), dim3(256), 0, st, dy, dy2, s, mean, rstd, gamma, ds, ds_drop, op16, part, M, D, dr);
     TDM_CHECK_LAUNCH("ln_bwd");
+    if (defer) return 0;
     ReduceArgs ra{};
     ra.nsec = 2;
     ra.sec[0].off = (int)gamma_off; ra.sec[0].len = 2 * D; ra.sec[0].nslab = (int)nb; ra.sec[0].src_delta = -gamma_off;
@@ -943,7 +953,7 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
         float* const wT_l2 = pre ? wT_l1 + (long)F * D : w.wT;               // W2^T: [F][D]
         // LayerNorm 2: hout = LN(h1 + dropout2(f2)); g_s = d(h1) residual part, g2 = d(f2); db2 = colsum(g2)
         TDM_TRY(ln_bwd(gh, nullptr, a.s2, a.mean2, a.rstd2, P + o.n2_w, w.g_s, (dropping && !s16) ? w.g_d : nullptr,
-                       s16 ? w.g16 : nullptr, dropping, drop.site(4 + 4 * l), w.part, G, o.n2_w, o.l2_b, M, D, st));
+                       s16 ? w.g16 : nullptr, dropping, drop.site(4 + 4 * l), slabs + sp.ln_base[l][1], G, o.n2_w, o.l2_b, M, D, st, true));
         const float* g2 = s16 ? w.g16 : (dropping ? w.g_d : w.g_s);
         // f2 = f1 W2^T + b2, f1 = dropout(relu(z1)): d(z1) = (g2 W2) * [f1 > 0] / (1 - p) in the GEMM epilogue
         TDM_TRY(linear_wgrad(g2, a.f1, slabs + sp.base[l][3], nullptr, s16, M, D, F, st));
@@ -966,7 +976,7 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
         if (!chain) TDM_TRY(linear_dgrad(w.g_f, P + o.l1_w, pre ? wT_l1 : w.wT, nullptr, nullptr, 1.f, w.g_h1, nullptr, s16, M, F, D, st, pre));
         // LayerNorm 1: h1 = LN(hin + dropout1(a)); d(h1) = g_h1 (FFN path) + g_s (residual)
         TDM_TRY(ln_bwd(w.g_h1, w.g_s, a.s1, a.mean1, a.rstd1, P + o.n1_w, w.g_s1, (dropping && !s16) ? w.g_d : nullptr,
-                       s16 ? w.g16 : nullptr, dropping, drop.site(2 + 4 * l), w.part, G, o.n1_w, o.out_b, M, D, st));
+                       s16 ? w.g16 : nullptr, dropping, drop.site(2 + 4 * l), slabs + sp.ln_base[l][0], G, o.n1_w, o.out_b, M, D, st, true));
         const float* g1 = s16 ? w.g16 : (dropping ? w.g_d : w.g_s1);
         // a = o Wout^T + bout
         TDM_TRY(linear_wgrad(g1, s16 ? a.o16 : a.o, slabs + sp.base[l][1], nullptr, s16, M, D, D, st));
@@ -1001,7 +1011,7 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
     ReduceArgs ra{};
     int n = 0;
     for (int l = 0; l < depth; ++l) {
-        if (n + 6 > TDM_MAX_SECS) {   // (depth 7 and 8 need more sections than one launch's table holds)
+        if (n + 10 > TDM_MAX_SECS) {   // (deep models need more sections than one launch's table holds)
             ra.nsec = n;
             TDM_TRY(tdm_launch_reduce(slabs, 0, ra, G, st));
             ra = ReduceArgs{};
@@ -1015,6 +1025,16 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
             ra.sec[n].src_delta = sp.base[l][k] - offs[k];
             ra.sec[n].stride_override = sp.len[k];
             ++n;
+        }
+        {   // the two LayerNorms' partial rows: d gamma | d beta (2 D at n*_w) and the column sums (D: out_proj / linear2 bias gradient)
+            const int nbl = ln_bwd_nb(M, D);
+            const long goff[2] = {o.n1_w, o.n2_w}, boff[2] = {o.out_b, o.l2_b};
+            for (int k = 0; k < 2; ++k) {
+                ra.sec[n].off = (int)goff[k]; ra.sec[n].len = 2 * D; ra.sec[n].nslab = nbl;
+                ra.sec[n].src_delta = sp.ln_base[l][k] - goff[k]; ra.sec[n].stride_override = 3L * D; ++n;
+                ra.sec[n].off = (int)boff[k]; ra.sec[n].len = D; ra.sec[n].nslab = nbl;
+                ra.sec[n].src_delta = sp.ln_base[l][k] + 2L * D - boff[k]; ra.sec[n].stride_override = 3L * D; ++n;
+            }
         }
         if (fused_bias) {
             const long boffs[2] = {o.in_b, o.l1_b};
