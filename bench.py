@@ -19,6 +19,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -512,6 +514,36 @@ def main():
         if dom["id"] != r9["id"]:
             out["roofline"]["second"] = roof(r9)      # the forward twin (round 2's roofline launch), for continuity
         del sts, gscratch
+
+        # ---- the same launch timed INSIDE the running step: the timed loop's steps issued eagerly (same launches, same
+        #      order, same stream; 35 launches of host work per ~1 ms of GPU work keep the queue full) with a HIP-event pair
+        #      recorded on the launch stream around that one launch (tdm_unet_mark_launch).  Its inputs are where the step's
+        #      previous launches left them (L2 / Infinity Cache), unlike the replay above, which alternates two 1.3 GB
+        #      workspaces so that every input comes from HBM; the kernel average of `rocprofv3 --kernel-trace` over the
+        #      timed loop (profiles/r04_bench_kernel_summary.txt) is this number. ----
+        def in_step(r, nsteps=96, drop=16):
+            was = trainer.use_graph
+            trainer.use_graph = False
+            try:
+                _lib.check(L.tdm_unet_mark_launch(r["id"], nsteps), "mark_launch")
+                run_steps(nsteps)
+                buf = np.zeros(nsteps, dtype=np.float32)
+                n = L.tdm_unet_mark_collect(buf.ctypes.data, nsteps)
+                assert n == nsteps, n
+            finally:
+                L.tdm_unet_mark_launch(-1, 0)
+                trainer.use_graph = was
+            us = float(np.median(buf[drop:]))
+            kb = next((c for n_, c in ALGO_CH.items() if r["launch"].startswith(n_)), 0) * 4 * 784 * B_TRAIN or r["bytes"]
+            ach = kb / (us * 1e-6) / 1e9
+            return {"ms_per_launch": round(us * 1e-3, 4), "achieved": round(ach, 1), "frac": round(ach / PEAK_HBM_GBS, 4),
+                    "steps": nsteps - drop, "min_us": round(float(buf[drop:].min()), 2), "max_us": round(float(buf[drop:].max()), 2),
+                    "timing": f"HIP-event pair around this launch in each of {nsteps - drop} consecutive eagerly issued train steps "
+                              f"(median; {drop} steps dropped), events on the launch stream, includes the event packets' own cost"}
+        if world == 1:
+            out["roofline"]["in_step"] = in_step(dom)
+            if "second" in out["roofline"]:
+                out["roofline"]["second"]["in_step"] = in_step(r9)
 
     # ---- the same step in the exact-fp32 arithmetic (--conv-mode 0), for the record ----
     if rank == 0 and world == 1 and args.conv_mode == 2:

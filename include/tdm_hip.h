@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TDM_VERSION 400
+#define TDM_VERSION 401
 #define TDM_TIMESTEPS 1000
 #define TDM_UNET_NPARAM 181473      /* SimpleUNet(), src/mnist.py:64-74 */
 #define TDM_UNET_NTENSOR 32         /* number of state_dict entries      */
@@ -208,6 +208,12 @@ const char* tdm_unet_launch_name(int id);
 int tdm_unet_replay_launch_f32(const float* params, const float* x_noisy, const int64_t* t, float* eps,
                                float* deps, const float* noise, float* grads, float* ws, float* slabs,
                                int64_t B, int id, void* stream);
+/* In-step timing: after tdm_unet_mark_launch(id, capacity) every EAGERLY issued train step (never during a stream capture)
+ * records a HIP-event pair on the launch stream around launch `id`; tdm_unet_mark_collect waits for the pairs recorded
+ * since the last collect, writes their elapsed microseconds (at most cap) and returns the count (-1 on error).
+ * id < 0 switches the marks off and frees the events.  State is per host thread.                          */
+int tdm_unet_mark_launch(int id, int capacity);
+int tdm_unet_mark_collect(float* us_out, int cap);
 
 /* ---- per-layer entry points (tests / profiling) --------------------------- */
 /* generic NHWC 3x3 (pad 1) or 1x1 convolution as implicit GEMM on fp32 MFMA.

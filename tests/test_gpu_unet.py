@@ -669,3 +669,43 @@ def test_epoch_mode_gathers_inside_the_step_and_equals_the_gather_per_step_loop(
     st = tr.state
     want = M.q_sample(d[perm[3 * B:4 * B]], st.t, st.noise)
     assert torch.equal(st.x_noisy, want)
+
+
+def test_in_step_launch_marks_time_one_launch_of_every_eager_step(dev, conv_mode):
+    """tdm_unet_mark_launch / tdm_unet_mark_collect (bench.py's in-step roofline timing): with marks on launch id k, every
+    eagerly issued train step records one event pair; collect returns one positive duration per step and forgets them; marks
+    change no result (same weights as the unmarked run, bit for bit); id < 0 switches them off; ids out of range are refused."""
+    if conv_mode != 2:
+        pytest.skip("the launch ids describe the default pipeline")
+    import numpy as np
+    from tinydiffusionmodels_amd import _lib, mnist as M
+    L = _lib.lib()
+    B, steps = 16, 6
+    data = M.synthetic_mnist(steps * B, seed=3).to(dev)
+    perm = torch.randperm(data.shape[0], generator=torch.Generator().manual_seed(2)).to(dev)
+    nl = L.tdm_unet_launch_count()
+    lid = next(i for i in range(nl) if L.tdm_unet_launch_name(i).decode().startswith("rb4.conv1 dgrad"))
+    finals = []
+    for marked in (False, True):
+        torch.manual_seed(11)
+        m = M.SimpleUNet().to(dev)
+        tr = M.DDPMTrainer(m, B, lr=1e-3, graph=False)
+        tr.begin_epoch(data, perm)
+        if marked:
+            assert L.tdm_unet_mark_launch(lid, steps + 2) == 0
+        try:
+            tr.steps_epoch(steps)
+            if marked:
+                buf = np.full(steps + 2, -1.0, dtype=np.float32)
+                assert L.tdm_unet_mark_collect(buf.ctypes.data, steps + 2) == steps
+                assert (buf[:steps] > 0).all() and (buf[:steps] < 1e5).all() and (buf[steps:] == -1).all()
+                assert L.tdm_unet_mark_collect(buf.ctypes.data, steps + 2) == 0          # forgotten after a collect
+                tr.steps_epoch(0)
+        finally:
+            assert L.tdm_unet_mark_launch(-1, 0) == 0
+        torch.cuda.synchronize()
+        finals.append(m.flat.detach().clone())
+    assert torch.equal(finals[0], finals[1])
+    assert L.tdm_unet_mark_launch(nl, 4) != 0 and L.tdm_unet_mark_launch(0, 0) != 0
+    buf = np.zeros(4, dtype=np.float32)
+    assert L.tdm_unet_mark_collect(buf.ctypes.data, 4) == 0

@@ -37,6 +37,8 @@ _SIGS = {
     "tdm_unet_launch_count": ([], c_int),
     "tdm_unet_launch_name": ([c_int], ctypes.c_char_p),
     "tdm_unet_replay_launch_f32": ([c_f] * 9 + [c_i64, c_int, c_f], c_int),
+    "tdm_unet_mark_launch": ([c_int, c_int], c_int),
+    "tdm_unet_mark_collect": ([c_f, c_int], c_int),
     "tdm_mse_fwd_bwd_f32": ([c_f, c_f, c_f, c_f, c_f, c_i64, c_f], c_int),
     "tdm_adamw_flat_f32": ([c_f, c_f, c_f, c_f, c_i64, c_float, c_float, c_float, c_float, c_float, c_i64,
                             c_float, c_f], c_int),

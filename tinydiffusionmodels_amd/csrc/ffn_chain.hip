@@ -82,6 +82,14 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 }
 
 // MODE 0: forward, nothing saved (inference, no dropout); 1: forward, hidden S16 + sign masks saved (training); 2: data gradient
+// v ^ K computed where it is used (volatile: never hoisted into a live range across the main loop)
+template <int K>
+__device__ __forceinline__ int xor_now(int v) {
+    int r;
+    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(r) : "n"(K), "v"(v));
+    return r;
+}
+
 template <int NPROD, int MODE>
 __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(ChainArgs a) {
     extern __shared__ float4 chain_smem4[];
@@ -149,14 +157,12 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(ChainArgs a) {
     // ---- DMA plan.  Wa item: one 1 KB row per wave-instruction, physical piece q of row R holds logical piece q ^ fA(R) (low 4
     // bits), fA(R) = 4 (R >> 3) + (R & 3).  Wb item: 8 rows of 128 B per wave-instruction, physical piece q of row R holds
     // logical piece q ^ ((R >> 1) & 7).
-    int voA[DPW], voB[DPW];
-#pragma unroll
-    for (int i = 0; i < DPW; ++i) {
-        const int row = wave * DPW + i;
-        voA[i] = row * (DK * 4) + ((lane ^ (((row >> 3) << 2) | (row & 3))) << 4);
-        const int rb = (wave * DPW + i) * 8 + (lane >> 3);
-        voB[i] = rb * (F * 4) + (((lane & 7) ^ ((rb >> 1) & 7)) << 4);
-    }
+    // ONE address register per stream: the other instructions' offsets are derived at the issue point (row R + i of the Wa item
+    // differs by i KB — a scalar — and by i in the low two bits of the XOR key; 8-row group i of the Wb item by 8 i rows — a
+    // scalar — and by 4 (i & 1) in the key), so six registers stay free for the accumulators
+    static_assert(DPW == 4 && DK == 256, "derived DMA offsets assume 4 instructions per wave and 1 KB Wa rows");
+    const int voA0 = (wave * DPW) * (DK * 4) + ((lane ^ ((wave >> 1) << 2)) << 4);
+    const int voB0 = (wave * DPW * 8 + (lane >> 3)) * (F * 4) + (((lane & 7) ^ (lane >> 4)) << 4);
     // Ring items in CONSUMPTION order (the first product runs one hidden block ahead of the second): q = 0: Wa(0);
     // q = 2 fb + 1: Wa(fb + 1); q = 2 fb + 2: Wb(fb); the last item, q = 2 NFB - 1, is Wb(NFB - 1).  Item q lives in slot q & 3
     // and is requested three items ahead.
@@ -169,12 +175,14 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(ChainArgs a) {
             const int fa = fb0 + (q == 0 ? 0 : fbq + 1);
 #pragma unroll
             for (int i = 0; i < DPW; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, TDM_LDS(dst + i * 1024), 16, voA[i], fa * (32 * DK * 4), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, TDM_LDS(dst + i * 1024), 16, i == 0 ? voA0 : (i == 1 ? xor_now<16>(voA0) : i == 2 ? xor_now<32>(voA0) : xor_now<48>(voA0)),
+                                                         fa * (32 * DK * 4) + i * (DK * 4), 0, 0);
         } else {
             const int fbb = fb0 + (((q - 1) & 1) == 0 ? fbq : (q >> 1) - 1);
 #pragma unroll
             for (int i = 0; i < DPW; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, TDM_LDS(dst + i * 1024), 16, voB[i], fbb * 128, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, TDM_LDS(dst + i * 1024), 16, (i & 1) == 0 ? voB0 : xor_now<64>(voB0),
+                                                         fbb * 128 + i * (8 * F * 4), 0, 0);
         }
     };
 
@@ -346,26 +354,28 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(ChainArgs a) {
         if (qB + 3 < total && fb + 1 < NFB) issue(qB + 3);
         {
             const char* const sb = lds + (qB & (NSLOT - 1)) * SLOT;
-            bf16x8 wh[3], wl[3];       // fragments of output blocks ob, ob + 1, ob + 2 (requested two blocks ahead)
+            // fragments of output blocks ob .. ob + PFD, requested PFD blocks ahead
+            constexpr int PFD = 2, NW = PFD + 1;
+            bf16x8 wh[NW], wl[NW];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < PFD; ++q) {
                 wh[q] = *reinterpret_cast<const bf16x8*>(sb + q * 2048 + offBh);
                 if constexpr (NPROD == 3) wl[q] = *reinterpret_cast<const bf16x8*>(sb + q * 2048 + offBl);
             }
 #pragma unroll
             for (int ob = 0; ob < 16; ++ob) {
-                if (ob + 2 < 16) {
-                    wh[(ob + 2) % 3] = *reinterpret_cast<const bf16x8*>(sb + (ob + 2) * 2048 + offBh);
-                    if constexpr (NPROD == 3) wl[(ob + 2) % 3] = *reinterpret_cast<const bf16x8*>(sb + (ob + 2) * 2048 + offBl);
+                if (ob + PFD < 16) {
+                    wh[(ob + PFD) % NW] = *reinterpret_cast<const bf16x8*>(sb + (ob + PFD) * 2048 + offBh);
+                    if constexpr (NPROD == 3) wl[(ob + PFD) % NW] = *reinterpret_cast<const bf16x8*>(sb + (ob + PFD) * 2048 + offBl);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (abl & 4) { asm volatile("" :: "v"(wh[ob % 3])); }
+                if (abl & 4) { asm volatile("" :: "v"(wh[ob % NW])); }
                 else {
                     if constexpr (NPROD == 3) {
-                        accY[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ob % 3], pl, accY[ob], 0, 0, 0);
-                        accY[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ob % 3], ph, accY[ob], 0, 0, 0);
+                        accY[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ob % NW], pl, accY[ob], 0, 0, 0);
+                        accY[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ob % NW], ph, accY[ob], 0, 0, 0);
                     }
-                    accY[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ob % 3], ph, accY[ob], 0, 0, 0);
+                    accY[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ob % NW], ph, accY[ob], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

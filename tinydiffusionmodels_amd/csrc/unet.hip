@@ -314,9 +314,29 @@ const char* const kLaunchNames[L_COUNT] = {
 #undef X
 };
 thread_local int g_only_launch = -1;   // >= 0: the S16 forward / backward issue only this launch
+// In-step timing of ONE launch id (tdm_unet_mark_launch): while whole steps are issued eagerly, HIP events are recorded on the
+// launch stream around that launch — its duration as it runs inside the step, caches as the step leaves them.
+struct StepMarks {
+    int id = -1;
+    std::vector<hipEvent_t> ev;     // pairs (before, after)
+    size_t used = 0;                // events recorded since the last collect
+};
+thread_local StepMarks g_marks;
+inline bool mark_begin(int id, hipStream_t st) {
+    if (g_marks.id != id || g_marks.used + 2 > g_marks.ev.size()) return false;
+    return hipEventRecord(g_marks.ev[g_marks.used], st) == hipSuccess;
+}
+inline void mark_end(hipStream_t st) {
+    (void)hipEventRecord(g_marks.ev[g_marks.used + 1], st);
+    g_marks.used += 2;
+}
 #define RUN(id, call)                                                   \
     do {                                                                \
-        if (g_only_launch < 0 || g_only_launch == (int)(L_##id)) TDM_TRY(call); \
+        if (g_only_launch < 0 || g_only_launch == (int)(L_##id)) {      \
+            const bool mk_ = mark_begin((int)(L_##id), st);             \
+            TDM_TRY(call);                                              \
+            if (mk_) mark_end(st);                                      \
+        }                                                               \
     } while (0)
 
 int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* eps, const Ws& w, int B, int save,
@@ -755,6 +775,41 @@ int tdm_unet_replay_launch_f32(const float* params, const float* x_noisy, const 
     if (rc == 0) rc = unet_backward_s16(params, x_noisy, noise ? nullptr : deps, grads, w, slabs, (int)B, (hipStream_t)stream, noise ? &mi : nullptr);
     g_only_launch = -1;
     return rc;
+}
+
+// Profiling: from now on every eagerly issued train step records a HIP-event pair around launch `id` (up to `capacity` steps
+// between two collects); id < 0 switches it off and frees the events.  Not for use while a stream is being captured.
+int tdm_unet_mark_launch(int id, int capacity) {
+    TDM_REQUIRE(id < (int)L_COUNT, "mark_launch: id %d out of range", id);
+    TDM_REQUIRE(id < 0 || (capacity > 0 && capacity <= 65536), "mark_launch: capacity %d", capacity);
+    for (hipEvent_t e : g_marks.ev) (void)hipEventDestroy(e);
+    g_marks.ev.clear();
+    g_marks.used = 0;
+    g_marks.id = -1;
+    if (id < 0) return 0;
+    g_marks.ev.resize(2 * (size_t)capacity);
+    for (size_t i = 0; i < g_marks.ev.size(); ++i)
+        if (hipEventCreate(&g_marks.ev[i]) != hipSuccess) {
+            for (size_t j = 0; j < i; ++j) (void)hipEventDestroy(g_marks.ev[j]);
+            g_marks.ev.clear();
+            TDM_REQUIRE(false, "mark_launch: hipEventCreate failed");
+        }
+    g_marks.id = id;
+    return 0;
+}
+// Waits for the recorded pairs, writes their elapsed times in microseconds to us_out (at most cap) and forgets them.
+// Returns the number written, or -1 on error.
+int tdm_unet_mark_collect(float* us_out, int cap) {
+    if (us_out == nullptr || cap < 0) return -1;
+    const size_t n = std::min(g_marks.used / 2, (size_t)cap);
+    for (size_t i = 0; i < n; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_marks.ev[2 * i + 1]) != hipSuccess ||
+            hipEventElapsedTime(&ms, g_marks.ev[2 * i], g_marks.ev[2 * i + 1]) != hipSuccess) return -1;
+        us_out[i] = ms * 1e3f;
+    }
+    g_marks.used = 0;
+    return (int)n;
 }
 
 int tdm_set_conv_mode(int mode) {
