@@ -10,8 +10,9 @@
 
 A "step" is the loop body of src/mnist.py:152-159 on one synthetic 512-image
 batch: draw t and noise, q_sample, UNet forward, MSE, backward, (RCCL
-all-reduce of the flat gradient), AdamW — one hipGraph replay per step (device-side
-Philox draws and AdamW step count; at N > 1: replay + all-reduce + AdamW).  Inputs are
+all-reduce of the flat gradient), AdamW — device-side Philox draws and AdamW step count,
+issued eagerly with the backward's weight-gradient launches on a side stream (--graph: the
+one-queue step as hipGraph replays; at N > 1: replay + all-reduce + AdamW).  Inputs are
 resident in HBM before the timed region.  Rank 0 prints ONE JSON line."""
 import argparse
 import json
@@ -254,7 +255,10 @@ def main():
                          "2 = plain bf16 MFMA, 0 = fp32 MFMA; modes 1 and 2 are both reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-table", action="store_true", help="skip the per-launch replay timing")
-    ap.add_argument("--no-graph", action="store_true", help="issue the train step's launches eagerly instead of one hipGraph replay")
+    ap.add_argument("--graph", action="store_true", help="replay the train step as hipGraphs (one queue) instead of the default eager issue "
+                                                         "with the backward's weight-gradient launches on the library's side stream")
+    ap.add_argument("--no-graph", action="store_true", help="(default now) eager issue of the train step")
+    ap.add_argument("--no-overlap", action="store_true", help="eager issue on ONE queue (tdm_set_bwd_overlap(0))")
     ap.add_argument("--conv-mode", type=int, default=2, choices=[0, 2],
                     help="UNet conv arithmetic: 2 = bf16x3 split MFMA over pre-split tensors (default), 0 = exact fp32 MFMA")
     args = ap.parse_args()
@@ -305,7 +309,9 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     x0 = torch.rand(B_TRAIN, 1, 28, 28, device=dev, generator=gen) * 2 - 1
     torch.manual_seed(4321 + rank)             # rank-distinct t / noise streams (seeds the trainer's Philox key)
-    trainer = DDPMTrainer(model, batch_size=B_TRAIN, lr=1e-3, graph=not args.no_graph)
+    if args.no_overlap:
+        _lib.check(L.tdm_set_bwd_overlap(0))
+    trainer = DDPMTrainer(model, batch_size=B_TRAIN, lr=1e-3, graph=bool(args.graph))
     xin = trainer.batch_buffer(B_TRAIN)        # (the per-launch table below replays single launches on this batch)
     xin.copy_(x0)
     x0 = xin
@@ -373,7 +379,7 @@ def main():
         ss_el = tt.item()
     steady = {"steps": ss_steps, "seconds": round(ss_el, 3), "steps_per_s": round(world * ss_steps / ss_el, 2),
               "ms_per_step": round(1e3 * ss_el / ss_steps, 4),
-              "note": "same hipGraph replay as `value`, run for >= 1 s after it (clock ramp of the short driver window excluded)"}
+              "note": "the same step as `value`, run for >= 1 s after it (clock ramp of the short driver window excluded)"}
 
     # the step's one collective, timed alone (725,892 B per rank per step; ring-equivalent bandwidth)
     allreduce = None
@@ -410,7 +416,9 @@ def main():
                    "batch_per_gpu": B_TRAIN, "global_batch": B_TRAIN * world, "parallelism": f"dp{world}",
                    "step_issue": ((f"hipGraph replays of {DDPMTrainer.EPOCH_UNROLL} consecutive steps (single-step replays for remainders)" if unrolled
                                    else "one hipGraph replay per step") + ("" if trainer._epoch_whole else " + all-reduce + AdamW launches")) if graph_on
-                   else "eager launches from one C-ABI call per step",
+                   else ("eager launches from one C-ABI call per step (+ AdamW), " +
+                         ("the backward's eight weight-gradient launches on the library's side stream next to the data-gradient chain "
+                          "(4 event forks + 1 join per step)" if L.tdm_get_bwd_overlap() else "one queue")),
                    "batch_source": f"gathered inside the step from a {n_data}-image synthetic dataset resident in HBM (device-side permutation per {its_per_epoch}-step epoch)",
                    "collective": dp.collective_name()},
         "images_per_s": round(value * B_TRAIN, 1),
@@ -516,14 +524,15 @@ def main():
         del sts, gscratch
 
         # ---- the same launch timed INSIDE the running step: the timed loop's steps issued eagerly (same launches, same
-        #      order, same stream; 35 launches of host work per ~1 ms of GPU work keep the queue full) with a HIP-event pair
+        #      order, ONE stream; 35 launches of host work per ~1 ms of GPU work keep the queue full) with a HIP-event pair
         #      recorded on the launch stream around that one launch (tdm_unet_mark_launch).  Its inputs are where the step's
         #      previous launches left them (L2 / Infinity Cache), unlike the replay above, which alternates two 1.3 GB
         #      workspaces so that every input comes from HBM; the kernel average of `rocprofv3 --kernel-trace` over the
         #      timed loop (profiles/r04_bench_kernel_summary.txt) is this number. ----
         def in_step(r, nsteps=96, drop=16):
-            was = trainer.use_graph
+            was, was_ov = trainer.use_graph, L.tdm_get_bwd_overlap()
             trainer.use_graph = False
+            _lib.check(L.tdm_set_bwd_overlap(0))      # one queue: the launch alone on the GPU, as in the replay it is compared with
             try:
                 _lib.check(L.tdm_unet_mark_launch(r["id"], nsteps), "mark_launch")
                 run_steps(nsteps)
@@ -532,6 +541,7 @@ def main():
                 assert n == nsteps, n
             finally:
                 L.tdm_unet_mark_launch(-1, 0)
+                L.tdm_set_bwd_overlap(was_ov)
                 trainer.use_graph = was
             us = float(np.median(buf[drop:]))
             kb = next((c for n_, c in ALGO_CH.items() if r["launch"].startswith(n_)), 0) * 4 * 784 * B_TRAIN or r["bytes"]

@@ -303,24 +303,25 @@ def test_native_rccl_world1_allreduce_broadcast_and_graph_capture(dev, L):
 
 
 def test_graph_replayed_training_converges(dev):
-    """Soak of the captured train steps (src/mnist.py:150-160, src/shakespeare.py:228-236 as the trainers run them: device draws,
+    """Soak of the train steps in both issue forms (src/mnist.py:150-160, src/shakespeare.py:228-236 as the trainers run them: device draws,
     MSE backward in the forward's last epilogue, AdamW with its step count on the device): 1500 UNet steps at B = 512 on a
     fixed synthetic image set and 300 denoiser steps on fixed embeddings — losses stay finite and fall far below their start."""
     from tinydiffusionmodels_amd.mnist import SimpleUNet, DDPMTrainer
     from tinydiffusionmodels_amd.shakespeare import TinyTransformer, DenoiserTrainer
-    torch.manual_seed(0)
-    m = SimpleUNet().to(dev)
-    tr = DDPMTrainer(m, batch_size=512, lr=1e-3)
     g = torch.Generator(device=dev).manual_seed(1)
     data = torch.nn.functional.interpolate(torch.rand(2048, 1, 7, 7, device=dev, generator=g), size=28, mode="bilinear") * 2 - 1
-    first = last = None
-    for step in range(1500):
-        loss = tr.step(data[torch.randint(0, 2048, (512,), device=dev, generator=g)])
-        if step == 0:
-            first = loss.item()
-    last = loss.item()
-    assert np.isfinite(first) and np.isfinite(last) and last < 0.1 * first, (first, last)
-    assert torch.isfinite(m.flat).all() and tr.steps_taken == 1500
+    for graph in (True, None):     # hipGraph replays (one queue), then the default: eager issue, weight gradients on the side stream
+        torch.manual_seed(0)
+        m = SimpleUNet().to(dev)
+        tr = DDPMTrainer(m, batch_size=512, lr=1e-3, graph=graph)
+        first = last = None
+        for step in range(1500):
+            loss = tr.step(data[torch.randint(0, 2048, (512,), device=dev, generator=g)])
+            if step == 0:
+                first = loss.item()
+        last = loss.item()
+        assert np.isfinite(first) and np.isfinite(last) and last < 0.1 * first, (graph, first, last)
+        assert torch.isfinite(m.flat).all() and tr.steps_taken == 1500
     t = TinyTransformer(64, dropout=0.1).to(dev)
     t.train()
     tt = DenoiserTrainer(t, 16, 32, lr=1e-3)

@@ -642,15 +642,18 @@ def test_epoch_mode_gathers_inside_the_step_and_equals_the_gather_per_step_loop(
     B = 16
     data = M.synthetic_mnist(5 * B + 3, seed=77)
     finals = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("TDM_EPOCH_GATHER", flag)
-        torch.manual_seed(5)
-        m = M.SimpleUNet().to(dev)
-        M.train(m, str(dev), epochs=2, batch_size=B, lr=1e-3, ckpt_path=str(tmp_path / f"ck{flag}.pth"), sample_every_epoch=False,
-                data=data, log_every=0)
-        torch.cuda.synchronize()
-        finals.append(m.flat.detach().clone())
-    assert torch.equal(finals[0], finals[1])
+    for graph in ("0", "1"):      # the default eager issue (side stream in the backward) and the hipGraph form (TDM_TRAIN_GRAPH=1)
+        monkeypatch.setenv("TDM_TRAIN_GRAPH", graph)
+        for flag in ("1", "0"):
+            monkeypatch.setenv("TDM_EPOCH_GATHER", flag)
+            torch.manual_seed(5)
+            m = M.SimpleUNet().to(dev)
+            M.train(m, str(dev), epochs=2, batch_size=B, lr=1e-3, ckpt_path=str(tmp_path / f"ck{graph}{flag}.pth"), sample_every_epoch=False,
+                    data=data, log_every=0)
+            torch.cuda.synchronize()
+            finals.append(m.flat.detach().clone())
+    monkeypatch.delenv("TDM_TRAIN_GRAPH")
+    assert all(torch.equal(finals[0], f) for f in finals[1:])
     # the epoch position really comes from the device-side step count: a fresh trainer, three steps, then the batch the
     # fourth step would read is perm[3 B : 4 B]
     torch.manual_seed(6)
@@ -709,3 +712,53 @@ def test_in_step_launch_marks_time_one_launch_of_every_eager_step(dev, conv_mode
     assert L.tdm_unet_mark_launch(nl, 4) != 0 and L.tdm_unet_mark_launch(0, 0) != 0
     buf = np.zeros(4, dtype=np.float32)
     assert L.tdm_unet_mark_collect(buf.ctypes.data, 4) == 0
+
+
+def test_backward_overlap_side_stream_is_bit_identical_eager_and_captured(dev, conv_mode):
+    """tdm_set_bwd_overlap: the weight-gradient launches on the library's side stream (fork / join by events; a parallel
+    branch of the graph under capture) give the same weights bit for bit as everything on one stream — eagerly and as
+    graph replays (epoch mode, unrolled graphs included), 9 steps at B = 37 (ragged tiles)."""
+    if conv_mode != 2:
+        pytest.skip("the side stream belongs to the default pipeline")
+    from tinydiffusionmodels_amd import _lib, mnist as M
+    L = _lib.lib()
+    B, steps = 37, 9
+    data = M.synthetic_mnist(steps * B, seed=8).to(dev)
+    perm = torch.randperm(data.shape[0], generator=torch.Generator().manual_seed(4)).to(dev)
+    finals = {}
+    try:
+        for overlap in (0, 1):
+            for graph in (False, True):
+                assert L.tdm_set_bwd_overlap(overlap) == 0 and L.tdm_get_bwd_overlap() == overlap
+                torch.manual_seed(21)
+                m = M.SimpleUNet().to(dev)
+                tr = M.DDPMTrainer(m, B, lr=1e-3, graph=graph)
+                tr.begin_epoch(data, perm)
+                loss = tr.steps_epoch(steps)
+                torch.cuda.synchronize()
+                finals[(overlap, graph)] = (m.flat.detach().clone(), float(loss.item()))
+    finally:
+        L.tdm_set_bwd_overlap(1)
+    ref = finals[(0, False)]
+    for k, v in finals.items():
+        assert torch.equal(v[0], ref[0]) and v[1] == ref[1], k
+    assert L.tdm_set_bwd_overlap(2) != 0
+    # the benchmarked size, eager: twice with the side stream (run-to-run determinism) and once without
+    B, steps = 512, 12
+    data = M.synthetic_mnist(4 * B, seed=9).to(dev)
+    perm = torch.randperm(data.shape[0], generator=torch.Generator().manual_seed(5)).to(dev)
+    big = []
+    try:
+        for overlap in (1, 1, 0):
+            assert L.tdm_set_bwd_overlap(overlap) == 0
+            torch.manual_seed(22)
+            m = M.SimpleUNet().to(dev)
+            tr = M.DDPMTrainer(m, B, lr=1e-3, graph=False)
+            for _ in range(steps // 4):
+                tr.begin_epoch(data, perm)
+                tr.steps_epoch(4)
+            torch.cuda.synchronize()
+            big.append(m.flat.detach().clone())
+    finally:
+        L.tdm_set_bwd_overlap(1)
+    assert torch.equal(big[0], big[1]) and torch.equal(big[0], big[2])

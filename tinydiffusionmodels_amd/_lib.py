@@ -47,6 +47,8 @@ _SIGS = {
     "tdm_conv_nhwc_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int, c_int, c_f], c_int),
     "tdm_conv_wgrad_nhwc_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int, c_f], c_int),
     "tdm_set_conv_mode": ([c_int], c_int),
+    "tdm_set_bwd_overlap": ([c_int], c_int),
+    "tdm_get_bwd_overlap": ([], c_int),
     "tdm_get_conv_mode": ([], c_int),
     "tdm_conv_nhwc_s16_f32": ([c_f] * 10 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_f], c_int),
     "tdm_conv_wgrad_nhwc_s16_f32": ([c_f] * 5 + [c_i64, c_int, c_int, c_int, c_int, c_f], c_int),

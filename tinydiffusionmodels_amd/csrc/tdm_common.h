@@ -35,6 +35,15 @@ void tdm_set_error(const char* fmt, ...);
 #define TDM_DIAG_BUILD 0
 #endif
 
+#define TDM_HIP(expr)                                                              \
+    do {                                                                           \
+        hipError_t e__ = (expr);                                                   \
+        if (e__ != hipSuccess) {                                                   \
+            tdm_set_error("%s: %s", #expr, hipGetErrorString(e__));                \
+            return 100 + (int)e__;                                                 \
+        }                                                                          \
+    } while (0)
+
 #define TDM_TRY(expr)               \
     do {                            \
         int rc__ = (expr);          \

@@ -330,14 +330,50 @@ inline void mark_end(hipStream_t st) {
     (void)hipEventRecord(g_marks.ev[g_marks.used + 1], st);
     g_marks.used += 2;
 }
-#define RUN(id, call)                                                   \
+#define RUN_ON(stream, id, call)                                        \
     do {                                                                \
         if (g_only_launch < 0 || g_only_launch == (int)(L_##id)) {      \
-            const bool mk_ = mark_begin((int)(L_##id), st);             \
+            const bool mk_ = mark_begin((int)(L_##id), stream);         \
             TDM_TRY(call);                                              \
-            if (mk_) mark_end(st);                                      \
+            if (mk_) mark_end(stream);                                  \
         }                                                               \
     } while (0)
+#define RUN(id, call) RUN_ON(st, id, call)
+
+// The backward's second launch queue (tdm_set_bwd_overlap): a weight-gradient launch depends on the gradient tensor the main
+// chain has just produced and on saved activations, never on the data-gradient launch that follows it, and nothing but the
+// final slab reduction reads what it writes (the workspace gives every tensor its own buffer).  Issued on a side stream behind
+// an event, it runs NEXT TO the data-gradient launches that follow: the tail round of one kernel (1568 tiles on 512 slots) and
+// the idle SIMDs of a 256-workgroup weight-gradient launch are filled by the other.  Fork / join are event record + stream wait, so a
+// stream capture takes the side stream in as a parallel branch of the same graph.  Measured (tools/step_modes.py, one box, ms per
+// step, B = 64 / 256 / 512): eager launches with the side queue 0.350 / 0.579 / 0.938 against 0.384 / 0.645 / 0.993 without
+// (hipGraph replays of the one-queue step: the same 0.384 / 0.645 / 0.993); the forked step REPLAYED AS A GRAPH is slower than
+// the one-queue graph (0.401 / 0.660 / 1.000: ROCm's graph executor pays more per cross-branch edge than the overlap returns),
+// and a second side queue is slower than one (0.403 / 0.639 / 0.958).
+// One rule found the hard way (text backward, where the same scheme needs main-waits-for-side edges because gradient buffers
+// are reused layer after layer): on this ROCm a hipStreamWaitEvent issued on a stream DIRECTLY after a hipEventRecord on the
+// same stream — kernel A, record, wait, kernel B — lets B read stale copies of what A wrote (last-bit-level differences from a
+// few stale lines, different from run to run; gone as soon as the wait is moved in front of A).  Here the main stream only
+// ever records (forks) and waits once, after a kernel (the join); the side stream's writes are read by nobody but the final
+// reduction.  tools/contention_check.py and the bitwise on / off tests at B = 37 ... 1000 guard the arrangement.  For the text
+// backward the scheme returned nothing at B = 256 (3.77 -> 3.76 ms) and 4-5 % at B = 32 / 64, and was not kept.
+struct SideLane {
+    hipStream_t side = nullptr;
+    hipEvent_t ready[4] = {}, done = nullptr;
+    bool ok = false;
+    bool init() {
+        if (ok) return true;
+        // events that only order two queues of this device: no timing, no system-scope fence (6 us per step at B = 512)
+        const unsigned flags = hipEventDisableTiming | hipEventDisableSystemFence;
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return false;
+        for (hipEvent_t& e : ready)
+            if (hipEventCreateWithFlags(&e, flags) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&done, flags) != hipSuccess) return false;
+        return ok = true;
+    }
+};
+thread_local SideLane g_lane;
+thread_local int g_bwd_overlap = 1;   // a selector like the arithmetic modes: per calling thread
 
 int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* eps, const Ws& w, int B, int save,
                      hipStream_t st, const MseIn* mse) {
@@ -421,6 +457,18 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     const long NP = SLAB_STRIDE;
     float* const es = slabs + ESLAB_BASE;
     TDM_REQUIRE(deps != nullptr || mse != nullptr, "unet_backward: no output gradient");
+    // weight-gradient launches go to the side queue (above) unless one launch is being replayed alone
+    const bool lane = g_bwd_overlap != 0 && g_only_launch < 0;
+    if (lane) TDM_REQUIRE(g_lane.init(), "unet_backward: side stream / events could not be created");
+    const hipStream_t ss = lane ? g_lane.side : st;
+    int nfork = 0;
+    auto fork = [&]() -> int {   // what the main chain has issued so far is what the side queue's next launches may read
+        if (!lane) return 0;
+        hipEvent_t e = g_lane.ready[nfork++ & 3];
+        TDM_HIP(hipEventRecord(e, st));
+        TDM_HIP(hipStreamWaitEvent(ss, e, 0));
+        return 0;
+    };
     // ---- out conv + rb4 ----  (dout4 = d x w_out is rank one and never written: out_bwd_s16_kernel's header)
     const float* const dvec = deps ? deps : mse->deps_out;   // d(loss)/d(eps), [M]
     TDM_REQUIRE(dvec != nullptr, "unet_backward: the fused MSE form needs a deps buffer");
@@ -433,11 +481,14 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
         RUN(B_OUT_BWD, tdm_launch_out_bwd_s16(deps, w.h4, P + kL.outw, w.m2[3], w.h1s, w.h3s, w.dc2s_4, es, ESTRIDE, E_OUT,
                                               E_OUT + 32, E_C2B4, E_SKB4, E_VSK, M28, ER28, st, deps ? nullptr : mse->eps,
                                               deps ? nullptr : mse->noise, deps ? nullptr : mse->deps_out, deps ? -1 : E_LOSS));
-    RUN(B_WG_RB4C2, wgrad_s16(st, 28, B, w.a1s_4, 32, 32, 0, 9, w.dc2s_4, 32, slabs, r4.c2w, 32, 0, NS));
     RUN(B_DG_RB4C2, conv_s16_1(st, w, 28, B, w.dc2s_4, 32, 9, kPack.dg[W_RB4C2], 32, nullptr, 0,
                                S16Out{nullptr, nullptr, nullptr, w.dh4s, nullptr, w.m1[3], w.gs[3]}));   // + ReLU backward of a1
-    RUN(B_WG_RB4C1A, wgrad_s16(st, 28, B, w.h3s, 64, 64, 1, 9, w.dh4s, 32, slabs, r4.c1w, 96, 0, NS));
-    RUN(B_WG_RB4C1B, wgrad_s16(st, 28, B, w.h1s, 32, 32, 0, 9, w.dh4s, 32, slabs, r4.c1w, 96, 64, NS));
+    // (a fork costs the main queue ~7 us — the event's marker packet drains it — so the eight weight-gradient launches go over
+    //  in FOUR groups, each behind the launch that produced the last of its operands)
+    TDM_TRY(fork());
+    RUN_ON(ss, B_WG_RB4C2, wgrad_s16(ss, 28, B, w.a1s_4, 32, 32, 0, 9, w.dc2s_4, 32, slabs, r4.c2w, 32, 0, NS));
+    RUN_ON(ss, B_WG_RB4C1A, wgrad_s16(ss, 28, B, w.h3s, 64, 64, 1, 9, w.dh4s, 32, slabs, r4.c1w, 96, 0, NS));
+    RUN_ON(ss, B_WG_RB4C1B, wgrad_s16(ss, 28, B, w.h1s, 32, 32, 0, 9, w.dh4s, 32, slabs, r4.c1w, 96, 64, NS));
     {   // d cat = conv1's transposed conv of dh4 (+ the skip path's rank-one share, added in the epilogue)
         ConvArgs a{};
         a.nsrc = 1;
@@ -448,18 +499,20 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     }
     // ---- rb3 ---- (upsample backward and the ReLU mask of rb3.conv2's output in one pass)
     RUN(B_SPLIT_DCAT, tdm_launch_split_dcat_mask_s16(dc_pair, w.m2[2], w.dout3, w.dc2s_3, es, ESTRIDE, E_C2B3, B, ER14, st));
-    RUN(B_WG_RB3C2, wgrad_s16(st, 14, B, w.a1s_3, 64, 64, 0, 9, w.dc2s_3, 64, slabs, r3.c2w, 64, 0, NS4));
     RUN(B_DG_RB3C2, conv_s16_1(st, w, 14, B, w.dc2s_3, 64, 9, kPack.dg[W_RB3C2], 64, nullptr, 0,
                                S16Out{nullptr, nullptr, nullptr, w.dh3s, nullptr, w.m1[2], w.gs[2]}));
-    RUN(B_WG_RB3C1, wgrad_s16(st, 14, B, w.h2s, 64, 64, 0, 9, w.dh3s, 64, slabs, r3.c1w, 64, 0, NS4));
+    TDM_TRY(fork());
+    RUN_ON(ss, B_WG_RB3C2, wgrad_s16(ss, 14, B, w.a1s_3, 64, 64, 0, 9, w.dc2s_3, 64, slabs, r3.c2w, 64, 0, NS4));
+    RUN_ON(ss, B_WG_RB3C1, wgrad_s16(ss, 14, B, w.h2s, 64, 64, 0, 9, w.dh3s, 64, slabs, r3.c1w, 64, 0, NS4));
     RUN(B_DG_RB3C1, conv_s16_1(st, w, 14, B, w.dh3s, 64, 9, kPack.dg[W_RB3C1], 64, nullptr, 0,
                                S16Out{w.dout2, nullptr, w.dout3, w.dout2s, nullptr}));   // + identity skip
     // ---- rb2 ----
     RUN(B_RELU_MASK2, tdm_launch_relu_mask_s16(w.dout2, w.m2[1], w.dc2s_2, es, ESTRIDE, E_C2B2, E_SKB2, M14, 64, ER14, st));
-    RUN(B_WG_RB2C2, wgrad_s16(st, 14, B, w.a1s_2, 64, 64, 0, 9, w.dc2s_2, 64, slabs, r2.c2w, 64, 0, NS4));
     RUN(B_DG_RB2C2, conv_s16_1(st, w, 14, B, w.dc2s_2, 64, 9, kPack.dg[W_RB2C2], 64, nullptr, 0,
                                S16Out{nullptr, nullptr, nullptr, w.dh2s, nullptr, w.m1[1], w.gs[1]}));
-    RUN(B_WG_RB2C1, wgrad_s16(st, 14, B, w.p1s, 32, 32, 0, 9, w.dh2s, 64, slabs, r2.c1w, 32, 0, NS2, w.dout2s, r2.skw));   // + rb2.skip
+    TDM_TRY(fork());
+    RUN_ON(ss, B_WG_RB2C2, wgrad_s16(ss, 14, B, w.a1s_2, 64, 64, 0, 9, w.dc2s_2, 64, slabs, r2.c2w, 64, 0, NS4));
+    RUN_ON(ss, B_WG_RB2C1, wgrad_s16(ss, 14, B, w.p1s, 32, 32, 0, 9, w.dh2s, 64, slabs, r2.c1w, 32, 0, NS2, w.dout2s, r2.skw));   // + rb2.skip
     {
         ConvArgs a{};
         a.nsrc = 2;
@@ -473,7 +526,8 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     //  dout1 is in registers — the fp32 tensor itself is never written)
     RUN(B_COMBINE_DH1, tdm_launch_combine_dh1_mask_s16(dc_h1, w.dp1, w.m2[0], nullptr, w.dc2s_1, es, ESTRIDE, E_C2B1, B, ER28, st,
                                                        x, E_SKW1, E_SKB1));
-    RUN(B_WG_RB1C2, wgrad_s16(st, 28, B, w.a1s_1, 32, 32, 0, 9, w.dc2s_1, 32, slabs, r1.c2w, 32, 0, NS));
+    TDM_TRY(fork());
+    RUN_ON(ss, B_WG_RB1C2, wgrad_s16(ss, 28, B, w.a1s_1, 32, 32, 0, 9, w.dc2s_1, 32, slabs, r1.c2w, 32, 0, NS));
     RUN(B_DG_RB1C2, conv_s16_1(st, w, 28, B, w.dc2s_1, 32, 9, kPack.dg[W_RB1C2], 32, nullptr, 0,
                                S16Out{w.dh1, nullptr, nullptr, nullptr, nullptr, w.m1[0], w.gs[0]}));   // dh1 <- masked, fp32 (rb1.conv1 wgrad)
     {   // time_emb gradients of all four blocks + conv1 bias gradients of rb2..rb4 as partial rows, one launch
@@ -510,6 +564,10 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
         ra.sec[n - 1].dst = mse->loss_out; ra.sec[n - 1].scale = 1.0f / (float)M28;
     }
     ra.nsec = n;
+    if (lane) {   // join: the reduction reads every slab
+        TDM_HIP(hipEventRecord(g_lane.done, ss));
+        TDM_HIP(hipStreamWaitEvent(st, g_lane.done, 0));
+    }
     RUN(B_REDUCE, tdm_launch_reduce(slabs, NP, ra, G, st));
     return 0;
 }
@@ -819,6 +877,14 @@ int tdm_set_conv_mode(int mode) {
     return 0;
 }
 int tdm_get_conv_mode(void) { return g_conv_mode; }
+// 1 (default): the train step's weight-gradient launches run on the library's side stream next to the data-gradient chain
+// (same results bit for bit: same kernels on the same buffers); 0: every launch on the caller's stream, in program order.
+int tdm_set_bwd_overlap(int on) {
+    TDM_REQUIRE(on == 0 || on == 1, "backward overlap %d (0 or 1)", on);
+    g_bwd_overlap = on;
+    return 0;
+}
+int tdm_get_bwd_overlap(void) { return g_bwd_overlap; }
 
 // generic conv through the S16 pipeline: the fp32 input (+tb) is pre-split into scratch, then conv_s16 runs.
 // scratch >= ksize^2*Cin*Cout + B*HW*HW*Cin floats.  out_s16 (optional) receives split(result + tb_out).

@@ -488,10 +488,14 @@ class DDPMTrainer(DPStepper):
     (data-parallel: one RCCL all-reduce of the flat 726 KB gradient), AdamW
     with torch defaults (lr passed, betas (0.9,0.999), eps 1e-8, wd 0.01).
 
-    With t / noise left to the trainer the whole step is ONE hipGraph replay: the draws come from a
-    device-side Philox stream, AdamW's step count lives in device memory, nothing is written by the host
-    (`graph=False` or TDM_TRAIN_GRAPH=0 runs the same launches eagerly).  At world > 1 the graph ends before
-    the collective (replay, all-reduce, AdamW = three host calls per step; the default) unless dp.graph_collective_ok():
+    With t / noise left to the trainer nothing in a step is written by the host: the draws come from a device-side
+    Philox stream, AdamW's step count lives in device memory.  The step's launches are issued EAGERLY by default (one C-ABI
+    call + the optimiser's), with the backward's weight-gradient launches on the library's side stream next to the data-
+    gradient chain (tdm_set_bwd_overlap; TDM_BWD_OVERLAP=0 keeps one queue): 5-10 % faster than the one-queue step at every
+    batch size from 25 to 1024, while the same step replayed as ONE hipGraph (`graph=True` or TDM_TRAIN_GRAPH=1; captured
+    with one queue, the forked graph replays slower) only ties the one-queue eager issue — the host is 2x ahead of the GPU
+    even at B = 25.  At world > 1 the graph form ends before
+    the collective (replay, all-reduce, AdamW = three host calls per step) unless dp.graph_collective_ok():
     opt-in (TDM_GRAPH_COLLECTIVE=1, or =auto for a capture / replay / compare self-check of the native RCCL all-reduce
     that every rank must pass) — then the all-reduce and AdamW are captured too and a step is ONE host call at any
     world size; unverified on hardware, hence not the default.  Explicit t / noise (teacher forcing, parity tests) run eagerly.
@@ -514,7 +518,9 @@ class DDPMTrainer(DPStepper):
         self.rng_state = torch.zeros(2, dtype=torch.long, device=dev)      # {Philox stream offset, scratch}
         # rank-distinct draw streams: a seed from torch's generator (so torch.manual_seed governs it) mixed with the rank
         self.seed = (int(torch.randint(0, 2 ** 62, (1,)).item()) ^ (self.rank * 0x9E3779B97F4A7C15)) & (2 ** 64 - 1)
-        self.use_graph = (os.environ.get("TDM_TRAIN_GRAPH", "1") != "0") if graph is None else bool(graph)
+        self.use_graph = (os.environ.get("TDM_TRAIN_GRAPH", "0") == "1") if graph is None else bool(graph)
+        if os.environ.get("TDM_BWD_OVERLAP") in ("0", "1"):     # weight-gradient launches next to the data-gradient chain (default on)
+            _lib.check(_lib.lib().tdm_set_bwd_overlap(int(os.environ["TDM_BWD_OVERLAP"])), "tdm_set_bwd_overlap")
         self._states = {}
         self._cur = self._state(batch_size)
         # epoch mode (begin_epoch / step_epoch): dataset and permutation resident on the device, the batch gathered inside the step
@@ -567,10 +573,22 @@ class DDPMTrainer(DPStepper):
                          self.weight_decay, grad_scale=grad_scale)
 
     # ---- the hipGraph form of step() ----
+    @staticmethod
+    @contextmanager
+    def _one_queue():
+        """Captures take the one-queue backward: the forked step replays slower as a graph than the plain one (unet.hip, SideLane)."""
+        L = _lib.lib()
+        was = L.tdm_get_bwd_overlap()
+        _lib.check(L.tdm_set_bwd_overlap(0), "tdm_set_bwd_overlap")
+        try:
+            yield
+        finally:
+            _lib.check(L.tdm_set_bwd_overlap(was), "tdm_set_bwd_overlap")
+
     def _capture(self, st: "E.TrainState") -> None:
         whole = self.world == 1 or dp.graph_collective_ok()      # (collective: every rank reaches this at its second step)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        with self._one_queue(), torch.cuda.graph(g, capture_error_mode="thread_local"):
             E.loss_and_grad_philox(self.flat, st, st.x0, self.seed, self.rng_state)
             if whole:
                 scale = dp.allreduce_grads_(self.grads)
@@ -627,7 +645,7 @@ class DDPMTrainer(DPStepper):
         if self._epoch_graph is None or self._epoch_key != key:
             whole = self.world == 1 or dp.graph_collective_ok()
             g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+            with self._one_queue(), torch.cuda.graph(g1, capture_error_mode="thread_local"):
                 self._epoch_launch(st)
                 if whole:
                     self.optimizer_step(dp.allreduce_grads_(self.grads))
@@ -636,7 +654,7 @@ class DDPMTrainer(DPStepper):
                 # consecutive steps in ONE replay: the ~20 us between two graph launches (the queue's end-of-graph / start-of-
                 # graph handshake) is paid once per EPOCH_UNROLL steps
                 gn = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gn, capture_error_mode="thread_local"):
+                with self._one_queue(), torch.cuda.graph(gn, capture_error_mode="thread_local"):
                     for _ in range(self.EPOCH_UNROLL):
                         self._epoch_launch(st)
                         self.optimizer_step(dp.allreduce_grads_(self.grads))
