@@ -12,8 +12,12 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python bench.py --steps 50 --warmup 10 --sample-steps 20 --sample-chains 0 --text-steps 5 --no-cpu-baseline > $O/prof_bench.log 2>&1
 f=$(ls $O/prof_bench/*/*kernel_trace.csv | head -1)
 python tools/prof_summary.py $f > $O/bench_kernel_summary.txt; head -12 $O/bench_kernel_summary.txt
-python tools/step_timeline.py $f > $O/step_timeline.txt; tail -2 $O/step_timeline.txt
+python tools/step_overlap.py $f > $O/step_overlap.txt; tail -2 $O/step_overlap.txt       # the default step: two queues in the backward
 cp $(ls $O/prof_bench/*/*kernel_stats.csv | head -1) $O/bench_kernel_stats.csv
+# the same step on ONE queue (--no-overlap): every launch in order, durations without a co-running kernel
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/prof_seq -- python bench.py --steps 50 --warmup 10 --sample-steps 0 --text-steps 0 --no-cpu-baseline --no-launch-table --no-overlap > $O/prof_seq.log 2>&1
+python tools/step_timeline.py $(ls $O/prof_seq/*/*kernel_trace.csv | head -1) > $O/step_timeline.txt; tail -2 $O/step_timeline.txt
+rm -rf $O/prof_seq
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/pmc/trace -- python tools/pmc_replay.py --iters 21 --ids $IDS --names-out $O/launch_names.json > $O/pmc_trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc/$c -- python tools/pmc_replay.py --iters 5 --ids $IDS > $O/pmc_$c.log 2>&1; done
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc/SQ -- python tools/pmc_replay.py --iters 5 --ids $IDS > $O/pmc_SQ.log 2>&1
