@@ -8,8 +8,13 @@
  *
  * Conventions
  *  - every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm
- *    allocates); the library never allocates, frees or synchronises, so every
- *    call is hipGraph-capturable;
+ *    allocates); the library never allocates, frees or synchronises device
+ *    memory or the caller's stream, so every call is hipGraph-capturable; the
+ *    only device-side objects it owns are, per host thread and created on
+ *    first use, ONE side stream and a handful of events (tdm_set_bwd_overlap):
+ *    work it puts there is forked from and joined back into the caller's
+ *    stream by events inside the same call, so for the caller every effect of
+ *    a call is ordered on the stream it passed;
  *  - `stream` is a hipStream_t passed as void*;
  *  - return 0 on success, non-zero on error; tdm_last_error() gives the text;
  *  - activations inside the library are NHWC fp32; the UNet input/output
