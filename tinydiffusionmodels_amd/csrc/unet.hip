@@ -350,13 +350,16 @@ inline void mark_end(hipStream_t st) {
 // (hipGraph replays of the one-queue step: the same 0.384 / 0.645 / 0.993); the forked step REPLAYED AS A GRAPH is slower than
 // the one-queue graph (0.401 / 0.660 / 1.000: ROCm's graph executor pays more per cross-branch edge than the overlap returns),
 // and a second side queue is slower than one (0.403 / 0.639 / 0.958).
-// One rule found the hard way (text backward, where the same scheme needs main-waits-for-side edges because gradient buffers
-// are reused layer after layer): on this ROCm a hipStreamWaitEvent issued on a stream DIRECTLY after a hipEventRecord on the
-// same stream — kernel A, record, wait, kernel B — lets B read stale copies of what A wrote (last-bit-level differences from a
-// few stale lines, different from run to run; gone as soon as the wait is moved in front of A).  Here the main stream only
-// ever records (forks) and waits once, after a kernel (the join); the side stream's writes are read by nobody but the final
-// reduction.  tools/contention_check.py and the bitwise on / off tests at B = 37 ... 1000 guard the arrangement.  For the text
-// backward the scheme returned nothing at B = 256 (3.77 -> 3.76 ms) and 4-5 % at B = 32 / 64, and was not kept.
+// The same scheme was tried on the TEXT backward (weight-gradient GEMMs behind the FFN chain / the attention backward) and NOT kept:
+// nothing at B = 256 (3.77 -> 3.76 ms), 4-5 % at B = 32 / 64 — and its results differed from the one-queue step in the last bits,
+// intermittently and from run to run, in both arrangements tried.  That backward reuses its gradient buffers layer after layer and
+// therefore needs main-waits-for-side edges in the middle of the stream; one arrangement stopped differing when a
+// hipStreamWaitEvent directly behind a hipEventRecord on the same stream (kernel A, record, wait, kernel B: B saw stale copies of
+// a few of A's lines) was moved, the other had no such sequence and still differed at B = 256.  The cause was not found.  Here
+// every tensor has its own buffer, the main stream only records (forks) and waits once (the join), no side kernel reads what
+// another side kernel wrote — and the two-queue step is held against the one-queue step bit for bit: the GPU tests at B = 37 and
+// 512, tools/overlap_bitwise.py over 200 steps at B = 1 ... 512 (small sizes keep whole tensors in L2 from step to step),
+// tools/contention_check.py with a foreign kernel stream next to the step.
 struct SideLane {
     hipStream_t side = nullptr;
     hipEvent_t ready[4] = {}, done = nullptr;
