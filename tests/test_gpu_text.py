@@ -1201,3 +1201,70 @@ def test_text_cli_train_then_sample_end_to_end(dev, gemm_mode, tmp_path, monkeyp
     texts = S.main(["--sample", "--byte_tokenizer", "--embed_dim", "32", "--n", "2", "--seq_len", "16", "--ckpt", ckpt, "--seed", "1"])
     assert len(texts) == 2 and all(isinstance(t, str) for t in texts)
     assert (tmp_path / "samples" / "sample_0.txt").exists() and (tmp_path / "samples" / "sample_1.txt").exists()
+
+
+def test_text_launches_keep_their_bits_next_to_a_foreign_kernel_stream(dev):
+    """Bit stability under concurrency: the LayerNorm backward and a whole denoiser train step give the same bits while a side
+    stream runs the library's own token-major GEMMs on unrelated buffers as when the GPU is quiet.  (Built WITH clang's SLP
+    vectoriser, the LayerNorm backward's packed-fp32 code returned a few rows off by 1e-4 relative whenever another kernel stream
+    competed for the GPU — tinydiffusionmodels_amd/build.py carries -fno-slp-vectorize because of this test.)"""
+    from tinydiffusionmodels_amd import _lib, transformer_engine as TE
+    from tinydiffusionmodels_amd.shakespeare import TinyTransformer, DenoiserTrainer
+    L = _lib.lib()
+    g = torch.Generator(device=dev).manual_seed(1)
+    Ms = 32768
+    with _lib.use_arithmetic((_lib.arithmetic()[0], 1, _lib.arithmetic()[2])):
+        def s16(t):
+            o = torch.empty_like(t)
+            _lib.check(L.tdm_split_s16_f32(_lib.ptr(t), _lib.ptr(o), t.numel(), _lib.stream()), "split")
+            return o
+        dy16 = s16(torch.randn(Ms, 2048, device=dev, generator=g) * 0.01)
+        x16 = s16(torch.randn(Ms, 256, device=dev, generator=g))
+        slab = torch.empty(8, 2048, 256, device=dev)
+        side = torch.cuda.Stream()
+
+        def run(fn, n):
+            side.wait_stream(torch.cuda.current_stream())
+            if n:
+                with torch.cuda.stream(side):
+                    for _ in range(n):
+                        _lib.check(L.tdm_gemm_f32(_lib.ptr(dy16), 1, 2048, _lib.ptr(x16), 256, 1, _lib.ptr(slab), 256, None, None, 2048, 256, Ms, 2, 8,
+                                                  2048 * 256, side.cuda_stream), "tn gemm")
+            fn()
+            torch.cuda.synchronize()
+        # LayerNorm backward alone
+        M, D = 32768, 256
+        dy = torch.randn(M, D, device=dev, generator=g)
+        s = torch.randn(M, D, device=dev, generator=g)
+        mean = s.mean(1).contiguous()
+        rstd = (1.0 / torch.sqrt(s.var(1, unbiased=False) + 1e-5)).contiguous()
+        gamma = torch.randn(D, device=dev, generator=g)
+        ds, dgb = torch.empty(M, D, device=dev), torch.empty(2, D, device=dev)
+        scratch = torch.empty(L.tdm_layernorm_scratch_floats(D), device=dev)
+
+        def ln():
+            _lib.check(L.tdm_layernorm_residual_bwd_f32(_lib.ptr(dy), _lib.ptr(s), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(ds),
+                                                        _lib.ptr(dgb), _lib.ptr(scratch), M, D, _lib.stream()), "ln_bwd")
+        run(ln, 0)
+        ref = (ds.clone(), dgb.clone())
+        for _ in range(3):
+            ds.zero_()
+            run(ln, 6)
+            assert torch.equal(ds, ref[0]) and torch.equal(dgb, ref[1])
+        # a whole denoiser train step (64 x 128 tokens, dropout 0.1, same draws each time)
+        torch.manual_seed(0)
+        tm = TinyTransformer(256, dropout=0.1).to(dev)
+        tm.train()
+        ttr = DenoiserTrainer(tm, 64, 128, lr=1e-4, weight_decay=1e-4, graph=False)
+        x = torch.randn(64, 128, 256, device=dev, generator=g) * 0.02
+        st = ttr.state
+        rng0 = ttr.rng_state.clone()
+
+        def step():
+            ttr.rng_state.copy_(rng0)
+            TE.tt_loss_and_grad_philox(ttr.flat, st, x, ttr.seed, ttr.rng_state, p_drop=0.1, drop_seed=ttr.drop_seed)
+        run(step, 0)
+        gref = st.grads.clone()
+        for _ in range(3):
+            run(step, 10)
+            assert torch.equal(st.grads, gref)

@@ -19,7 +19,13 @@ CFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", INCLUDE,
           "-Wno-unused-result", "-DNDEBUG",
           # HIP defaults to -ffp-contract=fast; the bit-exact elementwise kernels (q_sample, p_sample update,
           # AdamW) must round every mul/add separately like the reference's ATen ops. FMAs are explicit (fmaf).
-          "-ffp-contract=off"]
+          "-ffp-contract=off",
+          # No SLP vectorisation: on gfx950 / ROCm 7.2 the packed-fp32 code it produced for the LayerNorm backward (v_pk_mul_f32 /
+          # v_pk_add_f32 over freshly loaded register pairs) gave DIFFERENT results whenever another kernel stream competed for
+          # the GPU — a few rows off by 1e-4 relative, different from run to run (tools/contention_ops.py; quiet runs were always
+          # right).  Without it every launch is bit-stable next to foreign work, results are unchanged bit for bit, and the
+          # guide's measurement (packed f32 VALU beside MFMAs is an anti-lever) says nothing is lost.
+          "-fno-slp-vectorize"]
 # TDM_BUILD_DEFINES="-DTDM_DIAG": the diagnostic build (runtime ablation bits / phase probes in the hot kernels, tools/ only)
 CFLAGS += os.environ.get("TDM_BUILD_DEFINES", "").split()
 

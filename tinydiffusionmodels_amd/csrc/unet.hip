@@ -350,16 +350,13 @@ inline void mark_end(hipStream_t st) {
 // (hipGraph replays of the one-queue step: the same 0.384 / 0.645 / 0.993); the forked step REPLAYED AS A GRAPH is slower than
 // the one-queue graph (0.401 / 0.660 / 1.000: ROCm's graph executor pays more per cross-branch edge than the overlap returns),
 // and a second side queue is slower than one (0.403 / 0.639 / 0.958).
-// The same scheme was tried on the TEXT backward (weight-gradient GEMMs behind the FFN chain / the attention backward) and NOT kept:
-// nothing at B = 256 (3.77 -> 3.76 ms), 4-5 % at B = 32 / 64 — and its results differed from the one-queue step in the last bits,
-// intermittently and from run to run, in both arrangements tried.  That backward reuses its gradient buffers layer after layer and
-// therefore needs main-waits-for-side edges in the middle of the stream; one arrangement stopped differing when a
-// hipStreamWaitEvent directly behind a hipEventRecord on the same stream (kernel A, record, wait, kernel B: B saw stale copies of
-// a few of A's lines) was moved, the other had no such sequence and still differed at B = 256.  The cause was not found.  Here
-// every tensor has its own buffer, the main stream only records (forks) and waits once (the join), no side kernel reads what
-// another side kernel wrote — and the two-queue step is held against the one-queue step bit for bit: the GPU tests at B = 37 and
-// 512, tools/overlap_bitwise.py over 200 steps at B = 1 ... 512 (small sizes keep whole tensors in L2 from step to step),
-// tools/contention_check.py with a foreign kernel stream next to the step.
+// The same scheme was tried on the TEXT backward (weight-gradient GEMMs behind the FFN chain / the attention backward) and not
+// kept: nothing at B = 256 (3.77 -> 3.76 ms), 4-5 % at B = 32 / 64 only.  Its results differed from the one-queue step in a
+// few rows, intermittently — which turned out to have nothing to do with queues or events: built with clang's SLP vectoriser the
+// LayerNorm backward's packed-fp32 code gives different results whenever ANY other kernel stream competes for the GPU
+// (tools/contention_ops.py; build.py now passes -fno-slp-vectorize, results unchanged bit for bit, speed unchanged).  The two-queue
+// step is held against the one-queue step bit for bit: the GPU tests at B = 37 and 512, tools/overlap_bitwise.py over 200 steps at
+// B = 1 ... 512 and 3,000 steps at four sizes, tools/contention_check.py / contention_tn.py with foreign kernel streams.
 struct SideLane {
     hipStream_t side = nullptr;
     hipEvent_t ready[4] = {}, done = nullptr;
