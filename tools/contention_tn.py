@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Text denoiser step next to a side stream of the library's OWN token-major (weight-gradient) GEMMs on unrelated buffers:
+"""Text denoiser step (and the UNet step) next to a side stream of the library's OWN token-major (weight-gradient) GEMMs on unrelated buffers:
 gradients compared bit for bit with the quiet step.  python tools/contention_tn.py [--B 256] [--reps 4]"""
 import argparse
 import os
@@ -60,6 +60,29 @@ def main():
         torch.cuda.synchronize()
         d = (ref - s.grads).abs().max().item()
         print(f"B={B} rep {r}: step grads equal next to TN GEMMs: {torch.equal(ref, s.grads)} (max diff {d:.2e}); side GEMM result equal: {torch.equal(sref, slab)}", flush=True)
+    # the UNet train step (B = 512, one and two queues in the backward) next to the same side work
+    from tinydiffusionmodels_amd import mnist as MN, unet_engine as E
+    for ov in (0, 1):
+        _lib.check(L.tdm_set_bwd_overlap(ov))
+        torch.manual_seed(0)
+        m = MN.SimpleUNet().to(dev)
+        tr = MN.DDPMTrainer(m, 512, lr=1e-3, graph=False)
+        x0 = torch.rand(512, 1, 28, 28, device=dev) * 2 - 1
+        t = torch.randint(0, 1000, (512,), device=dev)
+        nz = torch.randn(512, 1, 28, 28, device=dev)
+        us = tr.state
+        E.loss_and_grad(tr.flat, us, x0, nz, t)
+        torch.cuda.synchronize()
+        uref = us.grads.clone()
+        ok = []
+        for r in range(args.reps):
+            side.wait_stream(torch.cuda.current_stream())
+            side_work(10)
+            E.loss_and_grad(tr.flat, us, x0, nz, t)
+            torch.cuda.synchronize()
+            ok.append(torch.equal(uref, us.grads))
+        print(f"UNet B=512, {'two queues' if ov else 'one queue'}: grads equal next to TN GEMMs: {ok}", flush=True)
+    _lib.check(L.tdm_set_bwd_overlap(1))
 
 
 if __name__ == "__main__":
