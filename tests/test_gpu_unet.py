@@ -718,8 +718,6 @@ def test_backward_overlap_side_stream_is_bit_identical_eager_and_captured(dev, c
     """tdm_set_bwd_overlap: the weight-gradient launches on the library's side stream (fork / join by events; a parallel
     branch of the graph under capture) give the same weights bit for bit as everything on one stream — eagerly and as
     graph replays (epoch mode, unrolled graphs included), 9 steps at B = 37 (ragged tiles)."""
-    if conv_mode != 2:
-        pytest.skip("the side stream belongs to the default pipeline")
     from tinydiffusionmodels_amd import _lib, mnist as M
     L = _lib.lib()
     B, steps = 37, 9

@@ -583,16 +583,30 @@ int unet_backward(const float* P, const float* x, const float* deps, float* G, c
     if (g_conv_mode == 2) return unet_backward_s16(P, x, deps, G, w, slabs, B, st);
     const BlockOff &r1 = kL.rb[0], &r2 = kL.rb[1], &r3 = kL.rb[2], &r4 = kL.rb[3];
     const int64_t M28 = (int64_t)B * 784, M14 = (int64_t)B * 196;
+    // the weight-gradient launches on the side queue, as in the S16 pipeline (SideLane): here too every tensor has its own
+    // buffer, and the in-place ReLU backward of a gradient tensor comes before the fork that lets the side queue read it
+    const bool lane = g_bwd_overlap != 0;
+    if (lane) TDM_REQUIRE(g_lane.init(), "unet_backward: side stream / events could not be created");
+    const hipStream_t ss = lane ? g_lane.side : st;
+    int nfork = 0;
+    auto fork = [&]() -> int {
+        if (!lane) return 0;
+        hipEvent_t e = g_lane.ready[nfork++ & 3];
+        TDM_HIP(hipEventRecord(e, st));
+        TDM_HIP(hipStreamWaitEvent(ss, e, 0));
+        return 0;
+    };
     // ---- out conv + rb4 ----
     TDM_TRY(tdm_launch_out_bwd(deps, w.h4, P + kL.outw, w.a2_4, w.dout4, w.dc2_4, slabs, TDM_UNET_NPARAM, kL.outw,
                                kL.outb, M28, NSLAB, st));
-    TDM_TRY(wgrad(st, 28, B, w.a1_4, 32, 32, 0, w.tb + 160, 9, w.dc2_4, 32, slabs, r4.c2w, 32, 0, r4.c2b, NSLAB));
     TDM_TRY(dgrad1(st, w, 28, B, w.dc2_4, 32, 9, P + r4.c2w, W_RB4C2, 32, nullptr, w.dh4));
     TDM_TRY(tdm_launch_relu_bwd_tb(w.dh4, w.a1_4, w.S[3], B, 784, 32, st));  // dh4 <- d(conv1 pre-activation)
-    TDM_TRY(wgrad(st, 28, B, w.h3, 64, 64, 1, nullptr, 9, w.dh4, 32, slabs, r4.c1w, 96, 0, r4.c1b, NSLAB));
-    TDM_TRY(wgrad(st, 28, B, w.h1, 32, 32, 0, nullptr, 9, w.dh4, 32, slabs, r4.c1w, 96, 64, -1, NSLAB));
-    TDM_TRY(wgrad(st, 28, B, w.h3, 64, 64, 1, nullptr, 1, w.dout4, 32, slabs, r4.skw, 96, 0, r4.skb, NSLAB));
-    TDM_TRY(wgrad(st, 28, B, w.h1, 32, 32, 0, nullptr, 1, w.dout4, 32, slabs, r4.skw, 96, 64, -1, NSLAB));
+    TDM_TRY(fork());
+    TDM_TRY(wgrad(ss, 28, B, w.a1_4, 32, 32, 0, w.tb + 160, 9, w.dc2_4, 32, slabs, r4.c2w, 32, 0, r4.c2b, NSLAB));
+    TDM_TRY(wgrad(ss, 28, B, w.h3, 64, 64, 1, nullptr, 9, w.dh4, 32, slabs, r4.c1w, 96, 0, r4.c1b, NSLAB));
+    TDM_TRY(wgrad(ss, 28, B, w.h1, 32, 32, 0, nullptr, 9, w.dh4, 32, slabs, r4.c1w, 96, 64, -1, NSLAB));
+    TDM_TRY(wgrad(ss, 28, B, w.h3, 64, 64, 1, nullptr, 1, w.dout4, 32, slabs, r4.skw, 96, 0, r4.skb, NSLAB));
+    TDM_TRY(wgrad(ss, 28, B, w.h1, 32, 32, 0, nullptr, 1, w.dout4, 32, slabs, r4.skw, 96, 64, -1, NSLAB));
     {
         ConvArgs a{};
         a.nsrc = 2;
@@ -604,18 +618,20 @@ int unet_backward(const float* P, const float* x, const float* deps, float* G, c
     TDM_TRY(tdm_launch_split_dcat(w.dcat, w.dout3, B, st));
     // ---- rb3 ----
     TDM_TRY(tdm_launch_relu_mask(w.dout3, w.a2_3, w.dc2_3, M14 * 64, st));
-    TDM_TRY(wgrad(st, 14, B, w.a1_3, 64, 64, 0, w.tb + 96, 9, w.dc2_3, 64, slabs, r3.c2w, 64, 0, r3.c2b, NSLAB));
     TDM_TRY(dgrad1(st, w, 14, B, w.dc2_3, 64, 9, P + r3.c2w, W_RB3C2, 64, nullptr, w.dh3));
     TDM_TRY(tdm_launch_relu_bwd_tb(w.dh3, w.a1_3, w.S[2], B, 196, 64, st));
-    TDM_TRY(wgrad(st, 14, B, w.h2, 64, 64, 0, nullptr, 9, w.dh3, 64, slabs, r3.c1w, 64, 0, r3.c1b, NSLAB));
+    TDM_TRY(fork());
+    TDM_TRY(wgrad(ss, 14, B, w.a1_3, 64, 64, 0, w.tb + 96, 9, w.dc2_3, 64, slabs, r3.c2w, 64, 0, r3.c2b, NSLAB));
+    TDM_TRY(wgrad(ss, 14, B, w.h2, 64, 64, 0, nullptr, 9, w.dh3, 64, slabs, r3.c1w, 64, 0, r3.c1b, NSLAB));
     TDM_TRY(dgrad1(st, w, 14, B, w.dh3, 64, 9, P + r3.c1w, W_RB3C1, 64, w.dout3, w.dout2));  // + identity skip
     // ---- rb2 ----
     TDM_TRY(tdm_launch_relu_mask(w.dout2, w.a2_2, w.dc2_2, M14 * 64, st));
-    TDM_TRY(wgrad(st, 14, B, w.a1_2, 64, 64, 0, w.tb + 32, 9, w.dc2_2, 64, slabs, r2.c2w, 64, 0, r2.c2b, NSLAB));
     TDM_TRY(dgrad1(st, w, 14, B, w.dc2_2, 64, 9, P + r2.c2w, W_RB2C2, 64, nullptr, w.dh2));
     TDM_TRY(tdm_launch_relu_bwd_tb(w.dh2, w.a1_2, w.S[1], B, 196, 64, st));
-    TDM_TRY(wgrad(st, 14, B, w.p1, 32, 32, 0, nullptr, 9, w.dh2, 64, slabs, r2.c1w, 32, 0, r2.c1b, NSLAB));
-    TDM_TRY(wgrad(st, 14, B, w.p1, 32, 32, 0, nullptr, 1, w.dout2, 64, slabs, r2.skw, 32, 0, r2.skb, NSLAB));
+    TDM_TRY(fork());
+    TDM_TRY(wgrad(ss, 14, B, w.a1_2, 64, 64, 0, w.tb + 32, 9, w.dc2_2, 64, slabs, r2.c2w, 64, 0, r2.c2b, NSLAB));
+    TDM_TRY(wgrad(ss, 14, B, w.p1, 32, 32, 0, nullptr, 9, w.dh2, 64, slabs, r2.c1w, 32, 0, r2.c1b, NSLAB));
+    TDM_TRY(wgrad(ss, 14, B, w.p1, 32, 32, 0, nullptr, 1, w.dout2, 64, slabs, r2.skw, 32, 0, r2.skb, NSLAB));
     {
         ConvArgs a{};
         a.nsrc = 2;
@@ -627,7 +643,8 @@ int unet_backward(const float* P, const float* x, const float* deps, float* G, c
     TDM_TRY(tdm_launch_combine_dh1(w.dcat, w.dp1, w.dout1, B, st));
     // ---- rb1 ----
     TDM_TRY(tdm_launch_relu_mask(w.dout1, w.a2_1, w.dc2_1, M28 * 32, st));
-    TDM_TRY(wgrad(st, 28, B, w.a1_1, 32, 32, 0, w.tb + 0, 9, w.dc2_1, 32, slabs, r1.c2w, 32, 0, r1.c2b, NSLAB));
+    TDM_TRY(fork());
+    TDM_TRY(wgrad(ss, 28, B, w.a1_1, 32, 32, 0, w.tb + 0, 9, w.dc2_1, 32, slabs, r1.c2w, 32, 0, r1.c2b, NSLAB));
     TDM_TRY(dgrad1(st, w, 28, B, w.dc2_1, 32, 9, P + r1.c2w, W_RB1C2, 32, nullptr, w.dh1));
     TDM_TRY(tdm_launch_relu_bwd_tb(w.dh1, w.a1_1, w.S[0], B, 784, 32, st));
     {   // gradients of the four time_emb Linear(1,C) layers in one launch
@@ -650,6 +667,10 @@ int unet_backward(const float* P, const float* x, const float* deps, float* G, c
     }
     sec(kL.outw, 33);
     ra.nsec = n;
+    if (lane) {   // join: the reduction reads every slab
+        TDM_HIP(hipEventRecord(g_lane.done, ss));
+        TDM_HIP(hipStreamWaitEvent(st, g_lane.done, 0));
+    }
     TDM_TRY(tdm_launch_reduce(slabs, TDM_UNET_NPARAM, ra, G, st));
     return 0;
 }
