@@ -259,8 +259,8 @@ int tdm_resblock_fwd_f32(const float* x, const float* that, const float* c1w, co
  * state (a process's only shared object is an explicit tdm_ctx).                                                  */
 int tdm_set_conv_mode(int mode);
 int tdm_get_conv_mode(void);
-/* Launch overlap inside the UNet backward (thread-local like the selectors above; default 1): the eight weight-gradient
- * launches are issued on a side stream the library owns (created on first use, one per host thread), each behind an event
+/* Launch overlap inside the backward passes (thread-local like the selectors above; default 1).  UNet: the eight weight-gradient
+ * launches (transformer, up to 16,384 tokens per batch: the four weight-gradient GEMMs of every layer) are issued on a side stream the library owns (created on first use, one per host thread), each behind an event
  * recorded after the launch that produced its gradient operand; the data-gradient chain continues on the caller's stream and
  * waits for the side stream before the final slab reduction.  Same kernels on the same buffers: results are bit-identical
  * to 0 (everything on the caller's stream in program order).  Under stream capture the side stream becomes a parallel

@@ -1268,3 +1268,35 @@ def test_text_launches_keep_their_bits_next_to_a_foreign_kernel_stream(dev):
         for _ in range(3):
             run(step, 10)
             assert torch.equal(st.grads, gref)
+
+
+def test_text_backward_side_stream_is_bit_identical_and_graphs_take_one_queue(dev):
+    """tdm_set_bwd_overlap in the transformer backward (weight-gradient GEMMs on the library's side stream, two forks per layer,
+    main-waits-for-side edges where gradient buffers are reused): the same weights bit for bit as one queue — DenoiserTrainer at
+    8 x 128 tokens, D = 256, dropout 0.1, eager with and without the side stream and as hipGraph replays (captured with one
+    queue) — and the default issue mode follows the batch size (eager up to 16,384 tokens, one graph above)."""
+    from tinydiffusionmodels_amd import _lib
+    from tinydiffusionmodels_amd import shakespeare as S
+    L = _lib.lib()
+    assert S._default_use_graph(None, 32 * 128) is False and S._default_use_graph(None, 256 * 128) is True
+    assert S._default_use_graph(True, 8) is True and S._default_use_graph(False, 10 ** 6) is False
+    x = torch.randn(8, 128, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(5)) * 0.02
+    finals = {}
+    try:
+        with _lib.use_arithmetic((_lib.arithmetic()[0], 1, _lib.arithmetic()[2])):
+            for name, graph, ov in (("eager", False, 0), ("eager+side", False, 1), ("eager+side again", False, 1), ("graph", True, 1)):
+                assert L.tdm_set_bwd_overlap(ov) == 0
+                torch.manual_seed(3)
+                m = S.TinyTransformer(256, dropout=0.1).to(dev)
+                m.train()
+                tr = S.DenoiserTrainer(m, 8, 128, lr=1e-3, graph=graph)
+                for _ in range(7):
+                    loss = tr.step(x)
+                torch.cuda.synchronize()
+                assert L.tdm_get_bwd_overlap() == ov                 # (a capture restores the selector)
+                finals[name] = (torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone(), float(loss.item()))
+    finally:
+        L.tdm_set_bwd_overlap(1)
+    ref = finals["eager"]
+    for k, v in finals.items():
+        assert torch.equal(v[0], ref[0]) and v[1] == ref[1], k

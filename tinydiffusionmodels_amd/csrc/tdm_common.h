@@ -44,6 +44,18 @@ void tdm_set_error(const char* fmt, ...);
         }                                                                          \
     } while (0)
 
+// The backward passes' second launch queue (tdm_set_bwd_overlap; defined and described in unet.hip): one per host thread, created
+// on first use.  `ready`: main -> side dependencies (forks); `back`: side -> main (a buffer the side queue's launches read is
+// about to be overwritten); `done`: the final join.
+struct TdmSideLane {
+    hipStream_t side = nullptr;
+    hipEvent_t ready[8] = {}, back[2] = {}, done = nullptr;
+    bool ok = false;
+    bool init();
+};
+TdmSideLane& tdm_side_lane();
+int tdm_bwd_overlap();   // the calling thread's selector (0 / 1)
+
 #define TDM_TRY(expr)               \
     do {                            \
         int rc__ = (expr);          \

@@ -932,6 +932,29 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
     // transposed weights of all layers in ONE launch (12 launches of ~5 us otherwise: the weights do not change inside a step)
     const bool pre = s16 && g_gemm_mode != 0 && w.wT_all != nullptr && 4 * depth <= TDM_TRANSPOSE_BATCH;
     const long per_layer = 4L * D * D + 2L * F * D;
+    // Weight-gradient GEMMs on the library's side queue (tdm_set_bwd_overlap; unet.hip describes the mechanism): each reads a
+    // gradient tensor the main chain has just produced and a saved activation, and only the final slab reduction reads what it
+    // writes.  Two forks per layer: {linear2, linear1} behind the FFN chain, {out-projection, in-projection} behind the
+    // attention backward.  Unlike the UNet's, this backward REUSES its gradient buffers layer after layer, so before the main
+    // chain overwrites one it waits for the side queue's readers of the layer above (`back` events); the two LayerNorm backwards
+    // of a layer get an S16 buffer each (g16 / the otherwise unused g_d) so that those waits are a whole layer away.
+    // Worth 4.5 / 5.7 / 6.1 % of the denoiser step at 32 / 64 / 128 sequences of 128 tokens (eager issue), 0.7 % at 256 and nothing
+    // for the full text step there (the chain kernels fill their CUs alone): used up to 16,384 tokens.
+    const bool lane = tdm_bwd_overlap() != 0 && pre && fused_bias && tt_fused_ffn(M, D, F) && M <= 16384;
+    TdmSideLane& ln = tdm_side_lane();
+    if (lane) TDM_REQUIRE(ln.init(), "tt_backward: side stream / events could not be created");
+    const hipStream_t ss = lane ? ln.side : st;
+    int nfork = 0;
+    auto fork = [&]() -> int {
+        if (!lane) return 0;
+        hipEvent_t e = ln.ready[nfork++ & 7];
+        TDM_HIP(hipEventRecord(e, st));
+        TDM_HIP(hipStreamWaitEvent(ss, e, 0));
+        return 0;
+    };
+    auto side_done = [&](int k) -> int { if (lane) TDM_HIP(hipEventRecord(ln.back[k], ss)); return 0; };
+    auto wait_side = [&](int k, int l) -> int { if (lane && l + 1 < depth) TDM_HIP(hipStreamWaitEvent(st, ln.back[k], 0)); return 0; };
+    float* const g16b = lane ? w.g_d : w.g16;   // LayerNorm 1's S16 output
     if (pre) {
         TransposeBatch tb{};
         for (int l = 0; l < depth; ++l) {
@@ -951,12 +974,13 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
         float* const wT_out = pre ? wT_in + 3L * D * D : w.wT;
         float* const wT_l1 = pre ? wT_in + 4L * D * D : w.wT2;              // W1^T: [D][F]
         float* const wT_l2 = pre ? wT_l1 + (long)F * D : w.wT;               // W2^T: [F][D]
+        TDM_TRY(wait_side(0, l));   // (the layer above's linear2 / linear1 weight gradients have read g16 and g_f)
         // LayerNorm 2: hout = LN(h1 + dropout2(f2)); g_s = d(h1) residual part, g2 = d(f2); db2 = colsum(g2)
         TDM_TRY(ln_bwd(gh, nullptr, a.s2, a.mean2, a.rstd2, P + o.n2_w, w.g_s, (dropping && !s16) ? w.g_d : nullptr,
                        s16 ? w.g16 : nullptr, dropping, drop.site(4 + 4 * l), slabs + sp.ln_base[l][1], G, o.n2_w, o.l2_b, M, D, st, true));
         const float* g2 = s16 ? w.g16 : (dropping ? w.g_d : w.g_s);
         // f2 = f1 W2^T + b2, f1 = dropout(relu(z1)): d(z1) = (g2 W2) * [f1 > 0] / (1 - p) in the GEMM epilogue
-        TDM_TRY(linear_wgrad(g2, a.f1, slabs + sp.base[l][3], nullptr, s16, M, D, F, st));
+        if (!lane) TDM_TRY(linear_wgrad(g2, a.f1, slabs + sp.base[l][3], nullptr, s16, M, D, F, st));
         const bool chain = tt_fused_ffn(M, D, F);
         if (chain) {
             // d(z1) = (g2 W2) gated by the saved sign masks, d(h1) = d(z1) W1: one launch, d(z1) written once (S16) for W1's gradient
@@ -971,15 +995,19 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
                              s16 ? w.g_f : nullptr, s16, M, D, F, st, pre));
         // z1 = h1 W1^T + b1
         if (!fused_bias) TDM_TRY(bias_grad(w.g_f, w.part, G + o.l1_b, M, F, st));
+        TDM_TRY(fork());
+        if (lane) TDM_TRY(linear_wgrad(g2, a.f1, slabs + sp.base[l][3], nullptr, s16, M, D, F, ss));
         TDM_TRY(linear_wgrad(w.g_f, s16 ? a.h1_16 : a.h1, slabs + sp.base[l][2], fused_bias ? slabs + sp.bias_base[l][2] : nullptr,
-                             s16, M, F, D, st));
+                             s16, M, F, D, ss));
+        TDM_TRY(side_done(0));
+        TDM_TRY(wait_side(1, l));   // (the layer above's projection weight gradients have read g16b and g_qkv16)
         if (!chain) TDM_TRY(linear_dgrad(w.g_f, P + o.l1_w, pre ? wT_l1 : w.wT, nullptr, nullptr, 1.f, w.g_h1, nullptr, s16, M, F, D, st, pre));
         // LayerNorm 1: h1 = LN(hin + dropout1(a)); d(h1) = g_h1 (FFN path) + g_s (residual)
         TDM_TRY(ln_bwd(w.g_h1, w.g_s, a.s1, a.mean1, a.rstd1, P + o.n1_w, w.g_s1, (dropping && !s16) ? w.g_d : nullptr,
-                       s16 ? w.g16 : nullptr, dropping, drop.site(2 + 4 * l), slabs + sp.ln_base[l][0], G, o.n1_w, o.out_b, M, D, st, true));
-        const float* g1 = s16 ? w.g16 : (dropping ? w.g_d : w.g_s1);
+                       s16 ? g16b : nullptr, dropping, drop.site(2 + 4 * l), slabs + sp.ln_base[l][0], G, o.n1_w, o.out_b, M, D, st, true));
+        const float* g1 = s16 ? g16b : (dropping ? w.g_d : w.g_s1);
         // a = o Wout^T + bout
-        TDM_TRY(linear_wgrad(g1, s16 ? a.o16 : a.o, slabs + sp.base[l][1], nullptr, s16, M, D, D, st));
+        if (!lane) TDM_TRY(linear_wgrad(g1, s16 ? a.o16 : a.o, slabs + sp.base[l][1], nullptr, s16, M, D, D, st));
         TDM_TRY(linear_dgrad(g1, P + o.out_w, wT_out, nullptr, nullptr, 1.f, w.g_o, nullptr, s16, M, D, D, st, pre));
         // attention
         const DropArgs da = drop.site(1 + 4 * l);
@@ -988,8 +1016,11 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
         // qkv = hin Win^T + bin ; d(hin) = g_qkv Win + g_s1 (residual)
         if (!fused_bias) TDM_TRY(bias_grad(w.g_qkv, w.part, G + o.in_b, M, 3 * D, st));
         const float* gq = s16 ? w.g_qkv16 : w.g_qkv;
+        TDM_TRY(fork());
+        if (lane) TDM_TRY(linear_wgrad(g1, s16 ? a.o16 : a.o, slabs + sp.base[l][1], nullptr, s16, M, D, D, ss));
         TDM_TRY(linear_wgrad(gq, s16 ? a.hin16 : a.hin, slabs + sp.base[l][0], fused_bias ? slabs + sp.bias_base[l][0] : nullptr, s16,
-                             M, 3 * D, D, st));
+                             M, 3 * D, D, ss));
+        TDM_TRY(side_done(1));
         gout = (l == 0 && dx != nullptr) ? dx : w.g_h;   // layer 0: this is d(loss)/d(dropout0(x + time bias))
         // (layer 0 in the bf16 GEMM modes: the input dropout's mask — d(x + time bias) = mask * g / (1 - p) — in this epilogue)
         const bool drop_here = dropping && l == 0 && g_gemm_mode != 0;
@@ -1007,6 +1038,10 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
     hipLaunchKernelGGL(seqsum_kernel, dim3((unsigned)B), dim3(256), 0, st, gh, w.Sb, L, D);
     TDM_CHECK_LAUNCH("seqsum");
     TDM_TRY(tdm_launch_time_grad(w.Sb, w.that, G + lay.te_w, G + lay.te_b, (int)B, D, st));
+    if (lane) {   // join: the reduction reads every slab
+        TDM_HIP(hipEventRecord(ln.done, ss));
+        TDM_HIP(hipStreamWaitEvent(st, ln.done, 0));
+    }
     // sum the split-K weight-gradient slabs
     ReduceArgs ra{};
     int n = 0;

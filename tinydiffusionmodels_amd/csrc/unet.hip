@@ -350,33 +350,15 @@ inline void mark_end(hipStream_t st) {
 // (hipGraph replays of the one-queue step: the same 0.384 / 0.645 / 0.993); the forked step REPLAYED AS A GRAPH is slower than
 // the one-queue graph (0.401 / 0.660 / 1.000: ROCm's graph executor pays more per cross-branch edge than the overlap returns),
 // and a second side queue is slower than one (0.403 / 0.639 / 0.958).
-// The same scheme was tried on the TEXT backward (weight-gradient GEMMs behind the FFN chain / the attention backward) and not
-// kept: nothing at B = 256 (3.77 -> 3.76 ms), 4-5 % at B = 32 / 64 only.  Its results differed from the one-queue step in a
-// few rows, intermittently — which turned out to have nothing to do with queues or events: built with clang's SLP vectoriser the
-// LayerNorm backward's packed-fp32 code gives different results whenever ANY other kernel stream competes for the GPU
-// (tools/contention_ops.py; build.py now passes -fno-slp-vectorize, results unchanged bit for bit, speed unchanged).  The two-queue
-// step is held against the one-queue step bit for bit: the GPU tests at B = 37 and 512, tools/overlap_bitwise.py over 200 steps at
-// B = 1 ... 512 and 3,000 steps at four sizes, tools/contention_check.py / contention_tn.py with foreign kernel streams.
-struct SideLane {
-    hipStream_t side = nullptr;
-    hipEvent_t ready[4] = {}, done = nullptr;
-    bool ok = false;
-    bool init() {
-        if (ok) return true;
-        // events that only order two queues of this device: no timing, no system-scope fence (6 us per step at B = 512)
-        const unsigned flags = hipEventDisableTiming | hipEventDisableSystemFence;
-        // the side queue at the LOWEST priority: its launches have slack (they only have to finish before the slab reduction), the
-        // data-gradient chain is the critical path — B = 512, same box: 1.003 (default priority) -> 0.989 ms; highest: 1.008
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least) != hipSuccess) return false;
-        for (hipEvent_t& e : ready)
-            if (hipEventCreateWithFlags(&e, flags) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&done, flags) != hipSuccess) return false;
-        return ok = true;
-    }
-};
-thread_local SideLane g_lane;
+// The TEXT backward uses the same queue for its weight-gradient GEMMs up to 16,384 tokens per batch (transformer.hip: 4.5-6 % of
+// the denoiser step at 32 ... 128 sequences; nothing at 256, where it stays off).  Its first version gave gradients that differed
+// from the one-queue step in a few rows, intermittently — which had nothing to do with queues or events: built with clang's SLP
+// vectoriser the LayerNorm backward's packed-fp32 code gives different results whenever ANY other kernel stream competes for the
+// GPU (tools/contention_ops.py; build.py now passes -fno-slp-vectorize: results unchanged bit for bit, speed unchanged).  Both
+// two-queue steps are held against their one-queue forms bit for bit: GPU tests (UNet B = 37 and 512 in both arithmetics, text
+// 8 x 128 tokens), tools/overlap_bitwise.py over 200 steps at B = 1 ... 512 and 3,000 steps at four sizes, tools/text_modes.py
+// --check, tools/contention_check.py / contention_tn.py with foreign kernel streams.
+thread_local TdmSideLane g_lane;
 thread_local int g_bwd_overlap = 1;   // a selector like the arithmetic modes: per calling thread
 
 int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* eps, const Ws& w, int B, int save,
@@ -690,6 +672,25 @@ int forward_loss_backward(const float* P, const float* x_noisy, const int64_t* t
 }
 
 }  // namespace
+
+bool TdmSideLane::init() {
+    if (ok) return true;
+    // events that only order two queues of this device: no timing, no system-scope fence (6 us per step at B = 512)
+    const unsigned flags = hipEventDisableTiming | hipEventDisableSystemFence;
+    // the side queue at the LOWEST priority: its launches have slack (they only have to finish before the slab reduction), the
+    // data-gradient chain is the critical path — B = 512, same box: 1.003 (default priority) -> 0.989 ms; highest: 1.008
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least) != hipSuccess) return false;
+    for (hipEvent_t& e : ready)
+        if (hipEventCreateWithFlags(&e, flags) != hipSuccess) return false;
+    for (hipEvent_t& e : back)
+        if (hipEventCreateWithFlags(&e, flags) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&done, flags) != hipSuccess) return false;
+    return ok = true;
+}
+TdmSideLane& tdm_side_lane() { return g_lane; }
+int tdm_bwd_overlap() { return g_bwd_overlap; }
 
 extern "C" {
 
