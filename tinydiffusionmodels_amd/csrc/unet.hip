@@ -681,7 +681,10 @@ bool TdmSideLane::init() {
     // data-gradient chain is the critical path — B = 512, same box: 1.003 (default priority) -> 0.989 ms; highest: 1.008
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least) != hipSuccess) return false;
+    if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least) != hipSuccess) {
+        (void)hipGetLastError();   // (no priorities on this device: a plain non-blocking stream does)
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return false;
+    }
     for (hipEvent_t& e : ready)
         if (hipEventCreateWithFlags(&e, flags) != hipSuccess) return false;
     for (hipEvent_t& e : back)
