@@ -12,7 +12,7 @@ A "step" is the loop body of src/mnist.py:152-159 on one synthetic 512-image
 batch: draw t and noise, q_sample, UNet forward, MSE, backward, (RCCL
 all-reduce of the flat gradient), AdamW — device-side Philox draws and AdamW step count,
 issued eagerly with the backward's weight-gradient launches on a side stream (--graph: the
-one-queue step as hipGraph replays; at N > 1: replay + all-reduce + AdamW).  Inputs are
+one-queue step as hipGraph replays; at N > 1: step call + all-reduce + AdamW).  Inputs are
 resident in HBM before the timed region.  Rank 0 prints ONE JSON line."""
 import argparse
 import json
