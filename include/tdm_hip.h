@@ -263,8 +263,8 @@ int tdm_get_conv_mode(void);
  * launches (transformer, up to 16,384 tokens per batch: the four weight-gradient GEMMs of every layer) are issued on a side stream the library owns (created on first use, one per host thread), each behind an event
  * recorded after the launch that produced its gradient operand; the data-gradient chain continues on the caller's stream and
  * waits for the side stream before the final slab reduction.  Same kernels on the same buffers: results are bit-identical
- * to 0 (everything on the caller's stream in program order).  Under stream capture the side stream becomes a parallel
- * branch of the captured graph.                                                                                  */
+ * to 0 (everything on the caller's stream in program order).  A call whose stream is being CAPTURED always takes one queue
+ * (the forked step replays slower as a hipGraph than the plain one).                                              */
 int tdm_set_bwd_overlap(int on);
 int tdm_get_bwd_overlap(void);
 /* per-layer entry points of the S16 pipeline (tests / profiling): the fp32 input is

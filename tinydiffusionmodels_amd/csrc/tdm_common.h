@@ -54,7 +54,9 @@ struct TdmSideLane {
     bool init();
 };
 TdmSideLane& tdm_side_lane();
-int tdm_bwd_overlap();   // the calling thread's selector (0 / 1)
+// 1 if the calling thread's selector is on AND `st` is not being captured: a forked step replayed as a hipGraph is slower than
+// the one-queue graph (ROCm's graph executor pays more per cross-branch edge than the overlap returns), so captures get one queue
+int tdm_bwd_overlap(hipStream_t st);
 
 #define TDM_TRY(expr)               \
     do {                            \

@@ -940,7 +940,7 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
     // of a layer get an S16 buffer each (g16 / the otherwise unused g_d) so that those waits are a whole layer away.
     // Worth 4.5 / 5.7 / 6.1 % of the denoiser step at 32 / 64 / 128 sequences of 128 tokens (eager issue), 0.7 % at 256 and nothing
     // for the full text step there (the chain kernels fill their CUs alone): used up to 16,384 tokens.
-    const bool lane = tdm_bwd_overlap() != 0 && pre && fused_bias && tt_fused_ffn(M, D, F) && M <= 16384;
+    const bool lane = pre && fused_bias && tt_fused_ffn(M, D, F) && M <= 16384 && tdm_bwd_overlap(st) != 0;
     TdmSideLane& ln = tdm_side_lane();
     if (lane) TDM_REQUIRE(ln.init(), "tt_backward: side stream / events could not be created");
     const hipStream_t ss = lane ? ln.side : st;

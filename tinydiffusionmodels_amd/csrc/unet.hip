@@ -344,8 +344,9 @@ inline void mark_end(hipStream_t st) {
 // chain has just produced and on saved activations, never on the data-gradient launch that follows it, and nothing but the
 // final slab reduction reads what it writes (the workspace gives every tensor its own buffer).  Issued on a side stream behind
 // an event, it runs NEXT TO the data-gradient launches that follow: the tail round of one kernel (1568 tiles on 512 slots) and
-// the idle SIMDs of a 256-workgroup weight-gradient launch are filled by the other.  Fork / join are event record + stream wait, so a
-// stream capture takes the side stream in as a parallel branch of the same graph.  Measured (tools/step_modes.py, one box, ms per
+// the idle SIMDs of a 256-workgroup weight-gradient launch are filled by the other.  Fork / join are event record + stream wait; a
+// stream capture would take the side stream in as a parallel branch of the same graph — which replays SLOWER than the plain
+// graph, so a call on a capturing stream takes one queue (tdm_bwd_overlap).  Measured (tools/step_modes.py, one box, ms per
 // step, B = 64 / 256 / 512): eager launches with the side queue 0.350 / 0.579 / 0.938 against 0.384 / 0.645 / 0.993 without
 // (hipGraph replays of the one-queue step: the same 0.384 / 0.645 / 0.993); the forked step REPLAYED AS A GRAPH is slower than
 // the one-queue graph (0.401 / 0.660 / 1.000: ROCm's graph executor pays more per cross-branch edge than the overlap returns),
@@ -444,7 +445,7 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     float* const es = slabs + ESLAB_BASE;
     TDM_REQUIRE(deps != nullptr || mse != nullptr, "unet_backward: no output gradient");
     // weight-gradient launches go to the side queue (above) unless one launch is being replayed alone
-    const bool lane = g_bwd_overlap != 0 && g_only_launch < 0;
+    const bool lane = g_only_launch < 0 && tdm_bwd_overlap(st) != 0;
     if (lane) TDM_REQUIRE(g_lane.init(), "unet_backward: side stream / events could not be created");
     const hipStream_t ss = lane ? g_lane.side : st;
     int nfork = 0;
@@ -567,7 +568,7 @@ int unet_backward(const float* P, const float* x, const float* deps, float* G, c
     const int64_t M28 = (int64_t)B * 784, M14 = (int64_t)B * 196;
     // the weight-gradient launches on the side queue, as in the S16 pipeline (SideLane): here too every tensor has its own
     // buffer, and the in-place ReLU backward of a gradient tensor comes before the fork that lets the side queue read it
-    const bool lane = g_bwd_overlap != 0;
+    const bool lane = tdm_bwd_overlap(st) != 0;
     if (lane) TDM_REQUIRE(g_lane.init(), "unet_backward: side stream / events could not be created");
     const hipStream_t ss = lane ? g_lane.side : st;
     int nfork = 0;
@@ -693,7 +694,12 @@ bool TdmSideLane::init() {
     return ok = true;
 }
 TdmSideLane& tdm_side_lane() { return g_lane; }
-int tdm_bwd_overlap() { return g_bwd_overlap; }
+int tdm_bwd_overlap(hipStream_t st) {
+    if (g_bwd_overlap == 0) return 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    return cs == hipStreamCaptureStatusNone ? 1 : 0;
+}
 
 extern "C" {
 
