@@ -14,7 +14,10 @@
  *    first use, ONE side stream and a handful of events (tdm_set_bwd_overlap):
  *    work it puts there is forked from and joined back into the caller's
  *    stream by events inside the same call, so for the caller every effect of
- *    a call is ordered on the stream it passed;
+ *    a call is ordered on the stream it passed — also when the call FAILS after
+ *    a fork (the join runs on every exit path).  They live on the device of the
+ *    stream the caller passed (rebuilt there if a thread moves to another GPU)
+ *    and are destroyed when the host thread exits;
  *  - `stream` is a hipStream_t passed as void*;
  *  - return 0 on success, non-zero on error; tdm_last_error() gives the text;
  *  - activations inside the library are NHWC fp32; the UNet input/output

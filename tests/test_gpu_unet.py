@@ -672,6 +672,18 @@ def test_epoch_mode_gathers_inside_the_step_and_equals_the_gather_per_step_loop(
     st = tr.state
     want = M.q_sample(d[perm[3 * B:4 * B]], st.t, st.noise)
     assert torch.equal(st.x_noisy, want)
+    # an epoch holds whole batches only: asking for more is refused on the host (the gather kernel would clamp its positions and
+    # silently train on repeats of the last sample), and so is a permutation of the wrong length
+    whole = d.shape[0] // B
+    tr.steps_epoch(whole - 4)
+    with pytest.raises(ValueError, match="whole iterations"):
+        tr.steps_epoch(1)
+    with pytest.raises(ValueError, match="perm has"):
+        tr.begin_epoch(d, perm[:-1])
+    tr.begin_epoch(d, perm)
+    with pytest.raises(ValueError, match="whole iterations"):
+        tr.steps_epoch(whole + 1)
+    tr.steps_epoch(whole)
 
 
 def test_in_step_launch_marks_time_one_launch_of_every_eager_step(dev, conv_mode):

@@ -25,6 +25,32 @@ def test_library_exports_every_header_symbol():
     assert L.tdm_version() == 401
 
 
+def test_no_packed_fp32_in_any_code_object():
+    """Build-time check behind tinydiffusionmodels_amd/build.py's flag comment: no shipped gfx950 code object holds a packed-fp32
+    VALU instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) or any op_sel: half-select.  Round 4's LayerNorm backward returned
+    wrong rows next to the library's token-major GEMM stream; round 5 traced every wrong value to `v_pk_add_f32 D, A, B op_sel:[0,1]`
+    (low result taken from the HIGH dword of B): lanes 48-63 of the low result come back without the B term, intermittently, and the
+    instruction alone reproduces it (tools/micro/pk_waw.hip, profiles/r05_pk_opsel_probe.txt).  The class of instruction
+    is switched off for the device (-target-feature -packed-fp32-ops), not one instance of it.  Disassembles every csrc/*.o (llvm-objcopy -> clang-offload-bundler -> llvm-objdump)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("codeobj", os.path.join(root, "tools", "codeobj.py"))
+    codeobj = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(codeobj)
+    if not os.path.exists(f"{codeobj.LLVM}/llvm-objdump"):
+        pytest.skip("no llvm-objdump on this machine")
+    _lib.lib()                                   # the objects exist (built by build())
+    objs = codeobj.objects()
+    assert len(objs) >= 14
+    found = codeobj.packed_fp32_instructions()
+    assert not found, {o: {k: v[:2] for k, v in ks.items()} for o, ks in found.items()}
+    # the reproduced erratum is a property of the VOP3P half-select (op_sel): nothing in the library uses one, packed or not
+    sel = codeobj.grep_instructions(r"\bop_sel:")
+    assert not sel, {o: {k: v[:2] for k, v in ks.items()} for o, ks in sel.items()}
+    # the disassembly really is of device code: the MFMA kernels are in it
+    assert codeobj.grep_instructions(r"v_mfma_f32_32x32x16_bf16")
+
+
 def test_layout_matches_library_and_param_count():
     E.check_layout_against_library()
     assert E.param_offsets()[-1] == 181473

@@ -20,12 +20,18 @@ CFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", INCLUDE,
           # HIP defaults to -ffp-contract=fast; the bit-exact elementwise kernels (q_sample, p_sample update,
           # AdamW) must round every mul/add separately like the reference's ATen ops. FMAs are explicit (fmaf).
           "-ffp-contract=off",
-          # No SLP vectorisation: on gfx950 / ROCm 7.2 the packed-fp32 code it produced for the LayerNorm backward (v_pk_mul_f32 /
-          # v_pk_add_f32 over freshly loaded register pairs) gave DIFFERENT results whenever another kernel stream competed for
-          # the GPU — a few rows off by 1e-4 relative, different from run to run (tools/contention_ops.py; quiet runs were always
-          # right).  Without it every launch is bit-stable next to foreign work, results are unchanged bit for bit, and the
-          # guide's measurement (packed f32 VALU beside MFMAs is an anti-lever) says nothing is lost.
-          "-fno-slp-vectorize"]
+          # No packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) anywhere in the library, by construction:
+          # the device target feature is switched off, so neither clang's SLP vectoriser nor the backend's selection of explicit
+          # ext_vector_type arithmetic can emit one (the host pass prints "not a recognized feature" and ignores it), and
+          # -fno-slp-vectorize keeps the vectoriser from building the v_mov-assembled register pairs in the first place.
+          # Why: on gfx950 `v_pk_add_f32 D, A, B op_sel:[0,1]` (low result taken from the HIGH dword of B) comes
+          # back, intermittently, WITHOUT the B term in lanes 48-63 of the low result while the library's token-major GEMM runs on
+          # another stream - the instruction alone reproduces it (tools/micro/pk_waw.hip, profiles/r05_pk_opsel_probe.txt), and
+          # every wrong row of round 4's SLP-built LayerNorm backward traces to one of its three uses of that form
+          # (tools/ln_slp_forensics.py, profiles/r05_ln_slp_forensics.txt).  tests/test_host_logic.py::
+          # test_no_packed_fp32_in_any_code_object disassembles every code object and holds this comment to the shipped bits
+          # (no v_pk_*_f32, no op_sel half-select of any kind).
+          "-fno-slp-vectorize", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 # TDM_BUILD_DEFINES="-DTDM_DIAG": the diagnostic build (runtime ablation bits / phase probes in the hot kernels, tools/ only)
 CFLAGS += os.environ.get("TDM_BUILD_DEFINES", "").split()
 

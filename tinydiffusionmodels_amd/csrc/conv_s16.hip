@@ -1,7 +1,7 @@
 // bf16x3 implicit-GEMM convolution, transposed convolution and weight gradient
-// over PRE-SPLIT ("S16", tdm_s16.h) activations — the loader-light form of
-// conv_bf16.hip.  Same padded-tall tiling, same packed weights
-// (pack_weights_kernel), same arithmetic (hi*hi + hi*lo + lo*hi, fp32
+// over PRE-SPLIT ("S16", tdm_s16.h) activations — the loader-light successor of
+// round 1's split-while-staging kernels (removed).  Padded-tall tiling, packed weights
+// (conv_pack.hip: pack_weights_kernel), one arithmetic (hi*hi + hi*lo + lo*hi, fp32
 // accumulate on v_mfma_f32_32x32x16_bf16); what changes:
 //   * staging a K chunk is a 16-byte copy per piece (the S16 group of a pixel is
 //     already [hi 32 B | lo 32 B], exactly the LDS pixel image);

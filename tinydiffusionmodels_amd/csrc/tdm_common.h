@@ -47,13 +47,36 @@ void tdm_set_error(const char* fmt, ...);
 // The backward passes' second launch queue (tdm_set_bwd_overlap; defined and described in unet.hip): one per host thread, created
 // on first use.  `ready`: main -> side dependencies (forks); `back`: side -> main (a buffer the side queue's launches read is
 // about to be overwritten); `done`: the final join.
+// Lifetime: the lane belongs to the calling host thread AND to one device — init(st) (re)creates stream and events on the device of
+// the caller's stream when that differs from the one they were made on (a thread that moves between GPUs), and the thread's exit
+// destroys them.  One lane per thread: a host thread drives one backward at a time.
 struct TdmSideLane {
     hipStream_t side = nullptr;
     hipEvent_t ready[8] = {}, back[2] = {}, done = nullptr;
     bool ok = false;
-    bool init();
+    int device = -1;
+    bool init(hipStream_t st);
+    void destroy();
+    ~TdmSideLane() { destroy(); }
 };
 TdmSideLane& tdm_side_lane();
+// Joins the side queue into the caller's stream on EVERY exit path of a backward that has forked — an error return between the
+// first fork and the regular join included — so that "every effect of a call is ordered on the stream the caller passed"
+// (tdm_hip.h) also holds for a failed call: the caller may free or reuse its buffers behind its own stream.
+struct TdmSideJoin {
+    TdmSideLane* ln;
+    hipStream_t st;
+    bool armed = false;
+    int join() {   // the regular join; disarms the guard
+        armed = false;
+        TDM_HIP(hipEventRecord(ln->done, ln->side));
+        TDM_HIP(hipStreamWaitEvent(st, ln->done, 0));
+        return 0;
+    }
+    ~TdmSideJoin() {
+        if (armed) { (void)hipEventRecord(ln->done, ln->side); (void)hipStreamWaitEvent(st, ln->done, 0); }
+    }
+};
 // 1 if the calling thread's selector is on AND `st` is not being captured: a forked step replayed as a hipGraph is slower than
 // the one-queue graph (ROCm's graph executor pays more per cross-branch edge than the overlap returns), so captures get one queue
 int tdm_bwd_overlap(hipStream_t st);
@@ -84,7 +107,7 @@ struct ConvSrc {
     int w_rows;         // rows per tap of w  (fwd: Cin_total; dgrad: Cin_total = N)
     int w_r0;           // fwd: first row of this source inside w
     int w_cols;         // columns of w (fwd: N; dgrad: Cout of the forward conv = K)
-    // bf16x3 path (conv_bf16.hip): weights pre-packed in MFMA B-fragment order
+    // bf16x3 path (conv_pack.hip / conv_s16.hip): weights pre-packed in MFMA B-fragment order
     const unsigned short* wp;   // packed tensor for this direction (hi/lo planes)
     int wchunk0;                // first 16-channel K chunk of this source inside wp
 };

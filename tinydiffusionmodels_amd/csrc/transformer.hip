@@ -942,11 +942,13 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
     // for the full text step there (the chain kernels fill their CUs alone): used up to 16,384 tokens.
     const bool lane = pre && fused_bias && tt_fused_ffn(M, D, F) && M <= 16384 && tdm_bwd_overlap(st) != 0;
     TdmSideLane& ln = tdm_side_lane();
-    if (lane) TDM_REQUIRE(ln.init(), "tt_backward: side stream / events could not be created");
+    if (lane) TDM_REQUIRE(ln.init(st), "tt_backward: side stream / events could not be created");
     const hipStream_t ss = lane ? ln.side : st;
+    TdmSideJoin sj{&ln, st};
     int nfork = 0;
     auto fork = [&]() -> int {
         if (!lane) return 0;
+        sj.armed = true;
         hipEvent_t e = ln.ready[nfork++ & 7];
         TDM_HIP(hipEventRecord(e, st));
         TDM_HIP(hipStreamWaitEvent(ss, e, 0));
@@ -1038,10 +1040,7 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
     hipLaunchKernelGGL(seqsum_kernel, dim3((unsigned)B), dim3(256), 0, st, gh, w.Sb, L, D);
     TDM_CHECK_LAUNCH("seqsum");
     TDM_TRY(tdm_launch_time_grad(w.Sb, w.that, G + lay.te_w, G + lay.te_b, (int)B, D, st));
-    if (lane) {   // join: the reduction reads every slab
-        TDM_HIP(hipEventRecord(ln.done, ss));
-        TDM_HIP(hipStreamWaitEvent(st, ln.done, 0));
-    }
+    if (lane) TDM_TRY(sj.join());   // the reduction reads every slab
     // sum the split-K weight-gradient slabs
     ReduceArgs ra{};
     int n = 0;

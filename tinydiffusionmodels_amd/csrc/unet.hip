@@ -58,7 +58,7 @@ constexpr Layout make_layout() {
 constexpr Layout kL = make_layout();
 static_assert(kL.total == TDM_UNET_NPARAM, "SimpleUNet parameter count");
 
-// ---- bf16x3 pre-packed weights (conv_bf16.hip) -----------------------------------
+// ---- bf16x3 pre-packed weights (conv_pack.hip) -----------------------------------
 // the nine MFMA convolutions: id, flat offset, Cin, Cout, taps
 enum { W_RB1C2, W_RB2C1, W_RB2C2, W_RB2SK, W_RB3C1, W_RB3C2, W_RB4C1, W_RB4C2, W_RB4SK, W_COUNT };
 struct PackTab {
@@ -88,7 +88,7 @@ PackTab make_pack() {
 }
 const PackTab kPack = make_pack();
 
-// 0: exact fp32 MFMA (conv_mfma.hip); 1: bf16x3, fp32 tensors split while staging (conv_bf16.hip);
+// 0: exact fp32 MFMA (conv_mfma.hip); 1: bf16x3, fp32 tensors split while staging (round 1; removed from the library);
 // 2: bf16x3 over pre-split "S16" tensors written by the producers (conv_s16.hip) — same arithmetic as 1
 thread_local int g_conv_mode = 2;   // per calling thread (tdm_set_conv_mode): no process-global mutable state
 
@@ -355,7 +355,8 @@ inline void mark_end(hipStream_t st) {
 // the denoiser step at 32 ... 128 sequences; nothing at 256, where it stays off).  Its first version gave gradients that differed
 // from the one-queue step in a few rows, intermittently — which had nothing to do with queues or events: built with clang's SLP
 // vectoriser the LayerNorm backward's packed-fp32 code gives different results whenever ANY other kernel stream competes for the
-// GPU (tools/contention_ops.py; build.py now passes -fno-slp-vectorize: results unchanged bit for bit, speed unchanged).  Both
+// GPU (tools/contention_ops.py).  Round 5 found the instruction: v_pk_add_f32 with op_sel:[0,1] loses its second operand in lanes
+// 48-63 of the low result next to the library's token-major GEMMs; build.py switches packed fp32 off for the device.  Both
 // two-queue steps are held against their one-queue forms bit for bit: GPU tests (UNet B = 37 and 512 in both arithmetics, text
 // 8 x 128 tokens), tools/overlap_bitwise.py over 200 steps at B = 1 ... 512 and 3,000 steps at four sizes, tools/text_modes.py
 // --check, tools/contention_check.py / contention_tn.py with foreign kernel streams.
@@ -446,11 +447,13 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     TDM_REQUIRE(deps != nullptr || mse != nullptr, "unet_backward: no output gradient");
     // weight-gradient launches go to the side queue (above) unless one launch is being replayed alone
     const bool lane = g_only_launch < 0 && tdm_bwd_overlap(st) != 0;
-    if (lane) TDM_REQUIRE(g_lane.init(), "unet_backward: side stream / events could not be created");
+    if (lane) TDM_REQUIRE(g_lane.init(st), "unet_backward: side stream / events could not be created");
     const hipStream_t ss = lane ? g_lane.side : st;
+    TdmSideJoin sj{&g_lane, st};
     int nfork = 0;
     auto fork = [&]() -> int {   // what the main chain has issued so far is what the side queue's next launches may read
         if (!lane) return 0;
+        sj.armed = true;
         hipEvent_t e = g_lane.ready[nfork++ & 3];
         TDM_HIP(hipEventRecord(e, st));
         TDM_HIP(hipStreamWaitEvent(ss, e, 0));
@@ -551,10 +554,7 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
         ra.sec[n - 1].dst = mse->loss_out; ra.sec[n - 1].scale = 1.0f / (float)M28;
     }
     ra.nsec = n;
-    if (lane) {   // join: the reduction reads every slab
-        TDM_HIP(hipEventRecord(g_lane.done, ss));
-        TDM_HIP(hipStreamWaitEvent(st, g_lane.done, 0));
-    }
+    if (lane) TDM_TRY(sj.join());   // the reduction reads every slab
     RUN(B_REDUCE, tdm_launch_reduce(slabs, NP, ra, G, st));
     return 0;
 }
@@ -569,11 +569,13 @@ int unet_backward(const float* P, const float* x, const float* deps, float* G, c
     // the weight-gradient launches on the side queue, as in the S16 pipeline (SideLane): here too every tensor has its own
     // buffer, and the in-place ReLU backward of a gradient tensor comes before the fork that lets the side queue read it
     const bool lane = tdm_bwd_overlap(st) != 0;
-    if (lane) TDM_REQUIRE(g_lane.init(), "unet_backward: side stream / events could not be created");
+    if (lane) TDM_REQUIRE(g_lane.init(st), "unet_backward: side stream / events could not be created");
     const hipStream_t ss = lane ? g_lane.side : st;
+    TdmSideJoin sj{&g_lane, st};
     int nfork = 0;
     auto fork = [&]() -> int {
         if (!lane) return 0;
+        sj.armed = true;
         hipEvent_t e = g_lane.ready[nfork++ & 3];
         TDM_HIP(hipEventRecord(e, st));
         TDM_HIP(hipStreamWaitEvent(ss, e, 0));
@@ -650,10 +652,7 @@ int unet_backward(const float* P, const float* x, const float* deps, float* G, c
     }
     sec(kL.outw, 33);
     ra.nsec = n;
-    if (lane) {   // join: the reduction reads every slab
-        TDM_HIP(hipEventRecord(g_lane.done, ss));
-        TDM_HIP(hipStreamWaitEvent(st, g_lane.done, 0));
-    }
+    if (lane) TDM_TRY(sj.join());   // the reduction reads every slab
     TDM_TRY(tdm_launch_reduce(slabs, TDM_UNET_NPARAM, ra, G, st));
     return 0;
 }
@@ -674,8 +673,25 @@ int forward_loss_backward(const float* P, const float* x_noisy, const int64_t* t
 
 }  // namespace
 
-bool TdmSideLane::init() {
-    if (ok) return true;
+void TdmSideLane::destroy() {
+    // (errors ignored: at process exit the runtime may already be gone)
+    if (side != nullptr) (void)hipStreamDestroy(side);
+    for (hipEvent_t& e : ready) if (e != nullptr) { (void)hipEventDestroy(e); e = nullptr; }
+    for (hipEvent_t& e : back) if (e != nullptr) { (void)hipEventDestroy(e); e = nullptr; }
+    if (done != nullptr) (void)hipEventDestroy(done);
+    side = nullptr; done = nullptr; ok = false; device = -1;
+    (void)hipGetLastError();
+}
+bool TdmSideLane::init(hipStream_t st) {
+    // the device the caller's stream lives on (the current device for the null stream)
+    int dev = -1;
+    if (st == nullptr || hipStreamGetDevice(st, &dev) != hipSuccess) { (void)hipGetLastError(); if (hipGetDevice(&dev) != hipSuccess) return false; }
+    if (ok && dev == device) return true;
+    if (ok || side != nullptr) destroy();   // made on another device: rebuild there
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return false;
+    if (cur != dev && hipSetDevice(dev) != hipSuccess) return false;
+    struct Restore { int cur, dev; ~Restore() { if (cur != dev) (void)hipSetDevice(cur); } } restore{cur, dev};
     // events that only order two queues of this device: no timing, no system-scope fence (6 us per step at B = 512)
     const unsigned flags = hipEventDisableTiming | hipEventDisableSystemFence;
     // the side queue at the LOWEST priority: its launches have slack (they only have to finish before the slab reduction), the
@@ -691,6 +707,7 @@ bool TdmSideLane::init() {
     for (hipEvent_t& e : back)
         if (hipEventCreateWithFlags(&e, flags) != hipSuccess) return false;
     if (hipEventCreateWithFlags(&done, flags) != hipSuccess) return false;
+    device = dev;
     return ok = true;
 }
 TdmSideLane& tdm_side_lane() { return g_lane; }

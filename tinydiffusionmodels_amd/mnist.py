@@ -526,6 +526,7 @@ class DDPMTrainer(DPStepper):
         # epoch mode (begin_epoch / step_epoch): dataset and permutation resident on the device, the batch gathered inside the step
         self._epoch_data = None
         self._epoch_perm = None
+        self._epoch_issued = 0
         self._epoch_base = torch.zeros(1, dtype=torch.long, device=dev)
         self._epoch_graph = None
         self._epoch_key = None
@@ -624,6 +625,9 @@ class DDPMTrainer(DPStepper):
         epoch's sample order, identical on every rank.  Iteration k of the epoch trains on positions
         (k * world + rank) * batch_size ... + batch_size of perm (dp.shard_batch_indices)."""
         E._need_cuda(data, perm)
+        if perm.numel() != data.shape[0]:
+            raise ValueError(f"begin_epoch: perm has {perm.numel()} entries for {data.shape[0]} samples")
+        self._epoch_issued = 0                             # host-side count of the epoch's steps (no device sync)
         if self._epoch_perm is None or self._epoch_perm.numel() != perm.numel():
             self._epoch_perm = torch.empty(perm.numel(), dtype=torch.long, device=self.flat.device)
         self._epoch_perm.copy_(perm)                       # fixed address: the captured step reads it
@@ -667,6 +671,12 @@ class DDPMTrainer(DPStepper):
         1-element device tensor (no host sync)."""
         if self._epoch_data is None:
             raise RuntimeError("steps_epoch() before begin_epoch()")
+        # whole batches only: past them the gather kernel would clamp its positions and train on repeats of the last sample
+        whole = int(self._epoch_data.shape[0]) // (self.batch_size * self.world)
+        if n < 0 or self._epoch_issued + n > whole:
+            raise ValueError(f"steps_epoch({n}): the epoch has {whole} whole iterations of {self.batch_size} x {self.world} samples, "
+                             f"{self._epoch_issued} already issued (run the ragged tail through step())")
+        self._epoch_issued += n
         st = self._cur = self._state(self.batch_size)
         done = 0
         while done < n:
