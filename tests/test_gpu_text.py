@@ -520,7 +520,7 @@ def test_transformer_oracle_shapes_and_autograd_bridge(dev, golden_tables, gemm_
     l2tol = _l2tol(gemm_mode)
     for k, v in leaf.items():
         assert O.rel_l2(got[k].cpu(), v.grad) < l2tol, k
-        if gemm_mode == 0:
+        if gemm_mode == 0 and _ATTN["mode"] != 2:          # exact fp32 everywhere: no mask flips, the max norm holds too
             assert O.rel_err(got[k].cpu(), v.grad) < 3e-2, k
     assert O.rel_l2(xd.grad.cpu(), xr.grad) < l2tol
 

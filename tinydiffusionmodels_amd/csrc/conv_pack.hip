@@ -15,6 +15,32 @@ namespace {
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void pack_body(const float* __restrict__ P, const PackDesc& d, unsigned short* __restrict__ out, int bx,
                                           int nbx) {
+    if (d.phase == 1) {   // phase form of an up-sampled source's forward weights (PackDesc's comment; conv_s16.hip "PH")
+        const int NTp = d.cout / 32;
+        const int total = (d.kuse / 16) * 16 * NTp * 512;
+        for (int e = bx * 256 + threadIdx.x; e < total; e += nbx * 256) {
+            const int jj = e & 7;
+            const int lane = (e >> 3) & 63;
+            int r = e >> 9;
+            const int nt = r % NTp; r /= NTp;
+            const int tap16 = r & 15;
+            const int chunk = r >> 4;
+            const int py = tap16 >> 3, px = (tap16 >> 2) & 1, ap = (tap16 >> 1) & 1, bp = tap16 & 1;
+            const int ky0 = ap ? (py ? 2 : 1) : 0, ky1 = ap ? 2 : (py ? 1 : 0);
+            const int kx0 = bp ? (px ? 2 : 1) : 0, kx1 = bp ? 2 : (px ? 1 : 0);
+            const int n = nt * 32 + (lane & 31);
+            const int k = chunk * 16 + 8 * (lane >> 5) + jj;
+            float x = 0.f;
+            for (int ky = ky0; ky <= ky1; ++ky)
+                for (int kx = kx0; kx <= kx1; ++kx) x += P[d.src_off + (long)((ky * 3 + kx) * d.cin + k) * d.cout + n];
+            const __bf16 hi = (__bf16)x;
+            const __bf16 lo = (__bf16)(x - (float)hi);
+            const long base = d.dst_off + ((long)((chunk * 16 + tap16) * NTp + nt) * 2) * 512 + lane * 8 + jj;
+            out[base] = __builtin_bit_cast(unsigned short, hi);
+            out[base + 512] = __builtin_bit_cast(unsigned short, lo);
+        }
+        return;
+    }
     const int K = d.dgrad ? d.cout : d.cin;       // contraction length
     const int Nn = d.dgrad ? d.cin : d.cout;      // output channels of this direction
     const int NT = Nn / 32;

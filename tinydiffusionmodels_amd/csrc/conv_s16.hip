@@ -161,14 +161,28 @@ __device__ __forceinline__ void gstore_s16_o(float* s16, unsigned o, int c, cons
 // per SIMD (32 accumulator registers instead of 16; single prefetch set).
 // MSE: the instantiation of rb4.conv2's forward launch in a train step (ConvArgs::o1_tgt): fused output conv + MSE backward;
 // it carries neither the rank-1 residual nor the ReLU-backward sums (their registers would push the walk over the 128 budget).
-template <int HW, int NT, bool SKIP, bool PROBE, int MT = 1, bool MSE = false>
+// PH ("phase" form, rb4.conv1's forward: ConvArgs::up_phase): source 0 is a HALF-resolution tensor that the reference up-samples
+// (nearest, x2: src/mnist.py:83) before a 3x3 convolution.  For an output pixel (2i + py, 2j + px) the three taps of a direction
+// fall on only TWO source pixels — py = 0: rows {i-1, i} with weights {W[-1], W[0] + W[+1]}; py = 1: rows {i, i+1} with
+// {W[-1] + W[0], W[+1]} — so the nine taps over the 4x up-sampled image are FOUR taps over the source image with weights
+// pre-summed per phase (py, px) (conv_pack.hip, PackDesc::phase): 4/9 of the MFMAs and of the pixel-fragment reads for those
+// channels, and the staged image is the 14x14 source itself (no up-sampled duplicate in LDS).  All 32 pixels of an MFMA must
+// share the weights, hence the tile: 64 consecutive SOURCE positions x 4 phases; wave w owns phase w & 3 of source positions
+// 32 (w >> 2) .. + 31, i.e. 32 same-parity output pixels.  Source 1 (h1, full resolution) runs through the ordinary nine taps
+// with the same lanes, reading a 28x28-domain image staged around the tile's output rows.
+template <int HW, int NT, bool SKIP, bool PROBE, int MT = 1, bool MSE = false, bool PH = false>
 __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kernel(ConvArgs ka) {
     using G = Geo<HW>;
-    constexpr int TPX = TILE_PX * MT;                                  // pixels of the workgroup's tile
-    constexpr int NRv = MT == 1 ? G::NR : ConvRows<HW, MT>::NR;        // staged rows of the padded-tall image
+    using G2 = Geo<14>;                                                // geometry of the half-resolution source (PH)
+    constexpr int TPX = PH ? 64 : TILE_PX * MT;                        // pixels of the workgroup's tile (PH: SOURCE positions)
+    constexpr int NR28 = 16, NR14 = 10;                                // PH: staged rows of the two images (64 positions: <= 6 source rows, + seam, + halo)
+    constexpr int NRv = PH ? NR28 : (MT == 1 ? G::NR : ConvRows<HW, MT>::NR);   // staged rows of the padded-tall image
     constexpr int NPINv = (NRv * G::WP * 4 + CONV_THREADS - 1) / CONV_THREADS;   // 16-byte input pieces per thread and K chunk
+    constexpr int PHT = 16;                                            // PH: packed taps per chunk of source 0 (4 phases x 4)
+    constexpr int WTAPS = PH ? PHT : 9;                                // weight fragments (per N tile) the LDS weight area holds
     static_assert(NRv <= 32, "the per-wave row table has 32 entries");
     static_assert(MT == 1 || (HW == 28 && NT == 1), "two M tiles per wave: built for the 28x28 N = 32 kernels");
+    static_assert(!PH || (HW == 28 && NT == 1 && SKIP && MT == 1 && !MSE), "the phase form is built for rb4.conv1's forward");
     // The ~300-byte argument block does not stay in scalar registers by itself: the compiler re-reads a field from the
     // kernarg segment (s_load + s_waitcnt lgkmcnt(0), a scalar-cache round trip) next to almost every use — before each
     // prefetch load, around every uniform branch of the epilogue.  Everything the kernel uses is copied ONCE into
@@ -212,16 +226,41 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     };
     stamp();
     const int Mtot = a.B * G::H * G::W;
+    // PH: the tile is 64 SOURCE positions [m0, mlast] of the (B, 14, 14) raster; the 28x28-domain image is staged from the halo
+    // row above output row 2 * i0 (ty0 = 2 * i0), the source image from the halo row above source row i0 (ty0s = i0)
+    const int Mtile = PH ? a.B * G2::H * G2::W : Mtot;        // positions the tiles walk
     const int m0 = t * TPX;
-    const int mlast = min(m0 + TPX - 1, Mtot - 1);
-    const int tb0 = m0 / (G::H * G::W);                       // image and row of the tile's first pixel:
-    const int ty0 = (m0 - tb0 * (G::H * G::W)) / G::W;        // the staged image starts at padded row PR0 = tb0 * HP + ty0
+    const int mlast = min(m0 + TPX - 1, Mtile - 1);
+    const int tb0 = m0 / (PH ? G2::H * G2::W : G::H * G::W);  // image and row of the tile's first pixel:
+    const int ty0s = PH ? (m0 - tb0 * (G2::H * G2::W)) / G2::W : 0;   // (PH: first source row)
+    const int ty0 = PH ? 2 * ty0s : (m0 - tb0 * (G::H * G::W)) / G::W;   // the staged image starts at padded row PR0 = tb0 * HP + ty0
     const int PR0 = tb0 * G::HP + ty0;
-    const int nrows = padded_row<HW>(mlast) - PR0 + 2;
+    int nrows, nrows_s = 0;
+    if constexpr (PH) {
+        const int b1 = mlast / (G2::H * G2::W);
+        const int i1 = (mlast - b1 * (G2::H * G2::W)) / G2::W;
+        nrows = (b1 * G::HP + 2 * i1 + 2) - PR0 + 2;          // last output row 2 i1 + 1 sits at padded row b1 HP + 2 i1 + 2
+        nrows_s = (b1 * G2::HP + i1 + 1) - (tb0 * G2::HP + ty0s) + 2;
+    } else nrows = padded_row<HW>(mlast) - PR0 + 2;
     const int nelem = nrows * G::WP * 4;      // 16-byte pieces of one chunk
-    const int mbase0 = m0 + wave * (32 * MT);   // this wave's first M tile (scalar); its MT tiles are consecutive
+    const int nelem_s = nrows_s * G2::WP * 4; // (PH: of a source-0 chunk)
+    const int mbase0 = PH ? m0 + (wave >> 2) * 32 : m0 + wave * (32 * MT);   // this wave's first M tile (scalar); its MT tiles are consecutive
+    const int ph_y = PH ? (wave >> 1) & 1 : 0, ph_x = PH ? wave & 1 : 0;      // PH: this wave's phase
 
     int aoff[MT];   // LDS byte offset of this lane's pixel (centre tap) in the staged image, per M tile
+    int aoff_s = 0; // PH: ... of its SOURCE pixel in the staged source image
+    int m_lane = 0; // PH: output pixel (index into the (B, 28, 28) raster) of this lane, -1 past the end
+    if constexpr (PH) {
+        const int sp = mbase0 + j;                            // source position of this lane (pixel j of the wave's M tile)
+        const int sc = min(sp, Mtile - 1);
+        const int b = sc / (G2::H * G2::W);
+        const int rem = sc - b * (G2::H * G2::W);
+        const int i = rem / G2::W, jx = rem - i * G2::W;
+        const int yo = 2 * i + ph_y, xo = 2 * jx + ph_x;
+        aoff[0] = (((b - tb0) * G::HP + yo + 1 - ty0) * G::WP + xo + 1) * PIXB + h * 16;
+        aoff_s = (((b - tb0) * G2::HP + i + 1 - ty0s) * G2::WP + jx + 1) * PIXB + h * 16;
+        m_lane = sp < Mtile ? (b * G::H + yo) * G::W + xo : -1;
+    } else
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         // (image, row, column) of the M tile's first pixel are scalar; a lane is q = x0 + j columns further: q / W by
@@ -264,7 +303,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     // Software pipeline over K chunks, register-staged.  At N = 32 input pieces are prefetched TWO chunks ahead (two
     // register sets, 4 x 16 B per thread each), the L2-resident packed weights one chunk ahead: with a single chunk of
     // distance a workgroup's MFMA phase is shorter than the HBM latency under load and every chunk stalled.
-    constexpr int WN = (9 * NT * 128 + CONV_THREADS - 1) / CONV_THREADS;
+    constexpr int WN = (WTAPS * NT * 128 + CONV_THREADS - 1) / CONV_THREADS;
     constexpr int STEP = CONV_THREADS / 4;   // staged positions between a thread's consecutive pieces
     char* const sdst = tile + (tid >> 2) * PIXB + (tid & 3) * 16;
     const int nc0 = a.s0.nch >> 4;
@@ -281,18 +320,48 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         const int si = (c >= nc0) ? 1 : 0;
         const int ch = si ? c - nc0 : c;
         const PinnedSrc s = a.src(si);
-        const int up = s.up, Hs = G::H >> up, Ws = G::W >> up;
+        const bool half = PH && si == 0;                      // PH: source 0 is staged at its own (14x14) resolution
+        const int up = PH ? 0 : s.up, Hs = half ? G2::H : G::H >> up, Ws = half ? G2::W : G::W >> up;
         if (plan_src != si && plan_other == si) {   // the other register set already holds this source's plan
 #pragma unroll
             for (int i = 0; i < NPINv; ++i) goff[i] = goff_other[i];
             plan_src = si;
         }
+        if constexpr (PH) {
+            if (plan_src != si) {
+                // the same plan as below for either image of the phase form: geometry (HP, H, W, WP), first staged row and row
+                // count are those of the source's own resolution
+                const int HPv = half ? G2::HP : G::HP, Hv = half ? G2::H : G::H, Wv = half ? G2::W : G::W, WPv = half ? G2::WP : G::WP;
+                const int ty0v = half ? ty0s : ty0, nrv = half ? nrows_s : nrows;
+                int* const rowtab = reinterpret_cast<int*>(wl + WTAPS * NT * 2048 + NT * 2048) + wave * 32;
+                if (lane < 32) {
+                    int py = ty0v + lane, b = tb0;
+                    if (py >= HPv) { py -= HPv; ++b; }
+                    const bool ok = lane < nrv && py >= 1 && py <= Hv && b < a.B;
+                    rowtab[lane] = ok ? __mul24(__mul24(__mul24(b, Hs) + (py - 1), Ws), s.C) * 4 : (int)0x80000000;
+                }
+                int lr = half ? (tid >> 2) / G2::WP : (tid >> 2) / G::WP;
+                int pc = (tid >> 2) - lr * WPv;
+                const int cbase = (s.c0 + (tid & 3) * 4) * 4;
+                const int stp = half ? STEP % G2::WP : STEP % G::WP, str = half ? STEP / G2::WP : STEP / G::WP;
+#pragma unroll
+                for (int i = 0; i < NPINv; ++i) {
+                    const int roff = rowtab[min(lr, 31)];
+                    const bool ok = lr < 32 && roff >= 0 && pc >= 1 && pc <= Wv;
+                    goff[i] = ok ? roff + __mul24(pc - 1, s.C) * 4 + cbase : (int)0x80000000;
+                    pc += stp;
+                    lr += str;
+                    if (pc >= WPv) { pc -= WPv; ++lr; }
+                }
+                plan_src = si;
+            }
+        } else
         if (plan_src != si) {
             // Staged position of piece e = tid + 512 i is (tid >> 2) + 128 i = (row lr, column pc) of the padded-tall image,
             // walked incrementally (no division per piece).  What depends on the ROW — image, validity, the three
             // multiplications of the source offset — is worked out once per row by lanes 0..31 of each wave and parked in
             // a wave-private LDS table; a piece then costs one LDS read, the column offset and a select.
-            int* const rowtab = reinterpret_cast<int*>(wl + 9 * NT * 2048 + (SKIP ? NT * 2048 : 0)) + wave * 32;
+            int* const rowtab = reinterpret_cast<int*>(wl + WTAPS * NT * 2048 + (SKIP ? NT * 2048 : 0)) + wave * 32;
             if (lane < 32) {
                 int py = ty0 + lane, b = tb0;
                 if (py >= G::HP) { py -= G::HP; ++b; }
@@ -326,7 +395,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         const int si = (c >= nc0) ? 1 : 0;
         const int ch = si ? c - nc0 : c;
         const PinnedSrc s = a.src(si);
-        const int nbytes = s.taps * NT * 2048;   // one chunk of packed weights
+        const int nbytes = s.taps * NT * 2048;   // one chunk of packed weights (PH, source 0: 16 phase taps)
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<unsigned short*>(s.wp) + (long)(s.wchunk0 + ch) * (s.taps * NT * 1024), 0, nbytes, 0x00020000);
 #pragma unroll
@@ -341,35 +410,50 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
             sk.psk = make_uint4(v[0], v[1], v[2], v[3]);
         }
     };
-    auto stage = [&](const uint4 (&pin)[NPINv]) {
+    auto stage = [&](const uint4 (&pin)[NPINv], int nel) {
         __syncthreads();      // everyone finished reading the previous chunk's LDS image
 #pragma unroll
         for (int i = 0; i < NPINv; ++i)
-            if (tid + CONV_THREADS * i < nelem) *reinterpret_cast<uint4*>(sdst + i * (STEP * PIXB)) = pin[i];
+            if (tid + CONV_THREADS * i < nel) *reinterpret_cast<uint4*>(sdst + i * (STEP * PIXB)) = pin[i];
 #pragma unroll
         for (int i = 0; i < WN; ++i)
-            if (tid + CONV_THREADS * i < 9 * NT * 128) reinterpret_cast<uint4*>(wl)[tid + CONV_THREADS * i] = pwt[i];
+            if (tid + CONV_THREADS * i < WTAPS * NT * 128) reinterpret_cast<uint4*>(wl)[tid + CONV_THREADS * i] = pwt[i];
         if constexpr (SKIP) {   // packed 1x1 weights of the chunk: NT x (hi 1 KB | lo 1 KB) behind the 3x3 weights
-            if (tid < NT * 128) reinterpret_cast<uint4*>(wl + 9 * NT * 2048)[tid] = sk.psk;
+            if (tid < NT * 128) reinterpret_cast<uint4*>(wl + WTAPS * NT * 2048)[tid] = sk.psk;
         }
         __syncthreads();
     };
     auto compute = [&](int c) {
         if (a.ablate & 4) return;
         const int taps = (c >= nc0) ? a.s1.taps : a.s0.taps;
+        // PH, chunk of the half-resolution source: sites 0..3 are the phase's four taps over the staged SOURCE image — site
+        // 2 a' + b' reads source pixel (i + ph_y - 1 + a', j + ph_x - 1 + b') with packed tap (2 ph_y + ph_x) * 4 + 2 a' + b' —
+        // and site 4 re-reads the source pixel itself (a' = 1 - ph_y, b' = 1 - ph_x) for the fused 1x1 skip conv alone
+        const bool halfc = PH && c < nc0;
+        const int pix0 = halfc ? aoff_s : aoff[0];
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
-            if (taps == 9 || tp == 4) {   // a 1x1 source uses the centre-tap site with packed tap 0
-                const int toff = ((tp / 3 - 1) * G::WP + (tp % 3 - 1)) * PIXB;
-                const int wt = (taps == 9) ? tp : 0;
+            if (PH ? (!halfc || tp <= 4) : (taps == 9 || tp == 4)) {   // a 1x1 source uses the centre-tap site with packed tap 0
+                int toff = ((tp / 3 - 1) * G::WP + (tp % 3 - 1)) * PIXB;
+                int wt = (taps == 9) ? tp : 0;
+                bool main_on = true;
+                if constexpr (PH) {
+                    if (halfc) {
+                        const int ap = tp < 4 ? (tp >> 1) : 1 - ph_y, bp = tp < 4 ? (tp & 1) : 1 - ph_x;
+                        toff = ((ph_y - 1 + ap) * G2::WP + (ph_x - 1 + bp)) * PIXB;
+                        wt = (2 * ph_y + ph_x) * 4 + (tp & 3);
+                        main_on = tp < 4;
+                    }
+                }
                 bf16x8 ah[MT], al[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    ah[mt] = *reinterpret_cast<const bf16x8*>(tile + aoff[mt] + toff);
-                    al[mt] = *reinterpret_cast<const bf16x8*>(tile + aoff[mt] + toff + 32);
+                    ah[mt] = *reinterpret_cast<const bf16x8*>(tile + (PH ? pix0 : aoff[mt]) + toff);
+                    al[mt] = *reinterpret_cast<const bf16x8*>(tile + (PH ? pix0 : aoff[mt]) + toff + 32);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
+                    if (main_on) {
                     const char* wb = wl + ((wt * NT + nt) * 2) * 1024 + lane * 16;
                     const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wb);
                     const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wb + 1024);
@@ -380,8 +464,9 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[mt], acc[mt][nt], 0, 0, 0);
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[mt], acc[mt][nt], 0, 0, 0);
                     }
+                    }
                     if constexpr (SKIP) if (tp == 4) {   // the block's 1x1 skip conv reads exactly the centre-tap pixels
-                        const char* sb = wl + 9 * NT * 2048 + (nt * 2) * 1024 + lane * 16;
+                        const char* sb = wl + WTAPS * NT * 2048 + (nt * 2) * 1024 + lane * 16;
                         const bf16x8 sh = *reinterpret_cast<const bf16x8*>(sb);
                         const bf16x8 sl = *reinterpret_cast<const bf16x8*>(sb + 1024);
 #pragma unroll
@@ -403,14 +488,14 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         if (nchunks > 1) prefetch_in(pinB, goffB, planB, goffA, planA, 1);
         stamp();
         for (int c = 0; c < nchunks; c += 2) {
-            stage(pinA);                                                  // chunk c
+            stage(pinA, nelem);                                           // chunk c
             stamp();
             if (c + 2 < nchunks && pf) prefetch_in(pinA, goffA, planA, goffB, planB, c + 2);
             if (c + 1 < nchunks && pf) prefetch_w(c + 1);
             compute(c);
             stamp();
             if (c + 1 >= nchunks) break;
-            stage(pinB);                                                  // chunk c + 1
+            stage(pinB, nelem);                                           // chunk c + 1
             stamp();
             if (c + 3 < nchunks && pf) prefetch_in(pinB, goffB, planB, goffA, planA, c + 3);
             if (c + 2 < nchunks && pf) prefetch_w(c + 2);
@@ -421,7 +506,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         // N = 64 / 96 (and N = 32 with the fused skip conv): a second input register set does not fit the 128-register
         // budget of four waves per SIMD, so these widths prefetch one chunk ahead
         for (int c = 0; c < nchunks; ++c) {
-            stage(pinA);
+            stage(pinA, (PH && c < nc0) ? nelem_s : nelem);
             if (c + 1 < nchunks && pf) { prefetch_in(pinA, goffA, planA, goffB, planB, c + 1); prefetch_w(c + 1); }
             compute(c);
         }
@@ -465,7 +550,14 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     static_for<0, MT>([&](auto mtc) {
     constexpr int mt = decltype(mtc)::value;
     const int mbase = mbase0 + mt * 32;
-    const int img0 = mbase / (G::H * G::W);         // image of the group's first pixel (scalar)
+    // PH: the wave's 32 pixels are not consecutive — pixel px of the tile is output pixel m_lane of lane px; pass `it` of the
+    // walk handles pixel 8 it + (lane >> 3) (N = 32: eight lanes per pixel), fetched once per pass (-1: past the end)
+    int mpx[PH ? 4 : 1];
+    if constexpr (PH) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) mpx[it] = __shfl(m_lane, it * 8 + (lane_e >> 3));
+    }
+    const int img0 = PH ? min(mbase, Mtile - 1) / (G2::H * G2::W) : mbase / (G::H * G::W);   // image of the group's first pixel (scalar)
     const int mnext = (img0 + 1) * (G::H * G::W);   // a 32-pixel group touches at most two images
     const bool has_epi_in = use_res || use_tb || bwd || (R1X && r1_x != nullptr) || MSE;
     auto preload = [&](int g) {
@@ -473,7 +565,8 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         for (int it = 0; it < GI; ++it) {
             const int e = (g * GI + it) * 64 + lane_e;
             const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
-            const int m = min(mbase + px, Mtot - 1);   // clamped: the walk skips pixels past the end
+            int m = min(mbase + px, Mtot - 1);   // clamped: the walk skips pixels past the end
+            if constexpr (PH) m = max(mpx[(g * GI + it) & 3], 0);
             const int o = m * N + c;
             const int otb = (img0 + (m >= mnext ? 1 : 0)) * a.tb_out_stride + c;
             const f32x4 r = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_rt, (use_res ? o : otb) * 4, 0, 0));
@@ -563,6 +656,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
             v[k] = *reinterpret_cast<const float4*>(T + px * EPI + c);
             o[k] = (unsigned)(mbase + px) * N + c;
             ok[k] = FULL || mbase + px < Mtot;
+            if constexpr (PH) { o[k] = (unsigned)max(mpx[(I0 + k) & 3], 0) * N + c; ok[k] = mpx[(I0 + k) & 3] >= 0; }
         }
         if (a.relu) {
 #pragma unroll
@@ -679,7 +773,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
             __builtin_amdgcn_sched_barrier(0);
         });
     };
-    if (mbase + 32 <= Mtot) groups(std::true_type{});
+    if (mbase + 32 <= (PH ? Mtile : Mtot)) groups(std::true_type{});
     else groups(std::false_type{});
     if constexpr (MSE) {   // lanes with equal lane % 8 hold the same channel quad: butterfly over bits 3..5
         float4 r = o1_gw;
@@ -721,7 +815,8 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         for (int it = 0; it < NIT; ++it) {
             const int e = it * 64 + lane_e;
             const int px = e / (N / 4), c = (e - px * (N / 4)) * 4;
-            const int m = mbase + px;
+            int m = mbase + px;
+            if constexpr (PH) m = mpx[it & 3] >= 0 ? mpx[it & 3] : Mtot;
             const float4 v = *reinterpret_cast<const float4*>(T + px * EPI + c);
             if (m < Mtot) gstore4(a.skip_out + ((unsigned)m * N + c), v);
         }
@@ -788,6 +883,30 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     }
     hipLaunchKernelGGL((conv_s16_kernel<HW, NT, SKIP, false, MT>), dim3(ntiles), dim3(CONV_THREADS), lds_req, st, a);
     TDM_CHECK_LAUNCH("conv_s16");
+    return 0;
+}
+
+// rb4.conv1's forward in the phase form (ConvArgs::up_phase; the kernel's PH instantiation)
+int launch_conv_phase(const ConvArgs& a, hipStream_t st) {
+    using G = Geo<28>;
+    constexpr size_t lds_op = (size_t)16 * G::WP * PIXB + (size_t)16 * 2048 + 2048 + (size_t)(CONV_THREADS / 64) * 32 * sizeof(int);
+    constexpr size_t lds_epi = (size_t)(CONV_THREADS / 64) * 32 * (32 + 4) * sizeof(float);
+    constexpr size_t lds = lds_op > lds_epi ? lds_op : lds_epi;
+    static_assert(lds <= 80 * 1024, "two workgroups per CU");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<28, 1, true, false, 1, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 110000);
+        if (e != hipSuccess) {
+            tdm_set_error("conv_s16(phase): hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+            return 100 + (int)e;
+        }
+        attr_set = true;
+    }
+    const long Msrc = (long)a.B * 196;
+    const int ntiles = (int)((Msrc + 63) / 64);
+    hipLaunchKernelGGL((conv_s16_kernel<28, 1, true, false, 1, false, true>), dim3(ntiles), dim3(CONV_THREADS), lds, st, a);
+    TDM_CHECK_LAUNCH("conv_s16(phase)");
     return 0;
 }
 
@@ -1130,6 +1249,18 @@ __global__ __launch_bounds__(256) void to_s16_kernel(const float* __restrict__ i
 }  // namespace
 
 int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st) {
+    if (a.up_phase) {   // rb4.conv1's forward: source 0 half-resolution with 16 phase taps per chunk, source 1 full resolution
+        TDM_REQUIRE(hw == 28 && N == 32 && a.nsrc == 2 && a.src[0].taps == 16 && a.src[1].taps == 9 && a.src[0].up == 1 && a.src[1].up == 0 &&
+                    a.skip_out != nullptr && a.skip_wp != nullptr && a.skip_bias != nullptr && a.res == nullptr && a.relu_mask_in == nullptr &&
+                    a.o1_out == nullptr && a.r1_x == nullptr && a.dc_pair == nullptr,
+                    "conv_s16: the phase form is built for rb4.conv1's forward (hw 28, N 32, up-sampled source + full-resolution source, fused skip)");
+        for (int i = 0; i < 2; ++i) {
+            TDM_REQUIRE(a.src[i].nch % CK == 0 && a.src[i].nch > 0 && (a.src[i].C % 16) == 0 && (a.src[i].c0 % 16) == 0 && a.src[i].tb == nullptr &&
+                        a.src[i].wp != nullptr && (((uintptr_t)a.src[i].wp) & 15) == 0, "conv_s16(phase): source %d layout", i);
+        }
+        TDM_REQUIRE(a.B > 0 && (long)a.B * hw * hw < TDM_S16_MAX_PIXELS, "conv_s16: batch %d out of range", a.B);
+        return launch_conv_phase(a, st);
+    }
     for (int i = 0; i < a.nsrc; ++i) {
         TDM_REQUIRE(a.src[i].nch % CK == 0 && a.src[i].nch > 0, "conv_s16: source %d channel count %d", i, a.src[i].nch);
         TDM_REQUIRE(a.src[i].taps == 9 || a.src[i].taps == 1, "conv_s16: taps must be 9 or 1");

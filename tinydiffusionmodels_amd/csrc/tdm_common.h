@@ -173,13 +173,21 @@ struct ConvArgs {
     float* o1_deps;
     float* o1_sums;
     float o1_dscale;
+    // rb4.conv1's forward in the PHASE form (S16 kernel; conv_s16.hip "PH"): src[0] is the half-resolution tensor the reference
+    // up-samples x2 (src/mnist.py:83), given with up = 1 and taps = 16 — its packed weights are the 4 phases x 4 taps of
+    // PackDesc::phase = 1 — and src[1] the full-resolution tensor with the ordinary nine taps.
+    int up_phase;
 };
 
 // hw in {28,14}; N in {32,64,96}; dgrad: transposed convolution with the forward weights
 int tdm_launch_conv(const ConvArgs& a, int hw, int N, bool dgrad, hipStream_t st);
 
 // weight pre-pack of the bf16x3 kernels (conv_pack.hip; direction-agnostic kernels: the pre-pack encodes fwd / dgrad)
-struct PackDesc { int src_off, cin, cout, taps, dgrad; long dst_off; };
+// phase = 1: forward weights of an up-sampled source in the phase form (conv_s16.hip "PH"): rows [0, kuse) of the cin input channels,
+// 16 packed taps per chunk, packed tap (2 py + px) * 4 + 2 a + b = sum of the 3x3 taps (ky, kx) that fall on source pixel
+// (i + py - 1 + a, j + px - 1 + b) for output pixel (2 i + py, 2 j + px): ky in {0} / {1, 2} for (py, a) = (0, 0) / (0, 1),
+// {0, 1} / {2} for (1, 0) / (1, 1); kx likewise (summed in fp32, then split hi / lo).
+struct PackDesc { int src_off, cin, cout, taps, dgrad; long dst_off; int phase, kuse; };
 #define TDM_MAX_PACK 24
 struct PackArgs { PackDesc d[TDM_MAX_PACK]; int n; };
 int tdm_launch_pack(const float* params, const PackArgs& pa, unsigned short* out, hipStream_t st);

@@ -64,6 +64,7 @@ enum { W_RB1C2, W_RB2C1, W_RB2C2, W_RB2SK, W_RB3C1, W_RB3C2, W_RB4C1, W_RB4C2, W
 struct PackTab {
     PackArgs pa;
     long fwd[W_COUNT], dg[W_COUNT];
+    long fwd_ph;      // rb4.conv1's up(h3) rows in the phase form (PackDesc::phase = 1): 4 chunks x 16 taps
     long total_u16;
 };
 PackTab make_pack() {
@@ -82,6 +83,12 @@ PackTab make_pack() {
             (dir ? t.dg[i] : t.fwd[i]) = o;
             o += 2L * cin[i] * cout[i] * taps[i];   // hi + lo planes, one bf16 each
         }
+    {   // rb4.conv1 forward, up-sampled source (concat channels 0..63): phase weights
+        PackDesc& d = t.pa.d[n++];
+        d.src_off = off[W_RB4C1]; d.cin = 96; d.cout = 32; d.taps = 16; d.dgrad = 0; d.dst_off = o; d.phase = 1; d.kuse = 64;
+        t.fwd_ph = o;
+        o += 2L * 64 * 32 * 16;
+    }
     t.pa.n = n;
     t.total_u16 = o;
     return t;
@@ -91,6 +98,8 @@ const PackTab kPack = make_pack();
 // 0: exact fp32 MFMA (conv_mfma.hip); 1: bf16x3, fp32 tensors split while staging (round 1; removed from the library);
 // 2: bf16x3 over pre-split "S16" tensors written by the producers (conv_s16.hip) — same arithmetic as 1
 thread_local int g_conv_mode = 2;   // per calling thread (tdm_set_conv_mode): no process-global mutable state
+// rb4.conv1 on the up-sampled h3 in the phase form (default); TDM_RB4_PHASE=0 keeps the nine-tap launches for A/B timing
+const bool g_rb4_phase = !(getenv("TDM_RB4_PHASE") && atoi(getenv("TDM_RB4_PHASE")) == 0);
 
 // ------------------------------ workspace --------------------------------------
 struct Ws {
@@ -400,6 +409,10 @@ int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* ep
         a.nsrc = 2;
         a.src[0] = s16_src(w.h3s, 64, 64, 1, 9, w.wpack + kPack.fwd[W_RB4C1], 0);
         a.src[1] = s16_src(w.h1s, 32, 32, 0, 9, w.wpack + kPack.fwd[W_RB4C1], 4);
+        if (g_rb4_phase) {   // four phase taps over the 14x14 source instead of nine over its up-sampled image (conv_s16.hip "PH")
+            a.up_phase = 1;
+            a.src[0] = s16_src(w.h3s, 64, 64, 1, 16, w.wpack + kPack.fwd_ph, 0);
+        }
         a.bias = P + r4.c1b; a.relu = 1; a.B = B;
         a.mask_out = save ? w.m1[3] : nullptr; a.out_s16 = w.a1s_4; a.tb_out = w.tb + 160; a.tb_out_stride = 192;
         // rb4.skip (1x1 over the same concat) rides on this launch as a second accumulator: s4 = skip(cat) + bias
