@@ -270,6 +270,18 @@ int tdm_get_conv_mode(void);
  * (the forked step replays slower as a hipGraph than the plain one).                                              */
 int tdm_set_bwd_overlap(int on);
 int tdm_get_bwd_overlap(void);
+/* Data-parallel training (thread-local, default 0; none in the reference, deployment/configs/mnist-training.yaml:5-6 is one GPU):
+ * with 1 the default-arithmetic backward finishes the flat gradient in TWO parts.  Floats [tdm_unet_early_grad_offset(),
+ * TDM_UNET_NPARAM) — every tensor of rb2, rb3, rb4 and the output conv, 95 % of the bytes — are final as soon as rb2's weight-gradient
+ * launches have retired, and an event marks that point; rb1's 9,760 floats follow with the last launch.
+ * tdm_unet_wait_early_grads(stream) makes `stream` (the caller's collective stream) wait for that event of the calling thread's LAST
+ * backward call (once per call), so the all-reduce of the early part runs under the rest of the backward.  Returns 1 if an event was recorded,
+ * 0 if not (selector off, or the call was being captured: order the collective behind the call's stream as usual), < 0 on error.
+ * Same kernels, same fixed-order sums: the gradient is bit-identical to the one-part form.                            */
+int tdm_set_early_grads(int on);
+int tdm_get_early_grads(void);
+int64_t tdm_unet_early_grad_offset(void);
+int tdm_unet_wait_early_grads(void* stream);
 /* per-layer entry points of the S16 pipeline (tests / profiling): the fp32 input is
  * pre-split into scratch first.  conv: scratch >= k*k*Cin*Cout + B*HW*HW*Cin + 64 floats;
  * out_s16 (optional, S16 layout: every 16-channel group = 16 bf16 hi then 16 bf16 lo)

@@ -247,3 +247,36 @@ def test_async_allreduce_matches_the_blocking_one(tmp_path):
             assert torch.equal(got, want)
         for got, ref in zip(x["got"], r[0]["got"]):
             assert torch.equal(got, ref)
+
+
+def _early_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from tinydiffusionmodels_amd import dp
+    dp.init_from_env("gloo")
+    n, off = 181473, 9760
+    g = torch.randn(n, generator=torch.Generator().manual_seed(50 + rank))
+    one = g.clone()
+    s1 = dp.allreduce_grads_(one)
+    two = g.clone()
+    s2 = dp.allreduce_grads_early_(two, off, wait_early=None)
+    torch.save({"one": one, "two": two, "scales": (s1, s2), "mine": g}, os.path.join(out_dir, f"e{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_early_two_part_allreduce_gloo(tmp_path, world):
+    """dp.allreduce_grads_early_ (the gradient all-reduce under the backward; none in the reference):
+    two collectives over [early_off:] and [:early_off] give every rank the same bits, the global SUM, and the scale 1 / world —
+    bit-identical to the one-collective form at world 2 (a + b has one order), to fp32 summation order at world 3."""
+    port = _free_port()
+    mp.spawn(_early_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(tmp_path / f"e{r}.pt") for r in range(world)]
+    total = sum(r["mine"].double() for r in rs)
+    for r in rs:
+        assert r["scales"] == (1.0 / world, 1.0 / world)
+        assert torch.equal(r["two"], rs[0]["two"]) and torch.equal(r["one"], rs[0]["one"])       # identical replicas
+        assert (r["two"].double() - total).abs().max() < 1e-5
+        if world == 2:
+            assert torch.equal(r["two"], r["one"])

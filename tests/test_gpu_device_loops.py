@@ -332,3 +332,81 @@ def test_graph_replayed_training_converges(dev):
     l1 = l1.item()
     assert np.isfinite(l0) and np.isfinite(l1) and l1 < 0.7 * l0, (l0, l1)
     assert torch.isfinite(t.flat).all() and tt.steps_taken == 300
+
+
+def test_early_gradient_parts_are_bit_identical_and_the_event_orders_a_collective_stream(dev, L):
+    """tdm_set_early_grads / tdm_unet_wait_early_grads (data-parallel training: the all-reduce under the backward; no
+    counterpart in the reference, deployment/configs/mnist-training.yaml:5-6 is one GPU).  The slab reduction in two parts
+    gives the same flat gradient bit for bit as the one reduction, with the backward on two queues and on one; the wait call
+    reports an event exactly once per backward call and none for a captured call; and the native early all-reduce — a real
+    RCCL communicator of one rank, the collective side stream behind the library's event — leaves the gradient as it is and
+    the caller's stream ordered behind both collectives (AdamW right after it sees the same bits as without)."""
+    from tinydiffusionmodels_amd import _lib, dp, unet_engine as E
+    from tinydiffusionmodels_amd.mnist import SimpleUNet
+    B = 96
+    torch.manual_seed(4)
+    model = SimpleUNet().to(dev)
+    flat = model.flat.detach()
+    g = torch.Generator(device=dev).manual_seed(8)
+    x0 = torch.rand(B, 1, 28, 28, device=dev, generator=g) * 2 - 1
+    t = torch.randint(0, 1000, (B,), device=dev, generator=g)
+    noise = torch.randn(B, 1, 28, 28, device=dev, generator=g)
+    off = int(L.tdm_unet_early_grad_offset())
+    assert off == 288 + 32 + 9216 + 32 + 32 + 32 + 32 + 32 and 0 < off < E.NPARAM      # rb1's tensors come first in state_dict order
+    was_ov = L.tdm_get_bwd_overlap()
+    grads = {}
+    try:
+        for ov in (1, 0):
+            for early in (0, 1):
+                _lib.check(L.tdm_set_bwd_overlap(ov))
+                _lib.check(L.tdm_set_early_grads(early))
+                assert L.tdm_get_early_grads() == early
+                st = E.TrainState(flat, B)
+                st.grads.fill_(float("nan"))
+                loss = E.loss_and_grad(flat, st, x0, noise, t)
+                side = torch.cuda.Stream()
+                rc = L.tdm_unet_wait_early_grads(side.cuda_stream)
+                assert rc == early and L.tdm_unet_wait_early_grads(side.cuda_stream) == 0      # one event per call, consumed
+                if early:   # what the side stream sees behind the event: the early part final (the rest may still be in flight)
+                    with torch.cuda.stream(side):
+                        hi = st.grads[off:].clone()
+                    torch.cuda.synchronize()
+                    assert torch.equal(hi, st.grads[off:]) and torch.isfinite(hi).all()
+                torch.cuda.synchronize()
+                grads[(ov, early)] = (st.grads.clone(), loss.clone())
+        ref = grads[(0, 0)]
+        for k, v in grads.items():
+            assert torch.equal(v[0], ref[0]) and torch.equal(v[1], ref[1]), k
+        # a captured call keeps the one reduction: no event
+        _lib.check(L.tdm_set_early_grads(1))
+        _lib.check(L.tdm_set_bwd_overlap(0))
+        st = E.TrainState(flat, B)
+        E.loss_and_grad(flat, st, x0, noise, t)                  # warm: lazily set kernel attributes are not capturable
+        L.tdm_unet_wait_early_grads(torch.cuda.current_stream().cuda_stream)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            E.loss_and_grad(flat, st, x0, noise, t)
+        assert L.tdm_unet_wait_early_grads(torch.cuda.current_stream().cuda_stream) == 0
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(st.grads, ref[0])
+        # the native early all-reduce (RCCL, one rank) behind the library's event
+        _lib.check(L.tdm_set_bwd_overlap(1))
+        comm = dp.NativeComm(0, 0, 1, dp.NativeComm.make_unique_id())
+        st = E.TrainState(flat, B)
+        p = flat.clone()
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        state = torch.zeros(4, dtype=torch.long, device=dev)
+        E.loss_and_grad(flat, st, x0, noise, t)
+        dp._early_native(comm, st.grads, off, lambda s: L.tdm_unet_wait_early_grads(s.cuda_stream) == 1)
+        E.adamw_step_dev(p, st.grads, m, v, state, lr=1e-3)
+        torch.cuda.synchronize()
+        assert torch.equal(st.grads, ref[0])
+        p2, m2, v2, state2 = flat.clone(), torch.zeros_like(p), torch.zeros_like(p), torch.zeros(4, dtype=torch.long, device=dev)
+        E.adamw_step_dev(p2, ref[0], m2, v2, state2, lr=1e-3)
+        torch.cuda.synchronize()
+        assert torch.equal(p, p2)
+        comm.close()
+    finally:
+        L.tdm_set_early_grads(0)
+        L.tdm_set_bwd_overlap(was_ov)

@@ -214,6 +214,10 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
     assert "allreduce" in out and out["allreduce"]["bytes"] == 181_473 * 4
     assert "torch.distributed all_reduce (gloo)" in out["config"]["collective"]
     assert out["sampling"]["sharding"].startswith("chains sharded")
+    # the line is the short form (it must survive in the driver's 2,000-character tail); everything measured is in the detail file
+    assert len(lines[0]) < 4000 and os.path.exists(out["detail"])
+    detail = json.load(open(out["detail"]))
+    assert detail["value"] == out["value"] and "steady_state" in detail and "sampling" in detail
 
 
 def test_bench_refuses_more_gpus_than_visible():

@@ -49,6 +49,10 @@ _SIGS = {
     "tdm_set_conv_mode": ([c_int], c_int),
     "tdm_set_bwd_overlap": ([c_int], c_int),
     "tdm_get_bwd_overlap": ([], c_int),
+    "tdm_set_early_grads": ([c_int], c_int),
+    "tdm_get_early_grads": ([], c_int),
+    "tdm_unet_early_grad_offset": ([], c_i64),
+    "tdm_unet_wait_early_grads": ([c_f], c_int),
     "tdm_get_conv_mode": ([], c_int),
     "tdm_conv_nhwc_s16_f32": ([c_f] * 10 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_f], c_int),
     "tdm_conv_wgrad_nhwc_s16_f32": ([c_f] * 5 + [c_i64, c_int, c_int, c_int, c_int, c_f], c_int),

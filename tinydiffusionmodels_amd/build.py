@@ -54,6 +54,19 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > mt for d in deps)
 
 
+def source_digest() -> str:
+    """sha256 (16 hex digits) over the library's sources, headers and compiler flags: what a measurement file under profiles/
+    records so that a later bench run can tell whether the numbers were taken on the code it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(_sources() + [d for d in _deps() if not d.endswith("build.py")]):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(CFLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     srcs = _sources()
     hdrs = _deps()

@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(EW_BLOCK) void group_sums_kernel(GroupSumJobs jb, c
     __shared__ float4 sh[EW_BLOCK];
     float* dst = slab + (long)blockIdx.x * slab_stride;
     {
-        const int job = blockIdx.y;   // the four blocks' sums side by side: grid = (partial rows, 4)
+        const int job = jb.job0 + blockIdx.y;   // the blocks' sums side by side: grid = (partial rows, jobs)
         const int C = jb.C[job], C4 = C >> 2, HW = jb.HWpix[job];
         const long M = (long)B * HW;
         const int G = (int)((M + 31) >> 5);
@@ -1280,9 +1280,11 @@ int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, c
 }
 int tdm_launch_group_sums(const GroupSumJobs& jb, const float* that, int B, float* slab, long slab_stride, int nslab,
                           hipStream_t st) {
-    for (int i = 0; i < 4; ++i)
+    const int njobs = jb.njobs > 0 ? jb.njobs : 4 - jb.job0;
+    TDM_REQUIRE(jb.job0 >= 0 && njobs >= 1 && jb.job0 + njobs <= 4, "group_sums: jobs %d .. +%d", jb.job0, njobs);
+    for (int i = jb.job0; i < jb.job0 + njobs; ++i)
         TDM_REQUIRE(jb.gs[i] != nullptr && jb.C[i] % 16 == 0 && EW_BLOCK % (jb.C[i] / 4) == 0, "group_sums: job %d", i);
-    hipLaunchKernelGGL(group_sums_kernel, dim3(nslab, 4), dim3(EW_BLOCK), 0, st, jb, that, B, slab, slab_stride);
+    hipLaunchKernelGGL(group_sums_kernel, dim3(nslab, njobs), dim3(EW_BLOCK), 0, st, jb, that, B, slab, slab_stride);
     TDM_CHECK_LAUNCH("group_sums");
     return 0;
 }

@@ -53,6 +53,8 @@ void tdm_set_error(const char* fmt, ...);
 struct TdmSideLane {
     hipStream_t side = nullptr;
     hipEvent_t ready[8] = {}, back[2] = {}, done = nullptr;
+    hipEvent_t early = nullptr;      // "the early part of the flat gradient is final" (tdm_set_early_grads / tdm_unet_wait_early_grads)
+    bool early_recorded = false;     // ... recorded by the calling thread's last backward
     bool ok = false;
     int device = -1;
     bool init(hipStream_t st);
@@ -296,7 +298,7 @@ int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, c
                            int loss_off = -1, const float* o1_sums = nullptr);
 // time_emb weight / bias gradients of the four blocks and the conv1 bias gradients of rb2..rb4 as slab partials, straight
 // from the per-32-pixel-group sums the data-gradient launches wrote (ConvArgs::sums; one buffer per block)
-struct GroupSumJobs { const float* gs[4]; int C[4]; int HWpix[4]; int tew[4]; int c1b[4]; };
+struct GroupSumJobs { const float* gs[4]; int C[4]; int HWpix[4]; int tew[4]; int c1b[4]; int job0; int njobs; };   // jobs job0 .. job0 + njobs - 1 (njobs 0: to the end)
 int tdm_launch_group_sums(const GroupSumJobs& jb, const float* that, int B, float* slab, long slab_stride, int nslab,
                           hipStream_t st);
 // dc_s16 = split(dout * (a > 0)); slab partial sums of the masked (and optionally unmasked) gradient per channel

@@ -371,6 +371,13 @@ inline void mark_end(hipStream_t st) {
 // --check, tools/contention_check.py / contention_tn.py with foreign kernel streams.
 thread_local TdmSideLane g_lane;
 thread_local int g_bwd_overlap = 1;   // a selector like the arithmetic modes: per calling thread
+// tdm_set_early_grads (data-parallel training; default 0): the slab reduction of the S16 backward runs in TWO parts.  Part A — every
+// gradient of rb2, rb3, rb4 and the output conv: flat offsets [kL.rb[1].c1w, total), 95 % of the 725,892 bytes — is reduced as soon
+// as rb2's weight-gradient launches have retired (on the side queue behind them when the backward runs on two queues), an event
+// marks it final, and the caller's collective stream can wait for THAT (tdm_unet_wait_early_grads) instead of the end of the
+// backward: the all-reduce of part A runs under rb1's data / weight gradients (~125 us at B = 512), and only part B (rb1: 39 KB)
+// is reduced after the last launch.  Same kernels, same slabs, same fixed summation order: the gradient is bit-identical.
+thread_local int g_early_grads = 0;
 
 int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* eps, const Ws& w, int B, int save,
                      hipStream_t st, const MseIn* mse) {
@@ -460,9 +467,59 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     TDM_REQUIRE(deps != nullptr || mse != nullptr, "unet_backward: no output gradient");
     // weight-gradient launches go to the side queue (above) unless one launch is being replayed alone
     const bool lane = g_only_launch < 0 && tdm_bwd_overlap(st) != 0;
-    if (lane) TDM_REQUIRE(g_lane.init(st), "unet_backward: side stream / events could not be created");
+    // the reduction in two parts with an event after the first (g_early_grads above); a captured call keeps the one reduction
+    bool early = g_only_launch < 0 && g_early_grads != 0;
+    if (early) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
+        early = cs == hipStreamCaptureStatusNone;
+    }
+    if (lane || early) TDM_REQUIRE(g_lane.init(st), "unet_backward: side stream / events could not be created");
+    g_lane.early_recorded = false;
     const hipStream_t ss = lane ? g_lane.side : st;
     TdmSideJoin sj{&g_lane, st};
+    // sections of the slab reduction: part 0 = rb2 .. out (final once rb2's weight gradients are), part 1 = rb1
+    ReduceArgs rpart[2]{};
+    int npart[2] = {0, 0};
+    auto sec = [&](int part, int off, int len, int ns) {
+        ReduceSec& r = rpart[part].sec[npart[part]++];
+        r.off = off; r.len = len; r.nslab = ns;
+    };
+    auto esec = [&](int part, int off, int len, int e_off, int rows) -> ReduceSec& {   // destination offset <- compact rows
+        sec(part, off, len, rows);
+        ReduceSec& r = rpart[part].sec[npart[part] - 1];
+        r.src_delta = ESLAB_BASE + e_off - off; r.stride_override = ESTRIDE;
+        return r;
+    };
+    {
+        // weight gradients (MFMA kernels, full-width slabs)
+        sec(0, r2.c1w, 18432, NS2); sec(0, r2.c2w, 36864, NS4); sec(0, r2.skw, 2048, NS2);
+        sec(0, r3.c1w, 36864, NS4); sec(0, r3.c2w, 36864, NS4);
+        sec(0, r4.c1w, 27648, NS); sec(0, r4.c2w, 9216, NS);
+        // partial rows of the elementwise producers
+        esec(0, kL.outw, 33, E_OUT, ER28); esec(0, r4.c2b, 32, E_C2B4, ER28); esec(0, r4.skb, 32, E_SKB4, ER28);
+        esec(0, r3.c2b, 64, E_C2B3, ER14); esec(0, r2.c2b, 64, E_C2B2, ER14); esec(0, r2.skb, 64, E_SKB2, ER14);
+        esec(0, r2.tew, 128, E_TE2, ERG); esec(0, r3.tew, 128, E_TE3, ERG); esec(0, r4.tew, 64, E_TE4, ERG);
+        esec(0, r2.c1b, 64, E_C1B2, ERG); esec(0, r3.c1b, 64, E_C1B3, ERG); esec(0, r4.c1b, 32, E_C1B4, ERG);
+        // rb4.skip's weight gradient = v (x) w_out (out_bwd_s16_kernel): the section sums the 96 partials of v and writes 96 x 32
+        ReduceSec& rs = esec(0, r4.skw, 96, E_VSK, ER28);
+        rs.outer_w = P + kL.outw; rs.outer_n = 32;
+        if (deps == nullptr) {   // loss = mean (eps - noise)^2
+            ReduceSec& rl = esec(0, 0, 1, E_LOSS, ER28);
+            rl.dst = mse->loss_out; rl.scale = 1.0f / (float)M28;
+        }
+        // rb1: rb1.conv1 (first_wgrad) + rb1.conv2 slabs, bias / 1-channel-skip / time-embedding rows
+        sec(1, r1.c1w, 288 + 32, NS); sec(1, r1.c2w, 9216, NS);
+        esec(1, r1.c2b, 32, E_C2B1, ER28); esec(1, r1.skw, 32, E_SKW1, ER28); esec(1, r1.skb, 32, E_SKB1, ER28);
+        esec(1, r1.tew, 64, E_TE1, ERG);
+        rpart[0].nsec = npart[0]; rpart[1].nsec = npart[1];
+    }
+    GroupSumJobs jb{};
+    {   // time_emb gradients of all four blocks + conv1 bias gradients of rb2..rb4 as partial rows
+        const int Cv[4] = {32, 64, 64, 32}, hwv[4] = {784, 196, 196, 784};
+        const int tev[4] = {E_TE1, E_TE2, E_TE3, E_TE4}, c1bv[4] = {-1, E_C1B2, E_C1B3, E_C1B4};
+        for (int i = 0; i < 4; ++i) { jb.gs[i] = w.gs[i]; jb.C[i] = Cv[i]; jb.HWpix[i] = hwv[i]; jb.tew[i] = tev[i]; jb.c1b[i] = c1bv[i]; }
+    }
     int nfork = 0;
     auto fork = [&]() -> int {   // what the main chain has issued so far is what the side queue's next launches may read
         if (!lane) return 0;
@@ -516,6 +573,16 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     TDM_TRY(fork());
     RUN_ON(ss, B_WG_RB2C2, wgrad_s16(ss, 14, B, w.a1s_2, 64, 64, 0, 9, w.dc2s_2, 64, slabs, r2.c2w, 64, 0, NS4));
     RUN_ON(ss, B_WG_RB2C1, wgrad_s16(ss, 14, B, w.p1s, 32, 32, 0, 9, w.dh2s, 64, slabs, r2.c1w, 32, 0, NS2, w.dout2s, r2.skw));   // + rb2.skip
+    if (early) {
+        // part 0 of the gradient is complete behind these launches (in the side queue's order when there is one: rb4 / rb3 / rb2
+        // weight gradients; their group sums and the elementwise producers' rows were written by the main chain before the fork)
+        GroupSumJobs ja = jb;
+        ja.job0 = 1; ja.njobs = 3;
+        TDM_TRY(tdm_launch_group_sums(ja, w.that, B, es, ESTRIDE, ERG, ss));
+        TDM_TRY(tdm_launch_reduce(slabs, NP, rpart[0], G, ss));
+        TDM_HIP(hipEventRecord(g_lane.early, ss));
+        g_lane.early_recorded = true;
+    }
     {
         ConvArgs a{};
         a.nsrc = 2;
@@ -533,42 +600,21 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     RUN_ON(ss, B_WG_RB1C2, wgrad_s16(ss, 28, B, w.a1s_1, 32, 32, 0, 9, w.dc2s_1, 32, slabs, r1.c2w, 32, 0, NS));
     RUN(B_DG_RB1C2, conv_s16_1(st, w, 28, B, w.dc2s_1, 32, 9, kPack.dg[W_RB1C2], 32, nullptr, 0,
                                S16Out{w.dh1, nullptr, nullptr, nullptr, nullptr, w.m1[0], w.gs[0]}));   // dh1 <- masked, fp32 (rb1.conv1 wgrad)
-    {   // time_emb gradients of all four blocks + conv1 bias gradients of rb2..rb4 as partial rows, one launch
-        GroupSumJobs jb{};
-        const int Cv[4] = {32, 64, 64, 32}, hwv[4] = {784, 196, 196, 784};
-        const int tev[4] = {E_TE1, E_TE2, E_TE3, E_TE4}, c1bv[4] = {-1, E_C1B2, E_C1B3, E_C1B4};
-        for (int i = 0; i < 4; ++i) { jb.gs[i] = w.gs[i]; jb.C[i] = Cv[i]; jb.HWpix[i] = hwv[i]; jb.tew[i] = tev[i]; jb.c1b[i] = c1bv[i]; }
-        RUN(B_GROUP_SUMS, tdm_launch_group_sums(jb, w.that, B, es, ESTRIDE, ERG, st));
-    }
+    if (early) { jb.job0 = 0; jb.njobs = 1; }     // (blocks 2..4 went with part 0)
+    RUN(B_GROUP_SUMS, tdm_launch_group_sums(jb, w.that, B, es, ESTRIDE, ERG, st));
     RUN(B_FIRST_WGRAD, tdm_launch_first_wgrad(x, w.dh1, nullptr, slabs, NP, r1.c1w, r1.c1b, r1.skw, r1.skb, B, NS, st));
-    ReduceArgs ra{};
-    int n = 0;
-    auto sec = [&](int off, int len, int ns) { ra.sec[n].off = off; ra.sec[n].len = len; ra.sec[n].nslab = ns; ++n; };
-    auto esec = [&](int off, int len, int e_off, int rows) {   // destination offset <- compact rows
-        sec(off, len, rows);
-        ra.sec[n - 1].src_delta = ESLAB_BASE + e_off - off; ra.sec[n - 1].stride_override = ESTRIDE;
-    };
-    // weight gradients (MFMA kernels, full-width slabs) + rb1.conv1 (first_wgrad)
-    sec(r1.c1w, 288 + 32, NS); sec(r1.c2w, 9216, NS);
-    sec(r2.c1w, 18432, NS2); sec(r2.c2w, 36864, NS4); sec(r2.skw, 2048, NS2);
-    sec(r3.c1w, 36864, NS4); sec(r3.c2w, 36864, NS4);
-    sec(r4.c1w, 27648, NS); sec(r4.c2w, 9216, NS);
-    // partial rows of the elementwise producers
-    esec(kL.outw, 33, E_OUT, ER28); esec(r4.c2b, 32, E_C2B4, ER28); esec(r4.skb, 32, E_SKB4, ER28);
-    esec(r3.c2b, 64, E_C2B3, ER14); esec(r2.c2b, 64, E_C2B2, ER14); esec(r2.skb, 64, E_SKB2, ER14);
-    esec(r1.c2b, 32, E_C2B1, ER28); esec(r1.skw, 32, E_SKW1, ER28); esec(r1.skb, 32, E_SKB1, ER28);
-    esec(r1.tew, 64, E_TE1, ERG); esec(r2.tew, 128, E_TE2, ERG); esec(r3.tew, 128, E_TE3, ERG); esec(r4.tew, 64, E_TE4, ERG);
-    esec(r2.c1b, 64, E_C1B2, ERG); esec(r3.c1b, 64, E_C1B3, ERG); esec(r4.c1b, 32, E_C1B4, ERG);
-    // rb4.skip's weight gradient = v (x) w_out (out_bwd_s16_kernel): the section sums the 96 partials of v and writes 96 x 32
-    esec(r4.skw, 96, E_VSK, ER28);
-    ra.sec[n - 1].outer_w = P + kL.outw; ra.sec[n - 1].outer_n = 32;
-    if (deps == nullptr) {   // loss = mean (eps - noise)^2
-        esec(0, 1, E_LOSS, ER28);
-        ra.sec[n - 1].dst = mse->loss_out; ra.sec[n - 1].scale = 1.0f / (float)M28;
-    }
-    ra.nsec = n;
     if (lane) TDM_TRY(sj.join());   // the reduction reads every slab
-    RUN(B_REDUCE, tdm_launch_reduce(slabs, NP, ra, G, st));
+    if (early) {
+        RUN(B_REDUCE, tdm_launch_reduce(slabs, NP, rpart[1], G, st));
+    } else {   // one launch: part 1's sections in front of part 0's (the order of the former single table)
+        ReduceArgs ra{};
+        int n = 0;
+        for (int k = 0; k < 2; ++k) ra.sec[n++] = rpart[1].sec[k];
+        for (int k = 0; k < npart[0]; ++k) ra.sec[n++] = rpart[0].sec[k];
+        for (int k = 2; k < npart[1]; ++k) ra.sec[n++] = rpart[1].sec[k];
+        ra.nsec = n;
+        RUN(B_REDUCE, tdm_launch_reduce(slabs, NP, ra, G, st));
+    }
     return 0;
 }
 
@@ -692,7 +738,8 @@ void TdmSideLane::destroy() {
     for (hipEvent_t& e : ready) if (e != nullptr) { (void)hipEventDestroy(e); e = nullptr; }
     for (hipEvent_t& e : back) if (e != nullptr) { (void)hipEventDestroy(e); e = nullptr; }
     if (done != nullptr) (void)hipEventDestroy(done);
-    side = nullptr; done = nullptr; ok = false; device = -1;
+    if (early != nullptr) (void)hipEventDestroy(early);
+    side = nullptr; done = nullptr; early = nullptr; early_recorded = false; ok = false; device = -1;
     (void)hipGetLastError();
 }
 bool TdmSideLane::init(hipStream_t st) {
@@ -720,6 +767,7 @@ bool TdmSideLane::init(hipStream_t st) {
     for (hipEvent_t& e : back)
         if (hipEventCreateWithFlags(&e, flags) != hipSuccess) return false;
     if (hipEventCreateWithFlags(&done, flags) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&early, flags) != hipSuccess) return false;
     device = dev;
     return ok = true;
 }
@@ -950,6 +998,28 @@ int tdm_set_bwd_overlap(int on) {
     return 0;
 }
 int tdm_get_bwd_overlap(void) { return g_bwd_overlap; }
+// Data-parallel training: the S16 backward's slab reduction in two parts, an event after the first (g_early_grads's comment)
+int tdm_set_early_grads(int on) {
+    TDM_REQUIRE(on == 0 || on == 1, "early gradients %d (0 or 1)", on);
+    g_early_grads = on;
+    return 0;
+}
+int tdm_get_early_grads(void) { return g_early_grads; }
+// first float of the early part inside the flat gradient (rb2.conv1.weight): [offset, TDM_UNET_NPARAM) is final at the event
+int64_t tdm_unet_early_grad_offset(void) { return kL.rb[1].c1w; }
+// `stream` waits until the early part of the gradient written by the calling thread's LAST backward call is final.  Returns 1
+// if such an event was recorded (the call ran with tdm_set_early_grads(1), not under capture), 0 if there is nothing to wait for
+// beyond the backward's own stream order (the caller then orders its collective behind that stream as before), < 0 on error.
+int tdm_unet_wait_early_grads(void* stream) {
+    if (!g_lane.ok || !g_lane.early_recorded) return 0;
+    if (hipStreamWaitEvent((hipStream_t)stream, g_lane.early, 0) != hipSuccess) {
+        tdm_set_error("unet_wait_early_grads: hipStreamWaitEvent failed");
+        (void)hipGetLastError();
+        return -1;
+    }
+    g_lane.early_recorded = false;   // one wait per backward: a later call (e.g. after a graph REPLAY, which records nothing) finds none
+    return 1;
+}
 
 // generic conv through the S16 pipeline: the fp32 input (+tb) is pre-split into scratch, then conv_s16 runs.
 // scratch >= ksize^2*Cin*Cout + B*HW*HW*Cin floats.  out_s16 (optional) receives split(result + tb_out).

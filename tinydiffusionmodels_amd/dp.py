@@ -280,6 +280,48 @@ def allreduce_grads_(flat_grads: torch.Tensor) -> float:
     return 1.0 / world
 
 
+def _early_native(comm: "NativeComm", flat_grads: torch.Tensor, early_off: int, wait_early) -> None:
+    """The native (RCCL behind the C ABI) form of allreduce_grads_early_: both collectives on the collective side stream, the
+    first behind the library's early event, the second behind the caller's stream; the caller's stream waits for the side stream."""
+    side = _comm_side_stream()
+    cur = torch.cuda.current_stream()
+    if not (wait_early is not None and wait_early(side)):
+        side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        comm.allreduce_sum_(flat_grads[early_off:])
+    side.wait_stream(cur)                           # rb1's part: behind the backward's last launch
+    with torch.cuda.stream(side):
+        comm.allreduce_sum_(flat_grads[:early_off])
+    flat_grads.record_stream(side)
+    cur.wait_stream(side)
+
+
+def allreduce_grads_early_(flat_grads: torch.Tensor, early_off: int, wait_early=None) -> float:
+    """allreduce_grads_ as TWO collectives so that the first can start before the backward has ended (DESIGN section 6 "the
+    gradient all-reduce under the backward"): floats [early_off:] of the flat gradient — rb2 .. out, final at the library's
+    early event (tdm_set_early_grads / tdm_unet_wait_early_grads) — are summed on the collective side stream as soon as that
+    event fires, i.e. under rb1's data- and weight-gradient launches; [:early_off] (rb1) follows behind the backward's last
+    launch; the caller's stream then waits for both.  `wait_early(stream) -> bool` orders `stream` behind the early event
+    and says whether there was one (False: the whole buffer is simply ordered behind the caller's stream, as in
+    allreduce_grads_).  Element-wise SUMs over the same ranks: every rank ends with the same bits, and with the bits of the
+    one-collective form whenever the reduction order per element does not depend on the message (always at world 2; gloo
+    and RCCL rings at larger worlds: replicas identical, last bits may differ from the one-message sum).  Returns 1 / world."""
+    rank, world = world_info()
+    if world == 1:
+        return 1.0
+    assert flat_grads.dim() == 1 and 0 < early_off < flat_grads.numel()
+    hi, lo = flat_grads[early_off:], flat_grads[:early_off]
+    comm = native_comm() if flat_grads.is_cuda else None
+    if comm is not None and not torch.cuda.is_current_stream_capturing():
+        _early_native(comm, flat_grads, early_off, wait_early)
+    elif comm is not None:
+        comm.allreduce_sum_(flat_grads)             # (under capture: one collective on the captured stream)
+    else:
+        dist.all_reduce(hi, op=dist.ReduceOp.SUM)
+        dist.all_reduce(lo, op=dist.ReduceOp.SUM)
+    return 1.0 / world
+
+
 class _Pending:
     """A collective in flight next to the caller's stream; wait() orders the caller's CURRENT stream (torch.distributed's
     NCCL work, the native side stream) or the host (gloo) behind it."""

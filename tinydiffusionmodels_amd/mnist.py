@@ -462,6 +462,10 @@ class DPStepper:
     def optimizer_step(self, grad_scale: float) -> None:
         raise NotImplementedError
 
+    def allreduce_equal_shards(self, g: torch.Tensor) -> float:
+        """The collective of an equal-shard step (implementers may split it: DDPMTrainer._allreduce)."""
+        return dp.allreduce_grads_(g)
+
     def step(self, x0: Optional[torch.Tensor], t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
              global_batch: Optional[int] = None):
         b_local = 0 if x0 is None else int(x0.shape[0])
@@ -470,7 +474,7 @@ class DPStepper:
         loss = self.local_loss_and_grad(x0, t, noise) if b_local else None
         g = self.grad_buffer()
         if global_batch is None:
-            scale = dp.allreduce_grads_(g)            # SUM over ranks; 1/world folded into AdamW
+            scale = self.allreduce_equal_shards(g)    # SUM over ranks; 1/world folded into AdamW
         else:
             if b_local:
                 g.mul_(b_local / float(global_batch))
@@ -510,6 +514,11 @@ class DDPMTrainer(DPStepper):
         E._need_cuda(self.flat)
         dev = self.flat.device
         self.rank, self.world = dp.world_info()
+        # data parallel, eager issue: the backward finishes the gradient in two parts so that most of the all-reduce runs under it
+        self._early = self.world > 1 and os.environ.get("TDM_EARLY_GRADS", "1") != "0"
+        self._early_off = int(_lib.lib().tdm_unet_early_grad_offset())
+        if self._early:
+            _lib.check(_lib.lib().tdm_set_early_grads(1), "tdm_set_early_grads")
         self.batch_size = batch_size
         self.grads = torch.zeros(E.NPARAM, dtype=torch.float32, device=dev)
         self.m = torch.zeros_like(self.grads)
@@ -572,6 +581,25 @@ class DDPMTrainer(DPStepper):
     def optimizer_step(self, grad_scale: float) -> None:
         E.adamw_step_dev(self.flat, self.grads, self.m, self.v, self.step_state, self.lr, self.betas, self.eps,
                          self.weight_decay, grad_scale=grad_scale)
+
+    def allreduce_equal_shards(self, g: torch.Tensor) -> float:
+        return self._allreduce()
+
+    def _allreduce(self) -> float:
+        """The step's collective behind an EAGERLY issued backward.  At world > 1 the library finishes the flat gradient in two
+        parts (tdm_set_early_grads, switched on by the constructor): rb2 .. out — 95 % of the bytes — are summed over ranks while
+        rb1's launches still run, rb1's 39 KB behind the last launch (dp.allreduce_grads_early_).  TDM_EARLY_GRADS=0: one
+        collective behind the whole backward."""
+        if self.world == 1 or not self._early:
+            return dp.allreduce_grads_(self.grads)
+        L = _lib.lib()
+
+        def wait_early(stream) -> bool:
+            rc = L.tdm_unet_wait_early_grads(stream.cuda_stream)
+            if rc < 0:
+                _lib.check(rc, "tdm_unet_wait_early_grads")
+            return rc == 1
+        return dp.allreduce_grads_early_(self.grads, self._early_off, wait_early)
 
     # ---- the hipGraph form of step() ----
     @staticmethod
@@ -683,7 +711,7 @@ class DDPMTrainer(DPStepper):
             if not self.use_graph or st.warm < 1:          # first step of a batch size eagerly (lazy kernel attributes, allocator warm-up)
                 st.warm += 1
                 self._epoch_launch(st)
-                self.optimizer_step(dp.allreduce_grads_(self.grads))
+                self.optimizer_step(self._allreduce())
                 done += 1
                 continue
             g1, gn, whole = self._epoch_graphs(st)

@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--trace-iters", type=int, default=21)
     ap.add_argument("--names", default=None, help="JSON {id: launch name} written by pmc_replay.py --names-out")
+    ap.add_argument("--script", default="tools/roundend5.sh", help="the evidence script that ran the passes (recorded in the output)")
     args = ap.parse_args()
     ids = [int(v) for v in args.ids.split(",")]
     agg = defaultdict(dict)
@@ -97,8 +98,13 @@ def main():
         if "duration_ns" in e and "hbm_bytes_per_launch" in e:
             e["hbm_gbs"] = round(e["hbm_bytes_per_launch"] / e["duration_ns"], 1)
         res[str(lid)] = e
-    doc = {"command": "tools/roundend3.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | TCC_* | SQ_* (separate passes) and --kernel-trace, "
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tinydiffusionmodels_amd.build import source_digest
+    doc = {"command": f"{args.script}: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_* (separate passes) and --kernel-trace, "
                       "each directly in front of python tools/pmc_replay.py (in-pipeline arguments, B=512, two alternating workspaces)",
+           "source_digest": source_digest(),      # bench.py carries `traffic` only when its own library has this digest
            "correction": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B), KB -> bytes; first launch of each block dropped",
            "by_launch_id": {k: v for k, v in res.items() if k != "gemm"}, "text_ffn1_gemm": res.get("gemm")}
     json.dump(doc, open(args.out, "w"), indent=1)
