@@ -62,8 +62,9 @@ LAUNCH_WORK = [
     (_C3(32, 32, 784), 2 * _T28(32) + _M28(32), 0),                          # rb4.conv2 dgrad
     (_C3(64, 32, 784), _T14(64) + _T28(32), 0),                              # rb4.conv1 wgrad (up(h3) part)
     (_C3(32, 32, 784), 2 * _T28(32), 0),                                     # rb4.conv1 wgrad (h1 part)
-    (_C3(32, 96, 784) + _C1(1, 96, 784), 3 * _T28(32) + 3136, 0),            # rb4.conv1 dgrad: dh4s in; pair-summed (B,28,14,64) + (M,32) out; + rank-1 skip share
-    (0, _T28(32) + _M14(64) + 2 * _T14(64), 0),                              # split_dcat_mask (reads the pair-summed tensor)
+    (_C3(32, 32, 784) + _C1(1, 32, 784), 2 * _T28(32) + 3136, 0),            # rb4.conv1 dgrad, h1 part: dh4s in, (M,32) out; + rank-1 skip share (side queue)
+    (_C3(32, 64, 784) + _C1(1, 64, 784), _T28(32) + _T14(64) + 3136, 0),     # rb4.conv1 dgrad, up(h3) part at 14x14: dh4s in, dout3 out; + rank-1 skip share (FLOP: the algorithm's nine taps at 28x28; as built 16 taps at 14x14 = 0.44 x)
+    (0, 2 * _T14(64) + _M14(64), 0),                                         # relu mask rb3
     (_C3(64, 64, 196), 2 * _T14(64), 0),                                     # rb3.conv2 wgrad
     (_C3(64, 64, 196), 2 * _T14(64) + _M14(64), 0),                          # rb3.conv2 dgrad
     (_C3(64, 64, 196), 2 * _T14(64), 0),                                     # rb3.conv1 wgrad
@@ -542,11 +543,12 @@ def main():
         #   floor_us = max(mfma_us, hbm_us);  bound = the larger term, or "latency" when the launch is below 0.4 of BOTH roofs.
         # The contract's fields stay as defined: achieved = ALGORITHMIC bytes (fp32 input + output elements of
         # the convolution the launch computes, a fused second conv's shared input counted once) / duration, peak = 8 TB/s.
-        ALGO_CH = {"rb4.conv1 + rb4.skip fwd": 96 + 32 + 32, "rb4.conv1 dgrad": 32 + 32 + 96, "rb1.conv2 fwd": 32 + 32 + 1,
+        ALGO_CH = {"rb4.conv1 + rb4.skip fwd": 96 + 32 + 32, "rb4.conv1 dgrad, h1 part": 32 + 32, "rb4.conv1 dgrad, up(h3) part": 32 + 16, "rb1.conv2 fwd": 32 + 32 + 1,
                    "rb4.conv2 + out conv fwd": 32 + 32 + 32 + 1, "rb4.conv2 dgrad": 64, "rb1.conv2 dgrad": 64}
         # MFMA work as built relative to the algorithm's FLOP: the phase form runs 4 of 9 taps over the 64 up-sampled channels
         phase_on = os.environ.get("TDM_RB4_PHASE", "1") != "0"
-        AS_BUILT = {"rb4.conv1 + rb4.skip fwd": (4 * 64 + 9 * 32 + 96) / (9 * 96 + 96) if phase_on else 1.0}
+        AS_BUILT = {"rb4.conv1 + rb4.skip fwd": (4 * 64 + 9 * 32 + 96) / (9 * 96 + 96) if phase_on else 1.0,
+                    "rb4.conv1 dgrad, up(h3) part": (16 * 196) / (9 * 784) if phase_on else 1.0}
         from tinydiffusionmodels_amd.build import source_digest
         digest = source_digest()
         traffic_by_name, traffic_src = {}, None

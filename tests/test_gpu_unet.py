@@ -699,7 +699,7 @@ def test_in_step_launch_marks_time_one_launch_of_every_eager_step(dev, conv_mode
     data = M.synthetic_mnist(steps * B, seed=3).to(dev)
     perm = torch.randperm(data.shape[0], generator=torch.Generator().manual_seed(2)).to(dev)
     nl = L.tdm_unet_launch_count()
-    lid = next(i for i in range(nl) if L.tdm_unet_launch_name(i).decode().startswith("rb4.conv1 dgrad"))
+    lid = next(i for i in range(nl) if L.tdm_unet_launch_name(i).decode().startswith("rb4.conv1 dgrad, up(h3) part"))
     finals = []
     for marked in (False, True):
         torch.manual_seed(11)

@@ -41,8 +41,35 @@ __device__ __forceinline__ void pack_body(const float* __restrict__ P, const Pac
         }
         return;
     }
+    if (d.phase == 2) {   // data gradient of an up-sampled source at SOURCE resolution (PackDesc's comment; conv_s16.hip "S2D")
+        const int NTp = d.kuse / 32, KC = d.cout / 16;
+        const int total = 4 * KC * 4 * NTp * 512;
+        for (int e = bx * 256 + threadIdx.x; e < total; e += nbx * 256) {
+            const int jj = e & 7;
+            const int lane = (e >> 3) & 63;
+            int r = e >> 9;
+            const int nt = r % NTp; r /= NTp;
+            const int tap4 = r & 3; r >>= 2;
+            const int chunk = r;                       // (2 p + q) * KC + kc
+            const int kc = chunk % KC, pq = chunk / KC, p = pq >> 1, q = pq & 1;
+            const int u = 2 * ((tap4 >> 1) - p) + p + 1, v = 2 * ((tap4 & 1) - q) + q + 1;   // dy = a - p, dx = b - q
+            const int ky0 = u == 0 ? 2 : (u == 1 ? 1 : 0), ky1 = u == 0 ? 2 : (u == 1 ? 2 : (u == 2 ? 1 : 0));
+            const int kx0 = v == 0 ? 2 : (v == 1 ? 1 : 0), kx1 = v == 0 ? 2 : (v == 1 ? 2 : (v == 2 ? 1 : 0));
+            const int n = nt * 32 + (lane & 31);
+            const int k = kc * 16 + 8 * (lane >> 5) + jj;
+            float x = 0.f;
+            for (int ky = ky0; ky <= ky1; ++ky)
+                for (int kx = kx0; kx <= kx1; ++kx) x += P[d.src_off + (long)((ky * 3 + kx) * d.cin + n) * d.cout + k];
+            const __bf16 hi = (__bf16)x;
+            const __bf16 lo = (__bf16)(x - (float)hi);
+            const long base = d.dst_off + ((long)((chunk * 4 + tap4) * NTp + nt) * 2) * 512 + lane * 8 + jj;
+            out[base] = __builtin_bit_cast(unsigned short, hi);
+            out[base + 512] = __builtin_bit_cast(unsigned short, lo);
+        }
+        return;
+    }
     const int K = d.dgrad ? d.cout : d.cin;       // contraction length
-    const int Nn = d.dgrad ? d.cin : d.cout;      // output channels of this direction
+    const int Nn = d.dgrad ? (d.nuse > 0 ? d.nuse : d.cin) : d.cout;      // output channels of this direction
     const int NT = Nn / 32;
     const int total = (K / 16) * d.taps * NT * 512;   // (hi, lo) pairs
     for (int e = bx * 256 + threadIdx.x; e < total; e += nbx * 256) {
@@ -56,7 +83,7 @@ __device__ __forceinline__ void pack_body(const float* __restrict__ P, const Pac
         const int k = chunk * 16 + 8 * (lane >> 5) + jj;
         float x;
         if (!d.dgrad) x = P[d.src_off + (long)(tap * d.cin + k) * d.cout + n];
-        else x = P[d.src_off + (long)((d.taps == 9 ? 8 - tap : 0) * d.cin + n) * d.cout + k];
+        else x = P[d.src_off + (long)((d.taps == 9 ? 8 - tap : 0) * d.cin + d.n0 + n) * d.cout + k];
         const __bf16 hi = (__bf16)x;
         const __bf16 lo = (__bf16)(x - (float)hi);
         const long base = d.dst_off + ((long)((chunk * d.taps + tap) * NT + nt) * 2) * 512 + lane * 8 + jj;

@@ -170,7 +170,13 @@ __device__ __forceinline__ void gstore_s16_o(float* s16, unsigned o, int c, cons
 // share the weights, hence the tile: 64 consecutive SOURCE positions x 4 phases; wave w owns phase w & 3 of source positions
 // 32 (w >> 2) .. + 31, i.e. 32 same-parity output pixels.  Source 1 (h1, full resolution) runs through the ordinary nine taps
 // with the same lanes, reading a 28x28-domain image staged around the tile's output rows.
-template <int HW, int NT, bool SKIP, bool PROBE, int MT = 1, bool MSE = false, bool PH = false>
+// S2D ("space to depth", rb4.conv1's data gradient w.r.t. the up-sampled h3: ConvArgs::s2d): the transpose of the phase form.  The
+// gradient of a source pixel (i, j) gathers the output gradient g over the 4x4 window g[2i-1 .. 2i+2][2j-1 .. 2j+2] with 16
+// pre-summed weight matrices (PackDesc::phase = 2) — 512 instead of 1152 K elements per source pixel, and the result IS the
+// 14x14 gradient (no pair-summed intermediate, no second pass to add rows).  g is read as its four parity sub-images
+// g_pq[i'][j'] = g[2i'+p][2j'+q]: K chunk c stages sub-image c / nc0 (16 channels) in the ordinary 14x14 geometry and uses the
+// FOUR taps of the 3x3 neighbourhood that sub-image contributes (rows {i, i+1} for p = 0, {i-1, i} for p = 1; columns likewise).
+template <int HW, int NT, bool SKIP, bool PROBE, int MT = 1, bool MSE = false, bool PH = false, bool S2D = false>
 __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kernel(ConvArgs ka) {
     using G = Geo<HW>;
     using G2 = Geo<14>;                                                // geometry of the half-resolution source (PH)
@@ -183,6 +189,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     static_assert(NRv <= 32, "the per-wave row table has 32 entries");
     static_assert(MT == 1 || (HW == 28 && NT == 1), "two M tiles per wave: built for the 28x28 N = 32 kernels");
     static_assert(!PH || (HW == 28 && NT == 1 && SKIP && MT == 1 && !MSE), "the phase form is built for rb4.conv1's forward");
+    static_assert(!S2D || (HW == 14 && NT == 2 && !SKIP && MT == 1 && !MSE && !PH), "the space-to-depth form is built for rb4.conv1's data gradient");
     // The ~300-byte argument block does not stay in scalar registers by itself: the compiler re-reads a field from the
     // kernarg segment (s_load + s_waitcnt lgkmcnt(0), a scalar-cache round trip) next to almost every use — before each
     // prefetch load, around every uniform branch of the epilogue.  Everything the kernel uses is copied ONCE into
@@ -203,6 +210,8 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     constexpr bool DCAT = HW == 28 && NT == 3 && !SKIP;
     float* dc_pair = DCAT ? ka.dc_pair : nullptr; float* dc_h1 = ka.dc_h1; const float* rk1_d = ka.rk1_d; const float* rk1_u = ka.rk1_u;
     if constexpr (DCAT) { TDM_PIN(dc_pair); TDM_PIN(dc_h1); TDM_PIN(rk1_d); TDM_PIN(rk1_u); }
+    const float* s2_d = S2D ? ka.rk1_d : nullptr; const float* s2_u = ka.rk1_u;   // S2D: the skip path's rank-one share (4 pixels' d summed)
+    if constexpr (S2D) { TDM_PIN(s2_d); TDM_PIN(s2_u); }
     constexpr int N = NT * 32;
     constexpr int TILE_B = NRv * G::WP * PIXB;
     extern __shared__ float4 smem4[];
@@ -306,8 +315,8 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     constexpr int WN = (WTAPS * NT * 128 + CONV_THREADS - 1) / CONV_THREADS;
     constexpr int STEP = CONV_THREADS / 4;   // staged positions between a thread's consecutive pieces
     char* const sdst = tile + (tid >> 2) * PIXB + (tid & 3) * 16;
-    const int nc0 = a.s0.nch >> 4;
-    const int nchunks = nc0 + (a.nsrc > 1 ? (a.s1.nch >> 4) : 0);
+    const int nc0 = S2D ? 2 : a.s0.nch >> 4;   // (S2D: 32 gradient channels, checked by the launcher)
+    const int nchunks = S2D ? 4 * nc0 : nc0 + (a.nsrc > 1 ? (a.s1.nch >> 4) : 0);   // S2D: four parity sub-images of source 0
     int goffA[NPINv], goffB[NPINv];   // staging plans of the sources the two input sets were loaded from
     int planA = -1, planB = -1;
     uint4 pinA[NPINv], pinB[NPINv], pwt[WN];
@@ -317,11 +326,11 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     // destination, and (straight-line code) exact vmcnt(n) waits, so the second register set really stays in flight
     // while the first is staged.
     auto prefetch_in = [&](uint4 (&pin)[NPINv], int (&goff)[NPINv], int& plan_src, const int (&goff_other)[NPINv], int plan_other, int c) {
-        const int si = (c >= nc0) ? 1 : 0;
-        const int ch = si ? c - nc0 : c;
-        const PinnedSrc s = a.src(si);
+        const int si = S2D ? c / nc0 : ((c >= nc0) ? 1 : 0);   // (S2D: the plan is per parity sub-image)
+        const int ch = S2D ? c - si * nc0 : (si ? c - nc0 : c);
+        const PinnedSrc s = a.src(S2D ? 0 : si);
         const bool half = PH && si == 0;                      // PH: source 0 is staged at its own (14x14) resolution
-        const int up = PH ? 0 : s.up, Hs = half ? G2::H : G::H >> up, Ws = half ? G2::W : G::W >> up;
+        const int up = PH ? 0 : s.up, Hs = S2D ? 28 : (half ? G2::H : G::H >> up), Ws = S2D ? 28 : (half ? G2::W : G::W >> up);
         if (plan_src != si && plan_other == si) {   // the other register set already holds this source's plan
 #pragma unroll
             for (int i = 0; i < NPINv; ++i) goff[i] = goff_other[i];
@@ -352,6 +361,32 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
                     pc += stp;
                     lr += str;
                     if (pc >= WPv) { pc -= WPv; ++lr; }
+                }
+                plan_src = si;
+            }
+        } else if constexpr (S2D) {
+            if (plan_src != si) {
+                // staged pixel (row py, column pc) of sub-image (p, q) is pixel (2 (py - 1) + p, 2 (pc - 1) + q) of the 28x28 tensor
+                const int sp = si >> 1, sq = si & 1;
+                int* const rowtab = reinterpret_cast<int*>(wl + WTAPS * NT * 2048) + wave * 32;
+                if (lane < 32) {
+                    int py = ty0 + lane, b = tb0;
+                    if (py >= G::HP) { py -= G::HP; ++b; }
+                    if (py >= G::HP) { py -= G::HP; ++b; }
+                    const bool ok = lane < nrows && py >= 1 && py <= G::H && b < a.B;
+                    rowtab[lane] = ok ? __mul24(__mul24(__mul24(b, 28) + 2 * (py - 1) + sp, 28), s.C) * 4 : (int)0x80000000;
+                }
+                int lr = (tid >> 2) / G::WP;
+                int pc = (tid >> 2) - lr * G::WP;
+                const int cbase = (s.c0 + (tid & 3) * 4) * 4;
+#pragma unroll
+                for (int i = 0; i < NPINv; ++i) {
+                    const int roff = rowtab[lr];
+                    const bool ok = roff >= 0 && pc >= 1 && pc <= G::W;
+                    goff[i] = ok ? roff + __mul24(2 * (pc - 1) + sq, s.C) * 4 + cbase : (int)0x80000000;
+                    pc += STEP % G::WP;
+                    lr += STEP / G::WP;
+                    if (pc >= G::WP) { pc -= G::WP; ++lr; }
                 }
                 plan_src = si;
             }
@@ -392,10 +427,10 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         }
     };
     auto prefetch_w = [&](int c) {
-        const int si = (c >= nc0) ? 1 : 0;
-        const int ch = si ? c - nc0 : c;
+        const int si = S2D ? 0 : ((c >= nc0) ? 1 : 0);
+        const int ch = S2D ? c : (si ? c - nc0 : c);   // (S2D: packed chunk = (sub-image, channel chunk) = c)
         const PinnedSrc s = a.src(si);
-        const int nbytes = s.taps * NT * 2048;   // one chunk of packed weights (PH, source 0: 16 phase taps)
+        const int nbytes = s.taps * NT * 2048;   // one chunk of packed weights (PH, source 0: 16 phase taps; S2D: 4)
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<unsigned short*>(s.wp) + (long)(s.wchunk0 + ch) * (s.taps * NT * 1024), 0, nbytes, 0x00020000);
 #pragma unroll
@@ -431,11 +466,15 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
         // and site 4 re-reads the source pixel itself (a' = 1 - ph_y, b' = 1 - ph_x) for the fused 1x1 skip conv alone
         const bool halfc = PH && c < nc0;
         const int pix0 = halfc ? aoff_s : aoff[0];
+        const int s2p = S2D ? (c / nc0) >> 1 : 0, s2q = S2D ? (c / nc0) & 1 : 0;   // S2D: parity of the chunk's sub-image
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
-            if (PH ? (!halfc || tp <= 4) : (taps == 9 || tp == 4)) {   // a 1x1 source uses the centre-tap site with packed tap 0
+            // S2D: sub-image (p, q) contributes rows {0, +1} (p = 0) or {-1, 0} (p = 1) of the 3x3 neighbourhood, columns likewise
+            const bool s2on = (s2p ? tp / 3 <= 1 : tp / 3 >= 1) && (s2q ? tp % 3 <= 1 : tp % 3 >= 1);
+            if (S2D ? s2on : (PH ? (!halfc || tp <= 4) : (taps == 9 || tp == 4))) {   // a 1x1 source uses the centre-tap site with packed tap 0
                 int toff = ((tp / 3 - 1) * G::WP + (tp % 3 - 1)) * PIXB;
                 int wt = (taps == 9) ? tp : 0;
+                if constexpr (S2D) wt = (tp / 3 - (s2p ? 0 : 1)) * 2 + (tp % 3 - (s2q ? 0 : 1));
                 bool main_on = true;
                 if constexpr (PH) {
                     if (halfc) {
@@ -556,6 +595,20 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     if constexpr (PH) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) mpx[it] = __shfl(m_lane, it * 8 + (lane_e >> 3));
+    }
+    // S2D: the skip path's rank-one share of a SOURCE pixel is (sum of d over its four output pixels) * u[c]; lane j holds the
+    // sum of pixel j of the tile, the walk fetches it per pass
+    float d4_lane = 0.f;
+    if constexpr (S2D) {
+        if (s2_d != nullptr) {
+            const int ms = min(mbase + j_e, Mtot - 1);
+            const int b = ms / (G::H * G::W);
+            const int rem = ms - b * (G::H * G::W);
+            const int i = rem / G::W, jx = rem - i * G::W;
+            const int m28 = (b * 28 + 2 * i) * 28 + 2 * jx;
+            const f32x2 r0 = gload<f32x2>(s2_d + m28), r1 = gload<f32x2>(s2_d + m28 + 28);
+            d4_lane = (r0[0] + r0[1]) + (r1[0] + r1[1]);
+        }
     }
     const int img0 = PH ? min(mbase, Mtile - 1) / (G2::H * G2::W) : mbase / (G::H * G::W);   // image of the group's first pixel (scalar)
     const int mnext = (img0 + 1) * (G::H * G::W);   // a 32-pixel group touches at most two images
@@ -706,6 +759,14 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
                 sacc[1][0].x += s1 ? u.x : 0.f; sacc[1][0].y += s1 ? u.y : 0.f; sacc[1][0].z += s1 ? u.z : 0.f; sacc[1][0].w += s1 ? u.w : 0.f;
                 sacc[1][1].x += s1 ? mv.x : 0.f; sacc[1][1].y += s1 ? mv.y : 0.f; sacc[1][1].z += s1 ? mv.z : 0.f; sacc[1][1].w += s1 ? mv.w : 0.f;
                 v[k] = mv;
+            }
+        }
+        if constexpr (S2D) if (s2_d != nullptr) {   // + (d summed over the source pixel's four output pixels) * u[c]
+            const float4 u4 = gload4(s2_u + (lane_e & (N / 4 - 1)) * 4);   // (a lane's channel quad is the same in every pass)
+#pragma unroll
+            for (int k = 0; k < GI; ++k) {
+                const float dq = __shfl(d4_lane, ((I0 + k) * 64 + lane_e) / (N / 4));
+                v[k].x = fmaf(dq, u4.x, v[k].x); v[k].y = fmaf(dq, u4.y, v[k].y); v[k].z = fmaf(dq, u4.z, v[k].z); v[k].w = fmaf(dq, u4.w, v[k].w);
             }
         }
         if (a.out != nullptr) {
@@ -907,6 +968,29 @@ int launch_conv_phase(const ConvArgs& a, hipStream_t st) {
     const int ntiles = (int)((Msrc + 63) / 64);
     hipLaunchKernelGGL((conv_s16_kernel<28, 1, true, false, 1, false, true>), dim3(ntiles), dim3(CONV_THREADS), lds, st, a);
     TDM_CHECK_LAUNCH("conv_s16(phase)");
+    return 0;
+}
+
+// rb4.conv1's data gradient w.r.t. the up-sampled source at source resolution (ConvArgs::s2d; the kernel's S2D instantiation)
+int launch_conv_s2d(const ConvArgs& a, hipStream_t st) {
+    using G = Geo<14>;
+    constexpr size_t lds_op = (size_t)G::NR * G::WP * PIXB + (size_t)9 * 2 * 2048 + (size_t)(CONV_THREADS / 64) * 32 * sizeof(int);
+    constexpr size_t lds_epi = (size_t)(CONV_THREADS / 64) * 32 * (64 + 4) * sizeof(float);
+    constexpr size_t lds = lds_op > lds_epi ? lds_op : lds_epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<14, 2, false, false, 1, false, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 110000);
+        if (e != hipSuccess) {
+            tdm_set_error("conv_s16(s2d): hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+            return 100 + (int)e;
+        }
+        attr_set = true;
+    }
+    const long Mtot = (long)a.B * 196;
+    const int ntiles = (int)((Mtot + TILE_PX - 1) / TILE_PX);
+    hipLaunchKernelGGL((conv_s16_kernel<14, 2, false, false, 1, false, false, true>), dim3(ntiles), dim3(CONV_THREADS), lds, st, a);
+    TDM_CHECK_LAUNCH("conv_s16(s2d)");
     return 0;
 }
 
@@ -1249,6 +1333,16 @@ __global__ __launch_bounds__(256) void to_s16_kernel(const float* __restrict__ i
 }  // namespace
 
 int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st) {
+    if (a.s2d) {   // rb4.conv1's data gradient w.r.t. up(h3), at 14x14: source = the 28x28 output gradient, 4 taps per parity sub-image
+        TDM_REQUIRE(hw == 14 && N == 64 && a.nsrc == 1 && a.src[0].taps == 4 && a.src[0].up == 0 && a.src[0].nch % CK == 0 && a.src[0].nch > 0 &&
+                    (a.src[0].C % 16) == 0 && (a.src[0].c0 % 16) == 0 && a.src[0].tb == nullptr && a.src[0].wp != nullptr &&
+                    (((uintptr_t)a.src[0].wp) & 15) == 0 && a.out != nullptr && a.skip_out == nullptr && a.o1_out == nullptr && a.r1_x == nullptr &&
+                    a.dc_pair == nullptr && (a.rk1_d == nullptr || a.rk1_u != nullptr) && a.src[0].nch == 32,
+                    "conv_s16: the space-to-depth form is built for rb4.conv1's data gradient (hw 14, N 64, one 28x28 source, fp32 output)");
+        TDM_REQUIRE(a.B > 0 && (long)a.B * 784 < TDM_S16_MAX_PIXELS && (long)a.B * 784 * a.src[0].C * 4 < 2147483647L,
+                    "conv_s16: batch %d out of range", a.B);
+        return launch_conv_s2d(a, st);
+    }
     if (a.up_phase) {   // rb4.conv1's forward: source 0 half-resolution with 16 phase taps per chunk, source 1 full resolution
         TDM_REQUIRE(hw == 28 && N == 32 && a.nsrc == 2 && a.src[0].taps == 16 && a.src[1].taps == 9 && a.src[0].up == 1 && a.src[1].up == 0 &&
                     a.skip_out != nullptr && a.skip_wp != nullptr && a.skip_bias != nullptr && a.res == nullptr && a.relu_mask_in == nullptr &&

@@ -179,6 +179,10 @@ struct ConvArgs {
     // up-samples x2 (src/mnist.py:83), given with up = 1 and taps = 16 — its packed weights are the 4 phases x 4 taps of
     // PackDesc::phase = 1 — and src[1] the full-resolution tensor with the ordinary nine taps.
     int up_phase;
+    // The transpose (conv_s16.hip "S2D"): rb4.conv1's data gradient w.r.t. the up-sampled tensor, computed at ITS resolution.  hw = 14,
+    // N = 64; src[0] = the 28x28 output gradient (S16, up = 0, taps = 4, packed weights of PackDesc::phase = 2); out = the 14x14
+    // gradient (fp32); rk1_d / rk1_u (optional): + (rk1_d summed over the source pixel's four output pixels) * rk1_u[c].
+    int s2d;
 };
 
 // hw in {28,14}; N in {32,64,96}; dgrad: transposed convolution with the forward weights
@@ -189,7 +193,13 @@ int tdm_launch_conv(const ConvArgs& a, int hw, int N, bool dgrad, hipStream_t st
 // 16 packed taps per chunk, packed tap (2 py + px) * 4 + 2 a + b = sum of the 3x3 taps (ky, kx) that fall on source pixel
 // (i + py - 1 + a, j + px - 1 + b) for output pixel (2 i + py, 2 j + px): ky in {0} / {1, 2} for (py, a) = (0, 0) / (0, 1),
 // {0, 1} / {2} for (1, 0) / (1, 1); kx likewise (summed in fp32, then split hi / lo).
-struct PackDesc { int src_off, cin, cout, taps, dgrad; long dst_off; int phase, kuse; };
+// phase = 2: the TRANSPOSED weights of the same source for its data gradient at source resolution (conv_s16.hip "S2D"): d h[i][j] is a
+// 4x4, stride-2 gather over the output gradient g, g[2i-1+u][2j-1+v], with weights sum_{ky in T(u)} sum_{kx in T(v)} W[ky][kx]^T,
+// T(0) = {2}, T(1) = {1, 2}, T(2) = {0, 1}, T(3) = {0}.  Packed per parity group (p, q) of g's rows / columns (g[2i'+p][2j'+q]):
+// chunk (2p + q) * (cout / 16) + kc holds g channels 16 kc .., 4 taps each: tap 2 a + b with u = 2 dy + p + 1 for
+// dy = a (p = 0) or a - 1 (p = 1), v likewise from (q, b); n = input channel < kuse, k = output-gradient channel.
+// n0 / nuse (dgrad = 1, phase = 0): only output channels [n0, n0 + nuse) of the transposed conv (a sub-block of the concat).
+struct PackDesc { int src_off, cin, cout, taps, dgrad; long dst_off; int phase, kuse, n0, nuse; };
 #define TDM_MAX_PACK 24
 struct PackArgs { PackDesc d[TDM_MAX_PACK]; int n; };
 int tdm_launch_pack(const float* params, const PackArgs& pa, unsigned short* out, hipStream_t st);

@@ -22,6 +22,7 @@ __device__ __forceinline__ void tdm_timebias_body(const TimebiasArgs& a, int bx,
         float acc = 0.f;
         for (int co = 0; co < 32; ++co) acc = fmaf(params[a.o.skw4 + threadIdx.x * 32 + co], params[a.o.outw + co], acc);
         a.u96[threadIdx.x] = acc;
+        if (threadIdx.x < 32) a.u96[96 + threadIdx.x] = 0.f;   // 32 zeros behind it: the bias of the rank-1 epilogue that adds d[m] * u[64 + c]
     }
     const int total = a.B * 192;
     for (int i = bx * 256 + threadIdx.x; i < total; i += nbx * 256) {

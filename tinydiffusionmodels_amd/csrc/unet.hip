@@ -65,6 +65,8 @@ struct PackTab {
     PackArgs pa;
     long fwd[W_COUNT], dg[W_COUNT];
     long fwd_ph;      // rb4.conv1's up(h3) rows in the phase form (PackDesc::phase = 1): 4 chunks x 16 taps
+    long dg_s2d;      // ... their data gradient at 14x14 (PackDesc::phase = 2): 8 chunks x 4 taps, N = 64
+    long dg_h1;       // rb4.conv1's transposed weights for the h1 channels of the concat alone (outputs 64..95)
     long total_u16;
 };
 PackTab make_pack() {
@@ -88,6 +90,18 @@ PackTab make_pack() {
         d.src_off = off[W_RB4C1]; d.cin = 96; d.cout = 32; d.taps = 16; d.dgrad = 0; d.dst_off = o; d.phase = 1; d.kuse = 64;
         t.fwd_ph = o;
         o += 2L * 64 * 32 * 16;
+    }
+    {   // rb4.conv1 data gradient: d h3 at source resolution (4 parity sub-images x 2 channel chunks x 4 taps x N = 64) ...
+        PackDesc& d = t.pa.d[n++];
+        d.src_off = off[W_RB4C1]; d.cin = 96; d.cout = 32; d.taps = 4; d.dgrad = 1; d.dst_off = o; d.phase = 2; d.kuse = 64;
+        t.dg_s2d = o;
+        o += 2L * 8 * 4 * 64 * 16;
+    }
+    {   // ... and d h1: the ordinary transposed 3x3 weights, output channels 64..95 of the concat only
+        PackDesc& d = t.pa.d[n++];
+        d.src_off = off[W_RB4C1]; d.cin = 96; d.cout = 32; d.taps = 9; d.dgrad = 1; d.dst_off = o; d.n0 = 64; d.nuse = 32;
+        t.dg_h1 = o;
+        o += 2L * 32 * 32 * 9;
     }
     t.pa.n = n;
     t.total_u16 = o;
@@ -301,7 +315,8 @@ int wgrad_s16(hipStream_t st, int hw, int B, const float* act_s16, int C, int c_
     X(B_DG_RB4C2, "rb4.conv2 dgrad 32->32 @28 (conv_s16<28,1>)")                                                        \
     X(B_WG_RB4C1A, "rb4.conv1 wgrad, up(h3) part (wgrad2_s16<28>)")                                             \
     X(B_WG_RB4C1B, "rb4.conv1 wgrad, h1 part (wgrad2_s16<28>)")                                                 \
-    X(B_DG_RB4C1, "rb4.conv1 dgrad 32->96 @28 + rank-1 skip share, paired (conv_s16<28,3>)") X(B_SPLIT_DCAT, "upsample bwd + relu mask (split_dcat_mask_s16)") \
+    X(B_DG_RB4C1H1, "rb4.conv1 dgrad, h1 part 32->32 @28 + rank-1 skip share (conv_s16<28,1>)")                          \
+    X(B_DG_RB4C1, "rb4.conv1 dgrad, up(h3) part 32->64 at 14x14 + rank-1 skip share (conv_s16<14,2,s2d>)") X(B_SPLIT_DCAT, "relu mask rb3 (relu_mask_s16)") \
     X(B_WG_RB3C2, "rb3.conv2 wgrad (wgrad2_s16<14>)") X(B_DG_RB3C2, "rb3.conv2 dgrad 64->64 @14 (conv_s16<14,2>)")      \
     X(B_WG_RB3C1, "rb3.conv1 wgrad (wgrad2_s16<14>)")                                                                   \
     X(B_DG_RB3C1, "rb3.conv1 dgrad 64->64 @14 (conv_s16<14,2>)") X(B_RELU_MASK2, "relu mask rb2 (relu_mask_s16)")       \
@@ -549,6 +564,23 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     RUN_ON(ss, B_WG_RB4C2, wgrad_s16(ss, 28, B, w.a1s_4, 32, 32, 0, 9, w.dc2s_4, 32, slabs, r4.c2w, 32, 0, NS));
     RUN_ON(ss, B_WG_RB4C1A, wgrad_s16(ss, 28, B, w.h3s, 64, 64, 1, 9, w.dh4s, 32, slabs, r4.c1w, 96, 0, NS));
     RUN_ON(ss, B_WG_RB4C1B, wgrad_s16(ss, 28, B, w.h1s, 32, 32, 0, 9, w.dh4s, 32, slabs, r4.c1w, 96, 64, NS));
+    if (g_rb4_phase) {
+        // d cat in two launches.  Channels 0..63 (the gradient of the up-sampled h3) are computed at 14x14 directly (conv_s16 "S2D":
+        // 512 instead of 1152 K elements per source pixel, no pair-summed intermediate).  Channels 64..95 (d h1) are an ordinary
+        // 32 -> 32 transposed conv (+ the skip path's rank-one share d[m] * u[64 + c] through the rank-1 epilogue, bias = the zeros
+        // behind u96); only combine_dh1 reads them, a dozen launches later, so that launch is issued THERE (below) and the rb3 chain
+        // starts behind a ~33 us launch instead of a ~95 us one.  (On the side queue it made that queue the longer one: its eight
+        // weight-gradient launches already take ~460 us next to the main chain — profiles/r05_step_overlap.txt.)
+        {
+            ConvArgs a{};
+            a.nsrc = 1;
+            a.src[0] = s16_src(w.dh4s, 32, 32, 0, 4, w.wpack + kPack.dg_s2d, 0);
+            a.B = B; a.out = w.dout3; a.s2d = 1; a.rk1_d = dvec; a.rk1_u = w.u96; a.tb_out_stride = 192;
+            RUN(B_DG_RB4C1, tdm_launch_conv_s16(a, 14, 64, st));
+        }
+        // ---- rb3 ---- (ReLU mask of rb3.conv2's output + its bias-gradient rows)
+        RUN(B_SPLIT_DCAT, tdm_launch_relu_mask_s16(w.dout3, w.m2[2], w.dc2s_3, es, ESTRIDE, E_C2B3, -1, M14, 64, ER14, st));
+    } else {
     {   // d cat = conv1's transposed conv of dh4 (+ the skip path's rank-one share, added in the epilogue)
         ConvArgs a{};
         a.nsrc = 1;
@@ -559,6 +591,7 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     }
     // ---- rb3 ---- (upsample backward and the ReLU mask of rb3.conv2's output in one pass)
     RUN(B_SPLIT_DCAT, tdm_launch_split_dcat_mask_s16(dc_pair, w.m2[2], w.dout3, w.dc2s_3, es, ESTRIDE, E_C2B3, B, ER14, st));
+    }
     RUN(B_DG_RB3C2, conv_s16_1(st, w, 14, B, w.dc2s_3, 64, 9, kPack.dg[W_RB3C2], 64, nullptr, 0,
                                S16Out{nullptr, nullptr, nullptr, w.dh3s, nullptr, w.m1[2], w.gs[2]}));
     TDM_TRY(fork());
@@ -594,6 +627,14 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     // ---- rb1 ---- (concat skip + avg-pool backward and the ReLU mask of rb1.conv2's output in one pass)
     // (rb1.skip has one input channel: its weight / bias gradients are sums over x * dout1 and dout1, taken here while
     //  dout1 is in registers — the fp32 tensor itself is never written)
+    if (g_rb4_phase) {   // d cat[.., 64:96] = rb4.conv1's data gradient w.r.t. h1 (see above)
+        ConvArgs a{};
+        a.nsrc = 1;
+        a.src[0] = s16_src(w.dh4s, 32, 32, 0, 9, w.wpack + kPack.dg_h1, 0);
+        a.B = B; a.out = dc_h1; a.tb_out_stride = 192;
+        a.r1_x = dvec; a.r1_w = w.u96 + 64; a.r1_b = w.u96 + 96;
+        RUN(B_DG_RB4C1H1, tdm_launch_conv_s16(a, 28, 32, st));
+    }
     RUN(B_COMBINE_DH1, tdm_launch_combine_dh1_mask_s16(dc_h1, w.dp1, w.m2[0], nullptr, w.dc2s_1, es, ESTRIDE, E_C2B1, B, ER28, st,
                                                        x, E_SKW1, E_SKB1));
     TDM_TRY(fork());
