@@ -81,7 +81,7 @@ LAUNCH_WORK = [
     (_C3(1, 32, 784), 3136 + _T28(32), 0),                                   # rb1.conv1 wgrad
     (0, 0, 4 * (256 * (320 + 9248 + 64 + 64 + 64 + 64 + 27648 + 9248 + 32 + 33 + 384 + 160 + 1 + 4 * 96) + 128 * (18432 + 2048) + 64 * 3 * 36864) + 725_892),  # reduce
 ]
-MFMA_LAUNCH = "conv_s16<", "wgrad2_s16<"    # launches whose FLOPs run on the matrix cores (bf16x3: 3 MFMA FLOP per FLOP)
+MFMA_LAUNCH = "conv_s16<", "wgrad2_s16<", "wgrad_s2d"    # launches whose FLOPs run on the matrix cores (bf16x3: 3 MFMA FLOP per FLOP)
 
 
 def _median(xs):
@@ -548,7 +548,8 @@ def main():
         # MFMA work as built relative to the algorithm's FLOP: the phase form runs 4 of 9 taps over the 64 up-sampled channels
         phase_on = os.environ.get("TDM_RB4_PHASE", "1") != "0"
         AS_BUILT = {"rb4.conv1 + rb4.skip fwd": (4 * 64 + 9 * 32 + 96) / (9 * 96 + 96) if phase_on else 1.0,
-                    "rb4.conv1 dgrad, up(h3) part": (16 * 196) / (9 * 784) if phase_on else 1.0}
+                    "rb4.conv1 dgrad, up(h3) part": (16 * 196) / (9 * 784) if phase_on else 1.0,
+                    "rb4.conv1 wgrad, up(h3) part": (16 * 196) / (9 * 784) if phase_on else 1.0}
         from tinydiffusionmodels_amd.build import source_digest
         digest = source_digest()
         traffic_by_name, traffic_src = {}, None

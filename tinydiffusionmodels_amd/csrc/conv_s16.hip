@@ -1292,6 +1292,232 @@ __global__ __launch_bounds__(1024) void wgrad2_s16_kernel(WgradArgs a) {
 }
 
 
+// ---------------------------------------------------------------------------
+// weight gradient of rb4.conv1's up-sampled source in the parity form (WgradArgs::s2d; the transpose of the "PH" / "S2D" conv
+// kernels above).  dW[ky][kx] = sum_p up(h3)[p + (ky-1, kx-1)] (x) g[p] over the 28x28 pixels p; with up(h3)[y][x] = h3[y>>1][x>>1] the
+// same sum is, per parity sub-image g_pq[i'][j'] = g[2i'+p][2j'+q] of the output gradient, a 14x14 weight gradient with FOUR taps:
+//     dWeff[(p,a),(q,b)] = sum_{i',j'} h3[i' - (a - p)][j' - (b - q)] (x) g_pq[i'][j'],        a, b in {0, 1}
+// and dW[ky][kx] is the sum of the four dWeff whose (p, a) reaches ky ((0,1),(1,1) -> 0; (0,0),(1,1) -> 1; (0,0),(1,0) -> 2) and
+// whose (q, b) reaches kx: 16 x 196 instead of 9 x 784 tap-pixel products per image.  Same producer / consumer structure as
+// wgrad2_s16_kernel: a tile is 64 positions of the 14x14 raster; producers stage the haloed h3 image ONCE and the four parity
+// sub-images of g (a stride-2 gather); consumer wave w owns sub-image w >> 1 and row offset a = w & 1, i.e. two effective taps
+// (b = 0, 1) over all four K steps of a tile — no K split, so the final step only combines the 16 effective taps into the nine
+// (ky, kx) slots (fixed order) and writes them to the workgroup's slab.
+// ---------------------------------------------------------------------------
+constexpr int W3_TP = 64;     // positions per tile
+constexpr int W3_NRW = 10;    // staged rows of the 14x14 image: <= 6 rows of positions + halo + one image seam
+__global__ __launch_bounds__(1024) void wgrad_s2d_kernel(WgradArgs a) {
+    using G = Geo<14>;
+    constexpr int NPX = W3_NRW * G::WP;
+    constexpr int APL = NPX * 64;            // one plane (hi or lo) of the activation image
+    constexpr int GPL = W3_TP * 64;          // one plane of ONE parity sub-image of the gradient tile
+    constexpr int PXO = 2 * APL + 8 * GPL;   // staged-pixel table
+    constexpr int BUF = PXO + W3_TP * (int)sizeof(int);
+    extern __shared__ float4 smem4[];
+    char* const lds = reinterpret_cast<char*>(smem4);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ci_tile = blockIdx.y % a.nci, co_tile = blockIdx.y / a.nci;
+    const int ci0 = ci_tile * 32, co0 = co_tile * 32;
+    const int Mtot = a.B * G::H * G::W;
+    const int ntiles = (Mtot + W3_TP - 1) / W3_TP;
+    const int step = gridDim.x;
+    const int slot = xcd_remap(blockIdx.x, gridDim.x);
+    const int nk = (ntiles - slot + step - 1) / step;   // tiles of this workgroup: slot + k * step
+    float* const slab = a.slab + (long)slot * a.slab_stride;
+
+    if (wave >= 8) {
+        // ------------------------------- producers -------------------------------
+        const int ptid = tid - 512;
+        const float* a_ptr = a.a.ptr; const float* g_ptr = a.g;
+        int a_C = a.a.C, a_c0 = a.a.c0, g_C = a.Cout, nB = a.B;
+        TDM_PIN(a_ptr); TDM_PIN(g_ptr); TDM_PIN(a_C); TDM_PIN(a_c0); TDM_PIN(g_C); TDM_PIN(nB);
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_ptr), 0, nB * G::H * G::W * a_C * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g_ptr), 0, nB * 784 * g_C * 4, 0x00020000);
+        const int piece8 = ptid & 7, grp = piece8 >> 2, pq = piece8 & 3;
+        const int dcol = grp * 32 + (pq & 1) * 16;
+        const int dplane_a = (pq >= 2) ? APL : 0, dplane_g = (pq >= 2) ? GPL : 0;
+        const int a_col = a_c0 + ci0 + grp * 16 + pq * 4;   // float column of this thread's piece inside a pixel row of A
+        const int g_col = co0 + grp * 16 + pq * 4;
+        constexpr int NA = (NPX * 8 + 511) / 512;
+        struct Stage { u32x4 pa[NA]; u32x4 pg[4]; int pix; int nelem; };
+        Stage s0, s1;
+        int* const rowtab = reinterpret_cast<int*>(lds + 2 * BUF) + (wave - 8) * 32;
+        int lr_i[NA], col_i[NA];
+        unsigned colok = 0u;
+        {
+            int lr = (ptid >> 3) / G::WP;
+            int pc = (ptid >> 3) - lr * G::WP;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                lr_i[i] = min(lr, W3_NRW - 1) * 4;                   // byte offset of the row's table entry
+                col_i[i] = ((pc - 1) * a_C + a_col) * 4;             // bytes
+                colok |= (pc >= 1 && pc <= G::W && lr < W3_NRW) ? (1u << i) : 0u;
+                pc += 64 % G::WP;
+                lr += 64 / G::WP;
+                if (pc >= G::WP) { pc -= G::WP; ++lr; }
+            }
+        }
+        auto prefetch = [&](Stage& st, int k) {
+            const int t = min(slot + k * step, ntiles - 1);   // (past the end: re-read the last tile, never staged)
+            const int m0 = t * W3_TP;
+            const int mlast = min(m0 + W3_TP - 1, Mtot - 1);
+            const int tb0 = m0 / (G::H * G::W);
+            const int rem0 = m0 - tb0 * (G::H * G::W);
+            const int ty0 = rem0 / G::W;
+            const int x0 = rem0 - ty0 * G::W;
+            const int PR0 = tb0 * G::HP + ty0;
+            const int nrows = min(padded_row<14>(mlast) - PR0 + 2, W3_NRW);
+            st.nelem = nrows * G::WP * 8;
+            if (lane < 16) {   // row table: staged row r = lane is padded row PR0 + r of the tall image
+                int py = ty0 + lane, b = tb0;
+                if (py >= G::HP) { py -= G::HP; ++b; }
+                const bool ok = lane < nrows && py >= 1 && py <= G::H && b < nB;
+                rowtab[lane] = ok ? __mul24(__mul24(__mul24(b, G::H) + (py - 1), G::W), a_C) * 4 : (int)0x80000000;
+            }
+            // tile position ptid >> 3 (< 64): its staged-pixel index (threads ptid < 64 keep the one of position ptid) and
+            // the 28x28 pixel of its parity-(0, 0) gradient sample
+            const int pos = ptid >> 3;
+            auto locate = [&](int tp, int& pixidx, int& m28) {
+                const int q = x0 + min(tp, mlast - m0);              // columns past the start of row ty0
+                const int dr = (q * 4682) >> 16;                     // q / 14 for q < 14 + 128
+                const int x = q - dr * G::W;
+                int y = ty0 + dr, bb = tb0, seam = 0;
+                if (y >= G::H) { y -= G::H; seam = G::HP; ++bb; }
+                pixidx = (seam + y + 1 - ty0) * G::WP + x + 1;
+                m28 = (bb * 28 + 2 * y) * 28 + 2 * x;
+            };
+            int pixg, m28;
+            locate(pos, pixg, m28);
+            st.pix = 0;
+            if (ptid < W3_TP) { int m28_; locate(ptid, st.pix, m28_); }
+            const bool live = m0 + pos <= mlast;                     // positions past the end: gradient rows read as zeros
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int roff = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(rowtab) + lr_i[i]);
+                const bool ok = ((colok >> i) & 1u) != 0u && roff >= 0;
+                st.pa[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? (roff + col_i[i]) : (int)0x80000000, 0, 0));
+            }
+#pragma unroll
+            for (int par = 0; par < 4; ++par) {                      // sub-image (p, q) = (par >> 1, par & 1)
+                const int m = m28 + (par >> 1) * 28 + (par & 1);
+                st.pg[par] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, live ? (__mul24(m, g_C) + g_col) * 4 : (int)0x80000000, 0, 0));
+            }
+        };
+        auto write = [&](const Stage& st, int buf) {
+            char* const base = lds + buf * BUF;
+            int* const pixoff = reinterpret_cast<int*>(base + PXO);
+            if (ptid < W3_TP) pixoff[ptid] = st.pix;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int e = ptid + 512 * i;
+                if (e < st.nelem) *reinterpret_cast<u32x4*>(base + dplane_a + dcol + (e >> 3) * 64) = st.pa[i];
+            }
+#pragma unroll
+            for (int par = 0; par < 4; ++par)
+                *reinterpret_cast<u32x4*>(base + 2 * APL + par * (2 * GPL) + dplane_g + dcol + (ptid >> 3) * 64) = st.pg[par];
+        };
+        prefetch(s0, 0);
+        prefetch(s1, 1);
+        write(s0, 0);
+        __syncthreads();                       // tile 0 staged
+        for (int k = 0; k < nk; k += 2) {
+            prefetch(s0, k + 2);
+            if (k + 1 < nk) write(s1, 1);
+            __syncthreads();
+            if (k + 1 >= nk) break;
+            prefetch(s1, k + 3);
+            if (k + 2 < nk) write(s0, 0);
+            __syncthreads();
+        }
+        __syncthreads();                       // the consumers' combination step: one barrier
+        return;
+    }
+
+    // ------------------------------- consumers -------------------------------
+    const int g4 = lane >> 4, cb = g4 & 1, hh = g4 >> 1, q = (lane >> 2) & 3, pcq = lane & 3;
+    const int colb = (cb * 16 + pcq * 4) * 2;
+    const int par = wave >> 1, ap = wave & 1;              // sub-image (p, q) = (par >> 1, par & 1); row offset index a
+    const int dy = ap - (par >> 1), qx = par & 1;          // h3 row read: i' - dy; columns: j' - (b - q), b = 0, 1
+    f32x16 acc[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    __syncthreads();                           // tile 0 staged
+    for (int k = 0; k < nk; ++k) {
+        const char* base = lds + (k & 1) * BUF;
+        const char* Ahi = base; const char* Alo = base + APL;
+        const char* Ghi = base + 2 * APL + par * (2 * GPL); const char* Glo = Ghi + GPL;
+        const int* pixoff = reinterpret_cast<const int*>(base + PXO);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int p0 = ks * 16 + hh * 8 + q;
+            const int gb0 = p0 * 64 + colb, gb1 = (p0 + 4) * 64 + colb;
+            const bf16x8 gh = tr_pair(Ghi + gb0, Ghi + gb1);
+            const bf16x8 gl = tr_pair(Glo + gb0, Glo + gb1);
+            const int ab0 = pixoff[p0] * 64 + colb, ab1 = pixoff[p0 + 4] * 64 + colb;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int to = ((-dy) * G::WP - (b - qx)) * 64;
+                const bf16x8 ah = tr_pair(Ahi + ab0 + to, Ahi + ab1 + to);
+                const bf16x8 al = tr_pair(Alo + ab0 + to, Alo + ab1 + to);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh, acc[b], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // the 16 effective taps -> LDS -> nine (ky, kx) sums in fixed order -> this workgroup's slab
+    float* red = reinterpret_cast<float*>(smem4);   // [16 effective taps = par * 4 + a * 2 + b][1024]
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((par * 4 + ap * 2 + b) << 10) + r * 64 + lane] = acc[b][r];
+    __syncthreads();
+    // (ky or kx) <- the two (parity, offset) pairs that reach it, as parity * 2 + offset
+    const int src0[3] = {1, 0, 0}, src1[3] = {3, 3, 2};
+    for (int o = tid; o < 9 * 1024; o += 512) {
+        const int tap9 = o >> 10, idx = o & 1023;
+        const int ky = tap9 / 3, kx = tap9 - ky * 3;
+        float sum = 0.f;
+#pragma unroll
+        for (int yi = 0; yi < 2; ++yi)
+#pragma unroll
+            for (int xi = 0; xi < 2; ++xi) {
+                const int yr = yi ? src1[ky] : src0[ky], xr = xi ? src1[kx] : src0[kx];
+                const int e = (((yr >> 1) * 2 + (xr >> 1)) * 4) + (yr & 1) * 2 + (xr & 1);
+                sum += red[(e << 10) + idx];
+            }
+        const int r = idx >> 6, ln = idx & 63;
+        const int ci = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        const int co = ln & 31;
+        slab[a.w_off + (long)(tap9 * a.a.w_rows + a.a.w_r0 + ci0 + ci) * a.Cout + co0 + co] = sum;
+    }
+}
+
+int launch_wgrad_s2d(const WgradArgs& a, int nslab, hipStream_t st) {
+    using G = Geo<14>;
+    constexpr size_t buf = (size_t)2 * W3_NRW * G::WP * 64 + 8 * W3_TP * 64 + W3_TP * sizeof(int);
+    constexpr size_t lds = 2 * buf + 8 * 32 * sizeof(int);
+    static_assert(lds >= 16 * 1024 * sizeof(float), "the combination step needs 64 KB");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_s2d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            tdm_set_error("wgrad_s2d: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return 100 + (int)e;
+        }
+        attr_set = true;
+    }
+    const int nco = a.Cout / 32;
+    hipLaunchKernelGGL(wgrad_s2d_kernel, dim3(nslab, a.nci * nco), dim3(1024), lds, st, a);
+    TDM_CHECK_LAUNCH("wgrad_s2d");
+    return 0;
+}
+
 template <int HW, bool SK2>
 int launch_wgrad2_t(const WgradArgs& a, int nslab, hipStream_t st) {
     using G = Geo<HW>;
@@ -1398,6 +1624,14 @@ int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st) {
 }
 
 int tdm_launch_wgrad_s16(const WgradArgs& a, int hw, int nslab, hipStream_t st) {
+    if (a.s2d) {   // rb4.conv1's up-sampled source in the parity form: activation at 14x14 (up = 0), gradient at 28x28
+        TDM_REQUIRE(hw == 14 && a.a.taps == 9 && a.a.up == 0 && a.Cout % 32 == 0 && a.nci >= 1 && (a.a.C % 16) == 0 && (a.a.c0 % 16) == 0 &&
+                    a.a.tb == nullptr && a.g2 == nullptr && nslab >= 1 && nslab <= TDM_UNET_MAX_SLABS,
+                    "wgrad_s16: the parity form is built for rb4.conv1's up-sampled source (hw 14, 3x3, no fused 1x1)");
+        TDM_REQUIRE(a.B > 0 && (long)a.B * 784 < TDM_S16_MAX_PIXELS && (long)a.B * 196 * a.a.C * 4 < 2147483647L &&
+                    (long)a.B * 784 * a.Cout * 4 < 2147483647L, "wgrad_s16: batch %d out of range", a.B);
+        return launch_wgrad_s2d(a, nslab, st);
+    }
     TDM_REQUIRE(a.Cout % 32 == 0 && a.nci >= 1, "wgrad_s16: Cout %d / nci %d", a.Cout, a.nci);
     TDM_REQUIRE(a.a.taps == 9 || a.a.taps == 1, "wgrad_s16: taps must be 9 or 1");
     TDM_REQUIRE((a.a.C % 16) == 0 && (a.a.c0 % 16) == 0 && a.a.tb == nullptr, "wgrad_s16: S16 source layout");

@@ -232,6 +232,9 @@ struct WgradArgs {
     // 1x1 weight tensor (rows a.w_r0 .. as for the 3x3 tensor).
     const float* g2;
     int w_off2;
+    // rb4.conv1's up-sampled source in the parity form (conv_s16.hip: wgrad_s2d_kernel): a = the HALF-resolution activation (hw = 14,
+    // up = 0), g = the full-resolution (28x28) output gradient; the nine 3x3 slots of the slab are written as usual.
+    int s2d;
 };
 int tdm_launch_wgrad(const WgradArgs& a, int hw, int nslab, hipStream_t st);
 int tdm_launch_wgrad_s16(const WgradArgs& a, int hw, int nslab, hipStream_t st);    // a.a.ptr and a.g are S16; no bias

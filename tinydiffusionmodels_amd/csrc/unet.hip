@@ -291,8 +291,9 @@ int conv_s16_1(hipStream_t st, const Ws& ws, int hw, int B, const float* in_s16,
 }
 int wgrad_s16(hipStream_t st, int hw, int B, const float* act_s16, int C, int c_used, int up, int taps,
               const float* g_s16, int Cout, float* slabs, int w_off, int w_rows, int w_r0, int nslab,
-              const float* g2_s16 = nullptr, int w_off2 = 0) {
+              const float* g2_s16 = nullptr, int w_off2 = 0, int s2d = 0) {
     WgradArgs a{};
+    a.s2d = s2d;                        // rb4.conv1's up-sampled source in the parity form (activation at hw, gradient at 2 hw)
     a.g2 = g2_s16; a.w_off2 = w_off2;   // the block's 1x1 skip weight gradient, fused into this 3x3 launch
     a.a = s16_src(act_s16, C, c_used, up, taps, nullptr, 0);
     a.a.w_rows = w_rows; a.a.w_r0 = w_r0;
@@ -313,7 +314,7 @@ int wgrad_s16(hipStream_t st, int hw, int B, const float* act_s16, int C, int c_
     X(F_RB4C2, "rb4.conv2 + out conv fwd + MSE fwd/bwd 32->32 @28 (conv_s16<28,1>)")                                                       \
     X(B_OUT_BWD, "relu mask of d x w_out + rb4.skip grads in factored form (out_bwd_s16)") X(B_WG_RB4C2, "rb4.conv2 wgrad (wgrad2_s16<28>)")            \
     X(B_DG_RB4C2, "rb4.conv2 dgrad 32->32 @28 (conv_s16<28,1>)")                                                        \
-    X(B_WG_RB4C1A, "rb4.conv1 wgrad, up(h3) part (wgrad2_s16<28>)")                                             \
+    X(B_WG_RB4C1A, "rb4.conv1 wgrad, up(h3) part in the parity form (wgrad_s2d)")                               \
     X(B_WG_RB4C1B, "rb4.conv1 wgrad, h1 part (wgrad2_s16<28>)")                                                 \
     X(B_DG_RB4C1H1, "rb4.conv1 dgrad, h1 part 32->32 @28 + rank-1 skip share (conv_s16<28,1>)")                          \
     X(B_DG_RB4C1, "rb4.conv1 dgrad, up(h3) part 32->64 at 14x14 + rank-1 skip share (conv_s16<14,2,s2d>)") X(B_SPLIT_DCAT, "relu mask rb3 (relu_mask_s16)") \
@@ -562,7 +563,10 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     //  in FOUR groups, each behind the launch that produced the last of its operands)
     TDM_TRY(fork());
     RUN_ON(ss, B_WG_RB4C2, wgrad_s16(ss, 28, B, w.a1s_4, 32, 32, 0, 9, w.dc2s_4, 32, slabs, r4.c2w, 32, 0, NS));
-    RUN_ON(ss, B_WG_RB4C1A, wgrad_s16(ss, 28, B, w.h3s, 64, 64, 1, 9, w.dh4s, 32, slabs, r4.c1w, 96, 0, NS));
+    if (g_rb4_phase)   // four parity sub-images of dh4 against h3 at 14x14: 16 x 196 instead of 9 x 784 tap-pixel products per image
+        RUN_ON(ss, B_WG_RB4C1A, wgrad_s16(ss, 14, B, w.h3s, 64, 64, 0, 9, w.dh4s, 32, slabs, r4.c1w, 96, 0, NS, nullptr, 0, 1));
+    else
+        RUN_ON(ss, B_WG_RB4C1A, wgrad_s16(ss, 28, B, w.h3s, 64, 64, 1, 9, w.dh4s, 32, slabs, r4.c1w, 96, 0, NS));
     RUN_ON(ss, B_WG_RB4C1B, wgrad_s16(ss, 28, B, w.h1s, 32, 32, 0, 9, w.dh4s, 32, slabs, r4.c1w, 96, 64, NS));
     if (g_rb4_phase) {
         // d cat in two launches.  Channels 0..63 (the gradient of the up-sampled h3) are computed at 14x14 directly (conv_s16 "S2D":

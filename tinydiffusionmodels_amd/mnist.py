@@ -517,7 +517,7 @@ class DDPMTrainer(DPStepper):
         # data parallel, eager issue: the backward finishes the gradient in two parts so that most of the all-reduce runs under it
         self._early = self.world > 1 and os.environ.get("TDM_EARLY_GRADS", "1") != "0"
         self._early_off = int(_lib.lib().tdm_unet_early_grad_offset())
-        if self._early:
+        if self._early or os.environ.get("TDM_EARLY_GRADS_W1") == "1":   # (W1: the two-part reduction on one GPU, A/B timing of the step's tail)
             _lib.check(_lib.lib().tdm_set_early_grads(1), "tdm_set_early_grads")
         self.batch_size = batch_size
         self.grads = torch.zeros(E.NPARAM, dtype=torch.float32, device=dev)
