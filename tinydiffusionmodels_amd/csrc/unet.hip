@@ -598,6 +598,8 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     }
     RUN(B_DG_RB3C2, conv_s16_1(st, w, 14, B, w.dc2s_3, 64, 9, kPack.dg[W_RB3C2], 64, nullptr, 0,
                                S16Out{nullptr, nullptr, nullptr, w.dh3s, nullptr, w.m1[2], w.gs[2]}));
+    // (round 5, re-measured with the shorter main chain: rb3's weight gradients sent over with rb2's — three forks — 1,095 -> 1,087
+    //  steps/s on one box; four groups stay)
     TDM_TRY(fork());
     RUN_ON(ss, B_WG_RB3C2, wgrad_s16(ss, 14, B, w.a1s_3, 64, 64, 0, 9, w.dc2s_3, 64, slabs, r3.c2w, 64, 0, NS4));
     RUN_ON(ss, B_WG_RB3C1, wgrad_s16(ss, 14, B, w.h2s, 64, 64, 0, 9, w.dh3s, 64, slabs, r3.c1w, 64, 0, NS4));
