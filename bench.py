@@ -63,8 +63,8 @@ LAUNCH_WORK = [
     (_C3(64, 32, 784), _T14(64) + _T28(32), 0),                              # rb4.conv1 wgrad (up(h3) part)
     (_C3(32, 32, 784), 2 * _T28(32), 0),                                     # rb4.conv1 wgrad (h1 part)
     (_C3(32, 32, 784) + _C1(1, 32, 784), 2 * _T28(32) + 3136, 0),            # rb4.conv1 dgrad, h1 part: dh4s in, (M,32) out; + rank-1 skip share (side queue)
-    (_C3(32, 64, 784) + _C1(1, 64, 784), _T28(32) + _T14(64) + 3136, 0),     # rb4.conv1 dgrad, up(h3) part at 14x14: dh4s in, dout3 out; + rank-1 skip share (FLOP: the algorithm's nine taps at 28x28; as built 16 taps at 14x14 = 0.44 x)
-    (0, 2 * _T14(64) + _M14(64), 0),                                         # relu mask rb3
+    (_C3(32, 64, 784) + _C1(1, 64, 784), _T28(32) + 2 * _T14(64) + _M14(64) + 3136, 0),   # rb4.conv1 dgrad, up(h3) part at 14x14: dh4s + mask in, dout3 + its masked S16 twin out; + rank-1 skip share (FLOP: the algorithm's nine taps at 28x28; as built 16 taps at 14x14 = 0.44 x)
+    (0, 0, 0),                                                               # (round 4's upsample-backward pass: fused into the launch before, not issued)
     (_C3(64, 64, 196), 2 * _T14(64), 0),                                     # rb3.conv2 wgrad
     (_C3(64, 64, 196), 2 * _T14(64) + _M14(64), 0),                          # rb3.conv2 dgrad
     (_C3(64, 64, 196), 2 * _T14(64), 0),                                     # rb3.conv1 wgrad

@@ -711,6 +711,14 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
             ok[k] = FULL || mbase + px < Mtot;
             if constexpr (PH) { o[k] = (unsigned)max(mpx[(I0 + k) & 3], 0) * N + c; ok[k] = mpx[(I0 + k) & 3] >= 0; }
         }
+        if constexpr (S2D) if (s2_d != nullptr) {   // FIRST (the saved copy `aux` = the complete gradient): + (d summed over the source pixel's four output pixels) * u[c]
+            const float4 u4 = gload4(s2_u + (lane_e & (N / 4 - 1)) * 4);   // (a lane's channel quad is the same in every pass)
+#pragma unroll
+            for (int k = 0; k < GI; ++k) {
+                const float dq = __shfl(d4_lane, ((I0 + k) * 64 + lane_e) / (N / 4));
+                v[k].x = fmaf(dq, u4.x, v[k].x); v[k].y = fmaf(dq, u4.y, v[k].y); v[k].z = fmaf(dq, u4.z, v[k].z); v[k].w = fmaf(dq, u4.w, v[k].w);
+            }
+        }
         if (a.relu) {
 #pragma unroll
             for (int k = 0; k < GI; ++k) {
@@ -759,14 +767,6 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
                 sacc[1][0].x += s1 ? u.x : 0.f; sacc[1][0].y += s1 ? u.y : 0.f; sacc[1][0].z += s1 ? u.z : 0.f; sacc[1][0].w += s1 ? u.w : 0.f;
                 sacc[1][1].x += s1 ? mv.x : 0.f; sacc[1][1].y += s1 ? mv.y : 0.f; sacc[1][1].z += s1 ? mv.z : 0.f; sacc[1][1].w += s1 ? mv.w : 0.f;
                 v[k] = mv;
-            }
-        }
-        if constexpr (S2D) if (s2_d != nullptr) {   // + (d summed over the source pixel's four output pixels) * u[c]
-            const float4 u4 = gload4(s2_u + (lane_e & (N / 4 - 1)) * 4);   // (a lane's channel quad is the same in every pass)
-#pragma unroll
-            for (int k = 0; k < GI; ++k) {
-                const float dq = __shfl(d4_lane, ((I0 + k) * 64 + lane_e) / (N / 4));
-                v[k].x = fmaf(dq, u4.x, v[k].x); v[k].y = fmaf(dq, u4.y, v[k].y); v[k].z = fmaf(dq, u4.z, v[k].z); v[k].w = fmaf(dq, u4.w, v[k].w);
             }
         }
         if (a.out != nullptr) {
@@ -1562,7 +1562,7 @@ int tdm_launch_conv_s16(const ConvArgs& a, int hw, int N, hipStream_t st) {
     if (a.s2d) {   // rb4.conv1's data gradient w.r.t. up(h3), at 14x14: source = the 28x28 output gradient, 4 taps per parity sub-image
         TDM_REQUIRE(hw == 14 && N == 64 && a.nsrc == 1 && a.src[0].taps == 4 && a.src[0].up == 0 && a.src[0].nch % CK == 0 && a.src[0].nch > 0 &&
                     (a.src[0].C % 16) == 0 && (a.src[0].c0 % 16) == 0 && a.src[0].tb == nullptr && a.src[0].wp != nullptr &&
-                    (((uintptr_t)a.src[0].wp) & 15) == 0 && a.out != nullptr && a.skip_out == nullptr && a.o1_out == nullptr && a.r1_x == nullptr &&
+                    (((uintptr_t)a.src[0].wp) & 15) == 0 && (a.out != nullptr || a.aux != nullptr) && a.skip_out == nullptr && a.o1_out == nullptr && a.r1_x == nullptr &&
                     a.dc_pair == nullptr && (a.rk1_d == nullptr || a.rk1_u != nullptr) && a.src[0].nch == 32,
                     "conv_s16: the space-to-depth form is built for rb4.conv1's data gradient (hw 14, N 64, one 28x28 source, fp32 output)");
         TDM_REQUIRE(a.B > 0 && (long)a.B * 784 < TDM_S16_MAX_PIXELS && (long)a.B * 784 * a.src[0].C * 4 < 2147483647L,

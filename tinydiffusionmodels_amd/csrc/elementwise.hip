@@ -1076,8 +1076,8 @@ __global__ __launch_bounds__(EW_BLOCK) void group_sums_kernel(GroupSumJobs jb, c
             ab.x += s00.x + s10.x; ab.y += s00.y + s10.y; ab.z += s00.z + s10.z; ab.w += s00.w + s10.w;
             a2.x += s01.x + s11.x; a2.y += s01.y + s11.y; a2.z += s01.z + s11.z; a2.w += s01.w + s11.w;
         }
-        quad_reduce_store(aw, sh, C4, dst + jb.tew[job]);
-        quad_reduce_store(ab, sh, C4, dst + jb.tew[job] + C);
+        quad_reduce_store(aw, sh, C4, jb.tew[job] >= 0 ? dst + jb.tew[job] : nullptr);
+        quad_reduce_store(ab, sh, C4, jb.tew[job] >= 0 ? dst + jb.tew[job] + C : nullptr);
         quad_reduce_store(a2, sh, C4, jb.c1b[job] >= 0 ? dst + jb.c1b[job] : nullptr);
     }
 }
@@ -1281,7 +1281,7 @@ int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, c
 int tdm_launch_group_sums(const GroupSumJobs& jb, const float* that, int B, float* slab, long slab_stride, int nslab,
                           hipStream_t st) {
     const int njobs = jb.njobs > 0 ? jb.njobs : 4 - jb.job0;
-    TDM_REQUIRE(jb.job0 >= 0 && njobs >= 1 && jb.job0 + njobs <= 4, "group_sums: jobs %d .. +%d", jb.job0, njobs);
+    TDM_REQUIRE(jb.job0 >= 0 && njobs >= 1 && jb.job0 + njobs <= TDM_GS_JOBS, "group_sums: jobs %d .. +%d", jb.job0, njobs);
     for (int i = jb.job0; i < jb.job0 + njobs; ++i)
         TDM_REQUIRE(jb.gs[i] != nullptr && jb.C[i] % 16 == 0 && EW_BLOCK % (jb.C[i] / 4) == 0, "group_sums: job %d", i);
     hipLaunchKernelGGL(group_sums_kernel, dim3(nslab, njobs), dim3(EW_BLOCK), 0, st, jb, that, B, slab, slab_stride);

@@ -311,7 +311,10 @@ int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, c
                            int loss_off = -1, const float* o1_sums = nullptr);
 // time_emb weight / bias gradients of the four blocks and the conv1 bias gradients of rb2..rb4 as slab partials, straight
 // from the per-32-pixel-group sums the data-gradient launches wrote (ConvArgs::sums; one buffer per block)
-struct GroupSumJobs { const float* gs[4]; int C[4]; int HWpix[4]; int tew[4]; int c1b[4]; int job0; int njobs; };   // jobs job0 .. job0 + njobs - 1 (njobs 0: to the end)
+// jobs job0 .. job0 + njobs - 1 (njobs 0: to the 4th).  tew[i] < 0: no time-embedding outputs (job 4: the masked sums of a tensor
+// that is NOT a conv1 pre-activation — rb3.conv2's output gradient, whose bias row the S2D data-gradient launch feeds)
+#define TDM_GS_JOBS 5
+struct GroupSumJobs { const float* gs[TDM_GS_JOBS]; int C[TDM_GS_JOBS]; int HWpix[TDM_GS_JOBS]; int tew[TDM_GS_JOBS]; int c1b[TDM_GS_JOBS]; int job0; int njobs; };
 int tdm_launch_group_sums(const GroupSumJobs& jb, const float* that, int B, float* slab, long slab_stride, int nslab,
                           hipStream_t st);
 // dc_s16 = split(dout * (a > 0)); slab partial sums of the masked (and optionally unmasked) gradient per channel

@@ -130,6 +130,7 @@ struct Ws {
     float *dout4s, *dc2s_4, *dh4s, *dc2s_3, *dh3s, *dc2s_2, *dh2s, *dout2s, *dc2s_1, *S2[4];
     float* gsum;                    // per-32-pixel-group partial sums of a data-gradient launch (ConvArgs::sums)
     float* gs[4];                   // ... one buffer per block in the S16 pipeline (consumed together by group_sums_kernel)
+    float* gs_c2b3;                 // ... and the S2D launch's sums of rb3.conv2's masked output gradient (its bias gradient)
     unsigned char *m1[4], *m2[4];   // ReLU byte masks of conv1 / conv2 outputs of the 4 blocks (S16 pipeline, training)
     int64_t total;
     int64_t* rng_bump = nullptr;    // set by the device-drawn train step: the forward's first kernel advances the Philox offset
@@ -167,6 +168,7 @@ Ws carve(float* base, int64_t B, int training) {
         w.gsum = take((M28 / 32 + 2) * 4 * 32 > (M14 / 32 + 2) * 4 * 64 ? (M28 / 32 + 2) * 4 * 32 : (M14 / 32 + 2) * 4 * 64);
         w.gs[0] = w.gsum; w.gs[1] = take((M14 / 32 + 2) * 4 * 64); w.gs[2] = take((M14 / 32 + 2) * 4 * 64);
         w.gs[3] = take((M28 / 32 + 2) * 4 * 32);
+        w.gs_c2b3 = take((M14 / 32 + 2) * 4 * 64);
         // byte masks: one byte per 4 channels = (pixels * C / 4) bytes = pixels * C / 16 floats
         const int64_t mfl[4] = {M28 * 32 / 16, M14 * 64 / 16, M14 * 64 / 16, M28 * 32 / 16};
         for (int i = 0; i < 4; ++i) {
@@ -317,7 +319,7 @@ int wgrad_s16(hipStream_t st, int hw, int B, const float* act_s16, int C, int c_
     X(B_WG_RB4C1A, "rb4.conv1 wgrad, up(h3) part in the parity form (wgrad_s2d)")                               \
     X(B_WG_RB4C1B, "rb4.conv1 wgrad, h1 part (wgrad2_s16<28>)")                                                 \
     X(B_DG_RB4C1H1, "rb4.conv1 dgrad, h1 part 32->32 @28 + rank-1 skip share (conv_s16<28,1>)")                          \
-    X(B_DG_RB4C1, "rb4.conv1 dgrad, up(h3) part 32->64 at 14x14 + rank-1 skip share (conv_s16<14,2,s2d>)") X(B_SPLIT_DCAT, "relu mask rb3 (relu_mask_s16)") \
+    X(B_DG_RB4C1, "rb4.conv1 dgrad, up(h3) part 32->64 at 14x14 + rank-1 skip share (conv_s16<14,2,s2d>)") X(B_SPLIT_DCAT, "upsample bwd + relu mask (split_dcat_mask_s16; phase form: fused into the launch before)") \
     X(B_WG_RB3C2, "rb3.conv2 wgrad (wgrad2_s16<14>)") X(B_DG_RB3C2, "rb3.conv2 dgrad 64->64 @14 (conv_s16<14,2>)")      \
     X(B_WG_RB3C1, "rb3.conv1 wgrad (wgrad2_s16<14>)")                                                                   \
     X(B_DG_RB3C1, "rb3.conv1 dgrad 64->64 @14 (conv_s16<14,2>)") X(B_RELU_MASK2, "relu mask rb2 (relu_mask_s16)")       \
@@ -514,7 +516,7 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
         sec(0, r4.c1w, 27648, NS); sec(0, r4.c2w, 9216, NS);
         // partial rows of the elementwise producers
         esec(0, kL.outw, 33, E_OUT, ER28); esec(0, r4.c2b, 32, E_C2B4, ER28); esec(0, r4.skb, 32, E_SKB4, ER28);
-        esec(0, r3.c2b, 64, E_C2B3, ER14); esec(0, r2.c2b, 64, E_C2B2, ER14); esec(0, r2.skb, 64, E_SKB2, ER14);
+        esec(0, r3.c2b, 64, E_C2B3, g_rb4_phase ? ERG : ER14); esec(0, r2.c2b, 64, E_C2B2, ER14); esec(0, r2.skb, 64, E_SKB2, ER14);
         esec(0, r2.tew, 128, E_TE2, ERG); esec(0, r3.tew, 128, E_TE3, ERG); esec(0, r4.tew, 64, E_TE4, ERG);
         esec(0, r2.c1b, 64, E_C1B2, ERG); esec(0, r3.c1b, 64, E_C1B3, ERG); esec(0, r4.c1b, 32, E_C1B4, ERG);
         // rb4.skip's weight gradient = v (x) w_out (out_bwd_s16_kernel): the section sums the 96 partials of v and writes 96 x 32
@@ -535,6 +537,9 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
         const int Cv[4] = {32, 64, 64, 32}, hwv[4] = {784, 196, 196, 784};
         const int tev[4] = {E_TE1, E_TE2, E_TE3, E_TE4}, c1bv[4] = {-1, E_C1B2, E_C1B3, E_C1B4};
         for (int i = 0; i < 4; ++i) { jb.gs[i] = w.gs[i]; jb.C[i] = Cv[i]; jb.HWpix[i] = hwv[i]; jb.tew[i] = tev[i]; jb.c1b[i] = c1bv[i]; }
+        // job 4 (phase form): rb3.conv2's bias gradient = the masked sums the S2D data-gradient launch leaves (no time-embedding rows)
+        jb.gs[4] = w.gs_c2b3; jb.C[4] = 64; jb.HWpix[4] = 196; jb.tew[4] = -1; jb.c1b[4] = E_C2B3;
+        jb.njobs = g_rb4_phase ? 5 : 4;
     }
     int nfork = 0;
     auto fork = [&]() -> int {   // what the main chain has issued so far is what the side queue's next launches may read
@@ -579,11 +584,12 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
             ConvArgs a{};
             a.nsrc = 1;
             a.src[0] = s16_src(w.dh4s, 32, 32, 0, 4, w.wpack + kPack.dg_s2d, 0);
-            a.B = B; a.out = w.dout3; a.s2d = 1; a.rk1_d = dvec; a.rk1_u = w.u96; a.tb_out_stride = 192;
+            a.B = B; a.s2d = 1; a.rk1_d = dvec; a.rk1_u = w.u96; a.tb_out_stride = 192;
+            // its epilogue is the whole upsample backward + ReLU backward of rb3.conv2's output: the complete gradient dout3 (fp32:
+            // rb3's identity skip adds it later), its masked S16 twin for the next launch, and the masked sums (-> bias gradient)
+            a.aux = w.dout3; a.relu_mask_in = w.m2[2]; a.out_s16 = w.dc2s_3; a.sums = w.gs_c2b3;
             RUN(B_DG_RB4C1, tdm_launch_conv_s16(a, 14, 64, st));
         }
-        // ---- rb3 ---- (ReLU mask of rb3.conv2's output + its bias-gradient rows)
-        RUN(B_SPLIT_DCAT, tdm_launch_relu_mask_s16(w.dout3, w.m2[2], w.dc2s_3, es, ESTRIDE, E_C2B3, -1, M14, 64, ER14, st));
     } else {
     {   // d cat = conv1's transposed conv of dh4 (+ the skip path's rank-one share, added in the epilogue)
         ConvArgs a{};
@@ -616,7 +622,7 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
         // part 0 of the gradient is complete behind these launches (in the side queue's order when there is one: rb4 / rb3 / rb2
         // weight gradients; their group sums and the elementwise producers' rows were written by the main chain before the fork)
         GroupSumJobs ja = jb;
-        ja.job0 = 1; ja.njobs = 3;
+        ja.job0 = 1; ja.njobs = g_rb4_phase ? 4 : 3;
         TDM_TRY(tdm_launch_group_sums(ja, w.that, B, es, ESTRIDE, ERG, ss));
         TDM_TRY(tdm_launch_reduce(slabs, NP, rpart[0], G, ss));
         TDM_HIP(hipEventRecord(g_lane.early, ss));

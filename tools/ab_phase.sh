@@ -9,7 +9,7 @@ for rep in 1 2; do
 import json, sys
 d = json.load(open(sys.argv[1]))
 lt = d.get("launch_table", {}).get("all_us", {})
-print(f"phase={sys.argv[2]} steps/s {d['value']:.1f}  ms/step {d['ms_per_step']:.4f}  rb4.conv1 fwd (id 8) {lt.get('8')} us  dgrad h1 (15) {lt.get('15')} + h3 (16) {lt.get('16')} us  mask rb3 (17) {lt.get('17')} us  sampling ms/rev {d.get('sampling', {}).get('ms_per_reverse_step')}")
+print(f"phase={sys.argv[2]} steps/s {d['value']:.1f}  ms/step {d['ms_per_step']:.4f}  rb4.conv1 fwd (id 8) {lt.get('8')} us  dgrad h1 (15) {lt.get('15')} + h3 (16) {lt.get('16')} us  (17) {lt.get('17')} us  sampling ms/rev {d.get('sampling', {}).get('ms_per_reverse_step')}")
 PY
   done
 done
