@@ -94,7 +94,7 @@ struct PinnedArgs {
     PinnedSrc s0, s1;
     int nsrc, relu, B, ablate, tb_out_stride;
     const float *bias, *res, *tb_out, *skip_bias;
-    float *out, *aux, *out_s16, *sums, *skip_out;
+    float *out, *aux, *out_s16, *sums, *skip_out, *out_s16_pre;
     unsigned char* mask_out;
     const unsigned char* relu_mask_in;
     const unsigned short* skip_wp;
@@ -102,14 +102,14 @@ struct PinnedArgs {
         s0.load(k.src[0]); s1.load(k.src[1]);
         nsrc = k.nsrc; relu = k.relu; B = k.B; ablate = TDM_ABLATE(k.ablate); tb_out_stride = k.tb_out_stride;
         bias = k.bias; res = k.res; tb_out = k.tb_out; skip_bias = k.skip_bias;
-        out = k.out; aux = k.aux; out_s16 = k.out_s16; sums = k.sums; skip_out = k.skip_out;
+        out = k.out; aux = k.aux; out_s16 = k.out_s16; sums = k.sums; skip_out = k.skip_out; out_s16_pre = k.out_s16_pre;
         mask_out = k.mask_out; relu_mask_in = k.relu_mask_in; skip_wp = k.skip_wp;
         TDM_PIN(nsrc); TDM_PIN(relu); TDM_PIN(B); TDM_PIN(tb_out_stride);
 #if TDM_DIAG_BUILD
         TDM_PIN(ablate);
 #endif
         TDM_PIN(bias); TDM_PIN(res); TDM_PIN(tb_out); TDM_PIN(skip_bias);
-        TDM_PIN(out); TDM_PIN(aux); TDM_PIN(out_s16); TDM_PIN(sums); TDM_PIN(skip_out);
+        TDM_PIN(out); TDM_PIN(aux); TDM_PIN(out_s16); TDM_PIN(sums); TDM_PIN(skip_out); TDM_PIN(out_s16_pre);
         TDM_PIN(mask_out); TDM_PIN(relu_mask_in); TDM_PIN(skip_wp);
     }
     // field of source si (uniform): scalar selects, no indexed kernarg read
@@ -751,6 +751,13 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
                 const float4 w4 = gload4(r1_w + c), b4 = gload4(r1_b + c);
                 v[k].x += fmaf(p.rx[k], w4.x, b4.x); v[k].y += fmaf(p.rx[k], w4.y, b4.y);
                 v[k].z += fmaf(p.rx[k], w4.z, b4.z); v[k].w += fmaf(p.rx[k], w4.w, b4.w);
+            }
+        }
+        if (bwd && a.out_s16_pre != nullptr) {   // the unmasked gradient's S16 twin (ConvArgs::out_s16_pre)
+#pragma unroll
+            for (int k = 0; k < GI; ++k) {
+                const int c = (((I0 + k) * 64 + lane_e) % (N / 4)) * 4;
+                if (ok[k]) gstore_s16_o(a.out_s16_pre, o[k], c, v[k]);
             }
         }
         if (bwd) {   // ReLU backward of the tensor this gradient belongs to + the sums its bias gradients need

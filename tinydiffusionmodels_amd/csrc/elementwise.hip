@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(EW_BLOCK) void group_sums_kernel(GroupSumJobs jb, c
             a2.x += s01.x + s11.x; a2.y += s01.y + s11.y; a2.z += s01.z + s11.z; a2.w += s01.w + s11.w;
         }
         quad_reduce_store(aw, sh, C4, jb.tew[job] >= 0 ? dst + jb.tew[job] : nullptr);
-        quad_reduce_store(ab, sh, C4, jb.tew[job] >= 0 ? dst + jb.tew[job] + C : nullptr);
+        quad_reduce_store(ab, sh, C4, jb.tew[job] >= 0 ? dst + jb.tew[job] + C : (jb.ub[job] > 0 ? dst + jb.ub[job] : nullptr));
         quad_reduce_store(a2, sh, C4, jb.c1b[job] >= 0 ? dst + jb.c1b[job] : nullptr);
     }
 }

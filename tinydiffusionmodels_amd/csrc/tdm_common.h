@@ -139,6 +139,9 @@ struct ConvArgs {
     // of the image the group's first pixel belongs to, slot 1 = pixels of the next image (a group may straddle two).
     const unsigned char* relu_mask_in;
     float* sums;
+    // ... and (optional) the S16 twin of v BEFORE the mask is applied: a tensor that is both the output gradient of a ReLU'd conv
+    // (masked: out_s16) and, unmasked, the output gradient of the block's skip path (rb2: dout2) leaves one launch in both forms
+    float* out_s16_pre;
     // Fused 1x1 "skip" conv of a residual block (src/mnist.py:52,61) over the SAME sources (N = 32 kernels, 3x3 sources):
     // a second accumulator fed by the centre-tap pixel fragments the 3x3 conv has already read.  skip_wp: packed 1x1
     // weights with the same chunk numbering as the sources' 3x3 weights; skip_out[M][N] = skip conv + skip_bias (fp32).
@@ -313,8 +316,10 @@ int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, c
 // from the per-32-pixel-group sums the data-gradient launches wrote (ConvArgs::sums; one buffer per block)
 // jobs job0 .. job0 + njobs - 1 (njobs 0: to the 4th).  tew[i] < 0: no time-embedding outputs (job 4: the masked sums of a tensor
 // that is NOT a conv1 pre-activation — rb3.conv2's output gradient, whose bias row the S2D data-gradient launch feeds)
-#define TDM_GS_JOBS 5
-struct GroupSumJobs { const float* gs[TDM_GS_JOBS]; int C[TDM_GS_JOBS]; int HWpix[TDM_GS_JOBS]; int tew[TDM_GS_JOBS]; int c1b[TDM_GS_JOBS]; int job0; int njobs; };
+// Jobs 4 / 5 (phase form of the backward): rb3.conv2's and rb2.conv2's output gradients; job 5 also emits the UNMASKED sum (ub[i] >= 0:
+// rb2.skip's bias gradient).  Jobs 0..3: ub = -1 (their unmasked sum is the time-embedding bias row at tew + C).
+#define TDM_GS_JOBS 6
+struct GroupSumJobs { const float* gs[TDM_GS_JOBS]; int C[TDM_GS_JOBS]; int HWpix[TDM_GS_JOBS]; int tew[TDM_GS_JOBS]; int c1b[TDM_GS_JOBS]; int ub[TDM_GS_JOBS]; int job0; int njobs; };
 int tdm_launch_group_sums(const GroupSumJobs& jb, const float* that, int B, float* slab, long slab_stride, int nslab,
                           hipStream_t st);
 // dc_s16 = split(dout * (a > 0)); slab partial sums of the masked (and optionally unmasked) gradient per channel

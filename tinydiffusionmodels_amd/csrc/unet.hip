@@ -131,6 +131,7 @@ struct Ws {
     float* gsum;                    // per-32-pixel-group partial sums of a data-gradient launch (ConvArgs::sums)
     float* gs[4];                   // ... one buffer per block in the S16 pipeline (consumed together by group_sums_kernel)
     float* gs_c2b3;                 // ... and the S2D launch's sums of rb3.conv2's masked output gradient (its bias gradient)
+    float* gs_c2b2;                 // ... rb3.conv1's data-gradient launch: sums of rb2.conv2's output gradient, masked (bias) and not (rb2.skip's bias)
     unsigned char *m1[4], *m2[4];   // ReLU byte masks of conv1 / conv2 outputs of the 4 blocks (S16 pipeline, training)
     int64_t total;
     int64_t* rng_bump = nullptr;    // set by the device-drawn train step: the forward's first kernel advances the Philox offset
@@ -169,6 +170,7 @@ Ws carve(float* base, int64_t B, int training) {
         w.gs[0] = w.gsum; w.gs[1] = take((M14 / 32 + 2) * 4 * 64); w.gs[2] = take((M14 / 32 + 2) * 4 * 64);
         w.gs[3] = take((M28 / 32 + 2) * 4 * 32);
         w.gs_c2b3 = take((M14 / 32 + 2) * 4 * 64);
+        w.gs_c2b2 = take((M14 / 32 + 2) * 4 * 64);
         // byte masks: one byte per 4 channels = (pixels * C / 4) bytes = pixels * C / 16 floats
         const int64_t mfl[4] = {M28 * 32 / 16, M14 * 64 / 16, M14 * 64 / 16, M28 * 32 / 16};
         for (int i = 0; i < 4; ++i) {
@@ -280,7 +282,7 @@ ConvSrc s16_src(const float* ptr, int C, int nch, int up, int taps, const unsign
     return s;
 }
 struct S16Out { float* out; unsigned char* mask; const float* res; float* out_s16; const float* tb_out;
-                const unsigned char* relu_mask_in = nullptr; float* sums = nullptr; };
+                const unsigned char* relu_mask_in = nullptr; float* sums = nullptr; float* out_s16_pre = nullptr; };
 int conv_s16_1(hipStream_t st, const Ws& ws, int hw, int B, const float* in_s16, int Cin, int taps, long wpoff, int N,
                const float* bias, int relu, const S16Out& o) {
     ConvArgs a{};
@@ -288,7 +290,7 @@ int conv_s16_1(hipStream_t st, const Ws& ws, int hw, int B, const float* in_s16,
     a.src[0] = s16_src(in_s16, Cin, Cin, 0, taps, ws.wpack + wpoff, 0);
     a.bias = bias; a.relu = relu; a.B = B;
     a.out = o.out; a.mask_out = o.mask; a.res = o.res; a.out_s16 = o.out_s16; a.tb_out = o.tb_out; a.tb_out_stride = 192;
-    a.relu_mask_in = o.relu_mask_in; a.sums = o.sums;
+    a.relu_mask_in = o.relu_mask_in; a.sums = o.sums; a.out_s16_pre = o.out_s16_pre;
     return tdm_launch_conv_s16(a, hw, N, st);
 }
 int wgrad_s16(hipStream_t st, int hw, int B, const float* act_s16, int C, int c_used, int up, int taps,
@@ -322,7 +324,7 @@ int wgrad_s16(hipStream_t st, int hw, int B, const float* act_s16, int C, int c_
     X(B_DG_RB4C1, "rb4.conv1 dgrad, up(h3) part 32->64 at 14x14 + rank-1 skip share (conv_s16<14,2,s2d>)") X(B_SPLIT_DCAT, "upsample bwd + relu mask (split_dcat_mask_s16; phase form: fused into the launch before)") \
     X(B_WG_RB3C2, "rb3.conv2 wgrad (wgrad2_s16<14>)") X(B_DG_RB3C2, "rb3.conv2 dgrad 64->64 @14 (conv_s16<14,2>)")      \
     X(B_WG_RB3C1, "rb3.conv1 wgrad (wgrad2_s16<14>)")                                                                   \
-    X(B_DG_RB3C1, "rb3.conv1 dgrad 64->64 @14 (conv_s16<14,2>)") X(B_RELU_MASK2, "relu mask rb2 (relu_mask_s16)")       \
+    X(B_DG_RB3C1, "rb3.conv1 dgrad 64->64 @14 (conv_s16<14,2>)") X(B_RELU_MASK2, "relu mask rb2 (relu_mask_s16; phase form: fused into the launch before)")       \
     X(B_WG_RB2C2, "rb2.conv2 wgrad (wgrad2_s16<14>)") X(B_DG_RB2C2, "rb2.conv2 dgrad 64->64 @14 (conv_s16<14,2>)")      \
     X(B_WG_RB2C1, "rb2.conv1+skip wgrad (wgrad2_s16<14,sk>)")                                                           \
     X(B_DG_RB2C1, "rb2.conv1+skip dgrad 64->32 @14 (conv_s16<14,1>)") X(B_COMBINE_DH1, "concat/pool bwd + relu mask (combine_dh1_mask_s16)") \
@@ -516,7 +518,8 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
         sec(0, r4.c1w, 27648, NS); sec(0, r4.c2w, 9216, NS);
         // partial rows of the elementwise producers
         esec(0, kL.outw, 33, E_OUT, ER28); esec(0, r4.c2b, 32, E_C2B4, ER28); esec(0, r4.skb, 32, E_SKB4, ER28);
-        esec(0, r3.c2b, 64, E_C2B3, g_rb4_phase ? ERG : ER14); esec(0, r2.c2b, 64, E_C2B2, ER14); esec(0, r2.skb, 64, E_SKB2, ER14);
+        esec(0, r3.c2b, 64, E_C2B3, g_rb4_phase ? ERG : ER14); esec(0, r2.c2b, 64, E_C2B2, g_rb4_phase ? ERG : ER14);
+        esec(0, r2.skb, 64, E_SKB2, g_rb4_phase ? ERG : ER14);
         esec(0, r2.tew, 128, E_TE2, ERG); esec(0, r3.tew, 128, E_TE3, ERG); esec(0, r4.tew, 64, E_TE4, ERG);
         esec(0, r2.c1b, 64, E_C1B2, ERG); esec(0, r3.c1b, 64, E_C1B3, ERG); esec(0, r4.c1b, 32, E_C1B4, ERG);
         // rb4.skip's weight gradient = v (x) w_out (out_bwd_s16_kernel): the section sums the 96 partials of v and writes 96 x 32
@@ -539,7 +542,9 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
         for (int i = 0; i < 4; ++i) { jb.gs[i] = w.gs[i]; jb.C[i] = Cv[i]; jb.HWpix[i] = hwv[i]; jb.tew[i] = tev[i]; jb.c1b[i] = c1bv[i]; }
         // job 4 (phase form): rb3.conv2's bias gradient = the masked sums the S2D data-gradient launch leaves (no time-embedding rows)
         jb.gs[4] = w.gs_c2b3; jb.C[4] = 64; jb.HWpix[4] = 196; jb.tew[4] = -1; jb.c1b[4] = E_C2B3;
-        jb.njobs = g_rb4_phase ? 5 : 4;
+        // job 5: rb2.conv2's output gradient from rb3.conv1's data-gradient launch: masked sums -> its bias, unmasked -> rb2.skip's bias
+        jb.gs[5] = w.gs_c2b2; jb.C[5] = 64; jb.HWpix[5] = 196; jb.tew[5] = -1; jb.c1b[5] = E_C2B2; jb.ub[5] = E_SKB2;
+        jb.njobs = g_rb4_phase ? 6 : 4;
     }
     int nfork = 0;
     auto fork = [&]() -> int {   // what the main chain has issued so far is what the side queue's next launches may read
@@ -609,10 +614,17 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     TDM_TRY(fork());
     RUN_ON(ss, B_WG_RB3C2, wgrad_s16(ss, 14, B, w.a1s_3, 64, 64, 0, 9, w.dc2s_3, 64, slabs, r3.c2w, 64, 0, NS4));
     RUN_ON(ss, B_WG_RB3C1, wgrad_s16(ss, 14, B, w.h2s, 64, 64, 0, 9, w.dh3s, 64, slabs, r3.c1w, 64, 0, NS4));
+    if (g_rb4_phase) {
+        // + identity skip; the epilogue is also rb2's ReLU backward: dout2 leaves as its unmasked S16 twin (rb2.skip's gradient
+        // operand) and as the masked one (rb2.conv2's), with both sums for the two bias rows — no fp32 copy, no relu_mask pass
+        RUN(B_DG_RB3C1, conv_s16_1(st, w, 14, B, w.dh3s, 64, 9, kPack.dg[W_RB3C1], 64, nullptr, 0,
+                                   S16Out{nullptr, nullptr, w.dout3, w.dc2s_2, nullptr, w.m2[1], w.gs_c2b2, w.dout2s}));
+    } else {
     RUN(B_DG_RB3C1, conv_s16_1(st, w, 14, B, w.dh3s, 64, 9, kPack.dg[W_RB3C1], 64, nullptr, 0,
                                S16Out{w.dout2, nullptr, w.dout3, w.dout2s, nullptr}));   // + identity skip
     // ---- rb2 ----
     RUN(B_RELU_MASK2, tdm_launch_relu_mask_s16(w.dout2, w.m2[1], w.dc2s_2, es, ESTRIDE, E_C2B2, E_SKB2, M14, 64, ER14, st));
+    }
     RUN(B_DG_RB2C2, conv_s16_1(st, w, 14, B, w.dc2s_2, 64, 9, kPack.dg[W_RB2C2], 64, nullptr, 0,
                                S16Out{nullptr, nullptr, nullptr, w.dh2s, nullptr, w.m1[1], w.gs[1]}));
     TDM_TRY(fork());
@@ -622,7 +634,7 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
         // part 0 of the gradient is complete behind these launches (in the side queue's order when there is one: rb4 / rb3 / rb2
         // weight gradients; their group sums and the elementwise producers' rows were written by the main chain before the fork)
         GroupSumJobs ja = jb;
-        ja.job0 = 1; ja.njobs = g_rb4_phase ? 4 : 3;
+        ja.job0 = 1; ja.njobs = g_rb4_phase ? 5 : 3;
         TDM_TRY(tdm_launch_group_sums(ja, w.that, B, es, ESTRIDE, ERG, ss));
         TDM_TRY(tdm_launch_reduce(slabs, NP, rpart[0], G, ss));
         TDM_HIP(hipEventRecord(g_lane.early, ss));
