@@ -68,8 +68,8 @@ LAUNCH_WORK = [
     (_C3(64, 64, 196), 2 * _T14(64), 0),                                     # rb3.conv2 wgrad
     (_C3(64, 64, 196), 2 * _T14(64) + _M14(64), 0),                          # rb3.conv2 dgrad
     (_C3(64, 64, 196), 2 * _T14(64), 0),                                     # rb3.conv1 wgrad
-    (_C3(64, 64, 196), 4 * _T14(64), 0),                                     # rb3.conv1 dgrad (in, res, dout2, dout2s)
-    (0, 2 * _T14(64) + _M14(64), 0),                                         # relu_mask rb2
+    (_C3(64, 64, 196), 4 * _T14(64) + _M14(64), 0),                          # rb3.conv1 dgrad + rb2's ReLU backward (in, res, mask; dout2s and its masked twin out)
+    (0, 0, 0),                                                               # (relu_mask rb2: fused into the launch before, not issued)
     (_C3(64, 64, 196), 2 * _T14(64), 0),                                     # rb2.conv2 wgrad
     (_C3(64, 64, 196), 2 * _T14(64) + _M14(64), 0),                          # rb2.conv2 dgrad
     (_C3(32, 64, 196) + _C1(32, 64, 196), _T14(32) + 2 * _T14(64), 0),       # rb2.conv1 wgrad

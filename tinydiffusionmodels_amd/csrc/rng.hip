@@ -152,20 +152,6 @@ __global__ __launch_bounds__(RB) void adamw_devstep_kernel(float* __restrict__ p
         pi = pi - step_size * (mi / denom);
         p[i] = pi; m[i] = mi; v[i] = vi;
     }
-    // The step count advances HERE (no one-workgroup launch behind this one: 5 us of an otherwise idle GPU per step): every
-    // workgroup has read state[0], [2], [3] before it arrives at the counter, so the last one to arrive may overwrite them.
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned long long prev = atomicAdd(reinterpret_cast<unsigned long long*>(&state[1]), 1ull);
-        if (prev == (unsigned long long)gridDim.x - 1ull) {
-            const int64_t taken = state[0];
-            state[1] = 0;
-            state[2] = __double_as_longlong(b1p);
-            state[3] = __double_as_longlong(b2p);
-            state[0] = taken + 1;
-        }
-    }
 }
 
 // AdamW whose learning rate and gradient scale come from DEVICE memory, so that a hipGraph-captured step survives a per-step LR
@@ -298,7 +284,11 @@ int tdm_adamw_flat_devstep_f32(float* p, const float* g, float* m, float* v, int
     TDM_REQUIRE(p && g && m && v && step_state && n > 0, "adamw_devstep: bad arguments (n=%lld)", (long long)n);
     hipLaunchKernelGGL(adamw_devstep_kernel, dim3(rng_grid(n)), dim3(RB), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
                        beta2, eps, weight_decay, step_state, grad_scale);
-    TDM_CHECK_LAUNCH("adamw_devstep");   // (advances step_state itself: the last workgroup to arrive)
+    TDM_CHECK_LAUNCH("adamw_devstep");
+    // (round 5 measured the step count advanced by the last-arriving workgroup of the kernel above instead of this launch: 709
+    //  arrivals on one counter made the 5 us kernel a 22 us one - profiles/r05: reverted)
+    hipLaunchKernelGGL(bump_adam_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_state, beta1, beta2);
+    TDM_CHECK_LAUNCH("bump_adam");
     return 0;
 }
 

@@ -5,8 +5,8 @@ set -e
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r5
 # launch ids of the default train step (tdm_unet_launch_name): 8 rb4.conv1 fwd (phase form), 16 rb4.conv1 dgrad up(h3) part (s2d),
-# 15 its h1 part, 2 rb1.conv2 fwd, 12 rb4.conv2 dgrad, 6 rb3.conv1 fwd, 13 rb4.conv1 wgrad A, 11 rb4.conv2 wgrad, 18 rb3.conv2 wgrad, 10 out_bwd, 17 relu mask rb3
-IDS=8,16,15,2,12,6,13,11,18,10,17
+# 15 its h1 part, 2 rb1.conv2 fwd, 12 rb4.conv2 dgrad, 6 rb3.conv1 fwd, 13 rb4.conv1 wgrad A, 11 rb4.conv2 wgrad, 18 rb3.conv2 wgrad, 10 out_bwd, 27 combine_dh1
+IDS=8,16,15,2,12,6,13,11,18,10,27
 rm -rf $O && mkdir -p $O
 timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -n 3 $O/pytest_gpu.log
 timeout -k 10 700 python bench.py --detail-out $O/bench_detail.json > $O/bench.json 2> $O/bench.err; cut -c1-300 $O/bench.json
