@@ -63,7 +63,7 @@ def source_digest() -> str:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(CFLAGS).encode())
+    h.update(" ".join(f for f in CFLAGS if not os.path.isabs(f)).encode())   # (flags, not the checkout's absolute include paths)
     return h.hexdigest()[:16]
 
 

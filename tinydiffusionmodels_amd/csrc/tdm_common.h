@@ -255,7 +255,7 @@ struct ReduceSec {
     int outer_n;
     int vec4;              // set by tdm_launch_reduce: the section is walked with 16-byte loads (lengths / offsets / stride multiples of 4)
 };
-#define TDM_MAX_SECS 40
+#define TDM_MAX_SECS 48
 struct ReduceArgs {
     ReduceSec sec[TDM_MAX_SECS];
     int nsec;

@@ -476,6 +476,9 @@ constexpr long ESLAB_BASE = (long)NSLAB * SLAB_STRIDE;   // float offset of the 
 int unet_backward_s16(const float* P, const float* x, const float* deps, float* G, const Ws& w, float* slabs, int B,
                       hipStream_t st, const MseIn* mse) {
     constexpr int NS = NSLAB;
+    // the parity-form weight gradient has two channel-tile combinations per slab slot: 128 slots make ONE round of 256 workgroups
+    // (39 -> 27 us alone; the one-combination 28x28 launches are fastest with a slot per CU: 28 us at 256, 40 at 128, 69 at 64)
+    constexpr int NSA = 128;
     // weight-gradient slabs of the 14x14 layers: with 2 / 4 (ci, co) channel-tile combinations per layer, 128 / 64
     // slabs make one round of 256 workgroups that each pipeline ~6 pixel tiles (256 slabs = 512-1024 workgroups of 1-3)
     constexpr int NS2 = 128, NS4 = 64;
@@ -515,7 +518,10 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
         // weight gradients (MFMA kernels, full-width slabs)
         sec(0, r2.c1w, 18432, NS2); sec(0, r2.c2w, 36864, NS4); sec(0, r2.skw, 2048, NS2);
         sec(0, r3.c1w, 36864, NS4); sec(0, r3.c2w, 36864, NS4);
-        sec(0, r4.c1w, 27648, NS); sec(0, r4.c2w, 9216, NS);
+        if (g_rb4_phase) {   // rb4.conv1: [tap][96 rows][32]; rows 0..63 (up(h3), parity form) live in NSA slabs, rows 64..95 (h1) in NS
+            for (int tp = 0; tp < 9; ++tp) { sec(0, r4.c1w + tp * 3072, 2048, NSA); sec(0, r4.c1w + tp * 3072 + 2048, 1024, NS); }
+        } else sec(0, r4.c1w, 27648, NS);
+        sec(0, r4.c2w, 9216, NS);
         // partial rows of the elementwise producers
         esec(0, kL.outw, 33, E_OUT, ER28); esec(0, r4.c2b, 32, E_C2B4, ER28); esec(0, r4.skb, 32, E_SKB4, ER28);
         esec(0, r3.c2b, 64, E_C2B3, g_rb4_phase ? ERG : ER14); esec(0, r2.c2b, 64, E_C2B2, g_rb4_phase ? ERG : ER14);
@@ -574,7 +580,7 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     TDM_TRY(fork());
     RUN_ON(ss, B_WG_RB4C2, wgrad_s16(ss, 28, B, w.a1s_4, 32, 32, 0, 9, w.dc2s_4, 32, slabs, r4.c2w, 32, 0, NS));
     if (g_rb4_phase)   // four parity sub-images of dh4 against h3 at 14x14: 16 x 196 instead of 9 x 784 tap-pixel products per image
-        RUN_ON(ss, B_WG_RB4C1A, wgrad_s16(ss, 14, B, w.h3s, 64, 64, 0, 9, w.dh4s, 32, slabs, r4.c1w, 96, 0, NS, nullptr, 0, 1));
+        RUN_ON(ss, B_WG_RB4C1A, wgrad_s16(ss, 14, B, w.h3s, 64, 64, 0, 9, w.dh4s, 32, slabs, r4.c1w, 96, 0, NSA, nullptr, 0, 1));
     else
         RUN_ON(ss, B_WG_RB4C1A, wgrad_s16(ss, 28, B, w.h3s, 64, 64, 1, 9, w.dh4s, 32, slabs, r4.c1w, 96, 0, NS));
     RUN_ON(ss, B_WG_RB4C1B, wgrad_s16(ss, 28, B, w.h1s, 32, 32, 0, 9, w.dh4s, 32, slabs, r4.c1w, 96, 64, NS));
