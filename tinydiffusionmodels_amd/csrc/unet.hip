@@ -482,7 +482,7 @@ int unet_backward_s16(const float* P, const float* x, const float* deps, float* 
     // weight-gradient slabs of the 14x14 layers: with 2 / 4 (ci, co) channel-tile combinations per layer, 128 / 64
     // slabs make one round of 256 workgroups that each pipeline ~6 pixel tiles (256 slabs = 512-1024 workgroups of 1-3)
     constexpr int NS2 = 128, NS4 = 64;
-    constexpr int ER28 = 1024, ER14 = 512, ERG = 64;   // partial rows of the elementwise producers (28x28 / 14x14 / group sums)
+    constexpr int ER28 = 1024, ER14 = 512, ERG = 64;   // partial rows of the elementwise producers (28x28 / 14x14 / group sums; 128 or 256 group-sum rows: no change)
     const BlockOff &r1 = kL.rb[0], &r2 = kL.rb[1], &r3 = kL.rb[2], &r4 = kL.rb[3];
     const int64_t M28 = (int64_t)B * 784, M14 = (int64_t)B * 196;
     const long NP = SLAB_STRIDE;
