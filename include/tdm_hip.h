@@ -486,7 +486,8 @@ int tdm_split_s16_f32(const float* in, float* out, int64_t n, void* stream);
  * C[i][j] = sum_k A[i*a_rs + k*a_cs] * B[k*b_rs + j*b_cs] (+bias[j]) (+res[i][j]) (relu)
  * `relu` is a flag word: bit 0 ReLU; bit 1 (bf16 modes): A and B are S16 tensors (K-contiguous form: K % 16
  * == 0; token-major form: M, N % 16 == 0); bit 2 (bf16 modes, K-contiguous form): C is written as an S16
- * tensor (N % 16 == 0).                                                                                */
+ * tensor (N % 16 == 0); bit 4 (bf16 modes, token-major form with S16 operands, M and N >= 256): the
+ * 256 x 256-tile LDS-DMA kernel the denoiser's weight gradients run on (gemm_tn_ring.hip).             */
 int tdm_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs,
                  float* C, int64_t c_rs, const float* bias, const float* res, int M, int N, int K,
                  int relu, int splitk, int64_t c_split_stride, void* stream);

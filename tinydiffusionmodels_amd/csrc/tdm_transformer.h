@@ -48,6 +48,17 @@ int tdm_launch_gemm_tn_bf16(const GemmArgs& g, int nprod, hipStream_t st);
 // serves K % 32 == 0, N % 8 == 0, operands < 2 GiB, problems of at least 32 tiles of 256 x 128
 bool tdm_gemm_nt_ring_ok(const GemmArgs& g);
 int tdm_launch_gemm_nt_ring(const GemmArgs& g, int nprod, hipStream_t st);
+// Token-major (TN, weight-gradient) products over S16 operands on 256 x 256 tiles with an LDS-DMA operand ring
+// (gemm_tn_ring.hip).  Up to TDM_TN_JOBS products of the same token count and split count run as ONE launch: build the table
+// with tdm_tn_ring_add_job (GemmArgs as for tdm_launch_gemm_tn_bf16: A(i,k) = A[k*a_cs + i], B(k,j) = B[k*b_rs + j], raw
+// split-K slabs at C + z*c_split_stride, optional column sums of A), then launch.  Serves M, N >= 256 (multiples of 16),
+// operands < 2 GiB.  Same arithmetic as the 128 x 128-tile kernel; not the same bits (a K step's tokens sit in another order).
+#define TDM_TN_JOBS 4
+struct TnJob { const float* A; const float* B; float* C; float* colsum; long a_cs, b_rs, c_rs, c_split_stride, colsum_stride; int M, N, tn, tile0; };
+struct TnJobs { TnJob j[TDM_TN_JOBS]; int njobs, ntiles, K, splitk, ablate; };
+bool tdm_gemm_tn_ring_ok(const GemmArgs& g);
+int tdm_tn_ring_add_job(TnJobs& js, const GemmArgs& g);
+int tdm_launch_gemm_tn_ring(const TnJobs& js, int nprod, hipStream_t st);
 int tdm_launch_transpose(const float* in, float* out, int R, int Cn, hipStream_t st);
 // out[c][r] = in[r][c] written as S16 (R % 16 == 0); out = S16 of in, elementwise over n (n % 16 == 0) floats
 int tdm_launch_transpose_s16(const float* in, float* out, int R, int Cn, hipStream_t st);

@@ -46,11 +46,26 @@ inline int wgrad_splitk(int N, int K) {
 }
 // slab regions (floats) of the 4 weight matrices of one layer, in order in_w, out_w, l1_w, l2_w
 struct SlabPlan { long base[8][4]; long bias_base[8][4]; long ln_base[8][2]; int sk[4]; long len[4]; int nout[4]; long total; };
-SlabPlan slab_plan(int D, int depth, int F) {
+// Weight gradients as PAIRS on the 256 x 256-tile ring kernel (gemm_tn_ring.hip): {in_proj, out_proj} and {linear1, linear2} are
+// one launch each, and the pair shares a split count chosen so that its tiles x splits ~ one workgroup per CU.
+inline bool wgrad_pairs_shape(int D, int F) {
+    static const bool off = getenv("TDM_TN_RING") && atoi(getenv("TDM_TN_RING")) == 0;   // A/B timing
+    return !off && D >= 256 && F >= 256 && (D % 16) == 0 && (F % 16) == 0;
+}
+inline int pair_splitk(int N0, int K0, int N1, int K1) {
+    const int tiles = ((N0 + 255) / 256) * ((K0 + 255) / 256) + ((N1 + 255) / 256) * ((K1 + 255) / 256);
+    int sk = (256 / tiles + 4) / 8 * 8;   // whole splits per XCD
+    return sk < 8 ? 8 : (sk > 128 ? 128 : sk);
+}
+SlabPlan slab_plan(int D, int depth, int F, bool pairs) {
     SlabPlan p{};
     const int Ns[4] = {3 * D, D, F, D}, Ks[4] = {D, D, D, F};
     long off = 0;
     for (int k = 0; k < 4; ++k) { p.sk[k] = wgrad_splitk(Ns[k], Ks[k]); p.len[k] = (long)Ns[k] * Ks[k]; p.nout[k] = Ns[k]; }
+    if (pairs) {
+        p.sk[0] = p.sk[1] = pair_splitk(Ns[0], Ks[0], Ns[1], Ks[1]);
+        p.sk[2] = p.sk[3] = pair_splitk(Ns[2], Ks[2], Ns[3], Ks[3]);
+    }
     for (int l = 0; l < depth; ++l)
         for (int k = 0; k < 4; ++k) { p.base[l][k] = off; off += p.sk[k] * p.len[k]; }
     // per-split partial bias gradients written by the weight-gradient GEMMs (bf16 modes)
@@ -923,10 +938,32 @@ int tt_forward(const float* P, const TTLayout& lay, const float* x, const int64_
 int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G, float* dx, const TTWs& w, float* slabs,
                 long B, int L, int D, int H, int depth, int F, Drop drop, hipStream_t st) {
     const long M = B * L;
-    const SlabPlan sp = slab_plan(D, depth, F);
     const bool dropping = drop.p > 0.f;
     const bool fused_bias = g_gemm_mode != 0;   // in_proj / linear1 bias gradients come out of the bf16 wgrad GEMM
     const bool s16 = tt_use16(D, F);            // GEMM operands pre-split (see tt_use16): S16 twins / S16-only tensors
+    // weight gradients two per launch on the 256 x 256-tile kernel (S16 operands, widths >= 256, operands < 2 GiB)
+    const bool pairs = s16 && fused_bias && wgrad_pairs_shape(D, F) && (M + 64) * (long)(3 * D > F ? 3 * D : F) * 4 < 2147483647L;
+    const SlabPlan sp = slab_plan(D, depth, F, pairs);
+    const int nprod = g_gemm_mode == 1 ? 3 : 1;
+    // {dY0, X0, region 0, bias 0, N0, K0} + {dY1, X1, ...}: dW[N][K] partials of both products in one launch
+    auto wgrad_pair = [&](const float* dY0, const float* X0, float* slab0, float* bias0, int N0, int K0, const float* dY1, const float* X1,
+                          float* slab1, float* bias1, int N1, int K1, int sk, hipStream_t q) -> int {
+        TnJobs js{};
+        const float* dYs[2] = {dY0, dY1}; const float* Xs[2] = {X0, X1};
+        float* slabs2[2] = {slab0, slab1}; float* bias2[2] = {bias0, bias1};
+        const int Nv[2] = {N0, N1}, Kv[2] = {K0, K1};
+        for (int k = 0; k < 2; ++k) {
+            GemmArgs g{};
+            g.A = dYs[k]; g.a_rs = 1; g.a_cs = Nv[k];
+            g.B = Xs[k]; g.b_rs = Kv[k]; g.b_cs = 1;
+            g.C = slabs2[k]; g.c_rs = Kv[k]; g.M = Nv[k]; g.N = Kv[k]; g.K = (int)M; g.splitk = sk;
+            g.c_split_stride = (long)Nv[k] * Kv[k];
+            g.colsum = bias2[k]; g.colsum_stride = (Nv[k] + 63) & ~63;
+            g.s16_in = 1;
+            TDM_TRY(tdm_tn_ring_add_job(js, g));
+        }
+        return tdm_launch_gemm_tn_ring(js, nprod, q);
+    };
     const float* gh = dout;  // gradient w.r.t. the current layer's output
     float* gout = nullptr;
     // transposed weights of all layers in ONE launch (12 launches of ~5 us otherwise: the weights do not change inside a step)
@@ -982,7 +1019,7 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
                        s16 ? w.g16 : nullptr, dropping, drop.site(4 + 4 * l), slabs + sp.ln_base[l][1], G, o.n2_w, o.l2_b, M, D, st, true));
         const float* g2 = s16 ? w.g16 : (dropping ? w.g_d : w.g_s);
         // f2 = f1 W2^T + b2, f1 = dropout(relu(z1)): d(z1) = (g2 W2) * [f1 > 0] / (1 - p) in the GEMM epilogue
-        if (!lane) TDM_TRY(linear_wgrad(g2, a.f1, slabs + sp.base[l][3], nullptr, s16, M, D, F, st));
+        if (!lane && !pairs) TDM_TRY(linear_wgrad(g2, a.f1, slabs + sp.base[l][3], nullptr, s16, M, D, F, st));
         const bool chain = tt_fused_ffn(M, D, F);
         if (chain) {
             // d(z1) = (g2 W2) gated by the saved sign masks, d(h1) = d(z1) W1: one launch, d(z1) written once (S16) for W1's gradient
@@ -998,9 +1035,14 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
         // z1 = h1 W1^T + b1
         if (!fused_bias) TDM_TRY(bias_grad(w.g_f, w.part, G + o.l1_b, M, F, st));
         TDM_TRY(fork());
+        if (pairs) {   // {linear1 (+ its bias gradient), linear2}: g2 and f1 are untouched until LayerNorm 1's backward below
+            TDM_TRY(wgrad_pair(w.g_f, a.h1_16, slabs + sp.base[l][2], slabs + sp.bias_base[l][2], F, D,
+                               g2, a.f1, slabs + sp.base[l][3], nullptr, D, F, sp.sk[2], ss));
+        } else {
         if (lane) TDM_TRY(linear_wgrad(g2, a.f1, slabs + sp.base[l][3], nullptr, s16, M, D, F, ss));
         TDM_TRY(linear_wgrad(w.g_f, s16 ? a.h1_16 : a.h1, slabs + sp.base[l][2], fused_bias ? slabs + sp.bias_base[l][2] : nullptr,
                              s16, M, F, D, ss));
+        }
         TDM_TRY(side_done(0));
         TDM_TRY(wait_side(1, l));   // (the layer above's projection weight gradients have read g16b and g_qkv16)
         if (!chain) TDM_TRY(linear_dgrad(w.g_f, P + o.l1_w, pre ? wT_l1 : w.wT, nullptr, nullptr, 1.f, w.g_h1, nullptr, s16, M, F, D, st, pre));
@@ -1009,7 +1051,7 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
                        s16 ? g16b : nullptr, dropping, drop.site(2 + 4 * l), slabs + sp.ln_base[l][0], G, o.n1_w, o.out_b, M, D, st, true));
         const float* g1 = s16 ? g16b : (dropping ? w.g_d : w.g_s1);
         // a = o Wout^T + bout
-        if (!lane) TDM_TRY(linear_wgrad(g1, s16 ? a.o16 : a.o, slabs + sp.base[l][1], nullptr, s16, M, D, D, st));
+        if (!lane && !pairs) TDM_TRY(linear_wgrad(g1, s16 ? a.o16 : a.o, slabs + sp.base[l][1], nullptr, s16, M, D, D, st));
         TDM_TRY(linear_dgrad(g1, P + o.out_w, wT_out, nullptr, nullptr, 1.f, w.g_o, nullptr, s16, M, D, D, st, pre));
         // attention
         const DropArgs da = drop.site(1 + 4 * l);
@@ -1019,9 +1061,14 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
         if (!fused_bias) TDM_TRY(bias_grad(w.g_qkv, w.part, G + o.in_b, M, 3 * D, st));
         const float* gq = s16 ? w.g_qkv16 : w.g_qkv;
         TDM_TRY(fork());
+        if (pairs) {   // {in_proj (+ its bias gradient), out_proj}: g1 lives until the next layer's LayerNorm 2 backward
+            TDM_TRY(wgrad_pair(gq, a.hin16, slabs + sp.base[l][0], slabs + sp.bias_base[l][0], 3 * D, D,
+                               g1, a.o16, slabs + sp.base[l][1], nullptr, D, D, sp.sk[0], ss));
+        } else {
         if (lane) TDM_TRY(linear_wgrad(g1, s16 ? a.o16 : a.o, slabs + sp.base[l][1], nullptr, s16, M, D, D, ss));
         TDM_TRY(linear_wgrad(gq, s16 ? a.hin16 : a.hin, slabs + sp.base[l][0], fused_bias ? slabs + sp.bias_base[l][0] : nullptr, s16,
                              M, 3 * D, D, ss));
+        }
         TDM_TRY(side_done(1));
         gout = (l == 0 && dx != nullptr) ? dx : w.g_h;   // layer 0: this is d(loss)/d(dropout0(x + time bias))
         // (layer 0 in the bf16 GEMM modes: the input dropout's mask — d(x + time bias) = mask * g / (1 - p) — in this epilogue)
@@ -1112,7 +1159,9 @@ int64_t tdm_tt_workspace_floats(int64_t B, int L, int D, int H, int depth, int f
 
 int64_t tdm_tt_slab_floats(int D, int depth, int ffn) {
     if (depth < 1 || depth > 8 || D <= 0 || ffn <= 0 || D > 8192 || ffn > 65536) return -1;
-    return slab_plan(D, depth, ffn).total;
+    const long a = slab_plan(D, depth, ffn, false).total;   // (the arithmetic mode of the later call decides which plan runs)
+    const long b = wgrad_pairs_shape(D, ffn) ? slab_plan(D, depth, ffn, true).total : 0;
+    return a > b ? a : b;
 }
 
 int tdm_tt_fwd_f32(const float* params, const float* x, const int64_t* t, float* out, float* ws, int64_t B, int L, int D,
@@ -1347,6 +1396,11 @@ int tdm_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int
         const int nprod = g_gemm_mode == 1 ? 3 : 1;
         if (a_cs == 1 && b_rs == 1 && splitk <= 1 && (c_rs % 4) == 0 && (K % 4) == 0)
             return tdm_launch_gemm_nt_bf16(g, nprod, (hipStream_t)stream);
+        if ((relu & 16) && a_rs == 1 && b_cs == 1 && bias == nullptr && res == nullptr && !(relu & 1)) {   // relu & 16: the 256 x 256-tile ring kernel
+            TnJobs js{};
+            TDM_TRY(tdm_tn_ring_add_job(js, g));
+            return tdm_launch_gemm_tn_ring(js, nprod, (hipStream_t)stream);
+        }
         if (a_rs == 1 && b_cs == 1 && bias == nullptr && res == nullptr && !(relu & 1) && (M % 4) == 0 && (N % 4) == 0)
             return tdm_launch_gemm_tn_bf16(g, nprod, (hipStream_t)stream);
         TDM_REQUIRE((relu & 6) == 0, "gemm: S16 operands / output need the NT or TN form");
