@@ -86,7 +86,10 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(TnJobs js) {
     int split, tile;
     {
         const int lin = blockIdx.x;
-        if ((js.splitk & 7) == 0) {
+        if (js.use_map) {
+            const unsigned e = js.map[lin];
+            tile = (int)(e & 255u); split = (int)(e >> 8);
+        } else if ((js.splitk & 7) == 0) {
             const int xcd = lin & 7, k = lin >> 3;
             split = xcd * (js.splitk >> 3) + k / js.ntiles;
             tile = k % js.ntiles;
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(TnJobs js) {
     // slab stores through a descriptor: one lane offset for the whole tile (columns past the matrix -> out of range), the row
     // as the scalar offset, rows past the matrix beyond num_records — no exec mask, no 64-bit address arithmetic per store
     // (128 stores per wave: the per-store mask + address sequence of plain stores was ~1,500 instructions per wave)
-    float* const C = J.C + (long)split * J.c_split_stride;
+    float* const C = J.C + ((TDM_ABLATE(js.ablate) & 8) ? 0L : (long)split * J.c_split_stride);   // (diagnostics, 8: every split stores into slab 0)
     const int h = lane >> 5, jl = lane & 31;
     const int c_rs4 = (int)J.c_rs * 4;
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(C, 0, M * c_rs4, 0x00020000);
@@ -309,8 +312,23 @@ int tdm_tn_ring_add_job(TnJobs& js, const GemmArgs& g) {
     return 0;
 }
 
-int tdm_launch_gemm_tn_ring(const TnJobs& js, int nprod, hipStream_t st) {
+int tdm_launch_gemm_tn_ring(TnJobs& js, int nprod, hipStream_t st) {
     TDM_REQUIRE(js.njobs >= 1 && js.ntiles >= 1 && js.splitk >= 1 && (nprod == 1 || nprod == 3), "gemm_tn_ring: empty launch");
+    js.use_map = 0;
+    if ((long)js.ntiles * js.splitk <= TDM_TN_MAP && js.ntiles <= 256 && js.splitk <= 256) {
+        // XCD x runs workgroups x, x + 8, ...: walk the (split, product) groups in order and fill XCD after XCD, so a group's
+        // tiles sit on one XCD (two where a share boundary cuts it)
+        const int total = js.ntiles * js.splitk;
+        int xcd = 0, used = 0;
+        auto cap = [&](int x) { return (total - x + 7) / 8; };
+        for (int z = 0; z < js.splitk; ++z)
+            for (int t = 0; t < js.ntiles; ++t) {
+                while (used >= cap(xcd)) { ++xcd; used = 0; }
+                js.map[xcd + 8 * used] = (unsigned short)(t | (z << 8));
+                ++used;
+            }
+        js.use_map = 1;
+    }
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);

@@ -53,12 +53,16 @@ int tdm_launch_gemm_nt_ring(const GemmArgs& g, int nprod, hipStream_t st);
 // with tdm_tn_ring_add_job (GemmArgs as for tdm_launch_gemm_tn_bf16: A(i,k) = A[k*a_cs + i], B(k,j) = B[k*b_rs + j], raw
 // split-K slabs at C + z*c_split_stride, optional column sums of A), then launch.  Serves M, N >= 256 (multiples of 16),
 // operands < 2 GiB.  Same arithmetic as the 128 x 128-tile kernel; not the same bits (a K step's tokens sit in another order).
-#define TDM_TN_JOBS 4
+// Workgroup -> (tile, split): the launcher fills `map` (tile | split << 8; up to TDM_TN_MAP workgroups, <= 256 tiles and splits) so
+// that the tiles of one (product, split) — which share an operand's token range — run on ONE XCD's L2 as far as the XCDs' equal
+// shares allow; larger launches fall back to whole splits per XCD (split count a multiple of 8) or plain split-major order.
+#define TDM_TN_JOBS 16
+#define TDM_TN_MAP 512
 struct TnJob { const float* A; const float* B; float* C; float* colsum; long a_cs, b_rs, c_rs, c_split_stride, colsum_stride; int M, N, tn, tile0; };
-struct TnJobs { TnJob j[TDM_TN_JOBS]; int njobs, ntiles, K, splitk, ablate; };
+struct TnJobs { TnJob j[TDM_TN_JOBS]; int njobs, ntiles, K, splitk, ablate, use_map; unsigned short map[TDM_TN_MAP]; };
 bool tdm_gemm_tn_ring_ok(const GemmArgs& g);
 int tdm_tn_ring_add_job(TnJobs& js, const GemmArgs& g);
-int tdm_launch_gemm_tn_ring(const TnJobs& js, int nprod, hipStream_t st);
+int tdm_launch_gemm_tn_ring(TnJobs& js, int nprod, hipStream_t st);
 int tdm_launch_transpose(const float* in, float* out, int R, int Cn, hipStream_t st);
 // out[c][r] = in[r][c] written as S16 (R % 16 == 0); out = S16 of in, elementwise over n (n % 16 == 0) floats
 int tdm_launch_transpose_s16(const float* in, float* out, int R, int Cn, hipStream_t st);

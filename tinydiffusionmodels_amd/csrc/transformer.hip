@@ -52,20 +52,20 @@ inline bool wgrad_pairs_shape(int D, int F) {
     static const bool off = getenv("TDM_TN_RING") && atoi(getenv("TDM_TN_RING")) == 0;   // A/B timing
     return !off && D >= 256 && F >= 256 && (D % 16) == 0 && (F % 16) == 0;
 }
-inline int pair_splitk(int N0, int K0, int N1, int K1) {
-    const int tiles = ((N0 + 255) / 256) * ((K0 + 255) / 256) + ((N1 + 255) / 256) * ((K1 + 255) / 256);
-    int sk = (256 / tiles + 4) / 8 * 8;   // whole splits per XCD
-    return sk < 8 ? 8 : (sk > 128 ? 128 : sk);
+inline int quad_splitk(int D, int F) {   // all four products of a layer in one launch: tiles x splits ~ one workgroup per CU
+    const int d = (D + 255) / 256, f = (F + 255) / 256, d3 = (3 * D + 255) / 256;
+    const int tiles = d3 * d + d * d + 2 * f * d;
+    const int sk = 256 / tiles;
+    return sk < 1 ? 1 : (sk > 128 ? 128 : sk);
 }
-SlabPlan slab_plan(int D, int depth, int F, bool pairs) {
+// pairs: 0 = one launch per product (128 x 128 tiles), 1 = two launches per layer (side-queue overlap), 2 = one launch per layer.
+// 1 and 2 cut the tokens into the SAME splits, so the two issue modes (and a graph captured on one queue) give the same bits.
+SlabPlan slab_plan(int D, int depth, int F, int pairs) {
     SlabPlan p{};
     const int Ns[4] = {3 * D, D, F, D}, Ks[4] = {D, D, D, F};
     long off = 0;
     for (int k = 0; k < 4; ++k) { p.sk[k] = wgrad_splitk(Ns[k], Ks[k]); p.len[k] = (long)Ns[k] * Ks[k]; p.nout[k] = Ns[k]; }
-    if (pairs) {
-        p.sk[0] = p.sk[1] = pair_splitk(Ns[0], Ks[0], Ns[1], Ks[1]);
-        p.sk[2] = p.sk[3] = pair_splitk(Ns[2], Ks[2], Ns[3], Ks[3]);
-    }
+    if (pairs != 0) p.sk[0] = p.sk[1] = p.sk[2] = p.sk[3] = quad_splitk(D, F);
     for (int l = 0; l < depth; ++l)
         for (int k = 0; k < 4; ++k) { p.base[l][k] = off; off += p.sk[k] * p.len[k]; }
     // per-split partial bias gradients written by the weight-gradient GEMMs (bf16 modes)
@@ -943,22 +943,18 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
     const bool s16 = tt_use16(D, F);            // GEMM operands pre-split (see tt_use16): S16 twins / S16-only tensors
     // weight gradients two per launch on the 256 x 256-tile kernel (S16 operands, widths >= 256, operands < 2 GiB)
     const bool pairs = s16 && fused_bias && wgrad_pairs_shape(D, F) && (M + 64) * (long)(3 * D > F ? 3 * D : F) * 4 < 2147483647L;
-    const SlabPlan sp = slab_plan(D, depth, F, pairs);
     const int nprod = g_gemm_mode == 1 ? 3 : 1;
     // {dY0, X0, region 0, bias 0, N0, K0} + {dY1, X1, ...}: dW[N][K] partials of both products in one launch
-    auto wgrad_pair = [&](const float* dY0, const float* X0, float* slab0, float* bias0, int N0, int K0, const float* dY1, const float* X1,
-                          float* slab1, float* bias1, int N1, int K1, int sk, hipStream_t q) -> int {
+    struct WgradJob { const float* dY; const float* X; float* slab; float* bias; int N, K; };
+    auto wgrad_jobs = [&](const WgradJob* jobs, int n, int sk, hipStream_t q) -> int {
         TnJobs js{};
-        const float* dYs[2] = {dY0, dY1}; const float* Xs[2] = {X0, X1};
-        float* slabs2[2] = {slab0, slab1}; float* bias2[2] = {bias0, bias1};
-        const int Nv[2] = {N0, N1}, Kv[2] = {K0, K1};
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < n; ++k) {
             GemmArgs g{};
-            g.A = dYs[k]; g.a_rs = 1; g.a_cs = Nv[k];
-            g.B = Xs[k]; g.b_rs = Kv[k]; g.b_cs = 1;
-            g.C = slabs2[k]; g.c_rs = Kv[k]; g.M = Nv[k]; g.N = Kv[k]; g.K = (int)M; g.splitk = sk;
-            g.c_split_stride = (long)Nv[k] * Kv[k];
-            g.colsum = bias2[k]; g.colsum_stride = (Nv[k] + 63) & ~63;
+            g.A = jobs[k].dY; g.a_rs = 1; g.a_cs = jobs[k].N;
+            g.B = jobs[k].X; g.b_rs = jobs[k].K; g.b_cs = 1;
+            g.C = jobs[k].slab; g.c_rs = jobs[k].K; g.M = jobs[k].N; g.N = jobs[k].K; g.K = (int)M; g.splitk = sk;
+            g.c_split_stride = (long)jobs[k].N * jobs[k].K;
+            g.colsum = jobs[k].bias; g.colsum_stride = (jobs[k].N + 63) & ~63;
             g.s16_in = 1;
             TDM_TRY(tdm_tn_ring_add_job(js, g));
         }
@@ -993,7 +989,13 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
     };
     auto side_done = [&](int k) -> int { if (lane) TDM_HIP(hipEventRecord(ln.back[k], ss)); return 0; };
     auto wait_side = [&](int k, int l) -> int { if (lane && l + 1 < depth) TDM_HIP(hipStreamWaitEvent(st, ln.back[k], 0)); return 0; };
-    float* const g16b = lane ? w.g_d : w.g16;   // LayerNorm 1's S16 output
+    // weight gradients: 0 one launch per product, 1 two launches per layer (on the side queue), 2 one launch per layer (its four
+    // products' 20 tiles x 12 token splits = 240 workgroups: HALF the slab bytes of two launches — a launch writes one 256 KB
+    // partial per workgroup whatever it computes, and those 64 MB cost 20-37 us per launch plus their share of the reduction)
+    static const bool quad_off = getenv("TDM_TN_QUAD") && atoi(getenv("TDM_TN_QUAD")) == 0;   // A/B timing: two launches of the same splits
+    const int wmode = !pairs ? 0 : ((lane || quad_off) ? 1 : 2);
+    const SlabPlan sp = slab_plan(D, depth, F, wmode);
+    float* const g16b = (lane || wmode == 2) ? w.g_d : w.g16;   // LayerNorm 1's S16 output (mode 2: g16 = LayerNorm 2's lives to the layer's end)
     if (pre) {
         TransposeBatch tb{};
         for (int l = 0; l < depth; ++l) {
@@ -1035,9 +1037,11 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
         // z1 = h1 W1^T + b1
         if (!fused_bias) TDM_TRY(bias_grad(w.g_f, w.part, G + o.l1_b, M, F, st));
         TDM_TRY(fork());
-        if (pairs) {   // {linear1 (+ its bias gradient), linear2}: g2 and f1 are untouched until LayerNorm 1's backward below
-            TDM_TRY(wgrad_pair(w.g_f, a.h1_16, slabs + sp.base[l][2], slabs + sp.bias_base[l][2], F, D,
-                               g2, a.f1, slabs + sp.base[l][3], nullptr, D, F, sp.sk[2], ss));
+        if (wmode == 2) {
+        } else if (pairs) {   // {linear1 (+ its bias gradient), linear2}: g2 and f1 are untouched until LayerNorm 1's backward below
+            const WgradJob jb[2] = {{w.g_f, a.h1_16, slabs + sp.base[l][2], slabs + sp.bias_base[l][2], F, D},
+                                    {g2, a.f1, slabs + sp.base[l][3], nullptr, D, F}};
+            TDM_TRY(wgrad_jobs(jb, 2, sp.sk[2], ss));
         } else {
         if (lane) TDM_TRY(linear_wgrad(g2, a.f1, slabs + sp.base[l][3], nullptr, s16, M, D, F, ss));
         TDM_TRY(linear_wgrad(w.g_f, s16 ? a.h1_16 : a.h1, slabs + sp.base[l][2], fused_bias ? slabs + sp.bias_base[l][2] : nullptr,
@@ -1061,9 +1065,16 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
         if (!fused_bias) TDM_TRY(bias_grad(w.g_qkv, w.part, G + o.in_b, M, 3 * D, st));
         const float* gq = s16 ? w.g_qkv16 : w.g_qkv;
         TDM_TRY(fork());
-        if (pairs) {   // {in_proj (+ its bias gradient), out_proj}: g1 lives until the next layer's LayerNorm 2 backward
-            TDM_TRY(wgrad_pair(gq, a.hin16, slabs + sp.base[l][0], slabs + sp.bias_base[l][0], 3 * D, D,
-                               g1, a.o16, slabs + sp.base[l][1], nullptr, D, D, sp.sk[0], ss));
+        if (wmode == 2) {   // all four: d(z1) = g_f, g2 (g16) and g1 (g_d) are not rewritten before the next layer's backward
+            const WgradJob jb[4] = {{w.g_f, a.h1_16, slabs + sp.base[l][2], slabs + sp.bias_base[l][2], F, D},
+                                    {g2, a.f1, slabs + sp.base[l][3], nullptr, D, F},
+                                    {gq, a.hin16, slabs + sp.base[l][0], slabs + sp.bias_base[l][0], 3 * D, D},
+                                    {g1, a.o16, slabs + sp.base[l][1], nullptr, D, D}};
+            TDM_TRY(wgrad_jobs(jb, 4, sp.sk[0], ss));
+        } else if (pairs) {   // {in_proj (+ its bias gradient), out_proj}: g1 lives until the next layer's LayerNorm 2 backward
+            const WgradJob jb[2] = {{gq, a.hin16, slabs + sp.base[l][0], slabs + sp.bias_base[l][0], 3 * D, D},
+                                    {g1, a.o16, slabs + sp.base[l][1], nullptr, D, D}};
+            TDM_TRY(wgrad_jobs(jb, 2, sp.sk[0], ss));
         } else {
         if (lane) TDM_TRY(linear_wgrad(g1, s16 ? a.o16 : a.o, slabs + sp.base[l][1], nullptr, s16, M, D, D, ss));
         TDM_TRY(linear_wgrad(gq, s16 ? a.hin16 : a.hin, slabs + sp.base[l][0], fused_bias ? slabs + sp.bias_base[l][0] : nullptr, s16,
@@ -1159,8 +1170,8 @@ int64_t tdm_tt_workspace_floats(int64_t B, int L, int D, int H, int depth, int f
 
 int64_t tdm_tt_slab_floats(int D, int depth, int ffn) {
     if (depth < 1 || depth > 8 || D <= 0 || ffn <= 0 || D > 8192 || ffn > 65536) return -1;
-    const long a = slab_plan(D, depth, ffn, false).total;   // (the arithmetic mode of the later call decides which plan runs)
-    const long b = wgrad_pairs_shape(D, ffn) ? slab_plan(D, depth, ffn, true).total : 0;
+    const long a = slab_plan(D, depth, ffn, 0).total;   // (the arithmetic mode of the later call decides which plan runs)
+    const long b = wgrad_pairs_shape(D, ffn) ? slab_plan(D, depth, ffn, 2).total : 0;
     return a > b ? a : b;
 }
 
