@@ -10,14 +10,18 @@
  *  - every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm
  *    allocates); the library never allocates, frees or synchronises device
  *    memory or the caller's stream, so every call is hipGraph-capturable; the
- *    only device-side objects it owns are, per host thread and created on
- *    first use, ONE side stream and a handful of events (tdm_set_bwd_overlap):
- *    work it puts there is forked from and joined back into the caller's
- *    stream by events inside the same call, so for the caller every effect of
- *    a call is ordered on the stream it passed — also when the call FAILS after
- *    a fork (the join runs on every exit path).  They live on the device of the
- *    stream the caller passed (rebuilt there if a thread moves to another GPU)
- *    and are destroyed when the host thread exits;
+ *    only device-side objects it owns are, per CONTEXT (tdm_ctx below) and
+ *    created by the first backward that forks, ONE side stream and a handful of
+ *    events (tdm_set_bwd_overlap): work it puts there is forked from and joined
+ *    back into the caller's stream by events inside the same call, so for the
+ *    caller every effect of a call is ordered on the stream it passed — also
+ *    when the call FAILS after a fork (the join runs on every exit path).  They
+ *    live on the device of the stream the caller passed (rebuilt there if the
+ *    context moves to another GPU) and are destroyed with the context
+ *    (tdm_ctx_destroy; a thread's default context: when the thread exits);
+ *  - selector state (arithmetic, launch overlap) lives in an explicit tdm_ctx;
+ *    the library has no process-global mutable state, and its only thread-local
+ *    state is which context a thread has bound;
  *  - `stream` is a hipStream_t passed as void*;
  *  - return 0 on success, non-zero on error; tdm_last_error() gives the text;
  *  - activations inside the library are NHWC fp32; the UNet input/output
@@ -35,7 +39,7 @@
 extern "C" {
 #endif
 
-#define TDM_VERSION 401
+#define TDM_VERSION 402
 #define TDM_TIMESTEPS 1000
 #define TDM_UNET_NPARAM 181473      /* SimpleUNet(), src/mnist.py:64-74 */
 #define TDM_UNET_NTENSOR 32         /* number of state_dict entries      */
@@ -248,6 +252,25 @@ int tdm_resblock_fwd_f32(const float* x, const float* that, const float* c1w, co
                          const float* c2b, const float* tew, const float* teb, const float* skw, const float* skb,
                          float* out, float* scratch, int64_t B, int HW, int Cin, int Cout, void* stream);
 
+/* Contexts: selector state (replaces: no reference counterpart — the reference is single-threaded PyTorch, src/mnist.py:129-166).
+ * A tdm_ctx owns every piece of state a call consults besides its arguments: the arithmetic of the convolutions / linear
+ * layers / attention, the launch-overlap switches, and the side stream + events of the two-queue backward.  Entry points use
+ * the calling thread's CURRENT context: the one bound with tdm_ctx_make_current, else a default context the thread owns
+ * (default arithmetic; destroyed at thread exit).  A context is current on at most one thread at a time (make_current on a
+ * second thread fails); two threads with two contexts share nothing.  tdm_set_conv_mode / _gemm_mode / _attn_mode /
+ * _bwd_overlap / _early_grads below are shorthands that set the field of the CURRENT context.
+ *   tdm_ctx_create        (section e above; the same object also owns the process's RCCL communicator) a context in the default
+ *                         arithmetic (conv 2, gemm 1, attention 2), overlap on, early gradients off
+ *   tdm_ctx_make_current  bind to the calling thread (NULL: back to the thread's default); tdm_ctx_current: the bound one or NULL
+ *   tdm_ctx_destroy       frees it and the side stream / events it created; unbinds it from the calling thread first; fails if
+ *                         another thread has it current.  Every backward joins its side queue before it returns, so a context
+ *                         is idle between calls and may be destroyed as soon as the caller's stream work is enqueued.       */
+int tdm_ctx_make_current(tdm_ctx* ctx);
+tdm_ctx* tdm_ctx_current(void);
+int tdm_ctx_set_arithmetic(tdm_ctx* ctx, int conv_mode, int gemm_mode, int attn_mode);
+int tdm_ctx_get_arithmetic(const tdm_ctx* ctx, int* conv_mode, int* gemm_mode, int* attn_mode);
+int tdm_ctx_set_overlap(tdm_ctx* ctx, int bwd_overlap, int early_grads);
+
 /* Arithmetic of the UNet's MFMA convolutions (forward, data and weight gradient):
  *   0  exact fp32 (v_mfma_f32_32x32x2_f32, bitwise an fp32 fmaf chain)
  *   2  bf16x3 split operands on v_mfma_f32_32x32x16_bf16 (hi*hi + hi*lo + lo*hi,
@@ -257,20 +280,19 @@ int tdm_resblock_fwd_f32(const float* x, const float* that, const float* c1w, co
  *      16-byte copies — default
  *   (1, the same arithmetic with fp32 tensors split while staging, was superseded
  *    by 2 in round 1 and is no longer built: tdm_set_conv_mode(1) fails)
- * The three arithmetic selectors (conv / gemm / attention mode) are THREAD-LOCAL: they configure the calls the calling
- * thread makes afterwards, every thread starts in the default arithmetic, and the library keeps no process-global mutable
- * state (a process's only shared object is an explicit tdm_ctx).                                                  */
+ * The three arithmetic selectors (conv / gemm / attention mode) are fields of the calling thread's CURRENT context (above):
+ * they configure the calls that thread makes afterwards; every context starts in the default arithmetic.            */
 int tdm_set_conv_mode(int mode);
 int tdm_get_conv_mode(void);
-/* Launch overlap inside the backward passes (thread-local like the selectors above; default 1).  UNet: the eight weight-gradient
- * launches (transformer, up to 16,384 tokens per batch: the four weight-gradient GEMMs of every layer) are issued on a side stream the library owns (created on first use, one per host thread), each behind an event
+/* Launch overlap inside the backward passes (a field of the current context like the selectors above; default 1).  UNet: the eight weight-gradient
+ * launches (transformer, up to 16,384 tokens per batch: the weight-gradient GEMMs of every layer) are issued on a side stream the context owns (created on first use), each behind an event
  * recorded after the launch that produced its gradient operand; the data-gradient chain continues on the caller's stream and
  * waits for the side stream before the final slab reduction.  Same kernels on the same buffers: results are bit-identical
  * to 0 (everything on the caller's stream in program order).  A call whose stream is being CAPTURED always takes one queue
  * (the forked step replays slower as a hipGraph than the plain one).                                              */
 int tdm_set_bwd_overlap(int on);
 int tdm_get_bwd_overlap(void);
-/* Data-parallel training (thread-local, default 0; none in the reference, deployment/configs/mnist-training.yaml:5-6 is one GPU):
+/* Data-parallel training (a field of the current context, default 0; none in the reference, deployment/configs/mnist-training.yaml:5-6 is one GPU):
  * with 1 the default-arithmetic backward finishes the flat gradient in TWO parts.  Floats [tdm_unet_early_grad_offset(),
  * TDM_UNET_NPARAM) — every tensor of rb2, rb3, rb4 and the output conv, 95 % of the bytes — are final as soon as rb2's weight-gradient
  * launches have retired, and an event marks that point; rb1's 9,760 floats follow with the last launch.

@@ -190,6 +190,29 @@ int main(void) {
         EXPECT(tdm_ctx_destroy(NULL) == 0 || tdm_last_error()[0] != 0);
     }
 
+    /* ---- contexts: selector state is a field of an explicit object; the set_* shorthands act on the CURRENT one ---- */
+    {
+        tdm_ctx *a = NULL, *b = NULL;
+        int cm = -1, gm = -1, am = -1;
+        EXPECT(tdm_ctx_current() == NULL);                                       /* a fresh thread works on its own default */
+        EXPECT(tdm_ctx_create(0, &a) == 0 && tdm_ctx_create(0, &b) == 0);
+        EXPECT(tdm_ctx_get_arithmetic(a, &cm, &gm, &am) == 0 && cm == 2 && gm == 1 && am == 2);
+        REFUSED(tdm_ctx_set_arithmetic(a, 1, 1, 2));                             /* conv mode 1 is no longer built */
+        REFUSED(tdm_ctx_set_arithmetic(NULL, 2, 1, 2));
+        REFUSED(tdm_ctx_set_overlap(a, 2, 0));
+        EXPECT(tdm_ctx_set_arithmetic(a, 0, 0, 1) == 0);
+        EXPECT(tdm_get_conv_mode() == 2 && tdm_get_gemm_mode() == 1);            /* ... and the thread's default is untouched */
+        EXPECT(tdm_ctx_make_current(a) == 0 && tdm_ctx_current() == a);
+        EXPECT(tdm_get_conv_mode() == 0 && tdm_get_gemm_mode() == 0 && tdm_get_attn_mode() == 1);
+        EXPECT(tdm_set_gemm_mode(2) == 0);                                       /* the shorthand writes the bound context */
+        EXPECT(tdm_ctx_get_arithmetic(a, &cm, &gm, &am) == 0 && gm == 2);
+        EXPECT(tdm_ctx_make_current(b) == 0 && tdm_get_gemm_mode() == 1);        /* b still has the defaults */
+        EXPECT(tdm_ctx_make_current(NULL) == 0 && tdm_ctx_current() == NULL && tdm_get_conv_mode() == 2);
+        EXPECT(tdm_ctx_make_current(a) == 0);
+        EXPECT(tdm_ctx_destroy(a) == 0 && tdm_ctx_current() == NULL);            /* destroying the bound context unbinds it */
+        EXPECT(tdm_ctx_destroy(b) == 0);
+    }
+
     if (failures) { printf("%d host-side check(s) failed\n", failures); return 1; }
     printf("host args OK\n");
     return 0;

@@ -410,3 +410,72 @@ def test_early_gradient_parts_are_bit_identical_and_the_event_orders_a_collectiv
     finally:
         L.tdm_set_early_grads(0)
         L.tdm_set_bwd_overlap(was_ov)
+
+
+@pytest.mark.gpu
+def test_two_threads_two_contexts_keep_their_own_arithmetic_and_side_queue(dev):
+    """include/tdm_hip.h "Contexts": selector state and the side queue live in explicit tdm_ctx objects.  Two host threads bind
+    two contexts — exact fp32 and the default bf16x3 — and run UNet loss + gradient calls concurrently on their own streams: each
+    gets the bits of its arithmetic run alone, the main thread's default context is untouched, a context that is current on one
+    thread cannot be bound or destroyed by another, and destroying a context releases the side queue it created."""
+    import threading
+    from tinydiffusionmodels_amd import _lib, unet_engine as E
+    L = _lib.lib()
+    g = torch.Generator(device=dev).manual_seed(0)
+    B = 37
+    params = torch.randn(E.NPARAM, device=dev, generator=g) * 0.05
+    x = torch.rand(B, 1, 28, 28, device=dev, generator=g) * 2 - 1
+    t = torch.randint(0, 1000, (B,), device=dev, generator=g)
+    deps = torch.randn(B, 1, 28, 28, device=dev, generator=g) / B
+
+    def fwd_bwd():
+        """predicted noise + flat gradient in the calling thread's current context (its own workspace and slabs)"""
+        ws = E.UNetWorkspace(B, dev, training=True)
+        eps = E.unet_forward(params, x, t, ws, save=True)
+        slabs = torch.empty(L.tdm_unet_slab_floats(), device=dev)
+        grads = torch.empty(E.NPARAM, device=dev)
+        _lib.check(L.tdm_unet_bwd_f32(_lib.ptr(params), _lib.ptr(x), _lib.ptr(deps), _lib.ptr(grads), _lib.ptr(ws.ws), _lib.ptr(slabs), B,
+                                      _lib.stream()), "unet_bwd")
+        return eps, grads
+
+    def run(modes):
+        with _lib.use_arithmetic(modes):
+            return fwd_bwd()
+
+    ref = {m: run(m) for m in ((0, 1, 2), (2, 1, 2))}          # alone, in the main thread's default context
+    assert _lib.arithmetic() == (2, 1, 2)
+    ctxs = {(0, 1, 2): _lib.Context(0, arithmetic=(0, 1, 2)), (2, 1, 2): _lib.Context(0, arithmetic=(2, 1, 2))}
+    out, errs = {}, []
+    gate = threading.Barrier(2)
+
+    def worker(modes):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                with ctxs[modes] as c:
+                    assert _lib.arithmetic() == modes and L.tdm_ctx_current() == c.handle.value
+                    gate.wait()
+                    if modes == (0, 1, 2):                      # the other thread has its context current: refused here
+                        assert L.tdm_ctx_make_current(ctxs[(2, 1, 2)].handle) != 0
+                        assert L.tdm_ctx_destroy(ctxs[(2, 1, 2)].handle) != 0
+                        assert L.tdm_ctx_make_current(c.handle) == 0
+                    gate.wait()
+                    for _ in range(3):
+                        out[modes] = fwd_bwd()
+                    torch.cuda.current_stream().synchronize()
+        except BaseException as e:   # noqa: BLE001
+            errs.append(e)
+            try:
+                gate.abort()
+            except Exception:
+                pass
+
+    th = [threading.Thread(target=worker, args=(m,)) for m in ctxs]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs
+    assert _lib.arithmetic() == (2, 1, 2) and L.tdm_ctx_current() is None      # the main thread never bound anything
+    for m in ctxs:
+        assert torch.equal(out[m][0], ref[m][0]) and torch.equal(out[m][1], ref[m][1]), m
+    assert not torch.equal(out[(0, 1, 2)][1], out[(2, 1, 2)][1])               # (the two arithmetics do differ)
+    for c in ctxs.values():
+        c.close()                                                              # joins nothing: idle between calls; frees the side queue

@@ -324,6 +324,34 @@ def test_s16_operands_give_the_same_gemm_bitwise(dev, gemm_mode, M, N, K):
     assert torch.equal(tn(dY16, X16, 2), tn(dY, X, 0))
 
 
+@pytest.mark.parametrize("T,N,K,sk", [(4096, 256, 256, 1), (1000, 2048, 256, 12), (1000, 256, 2048, 3), (37, 768, 256, 8), (8192, 272, 528, 12),
+                                      (2064, 768, 256, 64), (16, 256, 256, 5)])
+def test_tn_ring_gemm_vs_fp64_and_the_128_tile_kernel(dev, gemm_mode, T, N, K, sk):
+    """The token-major weight-gradient GEMM on 256 x 256 tiles (gemm_tn_ring.hip, flag bit 4 of tdm_gemm_f32): dW[N][K] = dY[T][N]^T X[T][K]
+    over S16 operands, split over the tokens into `sk` slabs — against fp64 torch and against the 128 x 128-tile kernel on the same
+    operands (same arithmetic, another summation order).  Token counts that are no multiple of the 16-token stage or of the split
+    count, splits that get no tokens at all (their slabs must be written as zeros), widths that are no multiple of the tile."""
+    if gemm_mode == 0:
+        pytest.skip("S16 operands exist in the bf16 GEMM modes")
+    from tinydiffusionmodels_amd import _lib
+    L_ = _lib.lib()
+    g = torch.Generator().manual_seed(T + N + K)
+    dY = torch.randn(T, N, generator=g).to(dev); X = torch.randn(T, K, generator=g).to(dev)
+    dY16, X16 = torch.empty_like(dY), torch.empty_like(X)
+    _lib.check(L_.tdm_split_s16_f32(_lib.ptr(dY), _lib.ptr(dY16), dY.numel(), _lib.stream()))
+    _lib.check(L_.tdm_split_s16_f32(_lib.ptr(X), _lib.ptr(X16), X.numel(), _lib.stream()))
+    def tn(flags):
+        c = torch.full((sk, N, K), float("nan"), device=dev)
+        _lib.check(L_.tdm_gemm_f32(_lib.ptr(dY16), 1, N, _lib.ptr(X16), K, 1, _lib.ptr(c), K, None, None, N, K, T, flags, sk, N * K, _lib.stream()))
+        assert torch.isfinite(c).all()          # every slab of every split was written
+        return c.sum(0)
+    want = dY.double().T @ X.double()
+    ring, old = tn(2 | 16), tn(2)
+    tol = 2e-5 if gemm_mode == 1 else 8e-3      # bf16x3 / plain bf16 operands
+    assert O.rel_err(ring.cpu().double(), want.cpu()) < tol
+    assert O.rel_err(ring.cpu().double(), old.cpu().double()) < (1e-6 if gemm_mode == 1 else 1e-5)
+
+
 @pytest.mark.parametrize("B,L,D,H,p_drop", [(2, 128, 256, 4, 0.0), (3, 37, 64, 4, 0.1), (1, 130, 128, 4, 0.0), (2, 96, 32, 4, 0.2),
                                             (1, 200, 64, 8, 0.1), (2, 64, 32, 1, 0.0)])
 def test_attention_per_op_vs_torch(dev, attn_mode, B, L, D, H, p_drop):

@@ -22,7 +22,7 @@ def test_library_exports_every_header_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/tdm_hip.h but not exported"
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
-    assert L.tdm_version() == 401
+    assert L.tdm_version() == 402
 
 
 def test_no_packed_fp32_in_any_code_object():

@@ -106,6 +106,11 @@ _SIGS = {
     "tdm_unet_p_sample_step_philox_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_u64, c_f, c_f, c_f, c_f, c_i64, c_f], c_int),
     "tdm_ctx_create": ([c_int, ctypes.POINTER(ctypes.c_void_p)], c_int),
     "tdm_ctx_destroy": ([c_f], c_int),
+    "tdm_ctx_make_current": ([c_f], c_int),
+    "tdm_ctx_current": ([], c_f),
+    "tdm_ctx_set_arithmetic": ([c_f, c_int, c_int, c_int], c_int),
+    "tdm_ctx_get_arithmetic": ([c_f, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)], c_int),
+    "tdm_ctx_set_overlap": ([c_f, c_int, c_int], c_int),
     "tdm_comm_unique_id_bytes": ([], c_int),
     "tdm_comm_unique_id": ([ctypes.c_char_p], c_int),
     "tdm_comm_init": ([c_f, ctypes.c_char_p, c_int, c_int], c_int),
@@ -161,17 +166,58 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+class Context:
+    """An explicit library context (`tdm_ctx`, include/tdm_hip.h): the arithmetic of the conv / GEMM / attention kernels, the
+    launch-overlap switches and the side queue of the two-queue backward.  `with ctx:` binds it to the calling thread for the block
+    (the library calls made there use it) and restores the previous binding; a context serves one thread at a time.  Threads that
+    bind nothing work on a default context of their own."""
+
+    def __init__(self, device: int = 0, arithmetic=None, bwd_overlap: int = 1, early_grads: int = 0):
+        L = lib()
+        self._h = ctypes.c_void_p()
+        check(L.tdm_ctx_create(device, ctypes.byref(self._h)), "ctx_create")
+        if arithmetic is not None:
+            check(L.tdm_ctx_set_arithmetic(self._h, *arithmetic), "ctx_set_arithmetic")
+        check(L.tdm_ctx_set_overlap(self._h, bwd_overlap, early_grads), "ctx_set_overlap")
+        self._prev = []
+
+    @property
+    def handle(self):
+        return self._h
+
+    def arithmetic(self):
+        c, g, a = c_int(), c_int(), c_int()
+        check(lib().tdm_ctx_get_arithmetic(self._h, ctypes.byref(c), ctypes.byref(g), ctypes.byref(a)), "ctx_get_arithmetic")
+        return c.value, g.value, a.value
+
+    def __enter__(self):
+        L = lib()
+        self._prev.append(L.tdm_ctx_current())
+        check(L.tdm_ctx_make_current(self._h), "ctx_make_current")
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().tdm_ctx_make_current(self._prev.pop()), "ctx_make_current")
+        return False
+
+    def close(self):
+        if self._h:
+            check(lib().tdm_ctx_destroy(self._h), "ctx_destroy")
+            self._h = ctypes.c_void_p()
+
+
 def arithmetic():
-    """(conv, gemm, attention) arithmetic selectors of the CALLING thread (they are thread-local in the library)."""
+    """(conv, gemm, attention) arithmetic selectors of the calling thread's CURRENT context (`Context`; a thread that has bound
+    none has a default context of its own)."""
     L = lib()
     return L.tdm_get_conv_mode(), L.tdm_get_gemm_mode(), L.tdm_get_attn_mode()
 
 
 class use_arithmetic:
     """Run a block under the selectors another thread recorded: torch runs autograd backward functions on its own engine
-    thread, which starts in the library's default arithmetic — a backward pass must run in the arithmetic of ITS forward
-    (the saved workspace holds that arithmetic's tensors), so the bridges record `arithmetic()` in forward and re-apply it
-    here."""
+    thread, whose current context is that thread's default (a context cannot be current on two threads) — a backward pass must
+    run in the arithmetic of ITS forward (the saved workspace holds that arithmetic's tensors), so the bridges record
+    `arithmetic()` in forward and copy it into the engine thread's context here."""
 
     def __init__(self, modes):
         self.modes = modes

@@ -13,12 +13,6 @@
 #include <mutex>
 #include <string.h>
 
-struct tdm_ctx {
-    int device;
-    int rank, world;
-    ncclComm_t comm;
-};
-
 namespace {
 
 struct Rccl {
@@ -82,17 +76,18 @@ extern "C" {
 
 int tdm_ctx_create(int device, tdm_ctx** out) {
     TDM_REQUIRE(out != nullptr && device >= 0, "ctx_create: bad arguments");
-    tdm_ctx* c = new tdm_ctx();
-    c->device = device; c->rank = 0; c->world = 1; c->comm = nullptr;
+    tdm_ctx* c = new tdm_ctx();   // default arithmetic, overlap on, no communicator, no side queue yet (tdm_common.h)
+    c->device = device;
     *out = c;
     return 0;
 }
 
 int tdm_ctx_destroy(tdm_ctx* ctx) {
     if (ctx == nullptr) return 0;
+    TDM_TRY(tdm_ctx_unbind_for_destroy(ctx));
     int rc = 0;
     if (ctx->comm != nullptr && g_rccl.handle != nullptr) {
-        ncclResult_t r = g_rccl.CommDestroy(ctx->comm);
+        ncclResult_t r = g_rccl.CommDestroy((ncclComm_t)ctx->comm);
         if (r != ncclSuccess) {
             tdm_set_error("comm: ncclCommDestroy failed: %s", g_rccl.GetErrorString(r));
             rc = 200 + (int)r;
@@ -144,14 +139,14 @@ int tdm_comm_rccl_version(void) {
 int tdm_allreduce_sum_f32(tdm_ctx* ctx, float* buf, int64_t n, void* stream) {
     TDM_REQUIRE(ctx != nullptr && ctx->comm != nullptr, "allreduce: communicator not initialised (tdm_comm_init)");
     TDM_REQUIRE(buf != nullptr && n > 0, "allreduce: empty buffer");
-    TDM_NCCL(g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, ctx->comm, (hipStream_t)stream), "ncclAllReduce");
+    TDM_NCCL(g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, (ncclComm_t)ctx->comm, (hipStream_t)stream), "ncclAllReduce");
     return 0;
 }
 
 int tdm_broadcast_f32(tdm_ctx* ctx, float* buf, int64_t n, int root, void* stream) {
     TDM_REQUIRE(ctx != nullptr && ctx->comm != nullptr, "broadcast: communicator not initialised (tdm_comm_init)");
     TDM_REQUIRE(buf != nullptr && n > 0 && root >= 0 && root < ctx->world, "broadcast: bad arguments");
-    TDM_NCCL(g_rccl.Broadcast(buf, buf, (size_t)n, ncclFloat32, root, ctx->comm, (hipStream_t)stream), "ncclBroadcast");
+    TDM_NCCL(g_rccl.Broadcast(buf, buf, (size_t)n, ncclFloat32, root, (ncclComm_t)ctx->comm, (hipStream_t)stream), "ncclBroadcast");
     return 0;
 }
 

@@ -61,7 +61,24 @@ struct TdmSideLane {
     void destroy();
     ~TdmSideLane() { destroy(); }
 };
-TdmSideLane& tdm_side_lane();
+// All selector state of the library lives in an explicit context object (tdm_hip.h: tdm_ctx_create / _destroy / _make_current): the
+// arithmetic of the conv / GEMM / attention kernels, the two-queue and early-gradient switches, and the side queue with its events
+// (created lazily by the first backward that forks, destroyed with the context).  A thread that never binds one works on its own
+// default context (thread-exit destroys it).  There is no process-global mutable state; the only thread-local is the BINDING.
+struct TdmCtx {
+    int conv_mode = 2;     // 0 exact fp32 MFMA, 2 bf16x3 over S16 tensors (default); 1 was round 1's in-loader split (removed)
+    int gemm_mode = 1;     // 0 fp32 MFMA, 1 bf16x3 (default), 2 plain bf16 operands
+    int attn_mode = 2;     // 0 scalar fp32, 1 fp32 MFMA, 2 bf16x3 MFMA (default)
+    int bwd_overlap = 1;   // weight-gradient launches on the context's side queue
+    int early_grads = 0;   // the UNet's slab reduction in two parts (data parallel)
+    TdmSideLane lane;
+    int bound = 0;         // 1 while some thread has it current (a context serves one thread at a time)
+};
+// the C ABI's context object (tdm_hip.h): the process's RCCL communicator (comm.hip; void* here: an ncclComm_t) + the selector state
+struct tdm_ctx { int device = 0; int rank = 0, world = 1; void* comm = nullptr; TdmCtx c; };
+TdmCtx& tdm_cur_ctx();
+int tdm_ctx_unbind_for_destroy(tdm_ctx* ctx);   // ctx.hip: unbinds from the calling thread; fails if another thread has it current
+inline TdmSideLane& tdm_side_lane() { return tdm_cur_ctx().lane; }
 // Joins the side queue into the caller's stream on EVERY exit path of a backward that has forked — an error return between the
 // first fork and the regular join included — so that "every effect of a call is ordered on the stream the caller passed"
 // (tdm_hip.h) also holds for a failed call: the caller may free or reuse its buffers behind its own stream.

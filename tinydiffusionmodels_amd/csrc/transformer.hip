@@ -18,9 +18,9 @@ namespace {
 
 // arithmetic of the linear layers: 0 exact fp32 MFMA, 1 bf16x3 split operands (default, meets the 1e-3
 // parity bound), 2 plain bf16 operands (throughput mode)
-thread_local int g_gemm_mode = 1;   // per calling thread: no process-global mutable state (threading)
+#define g_gemm_mode (tdm_cur_ctx().gemm_mode)   // a field of the calling thread's current context (threading)
 // attention: 0 scalar fp32 kernels (this file), 1 fp32 MFMA (attn_mfma.hip), 2 bf16x3 MFMA (attn_bf16.hip, default)
-thread_local int g_attn_mode = 2;
+#define g_attn_mode (tdm_cur_ctx().attn_mode)
 
 // train-mode dropout of one call: p = 0 -> off
 struct Drop {

@@ -111,7 +111,7 @@ const PackTab kPack = make_pack();
 
 // 0: exact fp32 MFMA (conv_mfma.hip); 1: bf16x3, fp32 tensors split while staging (round 1; removed from the library);
 // 2: bf16x3 over pre-split "S16" tensors written by the producers (conv_s16.hip) — same arithmetic as 1
-thread_local int g_conv_mode = 2;   // per calling thread (tdm_set_conv_mode): no process-global mutable state
+#define g_conv_mode (tdm_cur_ctx().conv_mode)   // (tdm_set_conv_mode: a field of the calling thread's current context)
 // rb4.conv1 on the up-sampled h3 in the phase form (default); TDM_RB4_PHASE=0 keeps the nine-tap launches for A/B timing
 const bool g_rb4_phase = !(getenv("TDM_RB4_PHASE") && atoi(getenv("TDM_RB4_PHASE")) == 0);
 
@@ -389,15 +389,15 @@ inline void mark_end(hipStream_t st) {
 // two-queue steps are held against their one-queue forms bit for bit: GPU tests (UNet B = 37 and 512 in both arithmetics, text
 // 8 x 128 tokens), tools/overlap_bitwise.py over 200 steps at B = 1 ... 512 and 3,000 steps at four sizes, tools/text_modes.py
 // --check, tools/contention_check.py / contention_tn.py with foreign kernel streams.
-thread_local TdmSideLane g_lane;
-thread_local int g_bwd_overlap = 1;   // a selector like the arithmetic modes: per calling thread
+#define g_lane (tdm_cur_ctx().lane)
+#define g_bwd_overlap (tdm_cur_ctx().bwd_overlap)   // a selector like the arithmetic modes: a field of the current context
 // tdm_set_early_grads (data-parallel training; default 0): the slab reduction of the S16 backward runs in TWO parts.  Part A — every
 // gradient of rb2, rb3, rb4 and the output conv: flat offsets [kL.rb[1].c1w, total), 95 % of the 725,892 bytes — is reduced as soon
 // as rb2's weight-gradient launches have retired (on the side queue behind them when the backward runs on two queues), an event
 // marks it final, and the caller's collective stream can wait for THAT (tdm_unet_wait_early_grads) instead of the end of the
 // backward: the all-reduce of part A runs under rb1's data / weight gradients (~125 us at B = 512), and only part B (rb1: 39 KB)
 // is reduced after the last launch.  Same kernels, same slabs, same fixed summation order: the gradient is bit-identical.
-thread_local int g_early_grads = 0;
+#define g_early_grads (tdm_cur_ctx().early_grads)
 
 int unet_forward_s16(const float* P, const float* x, const int64_t* t, float* eps, const Ws& w, int B, int save,
                      hipStream_t st, const MseIn* mse) {
@@ -842,7 +842,6 @@ bool TdmSideLane::init(hipStream_t st) {
     device = dev;
     return ok = true;
 }
-TdmSideLane& tdm_side_lane() { return g_lane; }
 int tdm_bwd_overlap(hipStream_t st) {
     if (g_bwd_overlap == 0) return 0;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
