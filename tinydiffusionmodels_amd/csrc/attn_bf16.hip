@@ -106,6 +106,43 @@ __device__ __forceinline__ void stage_block(char* rowimg, char* trimg, const flo
     }
 }
 
+// stage_block in two halves: the global loads of the NEXT 64-row block are requested into registers before the MFMA chunks of the
+// current one and written to LDS (split, both images) behind them — the block's HBM / L2 latency runs under the compute instead of
+// between two barriers (L = 128: two blocks per head, every second staging was a bare wait).  Same values, same LDS images.
+template <int HD> struct BlockRegs { float4 v[(RB * (HD / 4) + 255) / 256]; };
+template <int HD>
+__device__ __forceinline__ void load_block(BlockRegs<HD>& p, const float* __restrict__ src, long ld, int r0, int nrows, int tid) {
+#pragma unroll
+    for (int i = 0; i < (RB * (HD / 4) + 255) / 256; ++i) {
+        const int e = tid + 256 * i;
+        const int rr = e / (HD / 4), d4 = e - rr * (HD / 4);
+        p.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < RB * (HD / 4) && r0 + rr < nrows) p.v[i] = *reinterpret_cast<const float4*>(src + (long)(r0 + rr) * ld + d4 * 4);
+    }
+}
+template <int HD>
+__device__ __forceinline__ void write_block(char* rowimg, char* trimg, const BlockRegs<HD>& p, int tid) {
+    using C = Cfg<HD>;
+#pragma unroll
+    for (int i = 0; i < (RB * (HD / 4) + 255) / 256; ++i) {
+        const int e = tid + 256 * i;
+        if (e >= RB * (HD / 4)) break;
+        const int rr = e / (HD / 4), d4 = e - rr * (HD / 4);
+        tdm_bf16x4 hi, lo;
+        tdm_split4(p.v[i], hi, lo);
+        if (rowimg != nullptr) {
+            *reinterpret_cast<tdm_bf16x4*>(rowimg + rr * C::RP + d4 * 8) = hi;
+            *reinterpret_cast<tdm_bf16x4*>(rowimg + C::ROWPL + rr * C::RP + d4 * 8) = lo;
+        }
+        if (trimg != nullptr) {
+            const int pos = (rr & 32) + tr_pos(rr & 31);
+            const int off = (((d4 * 4) >> 5) * RB + pos) * 64 + ((d4 * 4) & 31) * 2;
+            *reinterpret_cast<tdm_bf16x4*>(trimg + off) = hi;
+            *reinterpret_cast<tdm_bf16x4*>(trimg + C::TRPL + off) = lo;
+        }
+    }
+}
+
 // B-operand registers of one owned row: k-step ks holds d = 16 ks + 8 h .. + 7, split
 template <int HD>
 __device__ __forceinline__ void load_breg(bf16x8 (&hi)[Cfg<HD>::KS], bf16x8 (&lo)[Cfg<HD>::KS], const float* __restrict__ row,
@@ -307,6 +344,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const float* __re
     const float* base = qkv + (long)b * L * 3 * D + hh * HD;
     if (HD < 32) clear_lds(Kr, C::ROWIMG + C::TRIMG, tid);
 
+    BlockRegs<HD> pk, pv;   // the next block of K / V rows, in flight
+    load_block<HD>(pk, base + D, 3L * D, 0, L, tid);
+    load_block<HD>(pv, base + 2 * D, 3L * D, 0, L, tid);
     bf16x8 qh[C::KS], ql[C::KS];
     load_breg<HD>(qh, ql, base + (long)qi * 3 * D, h, qvalid);
     f32x16 acc_o[C::NT];
@@ -319,8 +359,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const float* __re
     for (int k0 = 0; k0 < L; k0 += RB) {
         __syncthreads();
         if (!(ATTN_ABL & 2)) {
-        stage_block<HD>(Kr, nullptr, base + D, 3L * D, k0, L, tid);
-        stage_block<HD>(nullptr, Vt, base + 2 * D, 3L * D, k0, L, tid);
+        write_block<HD>(Kr, nullptr, pk, tid);
+        write_block<HD>(nullptr, Vt, pv, tid);
+        if (k0 + RB < L) {
+            load_block<HD>(pk, base + D, 3L * D, k0 + RB, L, tid);
+            load_block<HD>(pv, base + 2 * D, 3L * D, k0 + RB, L, tid);
+        }
         }
         __syncthreads();
         if (qw0 >= L) continue;   // wave-uniform: this wave has no query rows
@@ -385,6 +429,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const float* _
     const int qi = qw0 + j;
     const bool qvalid = qi < L;
     const float* base = qkv + (long)b * L * 3 * D + hh * HD;
+    BlockRegs<HD> pk, pv;   // the next block of K / V rows, in flight (requested before the own-row loads: they overlap)
+    load_block<HD>(pk, base + D, 3L * D, 0, L, tid);
+    load_block<HD>(pv, base + 2 * D, 3L * D, 0, L, tid);
     bf16x8 qh[C::KS], ql[C::KS], gh[C::KS], gl[C::KS];
     float Di = 0.f;   // D_i = dO_i . O_i, exact fp32 as in the fp32 kernels: it multiplies every probability of the row
     {
@@ -408,8 +455,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const float* _
     for (int k0 = 0; k0 < L; k0 += RB) {
         __syncthreads();
         if (!(ATTN_ABL & 2)) {
-        stage_block<HD>(Kr, Kt, base + D, 3L * D, k0, L, tid);
-        stage_block<HD>(Vr, nullptr, base + 2 * D, 3L * D, k0, L, tid);
+        write_block<HD>(Kr, Kt, pk, tid);
+        write_block<HD>(Vr, nullptr, pv, tid);
+        if (k0 + RB < L) {
+            load_block<HD>(pk, base + D, 3L * D, k0 + RB, L, tid);
+            load_block<HD>(pv, base + 2 * D, 3L * D, k0 + RB, L, tid);
+        }
         }
         __syncthreads();
         if (qw0 >= L) continue;
