@@ -26,7 +26,10 @@ def main():
     starts = [i for i, e in enumerate(ev) if e[0].startswith("draw_q_sample_kernel")]
     steps = [ev[a:b] for a, b in zip(starts[:-1], starts[1:])]
     n = Counter(len(s) for s in steps).most_common(1)[0][0]
-    steps = [s for s in steps if len(s) == n][skip:]
+    steps = [s for s in steps if len(s) == n]
+    # (the bench also runs the step at other batch sizes — same launch count: keep the steps of the most common workgroup signature)
+    sig = Counter(tuple(e[3] for e in s) for s in steps).most_common(1)[0][0]
+    steps = [s for s in steps if tuple(e[3] for e in s) == sig][skip:]
     acc = defaultdict(lambda: [0.0, 0.0, 0, 0, ""])
     busy = tot = span = 0.0
     for s in steps:

@@ -28,7 +28,9 @@ def main():
         print("no draw_q_sample_kernel dispatches found")
         return
     n = Counter(len(s) for s in steps).most_common(1)[0][0]
-    steps = [s for s in steps if len(s) == n][skip:]
+    steps = [s for s in steps if len(s) == n]
+    sig = Counter(tuple(e[3] for e in s) for s in steps).most_common(1)[0][0]   # (one batch size: the most common workgroup signature)
+    steps = [s for s in steps if tuple(e[3] for e in s) == sig][skip:]
     print(f"{len(steps)} steps of {n} launches")
     tot_d = tot_g = 0.0
     print(f"{'#':>3s} {'avg_us':>8s} {'gap_us':>7s} {'wgs':>6s}  kernel")
