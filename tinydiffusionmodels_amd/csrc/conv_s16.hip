@@ -544,10 +544,13 @@ __global__ __launch_bounds__(CONV_THREADS, (NT <= 2 ? 4 : 2)) void conv_s16_kern
     } else {
         // N = 64 / 96 (and N = 32 with the fused skip conv): a second input register set does not fit the 128-register
         // budget of four waves per SIMD, so these widths prefetch one chunk ahead
+        stamp();
         for (int c = 0; c < nchunks; ++c) {
             stage(pinA, (PH && c < nc0) ? nelem_s : nelem);
+            stamp();
             if (c + 1 < nchunks && pf) { prefetch_in(pinA, goffA, planA, goffB, planB, c + 1); prefetch_w(c + 1); }
             compute(c);
+            stamp();
         }
     }
 
@@ -918,7 +921,7 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     // ablate & 32 (probe): one workgroup per CU (LDS request > half of 160 KB) — phase times without a co-resident workgroup
     const size_t lds_req = (TDM_ABLATE(a.ablate) & 32) ? (size_t)110000 : lds;
 #if TDM_DIAG_BUILD
-    if constexpr (HW == 28 && NT == 1 && !SKIP && MT == 1) {
+    if constexpr (((HW == 28 && NT == 1) || (HW == 14 && NT == 2)) && !SKIP && MT == 1) {
         if (a.ablate & 16) {   // the instrumented instantiation (diagnostics only)
             static bool probe_attr = false;
             if (!probe_attr) {

@@ -18,12 +18,16 @@ def run(hw, cin, cout, B, k=3, solo=False):
     torch.cuda.synchronize()
     d = aux[y.numel():y.numel() + ntiles * 32].view(torch.int64).view(ntiles, 16).cpu().double()
     t0 = d[:, 0].min()
-    ph = d[:, 1:12] - d[:, 0:11]
-    names = ["prologue", "wait+stage0", "compute0", "stage1", "compute1", "epi: request inputs", "epi: barrier", "epi: to LDS", "epi: walk 0", "epi: walk 1", "store drain"]
-    print(f"hw={hw} {cin}->{cout} B={B} tiles={ntiles} {'ONE WORKGROUP PER CU' if solo else ''}; clock ticks (same unit as the stamps); kernel span {float(d[:, 11].max() - t0):.0f}")
+    nch = cin // 16
+    names = ["prologue"] + [x for c in range(nch) for x in ((f"wait+stage{c}" if c == 0 else f"stage{c}"), f"compute{c}")] + ["epi: request inputs", "epi: barrier", "epi: to LDS", "epi: walk 0", "epi: walk 1", "store drain"]
+    names = names[:15]
+    print(d[:3].tolist())
+    d = d[d[:, 0] > 0]
+    ph = d[:, 1:len(names) + 1] - d[:, 0:len(names)]
+    print(f"hw={hw} {cin}->{cout} B={B} tiles={ntiles} {'ONE WORKGROUP PER CU' if solo else ''}; clock ticks (same unit as the stamps); kernel span {float(d[:, 1:16].max() - t0):.0f}")
     print("  start of WG (min/median/max since first):", float((d[:, 0] - t0).min()), float((d[:, 0] - t0).median()), float((d[:, 0] - t0).max()))
     for i, n in enumerate(names):
         print(f"  {n:20s} median {float(ph[:, i].median()):8.0f}  p10 {float(ph[:, i].quantile(0.1)):8.0f}  p90 {float(ph[:, i].quantile(0.9)):8.0f}")
-    life = d[:, 11] - d[:, 0]
+    life = d[:, len(names)] - d[:, 0]
     print(f"  lifetime     median {float(life.median()):8.0f}  p10 {float(life.quantile(0.1)):8.0f}  p90 {float(life.quantile(0.9)):8.0f}")
-run(28, 32, 32, 4096); run(28, 32, 32, 4096, solo=True)
+run(14, 64, 64, 512); run(14, 64, 64, 512, solo=True)
