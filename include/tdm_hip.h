@@ -304,6 +304,14 @@ int tdm_set_early_grads(int on);
 int tdm_get_early_grads(void);
 int64_t tdm_unet_early_grad_offset(void);
 int tdm_unet_wait_early_grads(void* stream);
+/* The same for the transformer denoiser (src/shakespeare.py:105-120 backward; bf16 GEMM modes, eager issue): with early gradients on,
+ * tdm_tt_loss_grad_* / tdm_tt_bwd_f32 reduce layer l's slabs right behind that layer's weight-gradient launches — last layer first —
+ * and record an event per layer.  Floats [begin, end) of the flat gradient (tdm_tt_layer_grad_range: a layer's twelve tensors are
+ * contiguous) are final at layer l's event; tdm_tt_wait_layer_grads(stream, l) orders the caller's collective stream behind it
+ * (1 = ordered, 0 = no such event: order behind the call's stream, < 0 error).  The time embedding's 2 D floats at the end of the
+ * vector are final with the call's stream.  Same slabs, same fixed summation order: the gradient is bit-identical.         */
+int tdm_tt_wait_layer_grads(void* stream, int layer);
+int tdm_tt_layer_grad_range(int D, int depth, int ffn, int layer, int64_t* begin, int64_t* end);
 /* per-layer entry points of the S16 pipeline (tests / profiling): the fp32 input is
  * pre-split into scratch first.  conv: scratch >= k*k*Cin*Cout + B*HW*HW*Cin + 64 floats;
  * out_s16 (optional, S16 layout: every 16-channel group = 16 bf16 hi then 16 bf16 lo)

@@ -280,3 +280,37 @@ def test_early_two_part_allreduce_gloo(tmp_path, world):
         assert (r["two"].double() - total).abs().max() < 1e-5
         if world == 2:
             assert torch.equal(r["two"], r["one"])
+
+
+def _parts_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from tinydiffusionmodels_amd import dp
+    dp.init_from_env("gloo")
+    n = 3 * 1000 + 17                                   # three "layers" + a tail no part covers (the time embedding's floats)
+    parts = [(2000, 3000, 2), (1000, 2000, 1), (0, 1000, 0)]     # the order a backward finishes them: last layer first
+    g = torch.randn(n, generator=torch.Generator().manual_seed(70 + rank))
+    one = g.clone()
+    s1 = dp.allreduce_grads_(one)
+    many = g.clone()
+    seen = []
+    s2 = dp.allreduce_grads_parts_(many, parts, wait_part=lambda stream, key: seen.append(key) or False)
+    torch.save({"one": one, "many": many, "scales": (s1, s2), "mine": g, "seen": seen}, os.path.join(out_dir, f"p{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_per_layer_allreduce_parts_gloo(tmp_path, world):
+    """dp.allreduce_grads_parts_ (the denoiser's gradient all-reduced layer by layer under its backward; none in the reference): one
+    collective per part in the given order plus one for what the parts leave out — identical replicas, the global SUM, scale
+    1 / world, bit-identical to the one-collective form at world 2."""
+    mp.spawn(_parts_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(tmp_path / f"p{r}.pt") for r in range(world)]
+    total = sum(r["mine"].double() for r in rs)
+    for r in rs:
+        assert r["scales"] == (1.0 / world, 1.0 / world) and r["seen"] == []       # (CPU tensors: no events to wait for)
+        assert torch.equal(r["many"], rs[0]["many"])
+        assert (r["many"].double() - total).abs().max() < 1e-5
+        if world == 2:
+            assert torch.equal(r["many"], r["one"])

@@ -1532,3 +1532,63 @@ def test_text_backward_side_stream_is_bit_identical_and_graphs_take_one_queue(de
     ref = finals["eager"]
     for k, v in finals.items():
         assert torch.equal(v[0], ref[0]) and v[1] == ref[1], k
+
+
+@pytest.mark.gpu
+def test_denoiser_layer_gradients_are_final_at_their_events_and_bit_identical(dev):
+    """tdm_set_early_grads for the transformer denoiser (data parallel; include/tdm_hip.h): with the selector on, the backward reduces
+    each layer's slabs behind that layer's weight-gradient launches and records an event per layer.  The flat gradient is
+    bit-identical to the one-reduction form (one queue and two), every layer has an event exactly once per call, a collective
+    stream ordered behind layer l's event reads layer l's final values while the call is still running, and the layer ranges tile
+    the vector up to the time embedding's 2 D floats.  D = 256 (the ring weight-gradient path), 8 x 128 tokens, dropout 0.1."""
+    import ctypes
+    from tinydiffusionmodels_amd import _lib, transformer_engine as TE
+    L_ = _lib.lib()
+    dim, B, L = 256, 8, 128
+    m = _model(dim, dev)
+    cfg, flat = m.cfg, m.flat.detach()
+    g = torch.Generator(device=dev).manual_seed(4)
+    x0 = torch.randn(B, L, dim, device=dev, generator=g) * 0.02
+    noise = torch.randn(B, L, dim, device=dev, generator=g)
+    t = torch.randint(0, 1000, (B,), device=dev, generator=g)
+    ranges = []
+    for l in range(cfg.depth):
+        b, e = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(L_.tdm_tt_layer_grad_range(cfg.dim, cfg.depth, cfg.ffn, l, ctypes.byref(b), ctypes.byref(e)))
+        ranges.append((b.value, e.value))
+    assert ranges[0][0] == 0 and all(ranges[l][1] == ranges[l + 1][0] for l in range(cfg.depth - 1))
+    assert ranges[-1][1] == flat.numel() - 2 * dim
+    st = TE.TTTrainState(cfg, flat, B, L)
+    side = torch.cuda.Stream()
+    try:
+        res = {}
+        for ov in (0, 1):
+            assert L_.tdm_set_bwd_overlap(ov) == 0
+            assert L_.tdm_set_early_grads(0) == 0
+            TE.tt_loss_and_grad(flat, st, x0, noise, t, p_drop=0.1, seed=11)
+            ref = st.grads.clone()
+            assert all(L_.tdm_tt_wait_layer_grads(side.cuda_stream, l) == 0 for l in range(cfg.depth))     # selector off: no events
+            assert L_.tdm_set_early_grads(1) == 0
+            st.grads.zero_()
+            TE.tt_loss_and_grad(flat, st, x0, noise, t, p_drop=0.1, seed=11)
+            snaps = []
+            if _lib.arithmetic()[1] == 0:                               # fp32 GEMM mode: bias gradients have their own reductions — no parts
+                assert all(L_.tdm_tt_wait_layer_grads(side.cuda_stream, l) == 0 for l in range(cfg.depth))
+                torch.cuda.synchronize()
+                assert torch.equal(st.grads, ref), ov
+                continue
+            for l in range(cfg.depth - 1, -1, -1):                      # the order the backward finishes them
+                assert L_.tdm_tt_wait_layer_grads(side.cuda_stream, l) == 1
+                with torch.cuda.stream(side):
+                    snaps.append((l, st.grads[ranges[l][0]:ranges[l][1]].clone()))
+                assert L_.tdm_tt_wait_layer_grads(side.cuda_stream, l) == 0                                # consumed: once per call
+            torch.cuda.synchronize()
+            assert torch.equal(st.grads, ref), ov
+            for l, snap in snaps:
+                assert torch.equal(snap, ref[ranges[l][0]:ranges[l][1]]), (ov, l)
+            res[ov] = ref
+        if res:
+            assert torch.equal(res[0], res[1])
+    finally:
+        L_.tdm_set_early_grads(0)
+        L_.tdm_set_bwd_overlap(1)

@@ -106,6 +106,8 @@ _SIGS = {
     "tdm_unet_p_sample_step_philox_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_u64, c_f, c_f, c_f, c_f, c_i64, c_f], c_int),
     "tdm_ctx_create": ([c_int, ctypes.POINTER(ctypes.c_void_p)], c_int),
     "tdm_ctx_destroy": ([c_f], c_int),
+    "tdm_tt_wait_layer_grads": ([c_f, c_int], c_int),
+    "tdm_tt_layer_grad_range": ([c_int, c_int, c_int, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)], c_int),
     "tdm_ctx_make_current": ([c_f], c_int),
     "tdm_ctx_current": ([], c_f),
     "tdm_ctx_set_arithmetic": ([c_f, c_int, c_int, c_int], c_int),

@@ -55,6 +55,8 @@ struct TdmSideLane {
     hipEvent_t ready[8] = {}, back[2] = {}, done = nullptr;
     hipEvent_t early = nullptr;      // "the early part of the flat gradient is final" (tdm_set_early_grads / tdm_unet_wait_early_grads)
     bool early_recorded = false;     // ... recorded by the calling thread's last backward
+    hipEvent_t part[8] = {};         // denoiser: "layer l's gradient is final" (tdm_tt_wait_layer_grads)
+    unsigned part_mask = 0;          // ... bit l: recorded by the last denoiser backward and not yet consumed
     bool ok = false;
     int device = -1;
     bool init(hipStream_t st);
@@ -70,7 +72,7 @@ struct TdmCtx {
     int gemm_mode = 1;     // 0 fp32 MFMA, 1 bf16x3 (default), 2 plain bf16 operands
     int attn_mode = 2;     // 0 scalar fp32, 1 fp32 MFMA, 2 bf16x3 MFMA (default)
     int bwd_overlap = 1;   // weight-gradient launches on the context's side queue
-    int early_grads = 0;   // the UNet's slab reduction in two parts (data parallel)
+    int early_grads = 0;   // gradients final in parts behind events (data parallel): the UNet in two, the denoiser per layer
     TdmSideLane lane;
     int bound = 0;         // 1 while some thread has it current (a context serves one thread at a time)
 };

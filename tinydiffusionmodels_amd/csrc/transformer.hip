@@ -1008,6 +1008,48 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
         }
         TDM_TRY(tdm_launch_transpose_s16_batch(tb, st));
     }
+    // sections of the slab reduction that finish layer l's gradient (its flat range [L[l].in_w, L[l].n2_b + D) is contiguous)
+    auto layer_sections = [&](ReduceArgs& ra, int& n, int l) {
+        const LayerOff& o = lay.L[l];
+        const long offs[4] = {o.in_w, o.out_w, o.l1_w, o.l2_w};
+        const long lens[4] = {3L * D * D, (long)D * D, (long)F * D, (long)D * F};
+        for (int k = 0; k < 4; ++k) {
+            ra.sec[n].off = (int)offs[k]; ra.sec[n].len = (int)lens[k]; ra.sec[n].nslab = sp.sk[k];
+            ra.sec[n].src_delta = sp.base[l][k] - offs[k];
+            ra.sec[n].stride_override = sp.len[k];
+            ++n;
+        }
+        {   // the two LayerNorms' partial rows: d gamma | d beta (2 D at n*_w) and the column sums (D: out_proj / linear2 bias gradient)
+            const int nbl = ln_bwd_nb(M, D);
+            const long goff[2] = {o.n1_w, o.n2_w}, boff[2] = {o.out_b, o.l2_b};
+            for (int k = 0; k < 2; ++k) {
+                ra.sec[n].off = (int)goff[k]; ra.sec[n].len = 2 * D; ra.sec[n].nslab = nbl;
+                ra.sec[n].src_delta = sp.ln_base[l][k] - goff[k]; ra.sec[n].stride_override = 3L * D; ++n;
+                ra.sec[n].off = (int)boff[k]; ra.sec[n].len = D; ra.sec[n].nslab = nbl;
+                ra.sec[n].src_delta = sp.ln_base[l][k] + 2L * D - boff[k]; ra.sec[n].stride_override = 3L * D; ++n;
+            }
+        }
+        if (fused_bias) {
+            const long boffs[2] = {o.in_b, o.l1_b};
+            const int ks[2] = {0, 2};
+            for (int q = 0; q < 2; ++q) {
+                const int k = ks[q];
+                ra.sec[n].off = (int)boffs[q]; ra.sec[n].len = sp.nout[k]; ra.sec[n].nslab = sp.sk[k];
+                ra.sec[n].src_delta = sp.bias_base[l][k] - boffs[q];
+                ra.sec[n].stride_override = (sp.nout[k] + 63) & ~63;
+                ++n;
+            }
+        }
+    };
+    // tdm_set_early_grads (data-parallel training, eager issue): layer l's gradient is reduced as soon as its weight-gradient
+    // launches have retired — on the queue they ran on — and an event marks it final (tdm_tt_wait_layer_grads): the host's collective
+    // stream sums layer l over the ranks while layers l - 1 .. 0 are still in their backward.  Same slabs, same fixed order: the
+    // same bits as the one reduction at the end.  (bias gradients of the fp32 GEMM mode come from their own reduction launches.)
+    const bool early = tdm_cur_ctx().early_grads != 0 && fused_bias && [&] {   // (a captured call keeps the one reduction: a replay records no events)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        return hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone; }();
+    if (early) TDM_REQUIRE(ln.init(st), "tt_backward: events could not be created");
+    ln.part_mask = 0;
     for (int l = depth - 1; l >= 0; --l) {
         const LayerOff& o = lay.L[l];
         const LayerWs& a = w.L[l];
@@ -1081,6 +1123,15 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
                              M, 3 * D, D, ss));
         }
         TDM_TRY(side_done(1));
+        if (early) {   // every slab and partial row of layer l is written behind this point of `ss`
+            ReduceArgs ra{};
+            int n = 0;
+            layer_sections(ra, n, l);
+            ra.nsec = n;
+            TDM_TRY(tdm_launch_reduce(slabs, 0, ra, G, ss));
+            TDM_HIP(hipEventRecord(ln.part[l], ss));
+            ln.part_mask |= 1u << l;
+        }
         gout = (l == 0 && dx != nullptr) ? dx : w.g_h;   // layer 0: this is d(loss)/d(dropout0(x + time bias))
         // (layer 0 in the bf16 GEMM modes: the input dropout's mask — d(x + time bias) = mask * g / (1 - p) — in this epilogue)
         const bool drop_here = dropping && l == 0 && g_gemm_mode != 0;
@@ -1099,6 +1150,7 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
     TDM_CHECK_LAUNCH("seqsum");
     TDM_TRY(tdm_launch_time_grad(w.Sb, w.that, G + lay.te_w, G + lay.te_b, (int)B, D, st));
     if (lane) TDM_TRY(sj.join());   // the reduction reads every slab
+    if (early) return 0;   // (every layer was reduced behind its own launches; the time embedding's gradient is written directly)
     // sum the split-K weight-gradient slabs
     ReduceArgs ra{};
     int n = 0;
@@ -1109,36 +1161,7 @@ int tt_backward(const float* P, const TTLayout& lay, const float* dout, float* G
             ra = ReduceArgs{};
             n = 0;
         }
-        const LayerOff& o = lay.L[l];
-        const long offs[4] = {o.in_w, o.out_w, o.l1_w, o.l2_w};
-        const long lens[4] = {3L * D * D, (long)D * D, (long)F * D, (long)D * F};
-        for (int k = 0; k < 4; ++k) {
-            ra.sec[n].off = (int)offs[k]; ra.sec[n].len = (int)lens[k]; ra.sec[n].nslab = sp.sk[k];
-            ra.sec[n].src_delta = sp.base[l][k] - offs[k];
-            ra.sec[n].stride_override = sp.len[k];
-            ++n;
-        }
-        {   // the two LayerNorms' partial rows: d gamma | d beta (2 D at n*_w) and the column sums (D: out_proj / linear2 bias gradient)
-            const int nbl = ln_bwd_nb(M, D);
-            const long goff[2] = {o.n1_w, o.n2_w}, boff[2] = {o.out_b, o.l2_b};
-            for (int k = 0; k < 2; ++k) {
-                ra.sec[n].off = (int)goff[k]; ra.sec[n].len = 2 * D; ra.sec[n].nslab = nbl;
-                ra.sec[n].src_delta = sp.ln_base[l][k] - goff[k]; ra.sec[n].stride_override = 3L * D; ++n;
-                ra.sec[n].off = (int)boff[k]; ra.sec[n].len = D; ra.sec[n].nslab = nbl;
-                ra.sec[n].src_delta = sp.ln_base[l][k] + 2L * D - boff[k]; ra.sec[n].stride_override = 3L * D; ++n;
-            }
-        }
-        if (fused_bias) {
-            const long boffs[2] = {o.in_b, o.l1_b};
-            const int ks[2] = {0, 2};
-            for (int q = 0; q < 2; ++q) {
-                const int k = ks[q];
-                ra.sec[n].off = (int)boffs[q]; ra.sec[n].len = sp.nout[k]; ra.sec[n].nslab = sp.sk[k];
-                ra.sec[n].src_delta = sp.bias_base[l][k] - boffs[q];
-                ra.sec[n].stride_override = (sp.nout[k] + 63) & ~63;
-                ++n;
-            }
-        }
+        layer_sections(ra, n, l);
     }
     ra.nsec = n;
     return tdm_launch_reduce(slabs, 0, ra, G, st);
@@ -1283,6 +1306,31 @@ int tdm_set_gemm_mode(int mode) {
     return 0;
 }
 int tdm_get_gemm_mode(void) { return g_gemm_mode; }
+
+// Data-parallel denoiser training (tdm_set_early_grads(1), eager issue, bf16 GEMM modes): layer l's gradient — floats
+// [begin, end) of the flat gradient, tdm_tt_layer_grad_range — is final when the backward has retired that layer's weight-gradient
+// launches; tdm_tt_wait_layer_grads orders `stream` behind that point of the calling thread's LAST backward (once per layer and call).
+// Returns 1 if there was such an event, 0 if not (selector off, captured call, fp32 GEMM mode: order behind the call's stream), < 0 on error.
+int tdm_tt_wait_layer_grads(void* stream, int layer) {
+    TDM_REQUIRE(layer >= 0 && layer < 8, "tt_wait_layer_grads: layer %d", layer);
+    TdmSideLane& ln = tdm_side_lane();
+    if (!ln.ok || !(ln.part_mask & (1u << layer))) return 0;
+    if (hipStreamWaitEvent((hipStream_t)stream, ln.part[layer], 0) != hipSuccess) {
+        tdm_set_error("tt_wait_layer_grads: hipStreamWaitEvent failed");
+        (void)hipGetLastError();
+        return -1;
+    }
+    ln.part_mask &= ~(1u << layer);
+    return 1;
+}
+int tdm_tt_layer_grad_range(int D, int depth, int ffn, int layer, int64_t* begin, int64_t* end) {
+    TDM_REQUIRE(depth >= 1 && depth <= 8 && layer >= 0 && layer < depth && D > 0 && ffn > 0 && begin != nullptr && end != nullptr,
+                "tt_layer_grad_range: bad arguments (D=%d depth=%d ffn=%d layer=%d)", D, depth, ffn, layer);
+    const TTLayout t = tt_layout(D, depth, ffn);
+    *begin = t.L[layer].in_w;
+    *end = layer + 1 < depth ? t.L[layer + 1].in_w : t.te_w;
+    return 0;
+}
 
 int tdm_set_attn_mode(int mode) {
     TDM_REQUIRE(mode >= 0 && mode <= 2, "attention mode %d (0 = scalar fp32, 1 = fp32 MFMA, 2 = bf16x3 MFMA)", mode);

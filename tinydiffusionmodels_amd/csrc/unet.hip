@@ -810,7 +810,8 @@ void TdmSideLane::destroy() {
     for (hipEvent_t& e : back) if (e != nullptr) { (void)hipEventDestroy(e); e = nullptr; }
     if (done != nullptr) (void)hipEventDestroy(done);
     if (early != nullptr) (void)hipEventDestroy(early);
-    side = nullptr; done = nullptr; early = nullptr; early_recorded = false; ok = false; device = -1;
+    for (hipEvent_t& e : part) if (e != nullptr) { (void)hipEventDestroy(e); e = nullptr; }
+    side = nullptr; done = nullptr; early = nullptr; early_recorded = false; part_mask = 0; ok = false; device = -1;
     (void)hipGetLastError();
 }
 bool TdmSideLane::init(hipStream_t st) {
@@ -839,6 +840,8 @@ bool TdmSideLane::init(hipStream_t st) {
         if (hipEventCreateWithFlags(&e, flags) != hipSuccess) return false;
     if (hipEventCreateWithFlags(&done, flags) != hipSuccess) return false;
     if (hipEventCreateWithFlags(&early, flags) != hipSuccess) return false;
+    for (hipEvent_t& e : part)
+        if (hipEventCreateWithFlags(&e, flags) != hipSuccess) return false;
     device = dev;
     return ok = true;
 }

@@ -322,6 +322,54 @@ def allreduce_grads_early_(flat_grads: torch.Tensor, early_off: int, wait_early=
     return 1.0 / world
 
 
+def allreduce_grads_parts_(flat_grads: torch.Tensor, parts, wait_part=None) -> float:
+    """allreduce_grads_ as one collective per PART, each started as soon as that part of the gradient is final:
+    `parts` = [(begin, end, key), ...] in the order the backward finishes them (the denoiser: one per layer, last layer first —
+    tdm_tt_layer_grad_range / tdm_tt_wait_layer_grads); `wait_part(stream, key) -> bool` orders `stream` behind part `key`'s event
+    and says whether there was one (False: that part simply waits for the caller's stream).  Whatever the parts do not cover (the
+    time embedding's few floats) is summed last, behind the caller's stream.  The caller's stream waits for all of it.
+    Element-wise SUMs over the same ranks: replicas end bit-identical; against the one-message form the same remark as for
+    allreduce_grads_early_ holds.  Every rank must pass the same parts.  Returns 1 / world."""
+    rank, world = world_info()
+    if world == 1:
+        return 1.0
+    assert flat_grads.dim() == 1
+    n = flat_grads.numel()
+    covered = sorted((int(b), int(e)) for b, e, _ in parts)
+    rest, pos = [], 0
+    for b, e in covered:
+        assert pos <= b < e <= n, "parts must be disjoint ranges of the flat gradient"
+        if b > pos:
+            rest.append((pos, b))
+        pos = e
+    if pos < n:
+        rest.append((pos, n))
+    comm = native_comm() if flat_grads.is_cuda else None
+    if comm is not None and not torch.cuda.is_current_stream_capturing():
+        side = _comm_side_stream()
+        cur = torch.cuda.current_stream()
+        for b, e, key in parts:
+            if not (wait_part is not None and wait_part(side, key)):
+                side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                comm.allreduce_sum_(flat_grads[int(b):int(e)])
+        if rest:
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for b, e in rest:
+                    comm.allreduce_sum_(flat_grads[b:e])
+        flat_grads.record_stream(side)
+        cur.wait_stream(side)
+    elif comm is not None:
+        comm.allreduce_sum_(flat_grads)             # (under capture: one collective on the captured stream)
+    else:
+        for b, e, _ in parts:
+            dist.all_reduce(flat_grads[int(b):int(e)], op=dist.ReduceOp.SUM)
+        for b, e in rest:
+            dist.all_reduce(flat_grads[b:e], op=dist.ReduceOp.SUM)
+    return 1.0 / world
+
+
 class _Pending:
     """A collective in flight next to the caller's stream; wait() orders the caller's CURRENT stream (torch.distributed's
     NCCL work, the native side stream) or the host (gloo) behind it."""

@@ -12,6 +12,7 @@ Dropout: train mode applies the reference's 1 + 4*depth dropout sites natively;
 the masks come from a counter-based hash of (seed, site, element index) — torch's
 Philox stream cannot be replayed by anyone else — with one 64-bit seed per forward
 drawn from torch's CPU generator (so `torch.manual_seed` makes runs repeatable)."""
+import ctypes
 import math
 import os
 from collections import OrderedDict
@@ -562,6 +563,32 @@ class DenoiserTrainer:
         self._lr_written = float(lr)
         self._scheduled = False
         dp.broadcast_params_(self.flat, src=0)
+        # data parallel, eager issue: a layer's gradient is all-reduced as soon as its weight-gradient launches have retired —
+        # last layer first, under the backward of the layers below (tdm_set_early_grads; TDM_EARLY_GRADS=0: one collective behind the step)
+        self._early = self.world > 1 and os.environ.get("TDM_EARLY_GRADS", "1") != "0"
+        self._parts = []
+        if self._early:
+            L = _lib.lib()
+            _lib.check(L.tdm_set_early_grads(1), "tdm_set_early_grads")
+            cfg = model.cfg
+            for l in range(cfg.depth - 1, -1, -1):
+                b, e = ctypes.c_int64(), ctypes.c_int64()
+                _lib.check(L.tdm_tt_layer_grad_range(cfg.dim, cfg.depth, cfg.ffn, l, ctypes.byref(b), ctypes.byref(e)), "tt_layer_grad_range")
+                self._parts.append((b.value, e.value, l))
+
+    def _allreduce(self, grads) -> float:
+        """SUM of the flat gradient over the ranks; with early gradients one collective per layer, each behind that layer's event of
+        the backward just issued (dp.allreduce_grads_parts_), else one behind the step (a captured step records no events)."""
+        if not self._early or torch.cuda.is_current_stream_capturing():
+            return dp.allreduce_grads_(grads)
+        L = _lib.lib()
+
+        def wait_part(stream, layer) -> bool:
+            rc = L.tdm_tt_wait_layer_grads(stream.cuda_stream, layer)
+            if rc < 0:
+                _lib.check(rc, "tdm_tt_wait_layer_grads")
+            return rc == 1
+        return dp.allreduce_grads_parts_(grads, self._parts, wait_part)
 
     def set_lr_schedule(self, lr_lambda, n_steps: int) -> None:
         """Per-step schedule of the reference's LambdaLR (src/shakespeare.py:200-202, :250) evaluated once on the host into a
@@ -589,7 +616,7 @@ class DenoiserTrainer:
     def _device_step(self, st, x0, lr: float, whole: bool):
         TE.tt_loss_and_grad_philox(self.flat, st, x0, self.seed, self.rng_state, p_drop=self._p_drop(), drop_seed=self.drop_seed)
         if whole:
-            self._adamw(st, dp.allreduce_grads_(st.grads))
+            self._adamw(st, self._allreduce(st.grads))
 
     def step(self, x0, t=None, noise=None, lr: Optional[float] = None):
         st = self.state
@@ -604,7 +631,7 @@ class DenoiserTrainer:
             loss = TE.tt_loss_and_grad(self.flat, st, x0, noise, t, p_drop=p_drop, seed=seed)
             # (the same device-side step count as the graph form: a trainer may mix teacher-forced and device-drawn steps)
             self._sync_lr(lr)
-            self._adamw(st, dp.allreduce_grads_(st.grads))
+            self._adamw(st, self._allreduce(st.grads))
             return loss
         self._sync_lr(lr)
         if not self.use_graph or st.warm < 1:          # first step eagerly (lazy kernel attributes, allocator warm-up)
@@ -622,7 +649,7 @@ class DenoiserTrainer:
             st.graph, st.graph_whole, st.graph_key = g, whole, key
         st.graph.replay()
         if not st.graph_whole:
-            self._adamw(st, dp.allreduce_grads_(st.grads))
+            self._adamw(st, dp.allreduce_grads_(st.grads))   # (a replay records no events: one collective behind the graph)
         return st.loss
 
 
