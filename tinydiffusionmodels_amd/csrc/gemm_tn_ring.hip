@@ -123,7 +123,7 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(TnJobs js) {
     auto issue = [&](int s) {   // stage s & 3 <- tokens kbeg + 16 s .. +15; this wave: tokens 2 wave, 2 wave + 1
         if (no_dma && s > 3) return;
         char* const st = lds + (s & (NST - 1)) * STAGE + wave * 2 * PITCH;
-        const int tk = kbeg + s * SK + wave * 2;
+        const int tk = kbeg + ((TDM_ABLATE(js.ablate) & 16) ? 0 : s * SK) + wave * 2;   // (diagnostics, 16: every stage re-reads the split's first 16 tokens — L2 hits)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, TDM_LDS3(st + u * PITCH), 16, voffA, (tk + u) * a_cs4, 0, 0);

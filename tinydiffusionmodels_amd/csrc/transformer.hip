@@ -1444,7 +1444,7 @@ int tdm_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int
     GemmArgs g{};
     g.A = A; g.a_rs = a_rs; g.a_cs = a_cs; g.B = B; g.b_rs = b_rs; g.b_cs = b_cs; g.C = C; g.c_rs = c_rs;
     g.bias = bias; g.res = res; g.M = M; g.N = N; g.K = K; g.relu = relu & 1; g.splitk = splitk;
-    g.ablate = (relu >> 8) & 15;   // timing diagnostics only
+    g.ablate = (relu >> 8) & 31;   // timing diagnostics only
     g.c_split_stride = c_split_stride;
     // relu & 2: both operands are S16 tensors (tdm_split_s16_f32); relu & 4: C is written as an S16 tensor (NT form).
     // bf16 GEMM modes only.

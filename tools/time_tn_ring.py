@@ -26,9 +26,9 @@ def run(T, N, K, sk_old, sk_new):
     e_old = ((ref.double() - want).norm() / want.norm()).item()
     dW.zero_(); tn(2 | 16, sk_new)(); got = dW[:sk_new].sum(0)
     e_new = ((got.double() - want).norm() / want.norm()).item()
-    r = [t(tn(2, sk_old)), t(tn(2 | 16, sk_new))] + [t(tn(2 | 16 | (a << 8), sk_new)) for a in (1, 2, 4, 3, 7, 5, 6, 8)]
+    r = [t(tn(2, sk_old)), t(tn(2 | 16, sk_new))] + [t(tn(2 | 16 | (a << 8), sk_new)) for a in (1, 2, 4, 3, 7, 5, 6, 8, 16, 20)]
     print(f"dW[{N}][{K}] over {T} tokens: 128-tile (sk {sk_old}) {r[0]:.1f} us err {e_old:.1e} | ring (sk {sk_new}) {r[1]:.1f} us err {e_new:.1e} | "
-          f"no-DMA {r[2]:.1f}  no-MFMA {r[3]:.1f}  no-store {r[4]:.1f}  no-DMA+MFMA {r[5]:.1f}  nothing {r[6]:.1f}  no-DMA+store {r[7]:.1f}  no-MFMA+store {r[8]:.1f}  stores-to-slab-0 {r[9]:.1f}", flush=True)
+          f"no-DMA {r[2]:.1f}  no-MFMA {r[3]:.1f}  no-store {r[4]:.1f}  no-DMA+MFMA {r[5]:.1f}  nothing {r[6]:.1f}  no-DMA+store {r[7]:.1f}  no-MFMA+store {r[8]:.1f}  stores-to-slab-0 {r[9]:.1f}  L2-resident loads {r[10]:.1f}  L2-resident loads, no store {r[11]:.1f}", flush=True)
 _lib.check(L.tdm_set_gemm_mode(1))
 T = 32768
 run(T, 2048, 256, 16, 32); run(T, 256, 2048, 16, 32)
