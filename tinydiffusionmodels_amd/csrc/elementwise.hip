@@ -305,6 +305,66 @@ __global__ __launch_bounds__(EW_BLOCK) void out_bwd_kernel(const float* __restri
     }
 }
 
+// rb4.skip's weight / bias gradient of the exact-fp32 pipeline, factored (the S16 pipeline's out_bwd_s16_kernel does the same from
+// the S16 twins).  The gradient of rb4's output is rank one over the channels, dout4[p][co] = deps[p] * w_out[co]
+// (src/mnist.py:87: the output conv is 32 -> 1), so the 1 x 1 skip conv's gradient (src/mnist.py:52,61 backward) is
+//   dW[ci][co] = sum_p cat[p][ci] dout4[p][co] = v[ci] w_out[co],  v[ci] = sum_p cat[p][ci] deps[p],   db[co] = (sum_p deps[p]) w_out[co]
+// with cat = [up2(h3) (64 channels), h1 (32)]: a 96-vector reduction over the pixels instead of two token-major MFMA launches
+// (101 + 57 us at B = 512 on the fp32 matrix cores).  For the up-sampled channels the sum runs over the 14 x 14 SOURCE pixels with
+// deps summed over each pixel's four outputs.  Per-workgroup partials -> slab[block][skw_off + ci * 32 + co], [skb_off + co].
+__global__ __launch_bounds__(EW_BLOCK) void skip4_factored_kernel(const float* __restrict__ deps, const float* __restrict__ h1,
+                                                                  const float* __restrict__ h3, const float* __restrict__ w_out,
+                                                                  float* __restrict__ slab, long slab_stride, int skw_off,
+                                                                  int skb_off, int B) {
+    __shared__ float4 sh[EW_BLOCK];
+    __shared__ float shb[4];
+    __shared__ float vs[96];
+    __shared__ float sd_s;
+    const int64_t S = (int64_t)gridDim.x * EW_BLOCK;
+    // h1: 8 channel quads per 28 x 28 pixel
+    float4 g1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float gd = 0.f;
+    const int64_t n1 = (int64_t)B * 784 * 8;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n1; i += S) {
+        const float d = deps[i >> 3];
+        const float4 hv = reinterpret_cast<const float4*>(h1)[i];
+        g1.x += d * hv.x; g1.y += d * hv.y; g1.z += d * hv.z; g1.w += d * hv.w;
+        if ((threadIdx.x & 7) == 0) gd += d;
+    }
+    // h3: 16 channel quads per 14 x 14 source pixel, deps summed over its 2 x 2 outputs
+    float4 g3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t n3 = (int64_t)B * 196 * 16;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n3; i += S) {
+        const int s = (int)(i >> 4);
+        const int b = s / 196, r = s - b * 196, y = r / 14, x = r - y * 14;
+        const float* dp = deps + (long)b * 784 + (2 * y) * 28 + 2 * x;
+        const float d = (dp[0] + dp[1]) + (dp[28] + dp[29]);
+        const float4 hv = reinterpret_cast<const float4*>(h3)[i];
+        g3.x += d * hv.x; g3.y += d * hv.y; g3.z += d * hv.z; g3.w += d * hv.w;
+    }
+    // block sums per channel quad, fixed order: thread & 7 (h1) / thread & 15 (h3) is the quad (the grid stride is a multiple of 16)
+    sh[threadIdx.x] = g1;
+    const float sb = block_sum(gd, shb);   // (contains __syncthreads)
+    if (threadIdx.x < 8) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = threadIdx.x; k < EW_BLOCK; k += 8) { const float4 v = sh[k]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        vs[64 + threadIdx.x * 4 + 0] = a.x; vs[64 + threadIdx.x * 4 + 1] = a.y; vs[64 + threadIdx.x * 4 + 2] = a.z; vs[64 + threadIdx.x * 4 + 3] = a.w;
+    }
+    if (threadIdx.x == 0) sd_s = sb;
+    __syncthreads();
+    sh[threadIdx.x] = g3;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = threadIdx.x; k < EW_BLOCK; k += 16) { const float4 v = sh[k]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        vs[threadIdx.x * 4 + 0] = a.x; vs[threadIdx.x * 4 + 1] = a.y; vs[threadIdx.x * 4 + 2] = a.z; vs[threadIdx.x * 4 + 3] = a.w;
+    }
+    __syncthreads();
+    float* dst = slab + (long)blockIdx.x * slab_stride;
+    for (int e = threadIdx.x; e < 96 * 32; e += EW_BLOCK) dst[skw_off + e] = vs[e >> 5] * w_out[e & 31];
+    if (threadIdx.x < 32) dst[skb_off + threadIdx.x] = sd_s * w_out[threadIdx.x];
+}
+
 // dc = dout * (a > 0)
 __global__ __launch_bounds__(EW_BLOCK) void relu_mask_kernel(const float* __restrict__ dout, const float* __restrict__ a,
                                                              float* __restrict__ dc, int64_t n4) {
@@ -1121,6 +1181,13 @@ int tdm_launch_out_bwd(const float* deps, const float* h4, const float* w, const
     hipLaunchKernelGGL(out_bwd_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, deps, h4, w, a2, dout, dc2, slab, slab_stride,
                        w_off, b_off, M);
     TDM_CHECK_LAUNCH("out_bwd");
+    return 0;
+}
+int tdm_launch_skip4_factored(const float* deps, const float* h1, const float* h3, const float* w_out, float* slab, long slab_stride,
+                              int skw_off, int skb_off, int B, int nslab, hipStream_t st) {
+    hipLaunchKernelGGL(skip4_factored_kernel, dim3(nslab), dim3(EW_BLOCK), 0, st, deps, h1, h3, w_out, slab, slab_stride, skw_off,
+                       skb_off, B);
+    TDM_CHECK_LAUNCH("skip4_factored");
     return 0;
 }
 int tdm_launch_relu_mask(const float* dout, const float* a, float* dc, int64_t n, hipStream_t st) {

@@ -326,6 +326,8 @@ int tdm_launch_avgpool_s16(const float* in, float* out, float* out_s16, int B, i
 // given), and the slab partial of sum (eps - noise)^2 goes to slab offset loss_off (F.mse_loss, src/mnist.py:158).
 // dout4 = d x w_out is rank one and never written: the kernel emits rb4.skip's gradients in factored form (partial rows:
 // vsk_off: the 96-vector sum_m cat[m] d[m] over cat = [up2(h3s) | h1s]; skb_off: w_out * sum d) — elementwise.hip
+int tdm_launch_skip4_factored(const float* deps, const float* h1, const float* h3, const float* w_out, float* slab, long slab_stride,
+                              int skw_off, int skb_off, int B, int nslab, hipStream_t st);
 int tdm_launch_out_bwd_s16(const float* deps, const float* h4, const float* w, const unsigned char* a2m, const float* h1s,
                            const float* h3s, float* dc2_s16, float* slab, long slab_stride, int w_off, int b_off,
                            int c2b_off, int skb_off, int vsk_off, int64_t M, int nslab, hipStream_t st,

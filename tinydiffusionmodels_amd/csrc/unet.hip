@@ -720,8 +720,9 @@ int unet_backward(const float* P, const float* x, const float* deps, float* G, c
     TDM_TRY(wgrad(ss, 28, B, w.a1_4, 32, 32, 0, w.tb + 160, 9, w.dc2_4, 32, slabs, r4.c2w, 32, 0, r4.c2b, NSLAB));
     TDM_TRY(wgrad(ss, 28, B, w.h3, 64, 64, 1, nullptr, 9, w.dh4, 32, slabs, r4.c1w, 96, 0, r4.c1b, NSLAB));
     TDM_TRY(wgrad(ss, 28, B, w.h1, 32, 32, 0, nullptr, 9, w.dh4, 32, slabs, r4.c1w, 96, 64, -1, NSLAB));
-    TDM_TRY(wgrad(ss, 28, B, w.h3, 64, 64, 1, nullptr, 1, w.dout4, 32, slabs, r4.skw, 96, 0, r4.skb, NSLAB));
-    TDM_TRY(wgrad(ss, 28, B, w.h1, 32, 32, 0, nullptr, 1, w.dout4, 32, slabs, r4.skw, 96, 64, -1, NSLAB));
+    // rb4.skip: dout4 is rank one over the channels (deps x w_out), so its weight gradient is a 96-vector reduction x w_out
+    // (skip4_factored_kernel) instead of two 1 x 1 weight-gradient launches on the fp32 matrix cores (101 + 57 us at B = 512)
+    TDM_TRY(tdm_launch_skip4_factored(deps, w.h1, w.h3, P + kL.outw, slabs, TDM_UNET_NPARAM, r4.skw, r4.skb, B, NSLAB, ss));
     {
         ConvArgs a{};
         a.nsrc = 2;
