@@ -205,6 +205,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 const int m = m0 + (wave * 2 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m < Mtot) {
                     float v = acc[mt][nt][r] + bz;
+                    if (a.r1_x != nullptr) v = fmaf(a.r1_x[m], a.r1_w[co], v);   // a rank-one term x[m] * w[co] (rb4.skip's share of d cat)
                     if (a.relu) v = (v < 0.f) ? 0.f : v;
                     const long o = (long)m * N + co;
                     if (a.aux != nullptr) a.aux[o] = v;

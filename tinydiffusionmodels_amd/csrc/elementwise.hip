@@ -283,7 +283,7 @@ __global__ __launch_bounds__(EW_BLOCK) void out_bwd_kernel(const float* __restri
         const float4 av = reinterpret_cast<const float4*>(a2)[i];
         float4 o;
         o.x = d * wv.x; o.y = d * wv.y; o.z = d * wv.z; o.w = d * wv.w;
-        reinterpret_cast<float4*>(dout)[i] = o;
+        if (dout != nullptr) reinterpret_cast<float4*>(dout)[i] = o;   // (nullptr: nobody reads the rank-one gradient itself)
         float4 mk;
         mk.x = av.x > 0.f ? o.x : 0.f; mk.y = av.y > 0.f ? o.y : 0.f;
         mk.z = av.z > 0.f ? o.z : 0.f; mk.w = av.w > 0.f ? o.w : 0.f;

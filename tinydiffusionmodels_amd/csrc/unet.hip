@@ -240,7 +240,8 @@ int unet_forward(const float* P, const float* x, const int64_t* t, float* eps, c
     if (g_conv_mode == 2) return unet_forward_s16(P, x, t, eps, w, B, save, st);
     const int tew[4] = {kL.rb[0].tew, kL.rb[1].tew, kL.rb[2].tew, kL.rb[3].tew};
     const int teb[4] = {kL.rb[0].teb, kL.rb[1].teb, kL.rb[2].teb, kL.rb[3].teb};
-    TDM_TRY(tdm_launch_timebias(t, P, tew, teb, w.that, w.tb, B, st));
+    // (training: also u = W_skip(rb4) w_out, the 96-vector of the backward's rank-one skip gradient)
+    TDM_TRY(tdm_launch_timebias(t, P, tew, teb, w.that, w.tb, B, st, nullptr, save ? w.u96 : nullptr, kL.rb[3].skw, kL.outw));
     const BlockOff &r1 = kL.rb[0], &r2 = kL.rb[1], &r3 = kL.rb[2], &r4 = kL.rb[3];
     // rb1 (1 -> 32 @ 28x28)
     TDM_TRY(tdm_launch_conv_first(x, P + r1.c1w, P + r1.c1b, P + r1.skw, P + r1.skb, w.a1_1, w.s1, B, st));
@@ -712,7 +713,7 @@ int unet_backward(const float* P, const float* x, const float* deps, float* G, c
         return 0;
     };
     // ---- out conv + rb4 ----
-    TDM_TRY(tdm_launch_out_bwd(deps, w.h4, P + kL.outw, w.a2_4, w.dout4, w.dc2_4, slabs, TDM_UNET_NPARAM, kL.outw,
+    TDM_TRY(tdm_launch_out_bwd(deps, w.h4, P + kL.outw, w.a2_4, nullptr, w.dc2_4, slabs, TDM_UNET_NPARAM, kL.outw,
                                kL.outb, M28, NSLAB, st));
     TDM_TRY(dgrad1(st, w, 28, B, w.dc2_4, 32, 9, P + r4.c2w, W_RB4C2, 32, nullptr, w.dh4));
     TDM_TRY(tdm_launch_relu_bwd_tb(w.dh4, w.a1_4, w.S[3], B, 784, 32, st));  // dh4 <- d(conv1 pre-activation)
@@ -723,12 +724,13 @@ int unet_backward(const float* P, const float* x, const float* deps, float* G, c
     // rb4.skip: dout4 is rank one over the channels (deps x w_out), so its weight gradient is a 96-vector reduction x w_out
     // (skip4_factored_kernel) instead of two 1 x 1 weight-gradient launches on the fp32 matrix cores (101 + 57 us at B = 512)
     TDM_TRY(tdm_launch_skip4_factored(deps, w.h1, w.h3, P + kL.outw, slabs, TDM_UNET_NPARAM, r4.skw, r4.skb, B, NSLAB, ss));
-    {
+    {   // d cat = conv1's transposed conv of dh4 + the skip path's share, which is rank one: dout4 W_skip^T = deps[m] * u[ci]
+        // (u from the forward's prologue) — a term of the epilogue instead of a tenth of the launch's K
         ConvArgs a{};
-        a.nsrc = 2;
+        a.nsrc = 1;
         a.src[0] = mk_src(w.dh4, 32, 0, 32, 0, 9, P + r4.c1w, 96, 0, 32, nullptr, w.wpack + kPack.dg[W_RB4C1], 0);
-        a.src[1] = mk_src(w.dout4, 32, 0, 32, 0, 1, P + r4.skw, 96, 0, 32, nullptr, w.wpack + kPack.dg[W_RB4SK], 0);
         a.out = w.dcat; a.B = B;
+        a.r1_x = deps; a.r1_w = w.u96;
         TDM_TRY(launch_conv_any(a, 28, 96, true, st));
     }
     TDM_TRY(tdm_launch_split_dcat(w.dcat, w.dout3, B, st));
