@@ -20,8 +20,9 @@
  *    context moves to another GPU) and are destroyed with the context
  *    (tdm_ctx_destroy; a thread's default context: when the thread exits);
  *  - selector state (arithmetic, launch overlap) lives in an explicit tdm_ctx;
- *    the library has no process-global mutable state, and its only thread-local
- *    state is which context a thread has bound;
+ *    the library has no process-global mutable state, and its thread-local state
+ *    is which context a thread has bound, the last-error text (tdm_last_error)
+ *    and the profiling marks of tdm_unet_mark_launch;
  *  - `stream` is a hipStream_t passed as void*;
  *  - return 0 on success, non-zero on error; tdm_last_error() gives the text;
  *  - activations inside the library are NHWC fp32; the UNet input/output

@@ -44,12 +44,12 @@ void tdm_set_error(const char* fmt, ...);
         }                                                                          \
     } while (0)
 
-// The backward passes' second launch queue (tdm_set_bwd_overlap; defined and described in unet.hip): one per host thread, created
-// on first use.  `ready`: main -> side dependencies (forks); `back`: side -> main (a buffer the side queue's launches read is
+// The backward passes' second launch queue (tdm_set_bwd_overlap; defined and described in unet.hip): one per CONTEXT (TdmCtx below),
+// created on first use.  `ready`: main -> side dependencies (forks); `back`: side -> main (a buffer the side queue's launches read is
 // about to be overwritten); `done`: the final join.
-// Lifetime: the lane belongs to the calling host thread AND to one device — init(st) (re)creates stream and events on the device of
-// the caller's stream when that differs from the one they were made on (a thread that moves between GPUs), and the thread's exit
-// destroys them.  One lane per thread: a host thread drives one backward at a time.
+// Lifetime: the lane belongs to its context AND to one device — init(st) (re)creates stream and events on the device of the caller's
+// stream when that differs from the one they were made on (a context that moves between GPUs); tdm_ctx_destroy (a thread's default
+// context: the thread's exit) destroys them.  One lane per context: a context serves one thread, which drives one backward at a time.
 struct TdmSideLane {
     hipStream_t side = nullptr;
     hipEvent_t ready[8] = {}, back[2] = {}, done = nullptr;
